@@ -1,0 +1,78 @@
+"""Objectives of tflib/objs/gan_inference.py restated on the oracle tape.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED.
+"""
+import numpy as np
+from . import tape as tp
+
+
+def _bce_mean(logits, label):
+    return tp.reduce_mean(tp.bce_with_logits(logits, label))
+
+
+def local_ep_costs(disc_fake_list, disc_real_list):
+    """tflib/objs/gan_inference.py:81-106 -> (gen_cost, disc_cost)."""
+    gen, disc = 0.0, 0.0
+    for f, r in zip(disc_fake_list, disc_real_list):
+        gen = tp.add(tp.add(_bce_mean(f, 1.0), _bce_mean(r, 0.0)), gen)
+        disc = tp.add(tp.add(_bce_mean(f, 0.0), _bce_mean(r, 1.0)), disc)
+    n = float(len(disc_fake_list))
+    return tp.scale(gen, 1.0 / n), tp.scale(disc, 1.0 / n)
+
+
+def ali_costs(disc_fake, disc_real):
+    """tflib/objs/gan_inference.py:47-66 (== local_ep with one factor)."""
+    gen = tp.add(_bce_mean(disc_fake, 1.0), _bce_mean(disc_real, 0.0))
+    disc = tp.add(_bce_mean(disc_fake, 0.0), _bce_mean(disc_real, 1.0))
+    return gen, disc
+
+
+def weighted_local_epce_costs(disc_fake_list, disc_real_list, ratio_list):
+    """tflib/objs/gan_inference.py:307-345 (rec_penalty=None)."""
+    gen, disc = 0.0, 0.0
+    for f, r, ratio in zip(disc_fake_list, disc_real_list, ratio_list):
+        ratio = float(ratio)
+        gen = tp.add(tp.scale(tp.add(_bce_mean(f, 1.0), _bce_mean(r, 0.0)), ratio), gen)
+        disc = tp.add(tp.scale(tp.add(_bce_mean(f, 0.0), _bce_mean(r, 1.0)), ratio), disc)
+    return gen, disc
+
+
+def wali_gp_costs(disc_fake, disc_real, gradient_penalty):
+    """tflib/objs/gan_inference.py:28-32."""
+    gen = tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.reduce_mean(disc_real))
+    disc = tp.add(tp.add(tp.reduce_mean(disc_fake), tp.neg(tp.reduce_mean(disc_real))), gradient_penalty)
+    return gen, disc
+
+
+def gradient_penalty(critic, real_x, fake_x, q_z, p_z, alpha, lam=10.0):
+    """gan_inference_cifar10.py:353-364.  critic(x, z) -> logits [B].  Only the x-gradient
+    enters the penalty ([0] selects `interpolates`); no epsilon inside the sqrt."""
+    a = tp.T(np.asarray(alpha, dtype=real_x.v.dtype).reshape(-1, 1))
+    x_hat = tp.add(real_x, tp.mul(a, tp.add(fake_x, tp.neg(real_x))))
+    z_hat = tp.add(q_z, tp.mul(a, tp.add(p_z, tp.neg(q_z))))
+    d_hat = critic(x_hat, z_hat)
+    g = tp.grad(tp.reduce_sum(d_hat), [x_hat])[0]
+    slopes = tp.sqrt(tp.reduce_sum(tp.square(g), (1,)))
+    return tp.scale(tp.reduce_mean(tp.square(tp.add(slopes, -1.0))), lam)
+
+
+class Adam(object):
+    """tf.train.AdamOptimizer state for one var_list."""
+
+    def __init__(self, names, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8):
+        self.names, self.lr, self.b1, self.b2, self.eps = list(names), lr, beta1, beta2, eps
+        self.t = 0
+        self.m, self.v = {}, {}
+
+    def apply(self, P, grads):
+        """P: name -> ndarray (updated in place: entries are replaced); grads: name -> ndarray|None."""
+        from .ops import adam_update
+        self.t += 1
+        for n in self.names:
+            g = grads.get(n)
+            if g is None:                       # TF minimize drops (None, var) pairs
+                continue
+            m = self.m.get(n, np.zeros_like(P[n]))
+            v = self.v.get(n, np.zeros_like(P[n]))
+            P[n], self.m[n], self.v[n] = adam_update(P[n], g.astype(P[n].dtype), m, v, self.t,
+                                                     self.lr, self.b1, self.b2, self.eps)

@@ -1,0 +1,127 @@
+"""The training iteration of the reference's driver scripts, restated on the oracle.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED.
+
+Wiring follows gan_inference_cifar10.py:261-366 (MODE 'ali' / 'wali-gp') and
+gmgan_inference_cifar10.py:341-398 (MODE 'local_ep'); the loop follows
+gmgan_inference_cifar10.py:480-494: iteration 0 runs the critic step only, every
+session.run draws a fresh minibatch and fresh noise, gen and disc have independent Adam state.
+All randomness is injected through `feed` (the reference's TF RNG is unseeded).
+"""
+import numpy as np
+from . import tape as tp
+from . import nets as N
+from . import objs as J
+
+
+def make_feed(cfg, rng, mode='ali'):
+    """Synthetic inputs for one session.run."""
+    f = {}
+    if cfg.dataset == 'mnist':
+        f['real_x'] = rng.random((cfg.B, cfg.output_dim), dtype=np.float32)
+    else:
+        f['real_x_int'] = rng.integers(0, 256, size=(cfg.B, cfg.output_dim)).astype(np.int32)
+    if cfg.dataset == 'face':
+        f['dequant_u'] = (rng.random((cfg.B, cfg.output_dim), dtype=np.float32) / 128.0).astype(np.float32)
+    f['p_z_noise'] = rng.standard_normal((cfg.B, cfg.dim_latent), dtype=np.float32)
+    if cfg.K:
+        f['k_idx'] = rng.integers(0, cfg.K, size=(cfg.B,)).astype(np.int64)
+        f['gumbel_u'] = rng.random((cfg.B, cfg.K), dtype=np.float32)
+    if mode == 'wali-gp':
+        f['alpha'] = rng.random((cfg.B, 1), dtype=np.float32)
+    return f
+
+
+def real_x_from_feed(cfg, feed, dtype):
+    if cfg.dataset == 'mnist':                      # gmgan_inference_mnist.py:335
+        return np.asarray(feed['real_x'], dtype=dtype)
+    xi = feed['real_x_int'].astype(dtype)
+    if cfg.dataset == 'face':                       # gmgan_inference_face.py:242-243
+        return (dtype(2) * ((xi / dtype(256.)) - dtype(.5))) + feed['dequant_u'].astype(dtype)
+    return dtype(2) * ((xi / dtype(255.)) - dtype(.5))   # gmgan_inference_cifar10.py:342
+
+
+def forward(cfg, P, feed, mode='ali'):
+    """P: name -> tape.T.  Returns dict of taped tensors incl. gen_cost / disc_cost."""
+    dt = next(iter(P.values())).v.dtype.type
+    real_x = tp.T(real_x_from_feed(cfg, feed, dt))
+    q_z = N.Extractor(cfg, P, real_x)
+    noise = tp.T(feed['p_z_noise'].astype(dt))
+    out = {'real_x': real_x, 'q_z': q_z}
+    if cfg.K:
+        onehot = np.zeros((cfg.B, cfg.K), dtype=dt)
+        onehot[np.arange(cfg.B), feed['k_idx']] = 1
+        onehot = tp.T(onehot)
+        _, q_k = N.HyperExtractor(cfg, P, q_z, feed['gumbel_u'])
+        p_z = N.HyperGenerator(cfg, P, onehot, noise)
+        out['q_k'] = q_k
+    else:
+        p_z = noise
+    fake_x = N.Generator(cfg, P, p_z)
+    out.update(p_z=p_z, fake_x=fake_x)
+
+    def critic(x, z):
+        return N.Discriminator(cfg, P, x, z)
+
+    if cfg.K:
+        d_fake = [N.HyperDiscriminator(cfg, P, p_z, onehot), critic(fake_x, p_z)]
+        d_real = [N.HyperDiscriminator(cfg, P, q_z, q_k), critic(real_x, q_z)]
+        gen_cost, disc_cost = J.local_ep_costs(d_fake, d_real)
+    else:
+        d_fake, d_real = critic(fake_x, p_z), critic(real_x, q_z)
+        if mode == 'ali':
+            gen_cost, disc_cost = J.ali_costs(d_fake, d_real)
+        elif mode == 'wali-gp':
+            gp = J.gradient_penalty(critic, real_x, fake_x, q_z, p_z, feed['alpha'])
+            gen_cost, disc_cost = J.wali_gp_costs(d_fake, d_real, gp)
+            out['gradient_penalty'] = gp
+        else:
+            raise ValueError(mode)
+    out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=gen_cost, disc_cost=disc_cost)
+    return out
+
+
+class Trainer(object):
+    """Holds parameters + the two Adam states; gen_step / disc_step = one session.run each."""
+
+    def __init__(self, cfg, params, mode='ali', dtype=np.float64):
+        self.cfg, self.mode, self.dtype = cfg, mode, dtype
+        self.P = {k: np.asarray(v, dtype=dtype).copy() for k, v in params.items()}
+        gen_names = N.trainable(N.params_with_name(self.P, 'Generator') + N.params_with_name(self.P, 'Extractor'))
+        disc_names = N.trainable(N.params_with_name(self.P, 'Discriminator'))
+        if mode == 'wali-gp':                       # tflib/objs/gan_inference.py:34-43
+            hp = dict(lr=1e-4, beta1=0.5, beta2=0.9)
+        else:                                       # LR/BETA1 of the scripts, beta2 default
+            hp = dict(lr=2e-4, beta1=0.5, beta2=0.999)
+        self.gen_opt = J.Adam(gen_names, **hp)
+        self.disc_opt = J.Adam(disc_names, **hp)
+        self.critic_iters = 5 if mode == 'wali-gp' else 1   # gan_inference_cifar10.py:53-59
+
+    def _run(self, feed, which):
+        Pt = {k: tp.T(v) for k, v in self.P.items()}
+        out = forward(self.cfg, Pt, feed, self.mode)
+        opt = self.gen_opt if which == 'gen' else self.disc_opt
+        cost = out[which + '_cost']
+        gs = tp.grad(cost, [Pt[n] for n in opt.names])
+        grads = {n: (g.v if g is not None else None) for n, g in zip(opt.names, gs)}
+        return float(cost.v), grads, out
+
+    def gen_step(self, feed):
+        cost, grads, _ = self._run(feed, 'gen')
+        self.gen_opt.apply(self.P, grads)
+        return cost
+
+    def disc_step(self, feed):
+        cost, grads, _ = self._run(feed, 'disc')
+        self.disc_opt.apply(self.P, grads)
+        return cost
+
+    def iteration(self, it, feeds):
+        """feeds: iterator of feed dicts; consumes 1 (if it>0) + critic_iters of them.
+        gmgan_inference_cifar10.py:480-494."""
+        res = {}
+        if it > 0:
+            res['gen_cost'] = self.gen_step(next(feeds))
+        for _ in range(self.critic_iters):
+            res['disc_cost'] = self.disc_step(next(feeds))
+        return res
