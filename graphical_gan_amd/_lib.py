@@ -1,0 +1,110 @@
+"""ctypes binding of libggan.so (the C ABI declared in include/ggan.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libggan.so')
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+PACK_MAX = 64
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('N', 'Ci', 'H', 'W', 'Co', 'Ho', 'Wo', 'k', 'stride', 'pad_t', 'pad_l')]
+
+
+class ProfRec(C.Structure):
+    _fields_ = [('name', C.c_char * 48), ('total_ms', C.c_double), ('launches', C.c_long),
+                ('flops', C.c_double), ('bytes', C.c_double)]
+
+
+class GganError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_F = C.c_float
+_I = C.c_int
+_Z = C.c_size_t
+_G = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); must list every symbol include/ggan.h declares
+SIGNATURES = {
+    'ggan_version': (_I, []),
+    'ggan_last_error': (C.c_char_p, []),
+    'ggan_set_naive': (_I, [_I]),
+    'ggan_conv2d_workspace': (_Z, [_G]),
+    'ggan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_conv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_deconv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_deconv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _Z, _P]),
+    'ggan_deconv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_gemm_workspace': (_Z, [_I, _I, _I]),
+    'ggan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_colsum': (_I, [_P, _P, _I, _I, _P]),
+    'ggan_chansum': (_I, [_P, _P, _I, _I, _I, _P]),
+    'ggan_bn_fwd_train': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),
+    'ggan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'ggan_act_fwd': (_I, [_P, _P, _Z, _I, _F, _P]),
+    'ggan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
+    'ggan_bias_add': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'ggan_cast_scale_i32': (_I, [_P, _P, _P, _Z, _F, _F, _P]),
+    'ggan_axpby': (_I, [_P, _P, _P, _Z, _F, _F, _F, _P]),
+    'ggan_row_lerp': (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    'ggan_bce_logits_fwd': (_I, [_P, _F, _F, _P, _I, _I, _P]),
+    'ggan_bce_logits_bwd': (_I, [_P, _F, _F, _P, _P, _I, _P]),
+    'ggan_mean_fwd': (_I, [_P, _F, _P, _I, _I, _P]),
+    'ggan_mean_bwd': (_I, [_P, _F, _P, _I, _P]),
+    'ggan_gp_penalty_fwd': (_I, [_P, _P, _P, _I, _I, _F, _P]),
+    'ggan_gp_penalty_bwd': (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    'ggan_adam_step': (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P]),
+    'ggan_adam_advance': (_I, [_P, _P]),
+    'ggan_pack': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), _I, _P, _P]),
+    'ggan_prof_enable': (_I, [_I]),
+    'ggan_prof_reset': (_I, []),
+    'ggan_prof_report': (_I, [C.POINTER(ProfRec), _I]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libggan.so and bind every symbol; raises GganError when anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GganError('libggan.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(there is no CPU fallback)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise GganError('libggan.so does not export %s' % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ggan_last_error()
+        raise GganError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def prof_report(cap=256):
+    lib = load()
+    recs = (ProfRec * cap)()
+    n = lib.ggan_prof_report(recs, cap)
+    out = []
+    for i in range(n):
+        r = recs[i]
+        out.append(dict(name=r.name.decode(), total_ms=r.total_ms, launches=int(r.launches),
+                        flops=r.flops, bytes=r.bytes))
+    return out

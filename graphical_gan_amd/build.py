@@ -1,0 +1,64 @@
+"""Build libggan.so (all HIP kernels + the C ABI of include/ggan.h) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU; the resulting .so sits next to csrc/ so that it travels with the
+repo snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libggan.so')
+STAMP = os.path.join(HERE, '.libggan.stamp')
+SOURCES = ['runtime.hip', 'pointwise.hip', 'bn.hip', 'gemm.hip', 'conv_naive.hip', 'conv_mfma.hip', 'conv_api.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-Wall', '-Wno-unused-function']
+
+
+def _digest():
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(HERE, '..', 'include')):
+        for fn in sorted(os.listdir(root)):
+            with open(os.path.join(root, fn), 'rb') as f:
+                h.update(fn.encode())
+                h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip translation unit and link libggan.so.  Returns the library path."""
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
+        os.makedirs(os.path.dirname(obj), exist_ok=True)
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write('hipcc failed for %s:\n%s\n' % (src, out.decode(errors='replace')))
+        elif verbose and out:
+            sys.stderr.write(out.decode(errors='replace'))
+    if failed:
+        raise RuntimeError('libggan build failed')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    with open(STAMP, 'w') as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,192 @@
+// Training-mode batch normalisation (batch statistics, biased variance, eps inside the sqrt).
+// Replaces tf.nn.fused_batch_norm(NCHW) (tflib/ops/batchnorm.py:29-30) and the
+// tf.nn.moments + tf.nn.batch_normalization branch (:74-87) -- SURVEY.md A.4 / K8, K8', K9.
+//
+// HBM-bound: algorithmic traffic fwd = 2 reads + 1 write of the activation (stat passes hit L2),
+// bwd = 2 reads (x, gy) + 1 write.  Two layouts:
+//   HW > 1 : NCHW, one workgroup per channel; lanes stream the N contiguous HW-chunks; wave-shuffle
+//            + LDS tree for the per-channel sums (two-pass mean / centred variance for accuracy).
+//   HW == 1: [N, C] rows (Generator.BN1 over [B,4096]); lanes run along C so every row read is a
+//            coalesced 256-B segment; a 64x4 thread tile splits N four ways and combines through LDS.
+#include "common.h"
+using namespace ggan;
+
+namespace {
+
+constexpr int kThreads = 512;
+
+__global__ __launch_bounds__(kThreads) void bn_fwd_nchw_k(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ offset, float* __restrict__ y,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                          int N, int C, int HW, float eps, int act, float alpha) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x;
+    const int total = N * HW;
+    const float inv_cnt = 1.f / (float)total;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+        int n = i / HW, p = i - n * HW;
+        s += x[((size_t)n * C + c) * HW + p];
+    }
+    const float mean = block_sum(s, sm) * inv_cnt;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+        int n = i / HW, p = i - n * HW;
+        float d = x[((size_t)n * C + c) * HW + p] - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, sm) * inv_cnt;
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float g = scale[c], b = offset[c];
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+        int n = i / HW, p = i - n * HW;
+        size_t idx = ((size_t)n * C + c) * HW + p;
+        float v = g * ((x[idx] - mean) * invstd) + b;
+        y[idx] = act_apply(v, act, alpha);
+    }
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          const float* __restrict__ scale, const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, float* __restrict__ gx,
+                                                          float* __restrict__ gscale, float* __restrict__ goffset, int N,
+                                                          int C, int HW) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x;
+    const int total = N * HW;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+        int n = i / HW, p = i - n * HW;
+        size_t idx = ((size_t)n * C + c) * HW + p;
+        float g = gy[idx];
+        s1 += g;
+        s2 += g * ((x[idx] - mean) * invstd);
+    }
+    const float sum_g = block_sum(s1, sm);
+    const float sum_gx = block_sum(s2, sm);
+    const float inv_cnt = 1.f / (float)total;
+    const float k = scale[c] * invstd;
+    const float mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+        int n = i / HW, p = i - n * HW;
+        size_t idx = ((size_t)n * C + c) * HW + p;
+        float xh = (x[idx] - mean) * invstd;
+        gx[idx] = k * (gy[idx] - mg - xh * mgx);
+    }
+    if (threadIdx.x == 0) {
+        gscale[c] = sum_gx;
+        goffset[c] = sum_g;
+    }
+}
+
+// ---- [N, C] layout: block = 64 columns x 4 row-slices -----------------------------------------
+constexpr int kCols = 64, kSlices = 4;
+
+__device__ __forceinline__ float slice_sum(float v, float (*sm)[kCols]) {
+    const int col = threadIdx.x, sl = threadIdx.y;
+    __syncthreads();
+    sm[sl][col] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < kSlices; ++i) t += sm[i][col];
+    return t;
+}
+
+__global__ void bn_fwd_rows_k(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+                              float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd, int N,
+                              int C, float eps, int act, float alpha) {
+    __shared__ float sm[kSlices][kCols];
+    const int c = blockIdx.x * kCols + threadIdx.x;
+    const bool ok = c < C;
+    const float inv_cnt = 1.f / (float)N;
+    float s = 0.f;
+    if (ok) for (int n = threadIdx.y; n < N; n += kSlices) s += x[(size_t)n * C + c];
+    const float mean = slice_sum(s, sm) * inv_cnt;
+    float q = 0.f;
+    if (ok) for (int n = threadIdx.y; n < N; n += kSlices) {
+        float d = x[(size_t)n * C + c] - mean;
+        q += d * d;
+    }
+    const float var = slice_sum(q, sm) * inv_cnt;
+    const float invstd = 1.f / sqrtf(var + eps);
+    if (!ok) return;
+    const float g = scale[c], b = offset[c];
+    for (int n = threadIdx.y; n < N; n += kSlices) {
+        size_t idx = (size_t)n * C + c;
+        y[idx] = act_apply(g * ((x[idx] - mean) * invstd) + b, act, alpha);
+    }
+    if (threadIdx.y == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+    }
+}
+
+__global__ void bn_bwd_rows_k(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ scale,
+                              const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                              float* __restrict__ gx, float* __restrict__ gscale, float* __restrict__ goffset, int N, int C) {
+    __shared__ float sm[kSlices][kCols];
+    const int c = blockIdx.x * kCols + threadIdx.x;
+    const bool ok = c < C;
+    const float mean = ok ? save_mean[c] : 0.f, invstd = ok ? save_invstd[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) for (int n = threadIdx.y; n < N; n += kSlices) {
+        size_t idx = (size_t)n * C + c;
+        float g = gy[idx];
+        s1 += g;
+        s2 += g * ((x[idx] - mean) * invstd);
+    }
+    const float sum_g = slice_sum(s1, sm);
+    const float sum_gx = slice_sum(s2, sm);
+    if (!ok) return;
+    const float inv_cnt = 1.f / (float)N;
+    const float k = scale[c] * invstd, mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
+    for (int n = threadIdx.y; n < N; n += kSlices) {
+        size_t idx = (size_t)n * C + c;
+        float xh = (x[idx] - mean) * invstd;
+        gx[idx] = k * (gy[idx] - mg - xh * mgx);
+    }
+    if (threadIdx.y == 0) {
+        gscale[c] = sum_gx;
+        goffset[c] = sum_g;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ggan_bn_fwd_train(const float* x, const float* scale, const float* offset, float* y, float* save_mean,
+                      float* save_invstd, int N, int C, int HW, float eps, int act, float alpha, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && scale && offset && y && save_mean && save_invstd, "null pointer");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = 12.0 * N * C * HW;
+    if (HW > 1) {
+        GGAN_LAUNCH("bn_fwd_nchw", 0, bytes, bn_fwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, HW, eps, act, alpha);
+    } else {
+        GGAN_LAUNCH("bn_fwd_rows", 0, bytes, bn_fwd_rows_k, dim3(cdiv(C, kCols)), dim3(kCols, kSlices), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, eps, act, alpha);
+    }
+    return 0;
+}
+
+int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float* save_mean, const float* save_invstd,
+                float* gx, float* gscale, float* goffset, int N, int C, int HW, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && gy && scale && save_mean && save_invstd && gx && gscale && goffset, "null pointer");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const double bytes = 20.0 * N * C * HW;
+    if (HW > 1) {
+        GGAN_LAUNCH("bn_bwd_nchw", 0, bytes, bn_bwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
+    } else {
+        GGAN_LAUNCH("bn_bwd_rows", 0, bytes, bn_bwd_rows_k, dim3(cdiv(C, kCols)), dim3(kCols, kSlices), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Internal helpers shared by the libggan translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "../../include/ggan.h"
+
+namespace ggan {
+
+// ---- error plumbing: C ABI never throws -------------------------------------------------------
+void set_error(const char* fmt, ...);
+extern bool g_force_naive;
+
+#define GGAN_CHECK_ARG(cond, msg)                                  \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            ggan::set_error("%s: %s", __func__, msg);             \
+            return -1;                                             \
+        }                                                          \
+    } while (0)
+
+// ---- per-kernel profiling ---------------------------------------------------------------------
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t s, double flops, double bytes);
+    ~ProfScope();
+    hipStream_t s_;
+    int idx_;
+};
+int check_launch(const char* name);
+
+// LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, args...)
+#define GGAN_LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, ...)          \
+    do {                                                                                    \
+        ggan::ProfScope _ps(name, stream, (double)(flops), (double)(bytes));              \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
+    } while (0);                                                                            \
+    if (ggan::check_launch(name)) return -2
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+    switch (act) {
+        case GGAN_ACT_LRELU: return fmaxf(alpha * v, v);
+        case GGAN_ACT_RELU: return fmaxf(v, 0.f);
+        case GGAN_ACT_TANH: return tanhf(v);
+        case GGAN_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// wave64 all-reduce sum via DPP-free shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x multiple of 64 (<=1024); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += smem[i];
+    return t;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace ggan

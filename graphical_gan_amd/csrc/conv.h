@@ -1,0 +1,38 @@
+// Internal convolution entry points (host side), shared between conv_naive / conv_mfma / capi.
+#pragma once
+#include "common.h"
+
+namespace ggan {
+
+int conv_fwd_naive(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                   float alpha, hipStream_t s);
+int conv_dgrad_naive(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
+                     float alpha, hipStream_t s);
+int conv_wgrad_naive(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, hipStream_t s);
+
+// MFMA paths: return 1 when the geometry is not covered (caller falls back to the naive kernel),
+// 0 on success, <0 on error.
+int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                  float alpha, void* ws, size_t ws_bytes, hipStream_t s);
+int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
+                    float alpha, void* ws, size_t ws_bytes, hipStream_t s);
+int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, void* ws, size_t ws_bytes,
+                    hipStream_t s);
+size_t conv_workspace_bytes(const ggan_conv_geom& g);
+// out[i] = act(sum_s partial[s][i] + bias[(i/HW)%C]) -- deterministic split-K combine (conv + gemm)
+int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,
+                         float alpha, hipStream_t s);
+
+// exact n / d for n*d < 2^32 via one mulhi
+struct FastDiv {
+    uint32_t mul, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.mul = (d <= 1) ? 0u : (uint32_t)((0x100000000ull / d) + 1ull);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.d <= 1 ? n : __umulhi(n, f.mul); }
+
+}  // namespace ggan

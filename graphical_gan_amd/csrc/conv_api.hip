@@ -1,0 +1,93 @@
+// C-ABI entry points of the Conv2D / Deconv2D family: argument checks + dispatch between the MFMA kernels
+// (5x5 stride-2 hot path) and the plain kernels (everything else, or ggan_set_naive(1)).
+#include "common.h"
+#include "conv.h"
+using namespace ggan;
+
+namespace {
+
+int check_geom(const ggan_conv_geom* g) {
+    if (!g) { set_error("null geometry"); return -1; }
+    if (g->N <= 0 || g->Ci <= 0 || g->Co <= 0 || g->H <= 0 || g->W <= 0 || g->Ho <= 0 || g->Wo <= 0 || g->k <= 0 ||
+        g->stride <= 0 || g->pad_t < 0 || g->pad_l < 0) {
+        set_error("bad conv geometry N=%d Ci=%d H=%d W=%d Co=%d Ho=%d Wo=%d k=%d s=%d pad=(%d,%d)", g->N, g->Ci, g->H,
+                  g->W, g->Co, g->Ho, g->Wo, g->k, g->stride, g->pad_t, g->pad_l);
+        return -1;
+    }
+    // the last window must start inside the padded input
+    if ((g->Ho - 1) * g->stride - g->pad_t >= g->H || (g->Wo - 1) * g->stride - g->pad_l >= g->W) {
+        set_error("conv geometry: output grid larger than the input allows");
+        return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ggan_conv2d_workspace(const ggan_conv_geom* g) { return g ? conv_workspace_bytes(*g) : 0; }
+
+int ggan_conv2d_fwd(const ggan_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int act,
+                    float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    GGAN_CHECK_ARG(x && w && y, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!g_force_naive) {
+        int r = conv_fwd_mfma(*g, x, w, bias, y, act, alpha, ws, ws ? ws_bytes : 0, s);
+        if (r <= 0) return r;
+    }
+    return conv_fwd_naive(*g, x, w, bias, y, act, alpha, s);
+}
+
+int ggan_conv2d_bwd_data(const ggan_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx, int act,
+                         float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    GGAN_CHECK_ARG(gy && w && gx, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!g_force_naive) {
+        int r = conv_dgrad_mfma(*g, gy, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
+        if (r <= 0) return r;
+    }
+    return conv_dgrad_naive(*g, gy, w, bias, gx, act, alpha, s);
+}
+
+int ggan_conv2d_bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, float* gw, float* gbias, void* ws,
+                           size_t ws_bytes, ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    GGAN_CHECK_ARG(x && gy && gw, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (gbias) {
+        int r = ggan_chansum(gy, gbias, g->N, g->Co, g->Ho * g->Wo, stream);
+        if (r) return r;
+    }
+    if (!g_force_naive) {
+        int r = conv_wgrad_mfma(*g, x, gy, gw, ws, ws ? ws_bytes : 0, s);
+        if (r <= 0) return r;
+    }
+    return conv_wgrad_naive(*g, x, gy, gw, s);
+}
+
+// Deconv2D = the adjoint family with the same filter bytes (see ggan.h)
+int ggan_deconv2d_fwd(const ggan_conv_geom* g, const float* x_small, const float* w, const float* bias, float* y_big,
+                      int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    return ggan_conv2d_bwd_data(g, x_small, w, bias, y_big, act, alpha, ws, ws_bytes, stream);
+}
+
+int ggan_deconv2d_bwd_data(const ggan_conv_geom* g, const float* gy_big, const float* w, float* gx_small, void* ws,
+                           size_t ws_bytes, ggan_stream_t stream) {
+    return ggan_conv2d_fwd(g, gy_big, w, nullptr, gx_small, GGAN_ACT_NONE, 0.f, ws, ws_bytes, stream);
+}
+
+int ggan_deconv2d_bwd_filter(const ggan_conv_geom* g, const float* gy_big, const float* x_small, float* gw, float* gbias,
+                             void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    if (gbias) {
+        GGAN_CHECK_ARG(gy_big, "null pointer");
+        int r = ggan_chansum(gy_big, gbias, g->N, g->Ci, g->H * g->W, stream);
+        if (r) return r;
+    }
+    return ggan_conv2d_bwd_filter(g, gy_big, x_small, gw, nullptr, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

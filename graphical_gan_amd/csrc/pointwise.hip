@@ -1,0 +1,378 @@
+// HBM-bound pointwise / reduction kernels of the training step: activations, bias, input scaling,
+// interpolation, BCE / Wasserstein / gradient-penalty losses, Adam, gradient packing.
+// All are grid-stride, float4-vectorised where the layout allows, wave-shuffle reductions.
+#include "common.h"
+using namespace ggan;
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(size_t n, int per_thread = 4) {
+    size_t b = cdivz(n, (size_t)kBlock * per_thread);
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;   // 256 CUs x 8 blocks, grid-stride the rest
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void act_fwd_k(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float alpha) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    size_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (size_t j = i; j < n4; j += stride) {
+        float4 v = x4[j];
+        v.x = act_apply(v.x, act, alpha); v.y = act_apply(v.y, act, alpha);
+        v.z = act_apply(v.z, act, alpha); v.w = act_apply(v.w, act, alpha);
+        y4[j] = v;
+    }
+    for (size_t j = (n4 << 2) + i; j < n; j += stride) y[j] = act_apply(x[j], act, alpha);
+}
+
+__device__ __forceinline__ float act_grad(float g, float r, int act, float alpha) {
+    switch (act) {
+        case GGAN_ACT_LRELU: return r > 0.f ? g : alpha * g;      // ref = forward input
+        case GGAN_ACT_RELU: return r > 0.f ? g : 0.f;             // ref = forward input
+        case GGAN_ACT_TANH: return g * (1.f - r * r);             // ref = forward output
+        case GGAN_ACT_SIGMOID: return g * r * (1.f - r);          // ref = forward output
+        default: return g;
+    }
+}
+
+__global__ void act_bwd_k(const float* __restrict__ gy, const float* __restrict__ ref, float* __restrict__ gx,
+                          size_t n, int act, float alpha) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    size_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(gy);
+    const float4* r4 = reinterpret_cast<const float4*>(ref);
+    float4* o4 = reinterpret_cast<float4*>(gx);
+    for (size_t j = i; j < n4; j += stride) {
+        float4 g = g4[j], r = r4[j], o;
+        o.x = act_grad(g.x, r.x, act, alpha); o.y = act_grad(g.y, r.y, act, alpha);
+        o.z = act_grad(g.z, r.z, act, alpha); o.w = act_grad(g.w, r.w, act, alpha);
+        o4[j] = o;
+    }
+    for (size_t j = (n4 << 2) + i; j < n; j += stride) gx[j] = act_grad(gy[j], ref[j], act, alpha);
+}
+
+__global__ void bias_add_k(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
+                           size_t total, int C, int HW) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < total; j += stride) {
+        int c = (int)((j / (size_t)HW) % (size_t)C);
+        y[j] = x[j] + bias[c];
+    }
+}
+
+__global__ void cast_scale_k(const int32_t* __restrict__ x, const float* __restrict__ noise, float* __restrict__ y,
+                             size_t n, float div, float mul) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < n; j += stride) {
+        // reference op order: 2*((float(x)/255.)-.5)  (gmgan_inference_cifar10.py:342)
+        float v = mul * (((float)x[j] / div) - 0.5f);
+        if (noise) v += noise[j];
+        y[j] = v;
+    }
+}
+
+__global__ void axpby_k(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                        size_t n, float a, float b, float c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < n; j += stride) out[j] = a * x[j] + (y ? b * y[j] : 0.f) + c;
+}
+
+__global__ void row_lerp_k(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ alpha,
+                           float* __restrict__ out, int rows, int cols) {
+    size_t total = (size_t)rows * cols;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < total; j += stride) {
+        float a = alpha[j / (size_t)cols];
+        out[j] = x[j] + a * (y[j] - x[j]);
+    }
+}
+
+// ---- reductions -------------------------------------------------------------------------------
+// column sums of a [rows, cols] matrix: one thread per column chunk, lanes along columns (coalesced)
+__global__ void colsum_k(const float* __restrict__ x, float* __restrict__ out, int rows, int cols) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(size_t)r * cols + c];
+    out[c] = s;
+}
+
+// per-channel sum over (n, hw) of NCHW: one block per channel
+__global__ void chansum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    const int total = N * HW;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int n = i / HW, p = i - n * HW;
+        s += x[((size_t)n * C + c) * HW + p];
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) out[c] = s;
+}
+
+// ---- losses (single block: n is a minibatch of logits) ---------------------------------------------
+__global__ void bce_fwd_k(const float* __restrict__ x, float z, float weight, float* __restrict__ loss, int n,
+                          int accumulate) {
+    __shared__ float sm[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = x[i];
+        s += fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)));
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) {
+        float r = weight * (s / (float)n);
+        loss[0] = accumulate ? loss[0] + r : r;
+    }
+}
+
+__global__ void bce_bwd_k(const float* __restrict__ x, float z, float weight, const float* __restrict__ gloss,
+                          float* __restrict__ gx, int n) {
+    const float g = gloss[0] * weight / (float)n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float v = x[i];
+        float sg = 1.f / (1.f + expf(-v));
+        gx[i] = g * (sg - z);
+    }
+}
+
+__global__ void mean_fwd_k(const float* __restrict__ x, float weight, float* __restrict__ loss, int n, int accumulate) {
+    __shared__ float sm[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) {
+        float r = weight * (s / (float)n);
+        loss[0] = accumulate ? loss[0] + r : r;
+    }
+}
+
+__global__ void mean_bwd_k(const float* __restrict__ gloss, float weight, float* __restrict__ gx, int n) {
+    const float g = gloss[0] * weight / (float)n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) gx[i] = g;
+}
+
+// one block per sample row: slopes[b] = ||g[b,:]||_2
+__global__ void gp_slopes_k(const float* __restrict__ g, float* __restrict__ slopes, int D) {
+    __shared__ float sm[32];
+    const float* row = g + (size_t)blockIdx.x * D;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) s += row[i] * row[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) slopes[blockIdx.x] = sqrtf(s);
+}
+
+__global__ void gp_pen_k(const float* __restrict__ slopes, float* __restrict__ pen, int B, float lam) {
+    __shared__ float sm[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        float d = slopes[i] - 1.f;
+        s += d * d;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) pen[0] = lam * (s / (float)B);
+}
+
+__global__ void gp_bwd_k(const float* __restrict__ g, const float* __restrict__ slopes, const float* __restrict__ gpen,
+                         float* __restrict__ gg, int B, int D, float lam) {
+    const int b = blockIdx.x;
+    const float s = slopes[b];
+    const float coef = gpen[0] * lam * 2.f * (s - 1.f) / ((float)B * s);
+    const float* row = g + (size_t)b * D;
+    float* orow = gg + (size_t)b * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) orow[i] = coef * row[i];
+}
+
+// ---- Adam (TF flavour) ------------------------------------------------------------------------
+__global__ void adam_k(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, size_t n, const int32_t* __restrict__ step, float lr, float b1,
+                       float b2, float eps, float gscale) {
+    const float t = (float)(step[0] + 1);
+    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    size_t n4 = n >> 2;
+    float4* th4 = reinterpret_cast<float4*>(theta);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+#define ADAM1(TH, G, M, V)                                     \
+    {                                                          \
+        float gg = (G) * gscale;                               \
+        (M) = b1 * (M) + (1.f - b1) * gg;                      \
+        (V) = b2 * (V) + (1.f - b2) * gg * gg;                 \
+        (TH) = (TH) - lr_t * (M) / (sqrtf(V) + eps);           \
+    }
+    for (size_t j = i; j < n4; j += stride) {
+        float4 th = th4[j], gg4 = g4[j], mm = m4[j], vv = v4[j];
+        ADAM1(th.x, gg4.x, mm.x, vv.x) ADAM1(th.y, gg4.y, mm.y, vv.y)
+        ADAM1(th.z, gg4.z, mm.z, vv.z) ADAM1(th.w, gg4.w, mm.w, vv.w)
+        th4[j] = th; m4[j] = mm; v4[j] = vv;
+    }
+    for (size_t j = (n4 << 2) + i; j < n; j += stride) {
+        float th = theta[j], mm = m[j], vv = v[j];
+        ADAM1(th, g[j], mm, vv)
+        theta[j] = th; m[j] = mm; v[j] = vv;
+    }
+#undef ADAM1
+}
+
+__global__ void adam_advance_k(int32_t* step) { step[0] += 1; }
+
+struct PackTable {
+    const float* src[GGAN_PACK_MAX];
+    size_t size[GGAN_PACK_MAX];
+    size_t off[GGAN_PACK_MAX];
+    int count;
+};
+
+// blockIdx.y = tensor, blockIdx.x grid-strides inside it
+__global__ void pack_k(PackTable t, float* __restrict__ flat) {
+    const int k = blockIdx.y;
+    const float* s = t.src[k];
+    float* d = flat + t.off[k];
+    const size_t n = t.size[k];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        d[i] = s ? s[i] : 0.f;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ggan_act_fwd(const float* x, float* y, size_t n, int act, float alpha, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && y, "null pointer");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    GGAN_CHECK_ARG(aligned16(x) && aligned16(y), "buffers must be 16-byte aligned");
+    GGAN_LAUNCH("act_fwd", 0, 8.0 * n, act_fwd_k, dim3(grid_for(n, 16)), dim3(kBlock), 0, s, x, y, n, act, alpha);
+    return 0;
+}
+
+int ggan_act_bwd(const float* gy, const float* ref, float* gx, size_t n, int act, float alpha, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(gy && ref && gx, "null pointer");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    GGAN_CHECK_ARG(aligned16(gy) && aligned16(ref) && aligned16(gx), "buffers must be 16-byte aligned");
+    GGAN_LAUNCH("act_bwd", 0, 12.0 * n, act_bwd_k, dim3(grid_for(n, 16)), dim3(kBlock), 0, s, gy, ref, gx, n, act, alpha);
+    return 0;
+}
+
+int ggan_bias_add(const float* x, const float* bias, float* y, int N, int C, int HW, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && bias && y && N > 0 && C > 0 && HW > 0, "bad argument");
+    size_t total = (size_t)N * C * HW;
+    GGAN_LAUNCH("bias_add", 0, 8.0 * total, bias_add_k, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, bias, y, total, C, HW);
+    return 0;
+}
+
+int ggan_cast_scale_i32(const int32_t* x, const float* noise, float* y, size_t n, float div, float mul, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && y, "null pointer");
+    if (n == 0) return 0;
+    GGAN_LAUNCH("cast_scale_i32", 0, 8.0 * n, cast_scale_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, noise, y, n, div, mul);
+    return 0;
+}
+
+int ggan_axpby(const float* x, const float* y, float* out, size_t n, float a, float b, float c, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && out, "null pointer");
+    if (n == 0) return 0;
+    GGAN_LAUNCH("axpby", 0, 12.0 * n, axpby_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, out, n, a, b, c);
+    return 0;
+}
+
+int ggan_row_lerp(const float* x, const float* y, const float* alpha, float* out, int rows, int cols, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && y && alpha && out && rows > 0 && cols > 0, "bad argument");
+    size_t n = (size_t)rows * cols;
+    GGAN_LAUNCH("row_lerp", 0, 12.0 * n, row_lerp_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, alpha, out, rows, cols);
+    return 0;
+}
+
+int ggan_colsum(const float* x, float* out, int rows, int cols, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && out && rows > 0 && cols > 0, "bad argument");
+    GGAN_LAUNCH("colsum", 0, 4.0 * rows * cols, colsum_k, dim3(cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, x, out, rows, cols);
+    return 0;
+}
+
+int ggan_chansum(const float* x, float* out, int N, int C, int HW, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "bad argument");
+    GGAN_LAUNCH("chansum", 0, 4.0 * N * C * HW, chansum_k, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW);
+    return 0;
+}
+
+int ggan_bce_logits_fwd(const float* x, float label, float weight, float* loss, int n, int accumulate, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && loss && n > 0, "bad argument");
+    GGAN_LAUNCH("bce_logits_fwd", 0, 4.0 * n, bce_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, x, label, weight, loss, n, accumulate);
+    return 0;
+}
+
+int ggan_bce_logits_bwd(const float* x, float label, float weight, const float* gloss, float* gx, int n, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && gloss && gx && n > 0, "bad argument");
+    GGAN_LAUNCH("bce_logits_bwd", 0, 8.0 * n, bce_bwd_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, label, weight, gloss, gx, n);
+    return 0;
+}
+
+int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && loss && n > 0, "bad argument");
+    GGAN_LAUNCH("mean_fwd", 0, 4.0 * n, mean_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, x, weight, loss, n, accumulate);
+    return 0;
+}
+
+int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(gloss && gx && n > 0, "bad argument");
+    GGAN_LAUNCH("mean_bwd", 0, 4.0 * n, mean_bwd_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gloss, weight, gx, n);
+    return 0;
+}
+
+int ggan_gp_penalty_fwd(const float* g, float* slopes, float* pen, int B, int D, float lam, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(g && slopes && pen && B > 0 && D > 0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    GGAN_LAUNCH("gp_slopes", 0, 4.0 * B * D, gp_slopes_k, dim3(B), dim3(256), 0, s, g, slopes, D);
+    GGAN_LAUNCH("gp_penalty", 0, 4.0 * B, gp_pen_k, dim3(1), dim3(256), 0, s, slopes, pen, B, lam);
+    return 0;
+}
+
+int ggan_gp_penalty_bwd(const float* g, const float* slopes, const float* gpen, float* gg, int B, int D, float lam, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(g && slopes && gpen && gg && B > 0 && D > 0, "bad argument");
+    GGAN_LAUNCH("gp_penalty_bwd", 0, 8.0 * B * D, gp_bwd_k, dim3(B), dim3(256), 0, (hipStream_t)stream, g, slopes, gpen, gg, B, D, lam);
+    return 0;
+}
+
+int ggan_adam_step(float* theta, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr,
+                   float beta1, float beta2, float eps, float grad_scale, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(theta && g && m && v && step, "null pointer");
+    if (n == 0) return 0;
+    GGAN_CHECK_ARG(aligned16(theta) && aligned16(g) && aligned16(m) && aligned16(v), "buffers must be 16-byte aligned");
+    GGAN_LAUNCH("adam_step", 0, 28.0 * n, adam_k, dim3(grid_for(n, 8)), dim3(kBlock), 0, (hipStream_t)stream, theta, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale);
+    return 0;
+}
+
+int ggan_adam_advance(int32_t* step, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(step, "null pointer");
+    GGAN_LAUNCH("adam_advance", 0, 8, adam_advance_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    return 0;
+}
+
+int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count, float* flat, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(srcs && sizes && offsets && flat, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_PACK_MAX, "count out of range");
+    PackTable t;
+    size_t mx = 0, tot = 0;
+    for (int i = 0; i < count; ++i) {
+        t.src[i] = srcs[i]; t.size[i] = sizes[i]; t.off[i] = offsets[i];
+        if (sizes[i] > mx) mx = sizes[i];
+        tot += sizes[i];
+    }
+    t.count = count;
+    int gx = (int)cdivz(mx, (size_t)kBlock * 8);
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    GGAN_LAUNCH("pack", 0, 8.0 * tot, pack_k, dim3(gx, count), dim3(kBlock), 0, (hipStream_t)stream, t, flat);
+    return 0;
+}
+
+}  // extern "C"

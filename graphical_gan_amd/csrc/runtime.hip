@@ -1,0 +1,109 @@
+// libggan runtime: error strings, launch checks, per-kernel hipEvent timing.
+#include "common.h"
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+namespace ggan {
+
+static thread_local char t_err[512] = "";
+bool g_force_naive = false;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* name) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", name, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+struct ProfEntry {
+    const char* name;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfEntry> g_prof;
+
+ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes) : s_(s), idx_(-1) {
+    if (!g_prof_on) return;
+    ProfEntry e;
+    e.name = name;
+    e.flops = flops;
+    e.bytes = bytes;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+    (void)hipEventRecord(e.a, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(e);
+    idx_ = (int)g_prof.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (idx_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[idx_].b, s_);
+}
+
+}  // namespace ggan
+
+using namespace ggan;
+
+extern "C" {
+
+int ggan_version(void) { return 100; }
+const char* ggan_last_error(void) { return t_err; }
+int ggan_set_naive(int on) {
+    g_force_naive = on != 0;
+    return 0;
+}
+
+int ggan_prof_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int ggan_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& e : g_prof) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    g_prof.clear();
+    return 0;
+}
+
+int ggan_prof_report(ggan_prof_rec* out, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& e : g_prof) {
+        if (hipEventSynchronize(e.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
+        int j = 0;
+        for (; j < n; ++j)
+            if (strncmp(out[j].name, e.name, sizeof(out[j].name) - 1) == 0) break;
+        if (j == n) {
+            if (n >= cap) continue;
+            memset(&out[n], 0, sizeof(out[n]));
+            strncpy(out[n].name, e.name, sizeof(out[n].name) - 1);
+            ++n;
+        }
+        out[j].total_ms += ms;
+        out[j].launches += 1;
+        out[j].flops += e.flops;
+        out[j].bytes += e.bytes;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+"""torch.autograd bindings of the libggan C ABI.
+
+torch supplies device memory, the current HIP stream and the autograd tape (the role tf.gradients plays in
+the reference); every piece of arithmetic is a HIP kernel reached through include/ggan.h.  Each backward
+is itself built from these Functions, so the gradient-penalty double backward works:
+  conv_fwd'   = (conv_dgrad, conv_wgrad)        conv_dgrad' = (conv_fwd, conv_wgrad)
+  conv_wgrad' = (conv_dgrad, conv_fwd)          gemm'       = (gemm, gemm)
+There is no CPU path: tensors must live on a HIP device and libggan.so must load.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ConvGeom, check  # noqa: F401
+
+_WS = {}
+_WS_BYTES = 192 << 20
+
+
+def _L():
+    return _lib.load()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.GganError('graphical_gan_amd ops need tensors on a HIP device (got %s); there is no CPU path' % t.device)
+    return t
+
+
+def _c(t):
+    """contiguous fp32 device tensor"""
+    _dev(t)
+    if t.dtype != torch.float32:
+        raise _lib.GganError('fp32 expected, got %s' % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def workspace(device):
+    """Persistent split-K scratch, one per device (kernels on a stream are serialised, so it is shared)."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.GganError('workspace must be created before graph capture (run one eager warm-up step)')
+        ws = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+# ---------------------------------------------------------------------------------------------------
+# geometry (TF padding arithmetic)
+# ---------------------------------------------------------------------------------------------------
+def same_geometry(size, k, stride, padding='SAME'):
+    if padding == 'SAME':
+        out = -(-size // stride)
+        total = max((out - 1) * stride + k - size, 0)
+        return out, total // 2
+    if padding == 'VALID':
+        return (size - k) // stride + 1, 0
+    raise Exception('Unsupported configuration')
+
+
+def conv_geom(N, Ci, H, W, Co, k, stride, padding='SAME'):
+    Ho, pt = same_geometry(H, k, stride, padding)
+    Wo, pl = same_geometry(W, k, stride, padding)
+    return (N, Ci, H, W, Co, Ho, Wo, k, stride, pt, pl)
+
+
+def _geom(t):
+    return ConvGeom(*t)
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolution family
+# ---------------------------------------------------------------------------------------------------
+class ConvFwd(Function):
+    """y = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) + bias  (tf.nn.conv2d + bias_add; also the Deconv2D data-gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, geom, act, alpha):
+        x, w = _c(x), _c(w)
+        N, Ci, H, W, Co, Ho, Wo = geom[:7]
+        assert tuple(x.shape) == (N, Ci, H, W) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (x.shape, w.shape, geom)
+        y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        ws = workspace(x.device)
+        g = _geom(geom)
+        check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
+                                   act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
+        ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        if ctx.act != ACT_NONE:
+            ref = y if ctx.act in (ACT_TANH, ACT_SIGMOID) else y   # lrelu/relu: sign(y) == sign(pre-activation)
+            gy = ActBwd.apply(gy, ref, ctx.act, ctx.alpha)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            gw = ConvWgrad.apply(x, gy, ctx.geom)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = ChanSum.apply(gy)
+        return gx, gw, gb, None, None, None
+
+
+class ConvDgrad(Function):
+    """gx[N,Ci,H,W] = conv^T(gy[N,Co,Ho,Wo], w) + bias[Ci]  (Conv2DBackpropInput; also the Deconv2D forward)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, bias, geom, act, alpha):
+        gy, w = _c(gy), _c(w)
+        N, Ci, H, W, Co, Ho, Wo = geom[:7]
+        assert tuple(gy.shape) == (N, Co, Ho, Wo) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (gy.shape, w.shape, geom)
+        gx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gy.device)
+        ws = workspace(gy.device)
+        g = _geom(geom)
+        check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
+                                        _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
+        ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
+        ctx.save_for_backward(gy, w, gx if act != ACT_NONE else None)
+        return gx
+
+    @staticmethod
+    def backward(ctx, h):
+        gy, w, out = ctx.saved_tensors
+        if ctx.act != ACT_NONE:
+            h = ActBwd.apply(h, out, ctx.act, ctx.alpha)
+        d_gy = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            d_w = ConvWgrad.apply(h, gy, ctx.geom)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_b = ChanSum.apply(h)
+        return d_gy, d_w, d_b, None, None, None
+
+
+class ConvWgrad(Function):
+    """gw[k,k,Ci,Co] = sum_n,oh,ow x (*) gy  (Conv2DBackpropFilter)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, geom):
+        x, gy = _c(x), _c(gy)
+        N, Ci, H, W, Co, Ho, Wo, k = geom[:8]
+        assert tuple(x.shape) == (N, Ci, H, W) and tuple(gy.shape) == (N, Co, Ho, Wo), (x.shape, gy.shape, geom)
+        gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=x.device)
+        ws = workspace(x.device)
+        g = _geom(geom)
+        check(_L().ggan_conv2d_bwd_filter(C.byref(g), _p(x), _p(gy), _p(gw), _p(None), _p(ws), ws.numel(), _stream()),
+              'ggan_conv2d_bwd_filter')
+        ctx.geom = geom
+        ctx.save_for_backward(x, gy)
+        return gw
+
+    @staticmethod
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
+        d_x = d_gy = None
+        if ctx.needs_input_grad[0]:
+            d_x = ConvDgrad.apply(gy, h, None, ctx.geom, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            d_gy = ConvFwd.apply(x, h, None, ctx.geom, ACT_NONE, 0.0)
+        return d_x, d_gy, None
+
+
+class ChanSum(Function):
+    """out[c] = sum_{n,h,w} x[n,c,h,w]  (BiasAddGrad, NCHW)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * Cc)
+        out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        check(_L().ggan_chansum(_p(x), _p(out), N, Cc, HW, _stream()), 'ggan_chansum')
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shp = ctx.shape
+        return g.view(1, -1, *([1] * (len(shp) - 2))).expand(shp).contiguous()
+
+
+class ColSum(Function):
+    """out[c] = sum_r x[r,c]  (BiasAddGrad of Linear)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        rows, cols = x.shape
+        out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+        check(_L().ggan_colsum(_p(x), _p(out), rows, cols, _stream()), 'ggan_colsum')
+        ctx.rows = rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.view(1, -1).expand(ctx.rows, g.numel()).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# dense
+# ---------------------------------------------------------------------------------------------------
+class Gemm(Function):
+    """C[M,N] = op(A) op(B) + bias[N]; ta/tb read the stored operand transposed."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias, ta, tb, act, alpha):
+        a, b = _c(a), _c(b)
+        M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+        K2, N = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+        assert K == K2, (a.shape, b.shape, ta, tb)
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        ws = workspace(a.device)
+        check(_L().ggan_gemm(int(ta), int(tb), M, N, K, _p(a), _p(b), _p(_c(bias)) if bias is not None else _p(None),
+                             _p(out), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm')
+        ctx.ta, ctx.tb, ctx.act, ctx.alpha, ctx.has_bias = ta, tb, act, alpha, bias is not None
+        ctx.save_for_backward(a, b, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, out = ctx.saved_tensors
+        ta, tb = ctx.ta, ctx.tb
+        if ctx.act != ACT_NONE:
+            g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
+        da = db = dbias = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                da = Gemm.apply(g, b, None, False, not tb, ACT_NONE, 0.0)      # g op(B)^T
+            else:
+                da = Gemm.apply(b, g, None, tb, True, ACT_NONE, 0.0)           # op(B) g^T
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0)      # op(A)^T g
+            else:
+                db = Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)           # g^T op(A)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = ColSum.apply(g)
+        return da, db, dbias, None, None, None, None
+
+
+def linear(x, w, bias=None, act=ACT_NONE, alpha=0.0):
+    return Gemm.apply(x, w, bias, False, False, act, alpha)
+
+
+# ---------------------------------------------------------------------------------------------------
+# pointwise
+# ---------------------------------------------------------------------------------------------------
+class ActFwd(Function):
+    @staticmethod
+    def forward(ctx, x, act, alpha):
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(_L().ggan_act_fwd(_p(x), _p(y), x.numel(), act, alpha, _stream()), 'ggan_act_fwd')
+        ctx.act, ctx.alpha = act, alpha
+        ctx.save_for_backward(y if act in (ACT_TANH, ACT_SIGMOID) else x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (ref,) = ctx.saved_tensors
+        return ActBwd.apply(gy, ref, ctx.act, ctx.alpha), None, None
+
+
+class ActBwd(Function):
+    """gx = gy * act'(ref); ref = forward input (lrelu/relu: only its sign is used, so the forward output
+    works too) or forward output (tanh/sigmoid)."""
+
+    @staticmethod
+    def forward(ctx, gy, ref, act, alpha):
+        gy, ref = _c(gy), _c(ref)
+        gx = torch.empty_like(gy)
+        check(_L().ggan_act_bwd(_p(gy), _p(ref), _p(gx), gy.numel(), act, alpha, _stream()), 'ggan_act_bwd')
+        ctx.act, ctx.alpha = act, alpha
+        ctx.save_for_backward(gy, ref)
+        return gx
+
+    @staticmethod
+    def backward(ctx, h):
+        gy, ref = ctx.saved_tensors
+        d_gy = ActBwd.apply(h, ref, ctx.act, ctx.alpha) if ctx.needs_input_grad[0] else None
+        d_ref = None
+        if ctx.needs_input_grad[1] and ctx.act in (ACT_TANH, ACT_SIGMOID):
+            # off the hot path (second-order term through a smooth activation); piecewise-linear
+            # activations have zero second derivative a.e.
+            if ctx.act == ACT_TANH:
+                d_ref = h * gy * (-2.0 * ref)
+            else:
+                d_ref = h * gy * (1.0 - 2.0 * ref)
+        return d_gy, d_ref, None, None
+
+
+def leaky_relu(x, alpha=0.2):
+    return ActFwd.apply(x, ACT_LRELU, float(alpha))
+
+
+def relu(x):
+    return ActFwd.apply(x, ACT_RELU, 0.0)
+
+
+def tanh(x):
+    return ActFwd.apply(x, ACT_TANH, 0.0)
+
+
+def sigmoid(x):
+    return ActFwd.apply(x, ACT_SIGMOID, 0.0)
+
+
+class BatchNormTrain(Function):
+    """Training-mode BN over all axes but channel axis 1 (NCHW) or over axis 0 of [N,C]."""
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, eps, act, alpha):
+        x = _c(x)
+        N, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * Cc)
+        y = torch.empty_like(x)
+        mean = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        sc, of = _c(scale).reshape(-1), _c(offset).reshape(-1)
+        check(_L().ggan_bn_fwd_train(_p(x), _p(sc), _p(of), _p(y), _p(mean), _p(invstd), N, Cc, HW, eps, act, alpha,
+                                     _stream()), 'ggan_bn_fwd_train')
+        ctx.dims = (N, Cc, HW)
+        ctx.act, ctx.alpha = act, alpha
+        ctx.pshape = tuple(scale.shape)
+        ctx.save_for_backward(x, sc, mean, invstd, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, sc, mean, invstd, y = ctx.saved_tensors
+        N, Cc, HW = ctx.dims
+        gy = _c(gy)
+        if ctx.act != ACT_NONE:
+            g2 = torch.empty_like(gy)
+            check(_L().ggan_act_bwd(_p(gy), _p(y), _p(g2), gy.numel(), ctx.act, ctx.alpha, _stream()), 'ggan_act_bwd')
+            gy = g2
+        gx = torch.empty_like(x)
+        gs = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        go = torch.empty_like(gs)
+        check(_L().ggan_bn_bwd(_p(x), _p(gy), _p(sc), _p(mean), _p(invstd), _p(gx), _p(gs), _p(go), N, Cc, HW, _stream()),
+              'ggan_bn_bwd')
+        return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None
+
+
+class CastScaleI32(Function):
+    """real_x = mul*(float(x)/div - .5) + noise  (no gradient: the input is data)."""
+
+    @staticmethod
+    def forward(ctx, x_int, noise, div, mul):
+        _dev(x_int)
+        assert x_int.dtype == torch.int32
+        x_int = x_int.contiguous()
+        y = torch.empty(x_int.shape, dtype=torch.float32, device=x_int.device)
+        check(_L().ggan_cast_scale_i32(_p(x_int), _p(_c(noise)) if noise is not None else _p(None), _p(y), x_int.numel(),
+                                       div, mul, _stream()), 'ggan_cast_scale_i32')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None, None, None
+
+
+class Axpby(Function):
+    """out = a*x + b*y + c"""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b, c):
+        x = _c(x)
+        y = _c(y) if y is not None else None
+        out = torch.empty_like(x)
+        check(_L().ggan_axpby(_p(x), _p(y), _p(out), x.numel(), a, b, c, _stream()), 'ggan_axpby')
+        ctx.a, ctx.b, ctx.has_y = a, b, y is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = Axpby.apply(g, None, ctx.a, 0.0, 0.0) if ctx.needs_input_grad[0] else None
+        gy = Axpby.apply(g, None, ctx.b, 0.0, 0.0) if (ctx.has_y and ctx.needs_input_grad[1]) else None
+        return gx, gy, None, None, None
+
+
+class RowLerp(Function):
+    """out[r,:] = x[r,:] + alpha[r]*(y[r,:]-x[r,:])  (the wali-gp interpolates)."""
+
+    @staticmethod
+    def forward(ctx, x, y, alpha):
+        x, y, alpha = _c(x), _c(y), _c(alpha)
+        rows, cols = x.shape
+        out = torch.empty_like(x)
+        check(_L().ggan_row_lerp(_p(x), _p(y), _p(alpha), _p(out), rows, cols, _stream()), 'ggan_row_lerp')
+        ctx.save_for_backward(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (alpha,) = ctx.saved_tensors
+        z = torch.zeros_like(g)
+        gx = RowLerp.apply(g, z, alpha) if ctx.needs_input_grad[0] else None
+        gy = RowLerp.apply(z, g, alpha) if ctx.needs_input_grad[1] else None
+        return gx, gy, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------------
+class BceSum(Function):
+    """sum_i weight_i * mean(sigmoid_cross_entropy_with_logits(x_i, label_i)) -> 0-dim tensor."""
+
+    @staticmethod
+    def forward(ctx, labels, weights, *logits):
+        logits = [_c(x).reshape(-1) for x in logits]
+        loss = torch.empty((1,), dtype=torch.float32, device=logits[0].device)
+        for i, (x, z, w) in enumerate(zip(logits, labels, weights)):
+            check(_L().ggan_bce_logits_fwd(_p(x), float(z), float(w), _p(loss), x.numel(), int(i > 0), _stream()),
+                  'ggan_bce_logits_fwd')
+        ctx.labels, ctx.weights = labels, weights
+        ctx.save_for_backward(*logits)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g.reshape(1))
+        outs = []
+        for x, z, w in zip(ctx.saved_tensors, ctx.labels, ctx.weights):
+            gx = torch.empty_like(x)
+            check(_L().ggan_bce_logits_bwd(_p(x), float(z), float(w), _p(g), _p(gx), x.numel(), _stream()),
+                  'ggan_bce_logits_bwd')
+            outs.append(gx)
+        return (None, None) + tuple(outs)
+
+
+class MeanSum(Function):
+    """sum_i weight_i * mean(x_i) -> 0-dim tensor (Wasserstein costs)."""
+
+    @staticmethod
+    def forward(ctx, weights, *xs):
+        xs = [_c(x).reshape(-1) for x in xs]
+        loss = torch.empty((1,), dtype=torch.float32, device=xs[0].device)
+        for i, (x, w) in enumerate(zip(xs, weights)):
+            check(_L().ggan_mean_fwd(_p(x), float(w), _p(loss), x.numel(), int(i > 0), _stream()), 'ggan_mean_fwd')
+        ctx.weights = weights
+        ctx.sizes = [x.numel() for x in xs]
+        ctx.dev = xs[0].device
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g.reshape(1))
+        outs = []
+        for n, w in zip(ctx.sizes, ctx.weights):
+            gx = torch.empty((n,), dtype=torch.float32, device=ctx.dev)
+            check(_L().ggan_mean_bwd(_p(g), float(w), _p(gx), n, _stream()), 'ggan_mean_bwd')
+            outs.append(gx)
+        return (None,) + tuple(outs)
+
+
+class GradPenalty(Function):
+    """lam * mean_b((||g[b,:]||_2 - 1)^2)  (gan_inference_cifar10.py:363-364)."""
+
+    @staticmethod
+    def forward(ctx, g, lam):
+        g = _c(g)
+        B, D = g.shape
+        slopes = torch.empty((B,), dtype=torch.float32, device=g.device)
+        pen = torch.empty((1,), dtype=torch.float32, device=g.device)
+        check(_L().ggan_gp_penalty_fwd(_p(g), _p(slopes), _p(pen), B, D, lam, _stream()), 'ggan_gp_penalty_fwd')
+        ctx.lam = lam
+        ctx.save_for_backward(g, slopes)
+        return pen.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gpen):
+        g, slopes = ctx.saved_tensors
+        B, D = g.shape
+        gg = torch.empty_like(g)
+        check(_L().ggan_gp_penalty_bwd(_p(g), _p(slopes), _p(_c(gpen.reshape(1))), _p(gg), B, D, ctx.lam, _stream()),
+              'ggan_gp_penalty_bwd')
+        return gg, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# optimiser primitives (no autograd)
+# ---------------------------------------------------------------------------------------------------
+def adam_step_(theta, g, m, v, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0):
+    n = theta.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and step.dtype == torch.int32
+    L = _L()
+    check(L.ggan_adam_step(_p(theta), _p(g), _p(m), _p(v), n, _p(step), lr, beta1, beta2, eps, grad_scale, _stream()),
+          'ggan_adam_step')
+    check(L.ggan_adam_advance(_p(step), _stream()), 'ggan_adam_advance')
+
+
+def pack_(tensors, offsets, flat):
+    """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros)."""
+    L = _L()
+    for i0 in range(0, len(tensors), _lib.PACK_MAX):
+        chunk = tensors[i0:i0 + _lib.PACK_MAX]
+        n = len(chunk)
+        srcs = (C.c_void_p * n)(*[t.data_ptr() if t is not None else 0 for t in chunk])
+        sizes = (C.c_size_t * n)(*[int(s) for s in [o[1] for o in offsets[i0:i0 + n]]])
+        offs = (C.c_size_t * n)(*[int(o[0]) for o in offsets[i0:i0 + n]])
+        check(L.ggan_pack(srcs, sizes, offs, n, _p(flat), _stream()), 'ggan_pack')

@@ -1,0 +1,95 @@
+"""MI355X counterpart of the reference's `tflib` package (tflib/__init__.py): the name-keyed parameter
+registry that gives the driver scripts weight sharing, with torch device tensors in place of tf.Variable.
+
+Same functions, argument order and behaviour as tflib/__init__.py:9-47,100-120:
+  param(name, *args, **kwargs)   first call creates the parameter from the numpy initial value, every later
+                                 call with the same name returns the SAME object (that is how Generator is
+                                 instantiated several times with shared weights);
+  params_with_name(substr)       substring match over the registry keys (builds the optimiser var lists);
+  delete_all_params / alias_params / delete_param_aliases / print_model_settings*.
+"""
+import numpy as np
+import torch
+
+_params = {}
+_param_aliases = {}
+_device = [None]
+
+
+def set_device(device):
+    """Device new parameters are created on (default: the current HIP device)."""
+    _device[0] = torch.device(device)
+
+
+def get_device():
+    if _device[0] is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError('graphical_gan_amd.tflib needs a HIP device (no CPU path); none is visible')
+        _device[0] = torch.device('cuda', torch.cuda.current_device())
+    return _device[0]
+
+
+def param(name, *args, **kwargs):
+    """tflib/__init__.py:9-33.  args[0] is the initial value (numpy array); kwargs: trainable=False."""
+    if name not in _params:
+        value = args[0] if args else kwargs['initial_value']
+        trainable = kwargs.get('trainable', True)
+        t = torch.as_tensor(np.asarray(value), dtype=torch.float32).to(get_device()).contiguous()
+        p = torch.nn.Parameter(t, requires_grad=bool(trainable))
+        p.param = True
+        p.param_name = name
+        _params[name] = p
+    result = _params[name]
+    while id(result) in _param_aliases:
+        result = _param_aliases[id(result)]
+    return result
+
+
+def params_with_name(name):
+    return [p for n, p in _params.items() if name in n]
+
+
+def named_params():
+    return dict(_params)
+
+
+def delete_all_params():
+    _params.clear()
+
+
+def alias_params(replace_dict):
+    for old, new in replace_dict.items():
+        _param_aliases[id(old)] = new
+
+
+def delete_param_aliases():
+    _param_aliases.clear()
+
+
+def _settings(locals_):
+    all_vars = [(k, v) for (k, v) in locals_.items()
+                if (k.isupper() and k != 'T' and k != 'SETTINGS' and k != 'ALL_SETTINGS')]
+    return sorted(all_vars, key=lambda x: x[0])
+
+
+def print_model_settings(locals_):
+    print("Uppercase local vars:")
+    for var_name, var_value in _settings(locals_):
+        print("\t{}: {}".format(var_name, var_value))
+
+
+def print_model_settings_to_file(locals_, logfile):
+    print("Uppercase local vars:")
+    for var_name, var_value in _settings(locals_):
+        print("\t{}: {}".format(var_name, var_value))
+        with open(logfile, 'a') as f:
+            f.write("\t{}: {}".format(var_name, var_value))
+
+
+def print_model_settings_dict(settings):
+    print("Settings dict:")
+    for var_name, var_value in sorted(settings.items(), key=lambda x: x[0]):
+        print("\t{}: {}".format(var_name, var_value))
+
+
+from . import ops, objs, plot  # noqa: E402,F401

@@ -1,0 +1,81 @@
+"""Objectives of tflib/objs/gan_inference.py on the hot path: ali (:47-79), local_ep (:81-119),
+weighted_local_epce (:307-358), wali_gp (:28-45).  Same signatures and return tuples; `*_train_op` are
+callables (TrainOp) that run backward + one TF-flavoured Adam step, the costs are 0-dim device tensors.
+Losses are single fused kernels (ggan_bce_logits_* / ggan_mean_*), not per-term pointwise graphs."""
+import numpy as np
+
+from ... import functional as F
+from ...optim import TrainOp, get_optimizer
+
+
+def _bce_costs(fakes, reals, ratios):
+    """gen: fake->1, real->0 ; disc: fake->0, real->1 (sigmoid cross-entropy, mean over the batch)."""
+    logits, gl, dl, w = [], [], [], []
+    for f, r, ratio in zip(fakes, reals, ratios):
+        logits += [f, r]
+        gl += [1.0, 0.0]
+        dl += [0.0, 1.0]
+        w += [float(ratio), float(ratio)]
+    gen_cost = F.BceSum.apply(tuple(gl), tuple(w), *logits)
+    disc_cost = F.BceSum.apply(tuple(dl), tuple(w), *logits)
+    return gen_cost, disc_cost
+
+
+def ali(disc_fake, disc_real, gen_params, disc_params, lr=2e-4, beta1=0.5, beta2=0.999, s_f=None):
+    gen_cost, disc_cost = _bce_costs([disc_fake], [disc_real], [1.0])
+    if s_f is not None:
+        gen_cost = gen_cost + s_f
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def local_ep(disc_fake_list, disc_real_list, gen_params, disc_params, lr=2e-4, beta1=0.5, beta2=.999, s_f=None):
+    n = float(len(disc_fake_list))
+    if s_f is None:
+        gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0 / n] * len(disc_fake_list))
+    else:   # (sum + s_f) / n, as gan_inference.py:102-106
+        gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0] * len(disc_fake_list))
+        gen_cost = (gen_cost + s_f) / n
+        disc_cost = disc_cost / n
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def weighted_local_epce(disc_fake_list, disc_real_list, ratio_list, gen_params, disc_params, lr=2e-4, beta1=0.5,
+                        rec_penalty=None):
+    ratio_list = np.asarray(ratio_list)
+    assert len(disc_fake_list) == ratio_list.shape[0]
+    gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, list(ratio_list))
+    gen_debug_list, disc_debug_list = [], []   # per-factor terms are debug-only in the reference (:321-343)
+    if rec_penalty is not None:
+        gen_cost = gen_cost + rec_penalty
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
+    return (gen_cost, disc_cost, gen_debug_list, disc_debug_list,
+            TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost))
+
+
+def wali_gp(disc_fake, disc_real, gradient_penalty, gen_params, disc_params, lr=1e-4):
+    gen_cost = F.MeanSum.apply((-1.0, 1.0), disc_fake, disc_real)
+    disc_cost = F.MeanSum.apply((1.0, -1.0), disc_fake, disc_real)
+    disc_cost = disc_cost + gradient_penalty
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=0.5, beta2=0.9)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=0.5, beta2=0.9)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def gradient_penalty(critic, real_x, fake_x, q_z, p_z, alpha, lam=10.):
+    """The wali-gp construction of gan_inference_cifar10.py:353-364 (script-level code in the reference):
+    interpolate, third critic pass, x-gradient only, lam*mean((||g||-1)^2).  create_graph=True keeps the
+    backward kernels on the tape so minimize() differentiates THROUGH g (double backward)."""
+    import torch
+    x_hat = F.RowLerp.apply(real_x, fake_x, alpha)
+    z_hat = F.RowLerp.apply(q_z, p_z, alpha)
+    if not x_hat.requires_grad:
+        x_hat.requires_grad_(True)
+    d_hat = critic(x_hat, z_hat)
+    ones = torch.ones_like(d_hat)
+    (g,) = torch.autograd.grad(d_hat, [x_hat], grad_outputs=ones, create_graph=True)
+    return F.GradPenalty.apply(g.reshape(g.shape[0], -1), float(lam))

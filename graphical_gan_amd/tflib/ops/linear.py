@@ -1,0 +1,80 @@
+"""Linear (tflib/ops/linear.py:24-148): y = x @ W + b with W [in,out]; MFMA GEMM through ggan_gemm."""
+import numpy as np
+
+from ... import functional as F
+from .. import param as _param
+
+_default_weightnorm = False
+
+
+def enable_default_weightnorm():
+    global _default_weightnorm
+    _default_weightnorm = True
+
+
+def disable_default_weightnorm():
+    global _default_weightnorm
+    _default_weightnorm = False
+
+
+_weights_stdev = None
+
+
+def set_weights_stdev(weights_stdev):
+    global _weights_stdev
+    _weights_stdev = weights_stdev
+
+
+def unset_weights_stdev():
+    global _weights_stdev
+    _weights_stdev = None
+
+
+def _uniform(stdev, size):
+    if _weights_stdev is not None:
+        stdev = _weights_stdev
+    return np.random.uniform(low=-stdev * np.sqrt(3), high=stdev * np.sqrt(3), size=size).astype('float32')
+
+
+def _initial(initialization, input_dim, output_dim):
+    """The six schemes of tflib/ops/linear.py:48-104; values drawn from numpy's global RNG on every call
+    (even when the parameter already exists), exactly as the reference consumes RNG state."""
+    if initialization == 'lecun':
+        return _uniform(np.sqrt(1. / input_dim), (input_dim, output_dim))
+    if initialization == 'glorot' or initialization is None:
+        return _uniform(np.sqrt(2. / (input_dim + output_dim)), (input_dim, output_dim))
+    if initialization == 'he':
+        return _uniform(np.sqrt(2. / input_dim), (input_dim, output_dim))
+    if initialization == 'glorot_he':
+        return _uniform(np.sqrt(4. / (input_dim + output_dim)), (input_dim, output_dim))
+    if initialization == 'orthogonal':
+        a = np.random.normal(0.0, 1.0, (input_dim, output_dim))
+        u, _, v = np.linalg.svd(a, full_matrices=False)
+        q = u if u.shape == (input_dim, output_dim) else v
+        return q.reshape((input_dim, output_dim)).astype('float32')
+    if initialization[0] == 'uniform':
+        return np.random.uniform(low=-initialization[1], high=initialization[1],
+                                 size=(input_dim, output_dim)).astype('float32')
+    raise Exception('Invalid initialization!')
+
+
+def Linear(name, input_dim, output_dim, inputs, biases=True, initialization=None, weightnorm=None, gain=1.,
+           activation=None, alpha=0.2):
+    """Same signature as the reference; `activation`/`alpha` are an optional fused epilogue (extension)."""
+    weight_values = _initial(initialization, input_dim, output_dim)
+    weight_values *= gain
+    weight = _param(name + '.W', weight_values)
+    if weightnorm is None:
+        weightnorm = _default_weightnorm
+    if weightnorm:
+        norm_values = np.sqrt(np.sum(np.square(weight_values), axis=0))
+        target_norms = _param(name + '.g', norm_values)
+        norms = (weight * weight).sum(dim=0).sqrt()
+        weight = weight * (target_norms / norms)
+    b = _param(name + '.b', np.zeros((output_dim,), dtype='float32')) if biases else None
+    x = inputs if inputs.dim() == 2 else inputs.reshape(-1, input_dim)
+    act = F.ACT_NONE if activation is None else activation
+    result = F.Gemm.apply(x, weight, b, False, False, act, float(alpha))
+    if inputs.dim() != 2:
+        result = result.reshape(tuple(inputs.shape[:-1]) + (output_dim,))
+    return result

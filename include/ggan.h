@@ -1,0 +1,159 @@
+/*
+ * ggan.h -- C ABI of libggan.so, the MI355X (gfx950) kernels behind the tflib.ops operator API
+ * of zhenxuan00/graphical-gan.
+ *
+ * Boundary: the reference's Python operator constructors
+ *   tflib/ops/conv2d.py:20 Conv2D, tflib/ops/deconv2d.py:20 Deconv2D, tflib/ops/linear.py:24 Linear,
+ *   tflib/ops/batchnorm.py:6 Batchnorm, tflib/objs/gan_inference.py:28-119,307-358 objectives
+ * hand their arithmetic to TensorFlow kernels (tf.nn.conv2d, tf.nn.conv2d_transpose, tf.matmul,
+ * tf.nn.fused_batch_norm, tf.nn.sigmoid_cross_entropy_with_logits, AdamOptimizer, tf.gradients).
+ * Each entry point below replaces one of those TF kernels (cited per function).
+ *
+ * Conventions
+ *   - all tensors are dense fp32 in device memory; activations NCHW; the caller owns every buffer;
+ *   - Conv2D filters HWIO [k][k][Cin][Cout]; Deconv2D filters [k][k][Cout][Cin] (reference layouts);
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), allocates
+ *     nothing, keeps no state between calls and is hipGraph-capturable;
+ *   - `ws` is caller-provided scratch of at least ggan_*_workspace() bytes (may be NULL when 0);
+ *   - return value 0 = ok, negative = error; ggan_last_error() gives the message (thread-local).
+ */
+#ifndef GGAN_H
+#define GGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ggan_stream_t; /* hipStream_t */
+
+/* activation codes for fused epilogues and ggan_act_* */
+enum { GGAN_ACT_NONE = 0, GGAN_ACT_LRELU = 1, GGAN_ACT_RELU = 2, GGAN_ACT_TANH = 3, GGAN_ACT_SIGMOID = 4 };
+
+int ggan_version(void);
+const char* ggan_last_error(void);
+/* 0: MFMA kernels (default); 1: force the plain one-thread-per-output HIP kernels (debug cross-check). */
+int ggan_set_naive(int on);
+
+/* ---- convolution geometry ------------------------------------------------------------------
+ * A strided cross-correlation y[N,Co,Ho,Wo] = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) with explicit
+ * top/left padding (TF 'SAME' puts the extra row/col at the bottom/right -- SURVEY.md A.1; the
+ * caller computes pad_t/pad_l = pad_total/2, bottom/right padding is implied by Ho/Wo). */
+typedef struct {
+    int N, Ci, H, W;      /* the LARGE-spatial tensor (conv input / deconv output)  */
+    int Co, Ho, Wo;       /* the SMALL-spatial tensor (conv output / deconv input)  */
+    int k, stride, pad_t, pad_l;
+} ggan_conv_geom;
+
+/* tf.nn.conv2d(NCHW) + tf.nn.bias_add (tflib/ops/conv2d.py:106-120).  bias may be NULL.
+ * act/alpha: optional fused pointwise epilogue (GGAN_ACT_NONE for reference behaviour). */
+size_t ggan_conv2d_workspace(const ggan_conv_geom* g);
+int ggan_conv2d_fwd(const ggan_conv_geom* g, const float* x, const float* w, const float* bias,
+                    float* y, int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
+/* Conv2DBackpropInput: gx[N,Ci,H,W] from gy[N,Co,Ho,Wo] (what tf.gradients derives from conv2d.py:106).
+ * bias (len Ci, may be NULL) / act are a fused epilogue used by the Deconv2D forward. */
+int ggan_conv2d_bwd_data(const ggan_conv_geom* g, const float* gy, const float* w, const float* bias,
+                         float* gx, int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
+/* Conv2DBackpropFilter: gw[k,k,Ci,Co]; gbias[Co] = sum over N,Ho,Wo of gy (BiasAddGrad), may be NULL. */
+int ggan_conv2d_bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, float* gw,
+                           float* gbias, void* ws, size_t ws_bytes, ggan_stream_t stream);
+
+/* tf.nn.conv2d_transpose + bias_add (tflib/ops/deconv2d.py:101-114) computed natively in NCHW (the two
+ * layout transposes at :91/:116 are mathematically no-ops).  g describes the forward conv whose
+ * input-gradient this is: x_small[N,Co,Ho,Wo] -> y_big[N,Ci,H,W]; w is the Deconv2D filter
+ * [k,k,out=Ci,in=Co], which is bit-for-bit the HWIO filter of that forward conv. */
+int ggan_deconv2d_fwd(const ggan_conv_geom* g, const float* x_small, const float* w, const float* bias,
+                      float* y_big, int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
+int ggan_deconv2d_bwd_data(const ggan_conv_geom* g, const float* gy_big, const float* w, float* gx_small,
+                           void* ws, size_t ws_bytes, ggan_stream_t stream);
+int ggan_deconv2d_bwd_filter(const ggan_conv_geom* g, const float* gy_big, const float* x_small, float* gw,
+                             float* gbias /* [Ci], sum of gy_big */, void* ws, size_t ws_bytes,
+                             ggan_stream_t stream);
+
+/* ---- dense -------------------------------------------------------------------------------
+ * C[M,N] = op(A) * op(B) (+ bias[N]) (+act), row-major, ta/tb = 1 reads the operand transposed
+ * (A stored [K,M] / B stored [N,K]).  tf.matmul + bias_add of tflib/ops/linear.py:133-146 is
+ * (ta=0,tb=0); its gradients are (0,1) for dX = dY*W^T and (1,0) for dW = X^T*dY. */
+size_t ggan_gemm_workspace(int M, int N, int K);
+int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias,
+              float* C, int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
+/* out[c] = sum_r x[r,c] over a [rows,cols] matrix (BiasAddGrad of Linear). */
+int ggan_colsum(const float* x, float* out, int rows, int cols, ggan_stream_t stream);
+/* out[c] = sum_{n,hw} x[n,c,hw] (BiasAddGrad NCHW). */
+int ggan_chansum(const float* x, float* out, int N, int C, int HW, ggan_stream_t stream);
+
+/* ---- batch normalisation, training mode, batch statistics, biased variance -------------------
+ * tf.nn.fused_batch_norm(NCHW, eps) (tflib/ops/batchnorm.py:29-30) for HW>1 and the
+ * tf.nn.moments + tf.nn.batch_normalization branch (:74-87) as the HW=1 case over [N,C].
+ * save_mean/save_invstd: [C] each, written by fwd and consumed by bwd. */
+int ggan_bn_fwd_train(const float* x, const float* scale, const float* offset, float* y,
+                      float* save_mean, float* save_invstd, int N, int C, int HW, float eps,
+                      int act, float alpha, ggan_stream_t stream);
+int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float* save_mean,
+                const float* save_invstd, float* gx, float* gscale, float* goffset,
+                int N, int C, int HW, ggan_stream_t stream);
+
+/* ---- pointwise -------------------------------------------------------------------------------
+ * LeakyReLU = tf.maximum(alpha*x, x) (gmgan_inference_cifar10.py:122-123), tf.nn.relu, tf.tanh,
+ * tf.nn.sigmoid.  bwd takes the forward INPUT for lrelu/relu and the forward OUTPUT for
+ * tanh/sigmoid in `ref`. */
+int ggan_act_fwd(const float* x, float* y, size_t n, int act, float alpha, ggan_stream_t stream);
+int ggan_act_bwd(const float* gy, const float* ref, float* gx, size_t n, int act, float alpha,
+                 ggan_stream_t stream);
+/* y = x + bias broadcast: NCHW bias[C] (HW>1) or [rows,C] (HW=1).  tf.nn.bias_add. */
+int ggan_bias_add(const float* x, const float* bias, float* y, int N, int C, int HW, ggan_stream_t stream);
+/* real_x = mul*(float(int32)/div - .5) (+ noise) (gmgan_inference_cifar10.py:342; face :242-243). */
+int ggan_cast_scale_i32(const int32_t* x, const float* noise /* may be NULL */, float* y, size_t n,
+                        float div, float mul, ggan_stream_t stream);
+/* out = a*x + b*y (+c) elementwise (interpolates, residuals). */
+int ggan_axpby(const float* x, const float* y, float* out, size_t n, float a, float b, float c,
+               ggan_stream_t stream);
+/* out[r,:] = x[r,:] + alpha[r]*(y[r,:]-x[r,:])  (gan_inference_cifar10.py:358-361). */
+int ggan_row_lerp(const float* x, const float* y, const float* alpha, float* out, int rows, int cols,
+                  ggan_stream_t stream);
+
+/* ---- losses ----------------------------------------------------------------------------------
+ * loss[0] = weight * mean_i( max(x,0) - x*z + log1p(exp(-|x|)) ), z = label (0 or 1)
+ * (tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean, tflib/objs/gan_inference.py:85-101).
+ * accumulate != 0 adds into loss[0] instead of overwriting. */
+int ggan_bce_logits_fwd(const float* x, float label, float weight, float* loss, int n, int accumulate,
+                        ggan_stream_t stream);
+/* gx[i] = gloss[0]*weight*(sigmoid(x[i]) - z)/n */
+int ggan_bce_logits_bwd(const float* x, float label, float weight, const float* gloss, float* gx, int n,
+                        ggan_stream_t stream);
+/* loss[0] (+)= weight*mean(x); bwd gx[i] = gloss[0]*weight/n  (wali_gp, gan_inference.py:29-30). */
+int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
+int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
+/* slopes[b] = sqrt(sum_j g[b,j]^2); pen[0] = lam*mean_b((slopes-1)^2)  (gan_inference_cifar10.py:363-364).
+ * bwd: gg[b,j] = gpen[0]*lam*2*(slopes[b]-1)/B * g[b,j]/slopes[b]. */
+int ggan_gp_penalty_fwd(const float* g, float* slopes, float* pen, int B, int D, float lam,
+                        ggan_stream_t stream);
+int ggan_gp_penalty_bwd(const float* g, const float* slopes, const float* gpen, float* gg, int B, int D,
+                        float lam, ggan_stream_t stream);
+
+/* ---- optimiser --------------------------------------------------------------------------------
+ * tf.train.AdamOptimizer step over a flat parameter buffer (tflib/objs/gan_inference.py:108-117;
+ * SURVEY.md A.5): t = *step + 1; m,v EMA; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps).
+ * `step` lives in device memory so that a captured graph advances it: the kernel reads it and
+ * ggan_adam_advance increments it afterwards.  grad_scale multiplies g first (1/world for DP). */
+int ggan_adam_step(float* theta, const float* g, float* m, float* v, size_t n, const int32_t* step,
+                   float lr, float beta1, float beta2, float eps, float grad_scale, ggan_stream_t stream);
+int ggan_adam_advance(int32_t* step, ggan_stream_t stream);
+/* gather up to GGAN_PACK_MAX scattered tensors into one flat buffer (gradient bucket for RCCL). */
+#define GGAN_PACK_MAX 64
+int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count,
+              float* flat, ggan_stream_t stream);
+
+/* ---- per-kernel timing (bench.py roofline leg) -----------------------------------------------
+ * When enabled every launch is bracketed by hipEvents on its own stream.  ggan_prof_report
+ * synchronises, then writes up to `cap` records; returns the number of distinct kernels. */
+typedef struct { char name[48]; double total_ms; long launches; double flops; double bytes; } ggan_prof_rec;
+int ggan_prof_enable(int on);
+int ggan_prof_reset(void);
+int ggan_prof_report(ggan_prof_rec* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGAN_H */

@@ -1,0 +1,280 @@
+"""-m gpu: every C-ABI op (through graphical_gan_amd.functional) against the float64 oracle.
+
+Tolerance (fp32): per-op max |err| <= 2e-5 * max|ref| for K <= 3200-term fp32 dot products
+(observed ~1e-6); second-order (GP) <= 1e-4 relative.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = [  # (N, Ci, H, Co) 5x5 stride 2 SAME
+    (4, 8, 16, 64),
+    (64, 64, 16, 128),    # Extractor.2 / Discriminator.2 (CIFAR)
+    (64, 128, 8, 256),    # Extractor.3
+    (64, 3, 32, 64),      # Extractor.1
+    (5, 1, 28, 64),       # MNIST
+    (5, 64, 14, 128),
+    (5, 128, 7, 256),     # pad (2,2)
+    (3, 3, 64, 32),       # face conv1
+    (6, 32, 32, 64),      # face conv2
+    (2, 12, 8, 20),       # ragged channel counts
+    (1, 4, 4, 4),
+]
+
+
+def _rel(a, ref):
+    return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def _t(a, dev):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+
+
+@pytest.fixture(params=[0, 1], ids=['mfma', 'naive'])
+def naive(request, gpu):
+    from graphical_gan_amd import _lib
+    _lib.load().ggan_set_naive(request.param)
+    yield request.param
+    _lib.load().ggan_set_naive(0)
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_family(gpu, naive, case):
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    N, Ci, H, Co = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rng.standard_normal((N, Ci, H, H)).astype(np.float32)
+    w = (rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2, 'SAME')
+    Ho = geom[5]
+    gy = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    bi = rng.standard_normal(Ci).astype(np.float32)
+    x64, w64, gy64 = x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64)
+
+    y = F.ConvFwd.apply(_t(x, gpu), _t(w, gpu), _t(b, gpu), geom, F.ACT_NONE, 0.0).cpu().numpy()
+    ref = O.conv2d(x64, w64, 2, 'SAME') + b.reshape(1, -1, 1, 1)
+    assert y.shape == ref.shape
+    assert _rel(y, ref) < 2e-5, ('fwd', _rel(y, ref))
+
+    gx = F.ConvDgrad.apply(_t(gy, gpu), _t(w, gpu), _t(bi, gpu), geom, F.ACT_NONE, 0.0).cpu().numpy()
+    ref = O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME') + bi.reshape(1, -1, 1, 1)
+    assert _rel(gx, ref) < 2e-5, ('dgrad', _rel(gx, ref))
+
+    gw = F.ConvWgrad.apply(_t(x, gpu), _t(gy, gpu), geom).cpu().numpy()
+    ref = O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')
+    assert _rel(gw, ref) < 2e-5, ('wgrad', _rel(gw, ref))
+
+
+def test_conv_fused_epilogue(gpu):
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((8, 16, 16, 16)).astype(np.float32)
+    w = (rng.standard_normal((5, 5, 16, 32)) * .05).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    geom = F.conv_geom(8, 16, 16, 16, 32, 5, 2)
+    y = F.ConvFwd.apply(_t(x, gpu), _t(w, gpu), _t(b, gpu), geom, F.ACT_LRELU, 0.2).cpu().numpy()
+    ref = O.leaky_relu(O.conv2d(x.astype(np.float64), w.astype(np.float64), 2) + b.reshape(1, -1, 1, 1))
+    assert _rel(y, ref) < 2e-5
+
+
+def test_conv_other_geometry_uses_plain_kernels(gpu):
+    """stride-1 / VALID convolutions (off the hot path) go through the plain HIP kernels."""
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    rng = np.random.default_rng(6)
+    for k, s, pad, H in [(3, 1, 'SAME', 9), (5, 1, 'VALID', 12), (3, 2, 'SAME', 10)]:
+        x = rng.standard_normal((2, 5, H, H)).astype(np.float32)
+        w = rng.standard_normal((k, k, 5, 7)).astype(np.float32)
+        geom = F.conv_geom(2, 5, H, H, 7, k, s, pad)
+        y = F.ConvFwd.apply(_t(x, gpu), _t(w, gpu), None, geom, F.ACT_NONE, 0.0).cpu().numpy()
+        ref = O.conv2d(x.astype(np.float64), w.astype(np.float64), s, pad)
+        assert _rel(y, ref) < 2e-5
+        gy = rng.standard_normal(ref.shape).astype(np.float32)
+        gx = F.ConvDgrad.apply(_t(gy, gpu), _t(w, gpu), None, geom, F.ACT_NONE, 0.0).cpu().numpy()
+        assert _rel(gx, O.conv2d_bwd_data(gy.astype(np.float64), w.astype(np.float64), (H, H), s, pad)) < 2e-5
+        gw = F.ConvWgrad.apply(_t(x, gpu), _t(gy, gpu), geom).cpu().numpy()
+        assert _rel(gw, O.conv2d_bwd_filter(x.astype(np.float64), gy.astype(np.float64), k, s, pad)) < 2e-5
+
+
+def test_deconv_delta_alignment(gpu):
+    """Known answer: a delta at input (a,b) lands the filter at output rows 2a+kh-1."""
+    import torch
+    from graphical_gan_amd import functional as F
+    x = np.zeros((1, 1, 4, 4), np.float32)
+    x[0, 0, 1, 2] = 1.0
+    w = np.arange(25, dtype=np.float32).reshape(5, 5, 1, 1) + 1.0      # [k,k,out=1,in=1]
+    geom = F.conv_geom(1, 1, 8, 8, 1, 5, 2, 'SAME')
+    y = F.ConvDgrad.apply(_t(x, gpu), _t(w, gpu), None, geom, F.ACT_NONE, 0.0).cpu().numpy()[0, 0]
+    ref = np.zeros((8, 8))
+    for kh in range(5):
+        for kw in range(5):
+            oh, ow = 2 * 1 + kh - 1, 2 * 2 + kw - 1
+            if 0 <= oh < 8 and 0 <= ow < 8:
+                ref[oh, ow] = w[kh, kw, 0, 0]
+    assert np.array_equal(y, ref)
+
+
+GEMM_CASES = [(64, 4096, 128), (64, 128, 4096), (128, 512, 4608), (64, 512, 158), (64, 1, 512), (50, 30, 7),
+              (4608, 512, 64), (158, 512, 64), (512, 1, 64), (1, 1, 1), (65, 67, 33)]
+
+
+@pytest.mark.parametrize('mnk', GEMM_CASES)
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm(gpu, mnk, ta, tb):
+    from graphical_gan_amd import functional as F
+    M, N, K = mnk
+    rng = np.random.default_rng(M * 131 + N * 17 + K)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    out = F.Gemm.apply(_t(A, gpu), _t(B, gpu), _t(bias, gpu), bool(ta), bool(tb), F.ACT_NONE, 0.0).cpu().numpy()
+    a64 = A.astype(np.float64).T if ta else A.astype(np.float64)
+    b64 = B.astype(np.float64).T if tb else B.astype(np.float64)
+    ref = a64 @ b64 + bias
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize('shape', [(64, 128, 8, 8), (64, 64, 16, 16), (64, 256, 4, 4), (50, 128, 7, 7), (64, 4096), (7, 130)])
+def test_batchnorm(gpu, shape):
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import tape as tp
+    rng = np.random.default_rng(len(shape) * 1000 + shape[1])
+    x = (rng.standard_normal(shape) * 2 + 0.5).astype(np.float32)
+    Cc = shape[1]
+    sc = rng.standard_normal(Cc).astype(np.float32)
+    of = rng.standard_normal(Cc).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    axes = [0, 2, 3] if len(shape) == 4 else [0]
+    xt, st, ot = tp.T(x.astype(np.float64)), tp.T(sc.astype(np.float64)), tp.T(of.astype(np.float64))
+    yt = tp.batchnorm_train(xt, st, ot, axes, 1e-5)
+    gs = tp.grad(tp.reduce_sum(tp.mul(yt, tp.T(gy.astype(np.float64)))), [xt, st, ot])
+    xd = _t(x, gpu).requires_grad_(True)
+    pshape = (Cc,) if len(shape) == 4 else (1, Cc)
+    sd = _t(sc.reshape(pshape), gpu).requires_grad_(True)
+    od = _t(of.reshape(pshape), gpu).requires_grad_(True)
+    y = F.BatchNormTrain.apply(xd, sd, od, 1e-5, F.ACT_NONE, 0.0)
+    assert _rel(y.detach().cpu().numpy(), yt.v) < 1e-5
+    gx, gsd, god = torch.autograd.grad(y, [xd, sd, od], grad_outputs=_t(gy, gpu))
+    assert _rel(gx.cpu().numpy(), gs[0].v) < 2e-5
+    assert _rel(gsd.cpu().numpy().reshape(-1), gs[1].v) < 2e-5
+    assert _rel(god.cpu().numpy().reshape(-1), gs[2].v) < 2e-5
+    # known answer: per-channel mean 0, variance 1 - eps-correction
+    yn = F.BatchNormTrain.apply(xd, torch.ones_like(sd), torch.zeros_like(od), 1e-5, F.ACT_NONE, 0.0).detach().cpu().numpy()
+    red = tuple(axes)
+    assert np.abs(yn.mean(axis=red)).max() < 1e-5
+
+
+@pytest.mark.parametrize('act', [1, 2, 3, 4])
+def test_activations(gpu, act):
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    rng = np.random.default_rng(act)
+    x = rng.standard_normal(10007).astype(np.float32) * 3
+    g = rng.standard_normal(10007).astype(np.float32)
+    x64 = x.astype(np.float64)
+    ref = {1: O.leaky_relu(x64), 2: np.maximum(x64, 0), 3: np.tanh(x64), 4: O.sigmoid(x64)}[act]
+    gref = {1: np.where(x64 > 0, 1, .2), 2: (x64 > 0) * 1.0, 3: 1 - ref ** 2, 4: ref * (1 - ref)}[act] * g
+    xd = _t(x, gpu).requires_grad_(True)
+    y = F.ActFwd.apply(xd, act, 0.2)
+    assert np.abs(y.detach().cpu().numpy() - ref).max() < 1e-6
+    (gx,) = torch.autograd.grad(y, [xd], grad_outputs=_t(g, gpu))
+    assert np.abs(gx.cpu().numpy() - gref).max() < 1e-5
+
+
+def test_losses(gpu):
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    rng = np.random.default_rng(11)
+    xs = [rng.standard_normal(n).astype(np.float32) * 4 for n in (64, 64, 800, 50)]
+    labels, weights = (1.0, 0.0, 0.0, 1.0), (0.5, 0.5, 1 / 32., .25)
+    xd = [_t(x, gpu).requires_grad_(True) for x in xs]
+    loss = F.BceSum.apply(labels, weights, *xd)
+    ref = sum(w * O.bce_with_logits(x.astype(np.float64), z).mean() for x, z, w in zip(xs, labels, weights))
+    assert abs(float(loss.detach()) - ref) < 1e-5 * abs(ref)
+    gs = torch.autograd.grad(loss * 3.0, xd)
+    for x, z, w, g in zip(xs, labels, weights, gs):
+        gref = 3.0 * w * (O.sigmoid(x.astype(np.float64)) - z) / x.size
+        assert np.abs(g.cpu().numpy() - gref).max() < 1e-6
+    m = F.MeanSum.apply((1.0, -1.0), xd[0], xd[1])
+    assert abs(float(m.detach()) - (xs[0].astype(np.float64).mean() - xs[1].astype(np.float64).mean())) < 1e-5
+    # gradient penalty
+    g = rng.standard_normal((64, 3072)).astype(np.float32) * 0.02
+    gd = _t(g, gpu).requires_grad_(True)
+    pen = F.GradPenalty.apply(gd, 10.0)
+    s = np.sqrt((g.astype(np.float64) ** 2).sum(1))
+    assert abs(float(pen.detach()) - 10 * ((s - 1) ** 2).mean()) < 1e-4
+    (gg,) = torch.autograd.grad(pen, [gd])
+    ggref = (10 * 2 * (s - 1) / 64 / s)[:, None] * g
+    assert _rel(gg.cpu().numpy(), ggref) < 1e-5
+
+
+def test_adam_known_answer_and_trajectory(gpu):
+    """t=1 closed form: dtheta = -lr*g/(|g| + eps/sqrt(1-beta2)); then 5 steps vs the oracle."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    rng = np.random.default_rng(3)
+    n = 10007
+    th = rng.standard_normal(n).astype(np.float32)
+    lr, b1, b2, eps = 2e-4, 0.5, 0.999, 1e-8
+    theta, m, v = _t(th, gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    step = torch.zeros(1, dtype=torch.int32, device=gpu)
+    rt, rm, rv = th.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in range(1, 6):
+        g = rng.standard_normal(n).astype(np.float32)
+        F.adam_step_(theta, _t(g, gpu), m, v, step, lr, b1, b2, eps)
+        prev = rt.copy()
+        rt, rm, rv = O.adam_update(rt, g.astype(np.float64), rm, rv, t, lr, b1, b2, eps)
+        if t == 1:
+            closed = -lr * g / (np.abs(g) + eps / np.sqrt(1 - b2))
+            assert np.abs((theta.cpu().numpy() - th) - closed).max() < 5e-7   # 1 ulp of |theta|~2 in fp32
+        assert np.abs(theta.cpu().numpy() - rt).max() < 5e-7, t
+    assert int(step.item()) == 5
+
+
+def test_cast_scale_and_lerp(gpu):
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(2)
+    xi = rng.integers(0, 256, size=(64, 3072)).astype(np.int32)
+    y = F.CastScaleI32.apply(torch.as_tensor(xi, device=gpu), None, 255.0, 2.0).cpu().numpy()
+    ref = np.float32(2) * ((xi.astype(np.float32) / np.float32(255.)) - np.float32(.5))
+    assert np.array_equal(y, ref)
+    a, b = rng.standard_normal((64, 300)).astype(np.float32), rng.standard_normal((64, 300)).astype(np.float32)
+    al = rng.random((64, 1)).astype(np.float32)
+    out = F.RowLerp.apply(_t(a, gpu), _t(b, gpu), _t(al, gpu)).cpu().numpy()
+    assert np.abs(out - (a + al * (b - a))).max() < 1e-6
+
+
+def test_pack(gpu):
+    import torch
+    from graphical_gan_amd import functional as F
+    ts = [torch.randn(n, device=gpu) for n in (5, 1000, 64, 333)]
+    slots, off = [], 0
+    for t in ts:
+        slots.append((off, t.numel()))
+        off += (t.numel() + 63) // 64 * 64
+    flat = torch.full((off,), 7.0, device=gpu)
+    F.pack_([ts[0], None, ts[2], ts[3]], slots, flat)
+    for i, (t, (o, n)) in enumerate(zip(ts, slots)):
+        exp = torch.zeros_like(t) if i == 1 else t
+        assert torch.equal(flat[o:o + n], exp)
+
+
+def test_c_abi_error_reporting(gpu):
+    from graphical_gan_amd import _lib
+    L = _lib.load()
+    g = _lib.ConvGeom(0, 1, 1, 1, 1, 1, 1, 5, 2, 1, 1)
+    rc = L.ggan_conv2d_fwd(C.byref(g), None, None, None, None, 0, 0.0, None, 0, None)
+    assert rc != 0 and b'geometry' in L.ggan_last_error()
