@@ -1,0 +1,204 @@
+"""Step scheduler of the training loop (gmgan_inference_cifar10.py:480-494 and its nine siblings).
+
+  iteration 0        : CRITIC_ITERS critic steps only
+  iteration it > 0   : one generator(+extractor) step, then CRITIC_ITERS critic steps
+  every step         : fresh minibatch + fresh noise, forward of all nets, backward, one Adam step
+The reference re-enters TensorFlow (`session.run`) per step with a feed_dict host->device copy.  Here a step
+is a HIP graph: the first call runs eagerly (warm-up, allocator priming), then forward + backward + gradient
+packing + Adam are captured once with torch.cuda.CUDAGraph and replayed; inputs live in static device
+buffers (a device-resident ring of pre-staged minibatches feeds them with one d2d copy), noise is drawn on
+device inside the graph.  With data parallelism the graph is split around the gradient all-reduce:
+[fwd+bwd+pack] -> RCCL all-reduce of the flat bucket -> [Adam].
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import tflib as lib
+from .models import GraphicalGAN
+
+
+class Trainer(object):
+    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False):
+        self.cfg = cfg
+        self.device = torch.device(device) if device is not None else lib.get_device()
+        lib.set_device(self.device)
+        self.model = GraphicalGAN(cfg)
+        self.graph_enabled = graph
+        self.inject_noise = inject_noise
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        B, c = cfg.B, cfg
+        dev = self.device
+        # static input buffers (what the reference feeds / samples per session.run)
+        self.feed = {}
+        if c.dataset == 'mnist':
+            self.feed['real_x'] = torch.zeros(B, c.output_dim, device=dev)
+        else:
+            self.feed['real_x_int'] = torch.zeros(B, c.output_dim, dtype=torch.int32, device=dev)
+        if c.dataset == 'face':
+            self.feed['dequant_u'] = torch.zeros(B, c.output_dim, device=dev)
+        self.feed['p_z_noise'] = torch.zeros(B, c.dim_latent, device=dev)
+        if c.K:
+            self.feed['k_onehot'] = torch.zeros(B, c.K, device=dev)
+            self.feed['gumbel_u'] = torch.zeros(B, c.K, device=dev)
+        if c.mode == 'wali-gp':
+            self.feed['alpha'] = torch.zeros(B, 1, device=dev)
+        self._graphs = {}
+        self._calls = {'gen': 0, 'disc': 0}
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._opts = None
+
+    # ---- inputs ---------------------------------------------------------------------------------------
+    def set_feed(self, feed):
+        """Copy injected numpy inputs/noise (oracle.step.make_feed layout) into the static buffers."""
+        c = self.cfg
+        for k, v in feed.items():
+            if k == 'k_idx':
+                oh = np.zeros((c.B, c.K), np.float32)
+                oh[np.arange(c.B), v] = 1
+                self.feed['k_onehot'].copy_(torch.as_tensor(oh))
+            else:
+                self.feed[k].copy_(torch.as_tensor(np.asarray(v)))
+
+    def set_batch(self, batch):
+        key = 'real_x' if self.cfg.dataset == 'mnist' else 'real_x_int'
+        self.feed[key].copy_(batch, non_blocking=True)
+
+    def _sample_noise(self):
+        """Fresh noise for one session.run, drawn on device (graph-capturable)."""
+        c, f = self.cfg, self.feed
+        f['p_z_noise'].normal_()
+        if c.K:
+            idx = torch.randint(0, c.K, (c.B, 1), device=self.device)
+            f['k_onehot'].zero_().scatter_(1, idx, 1.0)
+            f['gumbel_u'].uniform_()
+        if c.mode == 'wali-gp':
+            f['alpha'].uniform_()
+        if c.dataset == 'face':
+            f['dequant_u'].uniform_(0., 1. / 128)
+
+    # ---- one session.run ------------------------------------------------------------------------------
+    def _fwd_bwd(self, which):
+        if not self.inject_noise:
+            self._sample_noise()
+        out = self.model.forward(self.feed, which)
+        op = out[which + '_train_op']
+        opt = op.optimizer
+        grads = opt.compute_gradients(op.cost)
+        keep = opt.pack(grads)
+        return out[which + '_cost'].detach(), opt, keep
+
+    def _eager(self, which):
+        cost, opt, _ = self._fwd_bwd(which)
+        opt.all_reduce()
+        opt.update()
+        return cost
+
+    def _optimizers(self):
+        from .optim import _optimizers
+        return list(_optimizers.values())
+
+    def _capture(self, which):
+        # warm-up eagerly on a side stream (allocator + lazy init), restoring optimizer state afterwards
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            # (the optimizers exist: the first call of each kind ran eagerly)
+            snap = [(o, o.theta.clone(), o.m.clone(), o.v.clone(), o.step.clone()) for o in self._optimizers()]
+            for _ in range(2):
+                self._eager(which)
+            for o, th, m, v, st in snap:
+                o.theta.copy_(th); o.m.copy_(m); o.v.copy_(v); o.step.copy_(st)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g1 = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(g1):
+                cost, opt, keep = self._fwd_bwd(which)
+                opt.update()
+            return dict(g1=g1, g2=None, cost=cost, opt=opt, keep=keep)
+        with torch.cuda.graph(g1):
+            cost, opt, keep = self._fwd_bwd(which)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            opt.update()
+        return dict(g1=g1, g2=g2, cost=cost, opt=opt, keep=keep)
+
+    def step(self, which):
+        """One gen or disc session.run on the current contents of the static buffers -> 0-dim cost tensor."""
+        self._calls[which] += 1
+        if not self.graph_enabled:
+            return self._eager(which)
+        rec = self._graphs.get(which)
+        if rec is None:
+            if self._calls[which] == 1:
+                # the very first call of each kind runs eagerly AND counts as a real step
+                return self._eager(which)
+            rec = self._capture(which)
+            self._graphs[which] = rec
+        rec['g1'].replay()
+        if rec['g2'] is not None:
+            rec['opt'].all_reduce()
+            rec['g2'].replay()
+        return rec['cost']
+
+    def gen_step(self, feed=None):
+        if feed is not None:
+            self.set_feed(feed)
+        return self.step('gen')
+
+    def disc_step(self, feed=None):
+        if feed is not None:
+            self.set_feed(feed)
+        return self.step('disc')
+
+    def iteration(self, it, batches):
+        """batches: iterator of device minibatches (or feed dicts when inject_noise)."""
+        res = {}
+
+        def load(b):
+            if isinstance(b, dict):
+                self.set_feed(b)
+            else:
+                self.set_batch(b)
+        if it > 0:
+            load(next(batches))
+            res['gen_cost'] = self.step('gen')
+        for _ in range(self.cfg.critic_iters):
+            load(next(batches))
+            res['disc_cost'] = self.step('disc')
+        return res
+
+    # ---- parameters -------------------------------------------------------------------------------------
+    def load_params(self, params):
+        """name -> numpy array (e.g. oracle.nets.init_params) into the registry, creating entries as needed."""
+        with torch.no_grad():
+            for name, v in params.items():
+                trainable = not (name.endswith('.moving_mean') or name.endswith('.moving_variance'))
+                p = lib.param(name, np.asarray(v, dtype=np.float32), trainable=trainable)
+                p.data.copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(p.shape))
+
+    def get_params(self):
+        return {n: p.detach().cpu().numpy().copy() for n, p in lib.named_params().items()}
+
+
+def broadcast_params(src=0):
+    """Replicas start from rank-`src`'s weights (the reference has a single replica; DP adds this)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for _, p in sorted(lib.named_params().items()):
+            dist.broadcast(p.data, src=src)
+
+
+def synthetic_ring(cfg, device, n=8, seed=1234):
+    """Device-resident ring of pre-staged synthetic minibatches: uniform integers 0..255
+    (int32, as the reference's placeholder) or U[0,1) floats for MNIST."""
+    rng = np.random.default_rng(seed)
+    ring = []
+    for _ in range(n):
+        if cfg.dataset == 'mnist':
+            b = torch.as_tensor(rng.random((cfg.B, cfg.output_dim), dtype=np.float32))
+        else:
+            b = torch.as_tensor(rng.integers(0, 256, size=(cfg.B, cfg.output_dim)).astype(np.int32))
+        ring.append(b.to(device))
+    return ring

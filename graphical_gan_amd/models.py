@@ -1,0 +1,206 @@
+"""Net definitions + loss wiring of the reference's driver scripts, written against the tflib mirror.
+
+One parametrised definition covers the six image scripts (the reference repeats it per file):
+  gan_inference_cifar10.py:133-255,261-366      Generator / Extractor / Discriminator, MODE ali | wali-gp
+  gmgan_inference_cifar10.py:114-301,341-398    + HyperGenerator / HyperExtractor / HyperDiscriminator, MODE local_ep
+  gmgan_inference_mnist.py:166-300              28x28x1, crop [:,:,:7,:7], sigmoid output, float input
+  gmgan_inference_face.py:82-274                64x64x3, four conv stages, DIM 32, no BatchNorm, dequantisation
+Layer names are the reference's, so the registry keys match.
+`fuse=True` folds bias+activation into the producing conv/linear/BN kernel (identical math, fewer HBM passes).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import functional as F
+from . import tflib as lib
+from .tflib.ops.act import LRELU, RELU, TANH, SIGMOID
+
+
+class Config(object):
+    def __init__(self, dataset='cifar10', batch_size=64, n_coms=0, mode=None, dim=None, dim_latent=128, bn=None,
+                 temp=0.1, fuse=True, lr=None):
+        self.dataset, self.B, self.K, self.dim_latent, self.temp, self.fuse = dataset, batch_size, n_coms, dim_latent, temp, fuse
+        if dataset == 'cifar10':
+            self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, True, 'tanh'
+        elif dataset == 'mnist':
+            self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 1, 28, 64, 3, True, 'sigmoid'
+        elif dataset == 'face':
+            self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 64, 32, 4, False, 'tanh'
+        else:
+            raise ValueError(dataset)
+        if dim is not None:
+            self.dim = dim
+        if bn is not None:
+            self.bn = bn
+        self.mode = mode or ('local_ep' if n_coms else 'ali')
+        assert self.mode in ('ali', 'local_ep', 'wali-gp')
+        self.top = self.dim * 2 ** (self.nl - 1)
+        self.flat = 16 * self.top
+        self.output_dim = self.C * self.S * self.S
+        self.critic_iters = 5 if self.mode == 'wali-gp' else 1          # gan_inference_cifar10.py:53-59
+        self.lr = lr if lr is not None else (1e-4 if self.mode == 'wali-gp' else 2e-4)
+        self.beta1 = 0.5
+
+
+class GraphicalGAN(object):
+    """Builds the per-step graph of one script: forward(feed) -> dict with gen_cost / disc_cost / train ops."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    # ---- small helpers: an op followed by its pointwise, fused or not -------------------------------------
+    def _conv(self, name, cin, cout, x, act):
+        if self.cfg.fuse:
+            return lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, activation=act)
+        return F.ActFwd.apply(lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2), act, 0.2)
+
+    def _lin(self, name, nin, nout, x, act):
+        if self.cfg.fuse:
+            return lib.ops.linear.Linear(name, nin, nout, x, activation=act)
+        return F.ActFwd.apply(lib.ops.linear.Linear(name, nin, nout, x), act, 0.2)
+
+    def _bn(self, name, axes, x, act):
+        if self.cfg.fuse:
+            return lib.ops.batchnorm.Batchnorm(name, axes, x, activation=act)
+        return F.ActFwd.apply(lib.ops.batchnorm.Batchnorm(name, axes, x), act, 0.2)
+
+    # ---- nets ---------------------------------------------------------------------------------------
+    def Generator(self, noise):
+        c = self.cfg
+        if c.bn:
+            out = lib.ops.linear.Linear('Generator.Input', c.dim_latent, c.flat, noise)
+            out = self._bn('Generator.BN1', [0], out, RELU)
+        else:
+            out = self._lin('Generator.Input', c.dim_latent, c.flat, noise, RELU)
+        out = out.reshape(-1, c.top, 4, 4)
+        names = ['2', '3', '4', '5'] if c.nl == 4 else ['2', '3', '5']
+        ch = c.top
+        for i, nm in enumerate(names):
+            last = i == len(names) - 1
+            cout = c.C if last else ch // 2
+            final_act = TANH if c.out_act == 'tanh' else SIGMOID
+            if last:
+                if c.fuse:
+                    out = lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out, activation=final_act)
+                else:
+                    out = F.ActFwd.apply(lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out), final_act, 0.0)
+            elif c.bn:
+                out = lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out)
+                out = self._bn('Generator.BN' + nm, [0, 2, 3], out, RELU)
+            elif c.fuse:
+                out = lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out, activation=RELU)
+            else:
+                out = F.relu(lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out))
+            if c.dataset == 'mnist' and nm == '2':
+                out = out[:, :, :7, :7].contiguous()                     # gmgan_inference_mnist.py:179
+            ch = cout
+        return out.reshape(-1, c.output_dim)
+
+    def Extractor(self, inputs):
+        c = self.cfg
+        out = inputs.reshape(-1, c.C, c.S, c.S)
+        ch = c.C
+        for i in range(c.nl):
+            cout = c.dim * 2 ** i
+            name = 'Extractor.%d' % (i + 1)
+            if c.bn and i > 0:
+                out = lib.ops.conv2d.Conv2D(name, ch, cout, 5, out, stride=2)
+                out = self._bn('Extractor.BN%d' % (i + 1), [0, 2, 3], out, LRELU)
+            else:
+                out = self._conv(name, ch, cout, out, LRELU)
+            ch = cout
+        out = out.reshape(-1, c.flat)
+        return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out)
+
+    def Discriminator(self, x, z):
+        c = self.cfg
+        out = x.reshape(-1, c.C, c.S, c.S)
+        ch = c.C
+        for i in range(c.nl):
+            cout = c.dim * 2 ** i
+            out = self._conv('Discriminator.%d' % (i + 1), ch, cout, out, LRELU)   # dropout == identity
+            ch = cout
+        out = out.reshape(-1, c.flat)
+        z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
+        out = torch.cat([out, z_out], 1)
+        out = self._lin('Discriminator.zx1', c.flat + 512, 512, out, LRELU)
+        out = lib.ops.linear.Linear('Discriminator.Output', 512, 1, out)
+        return out.reshape(-1)
+
+    def HyperDiscriminator(self, z, k):
+        c = self.cfg
+        out = torch.cat([z, k], 1)
+        out = self._lin('Discriminator.HyperInput', c.dim_latent + c.K, 512, out, LRELU)
+        out = self._lin('Discriminator.Hyper2', 512, 512, out, LRELU)
+        out = self._lin('Discriminator.Hyper3', 512, 512, out, LRELU)
+        out = lib.ops.linear.Linear('Discriminator.HyperOutput', 512, 1, out)
+        return out.reshape(-1)
+
+    def _mu(self):
+        c = self.cfg
+        return lib.param('Generator.Hyper.Mu', np.random.normal(size=(c.K, c.dim_latent)).astype('float32'))
+
+    def HyperGenerator(self, hyper_k, hyper_noise):
+        """gmgan_inference_cifar10.py:150-153: onehot(k) @ Mu + eps."""
+        return F.Axpby.apply(F.Gemm.apply(hyper_k, self._mu(), None, False, False, F.ACT_NONE, 0.0), hyper_noise, 1.0, 1.0, 0.0)
+
+    def HyperExtractor(self, latent_z, gumbel_u):
+        """gmgan_inference_cifar10.py:156-173 (MODE_K='CONCRETE').  [B,K] latent glue: <0.1% of the step's work,
+        composed from torch pointwise ops on tiny tensors."""
+        c = self.cfg
+        mu = self._mu()
+        diff = latent_z.unsqueeze(1) - mu.unsqueeze(0)
+        logits = -.5 * (diff * diff).sum(-1) + math.log(1. / c.K)
+        g = -torch.log(-torch.log(gumbel_u + 1e-20) + 1e-20)
+        k = torch.softmax((logits + g) / c.temp, dim=-1)
+        return logits, k
+
+    # ---- loss wiring ------------------------------------------------------------------------------------
+    def real_x(self, feed):
+        c = self.cfg
+        if c.dataset == 'mnist':
+            return feed['real_x']
+        if c.dataset == 'face':
+            return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'])
+        return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2.)
+
+    def forward(self, feed, which=None):
+        """which='gen'|'disc' builds only what that session.run fetches (TF prunes the rest: the gradient penalty
+        is not part of gen_cost); None builds everything."""
+        c = self.cfg
+        real_x = self.real_x(feed)
+        q_z = self.Extractor(real_x)
+        out = dict(real_x=real_x, q_z=q_z)
+        if c.K:
+            onehot = feed['k_onehot']
+            _, q_k = self.HyperExtractor(q_z, feed['gumbel_u'])
+            p_z = self.HyperGenerator(onehot, feed['p_z_noise'])
+            out['q_k'] = q_k
+        else:
+            p_z = feed['p_z_noise']
+        fake_x = self.Generator(p_z)
+        out.update(p_z=p_z, fake_x=fake_x)
+        gen_params = lib.params_with_name('Generator') + lib.params_with_name('Extractor')
+        disc_params = lib.params_with_name('Discriminator')
+        J = lib.objs.gan_inference
+        if c.K:
+            d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)]
+            d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)]
+            res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        else:
+            d_fake = self.Discriminator(fake_x, p_z)
+            d_real = self.Discriminator(real_x, q_z)
+            if c.mode == 'wali-gp':
+                if which == 'gen':
+                    gp = torch.zeros((), device=d_fake.device)
+                else:
+                    gp = J.gradient_penalty(self.Discriminator, real_x, fake_x, q_z, p_z, feed['alpha'])
+                res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
+                out['gradient_penalty'] = gp
+            else:
+                res = J.ali(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=res[0], disc_cost=res[1],
+                   gen_train_op=res[2], disc_train_op=res[3])
+        return out

@@ -1,0 +1,114 @@
+"""-m gpu: the full training iteration (all nets, objective, backward, TF-Adam; incl. the wali-gp double
+backward) on the HIP path vs the float64 oracle, same injected weights / minibatches / noise.
+
+Tolerances: costs rel <= 1e-5 on the first session.run, <= 1e-3 after a few Adam steps
+(Adam moves every weight by ~lr regardless of |g|, so fp32 sign flips of near-zero gradients are amplified);
+logits / gradients rel <= 1e-4 (GP second-order <= 1e-3 of the largest entry).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh():
+    from graphical_gan_amd import tflib as lib
+    from graphical_gan_amd import optim
+    optim.reset_optimizers()
+    lib.delete_all_params()
+
+
+def _mk(dataset, B, K, mode, dim, dl, fuse, graph, gpu):
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    from oracle import nets as N
+    ocfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl)
+    P0 = N.init_params(ocfg, seed=0)
+    rng = np.random.default_rng(7)
+    for k in P0:   # make biases / BN params non-trivial so their gradients paths are exercised
+        if P0[k].ndim <= 2 and ('Biases' in k or k.endswith('.b') or 'offset' in k):
+            P0[k] = (0.1 * rng.standard_normal(P0[k].shape)).astype(np.float32)
+        if k.endswith('.scale'):
+            P0[k] = (1 + 0.1 * rng.standard_normal(P0[k].shape)).astype(np.float32)
+    _fresh()
+    cfg = Config(dataset, batch_size=B, n_coms=K, mode=mode, dim=dim, dim_latent=dl, fuse=fuse)
+    tr = Trainer(cfg, device=gpu, graph=graph, inject_noise=True)
+    tr.load_params(P0)
+    return ocfg, P0, cfg, tr
+
+
+CASES = [  # dataset, B, K, mode, dim, dim_latent
+    ('cifar10', 8, 0, 'ali', 8, 16),
+    ('cifar10', 8, 5, 'local_ep', 8, 16),
+    ('cifar10', 8, 0, 'wali-gp', 8, 16),
+    ('mnist', 6, 4, 'local_ep', 8, 16),
+    ('face', 4, 6, 'local_ep', 4, 16),
+    ('cifar10', 64, 0, 'ali', None, 128),      # BASELINE config 2 at full size
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: '-'.join(str(x) for x in c))
+@pytest.mark.parametrize('fuse', [True, False], ids=['fused', 'unfused'])
+def test_first_step_costs_and_grads(gpu, case, fuse):
+    """One forward/backward: costs, critic logits and every parameter gradient vs the oracle."""
+    import torch
+    from oracle import step as S, tape as tp, nets as N
+    dataset, B, K, mode, dim, dl = case
+    if dim is None and not fuse:
+        pytest.skip('full-size case runs fused only (oracle time)')
+    ocfg, P0, cfg, tr = _mk(dataset, B, K, mode, dim, dl, fuse, False, gpu)
+    omode = 'wali-gp' if mode == 'wali-gp' else 'ali'
+    feed = S.make_feed(ocfg, np.random.default_rng(11), omode)
+    Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
+    oout = S.forward(ocfg, Pt, feed, omode)
+    tr.set_feed(feed)
+    out = tr.model.forward(tr.feed)
+    for which in ('gen', 'disc'):
+        oc = float(oout[which + '_cost'].v)
+        c = float(out[which + '_cost'].detach())
+        assert abs(c - oc) <= 1e-5 * max(1.0, abs(oc)), (which, c, oc)
+        opt = out[which + '_train_op'].optimizer
+        names = [p.param_name for p in opt.params]
+        grads = torch.autograd.grad(out[which + '_cost'], opt.params, allow_unused=True, retain_graph=True)
+        ogs = tp.grad(oout[which + '_cost'], [Pt[n] for n in names])
+        tol = 1e-3 if mode == 'wali-gp' and which == 'disc' else 1e-4
+        gmax = max(np.abs(og.v).max() for og in ogs if og is not None)   # scale for mathematically-zero grads
+        for n, g, og in zip(names, grads, ogs):
+            if og is None:
+                assert g is None or float(g.abs().max()) == 0.0, n
+                continue
+            ref = og.v
+            err = np.abs(g.cpu().numpy().reshape(ref.shape) - ref).max()
+            assert err <= tol * max(np.abs(ref).max(), 1e-2 * gmax), (which, n, err, np.abs(ref).max(), gmax)
+
+
+@pytest.mark.parametrize('case', CASES[:5], ids=lambda c: '-'.join(str(x) for x in c))
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hipgraph'])
+def test_trajectory(gpu, case, graph):
+    """3 iterations of the loop (iteration 0 = critic only), scripted minibatches + noise: cost sequence and
+    post-step weights vs the oracle; eager and HIP-graph replay must agree with it equally."""
+    from oracle import step as S
+    dataset, B, K, mode, dim, dl = case
+    ocfg, P0, cfg, tr = _mk(dataset, B, K, mode, dim, dl, True, graph, gpu)
+    omode = 'wali-gp' if mode == 'wali-gp' else 'ali'
+    otr = S.Trainer(ocfg, P0, omode, np.float64)
+    n_it = 4 if graph else 3        # graph path: call 1 eager, call 2 captures+replays, ...
+    n_feeds = n_it * (1 + otr.critic_iters)
+    feeds = [S.make_feed(ocfg, np.random.default_rng(100 + i), omode) for i in range(n_feeds)]
+    fo, fp = iter(feeds), iter(feeds)
+    for it in range(n_it):
+        ro = otr.iteration(it, fo)
+        rp = tr.iteration(it, fp)
+        for k in ro:
+            a, b = float(rp[k]), ro[k]
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (it, k, a, b)
+    P = tr.get_params()
+    lr = cfg.lr
+    steps = n_it * (1 + otr.critic_iters)
+    for n, ref in otr.P.items():
+        if cfg.bn and (n.endswith('.Biases') or n == 'Generator.Input.b') and not n.startswith('Discriminator') \
+                and n not in ('Extractor.1.Biases', 'Generator.5.Biases'):
+            continue   # bias feeding BatchNorm: true gradient is 0, Adam random-walks on rounding noise (fp64 too)
+        d = np.abs(P[n].reshape(ref.shape) - ref)
+        assert d.max() <= 2.5 * lr * steps, (n, d.max())
+        assert (d > 2e-5).mean() <= 0.02, (n, (d > 2e-5).mean())
