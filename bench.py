@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the Graphical-GAN training iteration on N MI355X GPUs (one process per GPU).
+
+A "step" is one iteration of the reference loop (gmgan_inference_cifar10.py:480-494): one generator+extractor
+session.run followed by CRITIC_ITERS critic session.runs, each on a fresh synthetic minibatch + fresh noise,
+each including forward, backward and the TF-Adam update.  Workload at N=1: BASELINE.json configs[1],
+gan_inference_cifar10.py (32x32x3, BATCH_SIZE=64, MODE='ali'); per-GPU batch stays 64 as N grows (weak scaling).
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def algorithmic_gflop_per_iteration(cfg):
+    """GEMM-like layers only, 2*M*N*K, forward + exactly the gradients the step needs."""
+    B, d, nl = cfg.B, cfg.dim, cfg.nl
+    chans = [cfg.C] + [d * 2 ** i for i in range(nl)]
+    conv = []
+    s = cfg.S
+    for i in range(nl):
+        s //= 2 if cfg.dataset != 'mnist' else 1
+        if cfg.dataset == 'mnist':
+            s = {0: 14, 1: 7, 2: 4}[i]
+        conv.append(2.0 * B * chans[i + 1] * s * s * chans[i] * 25)
+    if cfg.dataset == 'mnist':
+        deconv = [2.0 * B * 256 * 16 * 128 * 25, 2.0 * B * 128 * 49 * 64 * 25, 2.0 * B * 64 * 196 * 1 * 25]
+    else:
+        deconv = list(reversed(conv))                # the generator mirrors the extractor
+    lin = lambda i, o: 2.0 * B * i * o
+    fE = sum(conv) + lin(cfg.flat, cfg.dim_latent)
+    fG = sum(deconv) + lin(cfg.dim_latent, cfg.flat)
+    fDconv = sum(conv)
+    fz1, fzx1, fout = lin(cfg.dim_latent, 512), lin(cfg.flat + 512, 512), lin(512, 1)
+    fDlin = fz1 + fzx1 + fout
+    fH = fHin = 0.0
+    if cfg.K:
+        fHin = lin(cfg.dim_latent + cfg.K, 512)
+        fH = fHin + 2 * lin(512, 512) + lin(512, 1)
+    fwd = fE + fG + 2 * (fDconv + fDlin) + 2 * fH
+    gen_bwd = (2 * fE - conv[0]) + (2 * fG - (0 if cfg.K else lin(cfg.dim_latent, cfg.flat))) + fDconv + 2 * fDlin + 2 * fH
+    disc_bwd = 2 * (fDconv + fDlin) + 2 * (fDconv - conv[0] + fzx1 + fout) + 2 * fH + 2 * (fH - fHin)
+    total = (fwd + gen_bwd) + cfg.critic_iters * (fwd + disc_bwd)
+    if cfg.mode == 'wali-gp':
+        # extra critic pass + x-gradient + double backward ~ 6x one critic-branch forward per critic step
+        total += cfg.critic_iters * 6 * (fDconv + fDlin)
+    return total / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--dataset', default='cifar10')
+    ap.add_argument('--mode', default='ali', help="ali | wali-gp | local_ep (gmgan, N_COMS=30)")
+    ap.add_argument('--batch-size', type=int, default=64)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-fuse', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (there is no CPU path); use gpurun')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' %
+                         (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from graphical_gan_amd import _lib, tflib as lib
+    from graphical_gan_amd.engine import Trainer, synthetic_ring, broadcast_params
+    from graphical_gan_amd.models import Config
+
+    K = 30 if args.mode == 'local_ep' else 0
+    cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse)
+    np.random.seed(0)                                  # reference initialisers draw from numpy's global RNG
+    tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
+    torch.manual_seed(1234 + rank)
+    ring = synthetic_ring(cfg, dev, n=8, seed=1234 + rank)
+
+    def batches():
+        i = 0
+        while True:
+            yield ring[i % len(ring)]
+            i += 1
+    bi = batches()
+    it = 0
+    tr.iteration(it, bi); it += 1                      # creates parameters + optimizers (eager)
+    tr.iteration(it, bi); it += 1
+    broadcast_params(0)
+    for _ in range(max(args.warmup, 2)):               # includes graph capture
+        tr.iteration(it, bi); it += 1
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = tr.iteration(it, bi); it += 1
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = all(np.isfinite(float(v)) for v in last.values())
+
+    ms_per_step = 1e3 * dt / args.steps
+    images_per_s = cfg.B * world * args.steps / dt
+    gflop_it = algorithmic_gflop_per_iteration(cfg)
+    step_tflops = gflop_it * args.steps / dt / 1e3      # per GPU
+
+    # ---- per-kernel timing of the same step with HIP events (eager, on the launch stream) ---------------------
+    roofline = None
+    kernels = None
+    if rank == 0 and not args.no_kernel_profile:
+        tr_graph = tr.graph_enabled
+        tr.graph_enabled = False
+        L = _lib.load()
+        for _ in range(2):
+            tr.iteration(it, bi); it += 1
+        torch.cuda.synchronize(dev)
+        L.ggan_prof_reset(); L.ggan_prof_enable(1)
+        n_prof = 5
+        for _ in range(n_prof):
+            tr.iteration(it, bi); it += 1
+        torch.cuda.synchronize(dev)
+        L.ggan_prof_enable(0)
+        recs = _lib.prof_report()
+        L.ggan_prof_reset()
+        tr.graph_enabled = tr_graph
+        recs.sort(key=lambda r: -r['total_ms'])
+        kernels = [dict(name=r['name'], launches_per_iter=r['launches'] / n_prof,
+                        ms_per_iter=round(r['total_ms'] / n_prof, 4),
+                        avg_us=round(1e3 * r['total_ms'] / r['launches'], 2),
+                        tflops=round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 2) if r['flops'] else None)
+                   for r in recs]
+        dom = next((r for r in recs if r['flops'] > 0), None)
+        if dom is not None:
+            ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            roofline = dict(bound='mfma', kernel=dom['name'], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
+                            unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                            avg_launch_us=round(1e3 * dom['total_ms'] / dom['launches'], 2),
+                            flop_per_launch=dom['flops'] / dom['launches'],
+                            whole_step_tflops=round(step_tflops, 2),
+                            whole_step_frac=round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4))
+    if world > 1:
+        dist.barrier()
+
+    # ---- CPU baseline: the numpy oracle (a port; the reference is Python2+TF1 and cannot run) ------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import nets as ON, step as OS
+        ocfg = ON.Cfg(args.dataset, batch_size=cfg.B, n_coms=K)
+        otr = OS.Trainer(ocfg, ON.init_params(ocfg, 0), 'wali-gp' if args.mode == 'wali-gp' else 'ali', np.float32)
+        feeds = iter([OS.make_feed(ocfg, np.random.default_rng(i), otr.mode) for i in range(64)])
+        otr.iteration(1, feeds)                        # warm numpy/BLAS
+        t1 = time.perf_counter()
+        for j in range(args.cpu_iters):
+            otr.iteration(2 + j, feeds)
+        cdt = time.perf_counter() - t1
+        cpu = dict(value=round(cfg.B * args.cpu_iters / cdt, 2), unit='images/sec', cores=os.cpu_count(),
+                   kind='port', sample='%d iterations (gen step + %d critic step(s)) of the same workload, numpy fp32 '
+                   'oracle with multi-threaded BLAS' % (args.cpu_iters, cfg.critic_iters))
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec (G+D%s step) %s %dx%d bs=%d' % ('+GP' if args.mode == 'wali-gp' else '', args.dataset, cfg.S, cfg.S, cfg.B),
+            'value': round(images_per_s, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'gan_inference_%s.py MODE=%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
+                args.dataset if not K else args.dataset + ' (gmgan, N_COMS=%d)' % K, args.mode, cfg.B, cfg.S, cfg.S, cfg.C,
+                cfg.critic_iters, '' if not args.no_graph else ', eager'),
+                'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world, 'hip_graph': not args.no_graph,
+                'fused_epilogues': not args.no_fuse, 'minibatches_per_step': 1 + cfg.critic_iters,
+                'algorithmic_gflop_per_step': round(gflop_it, 2), 'finite_costs': bool(finite)},
+            'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

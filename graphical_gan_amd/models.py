@@ -157,6 +157,12 @@ class GraphicalGAN(object):
         k = torch.softmax((logits + g) / c.temp, dim=-1)
         return logits, k
 
+    @staticmethod
+    def _var_lists():
+        """gmgan_inference_cifar10.py:381-383 -- substring match over the registry, after every net exists."""
+        return (lib.params_with_name('Generator') + lib.params_with_name('Extractor'),
+                lib.params_with_name('Discriminator'))
+
     # ---- loss wiring ------------------------------------------------------------------------------------
     def real_x(self, feed):
         c = self.cfg
@@ -182,16 +188,16 @@ class GraphicalGAN(object):
             p_z = feed['p_z_noise']
         fake_x = self.Generator(p_z)
         out.update(p_z=p_z, fake_x=fake_x)
-        gen_params = lib.params_with_name('Generator') + lib.params_with_name('Extractor')
-        disc_params = lib.params_with_name('Discriminator')
         J = lib.objs.gan_inference
         if c.K:
             d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)]
             d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)]
+            gen_params, disc_params = self._var_lists()
             res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
         else:
             d_fake = self.Discriminator(fake_x, p_z)
             d_real = self.Discriminator(real_x, q_z)
+            gen_params, disc_params = self._var_lists()
             if c.mode == 'wali-gp':
                 if which == 'gen':
                     gp = torch.zeros((), device=d_fake.device)
