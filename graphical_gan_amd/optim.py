@@ -16,6 +16,34 @@ from . import functional as F
 _ALIGN = 64  # floats (256 B): keeps every view float4-aligned for the MFMA filter loads and Adam
 
 
+def layout_slots(sizes, align=_ALIGN):
+    """[(offset, numel)] of tensors packed into one flat buffer, each start aligned; -> (slots, total)."""
+    slots, off = [], 0
+    for n in sizes:
+        slots.append((off, int(n)))
+        off += (int(n) + align - 1) // align * align
+    return slots, off
+
+
+class GradBucket(object):
+    """The data-parallel exchange step: ONE sum-all-reduce of a flat gradient buffer per optimizer step
+    (SURVEY.md 8e).  Every replica holds the full model and an equal-size local minibatch, so
+    sum/world == the gradient of the global-batch mean cost; `scale` (= 1/world) is folded into the Adam
+    kernel's gradient read instead of a separate pass.  Works on any torch.distributed backend
+    (RCCL on the GPUs; the CPU tests drive it with gloo)."""
+
+    def __init__(self, flat, group=None):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.scale = 1.0 / self.world
+
+    def all_reduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        return self.flat
+
+
 class AdamOptimizer(object):
     def __init__(self, params, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8):
         params = [p for p in params if p.requires_grad]       # TF minimize drops (None, var) pairs
@@ -29,15 +57,11 @@ class AdamOptimizer(object):
         if not self.params:
             raise ValueError('No variables to optimize.')
         dev = self.params[0].device
-        self.slots = []
-        off = 0
         for p in self.params:
             if getattr(p, '_flat_owner', None) is not None:
                 raise NotImplementedError('parameter %s already belongs to another optimizer' %
                                           getattr(p, 'param_name', '?'))
-            n = p.numel()
-            self.slots.append((off, n))
-            off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.slots, off = layout_slots([p.numel() for p in self.params])
         self.total = off
         self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
         self.m = torch.zeros_like(self.theta)
@@ -50,7 +74,8 @@ class AdamOptimizer(object):
                 view.copy_(p.data)
                 p.data = view
                 p._flat_owner = self
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.bucket = GradBucket(self.g)
+        self.world = self.bucket.world
 
     # -- one optimizer step ---------------------------------------------------------------------------
     def compute_gradients(self, cost):
@@ -63,12 +88,11 @@ class AdamOptimizer(object):
 
     def all_reduce(self):
         """Sum the flat gradient bucket over the data-parallel replicas (RCCL over xGMI)."""
-        if self.world > 1:
-            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
+        self.bucket.all_reduce()
 
     def update(self):
         F.adam_step_(self.theta, self.g, self.m, self.v, self.step, self.lr, self.beta1, self.beta2, self.eps,
-                     1.0 / self.world)
+                     self.bucket.scale)
 
     def apply_gradients(self, grads):
         keep = self.pack(grads)

@@ -17,7 +17,8 @@ _device = [None]
 
 
 def set_device(device):
-    """Device new parameters are created on (default: the current HIP device)."""
+    """Device new parameters are created on (default: the current HIP device).  The registry itself is host
+    logic and also works with 'cpu' tensors (used by the CPU test-suite); every op refuses CPU tensors."""
     _device[0] = torch.device(device)
 
 

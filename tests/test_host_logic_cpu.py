@@ -1,0 +1,137 @@
+"""not-gpu: host-side logic of the tflib mirror -- parameter registry semantics (tflib/__init__.py:9-47),
+TF padding arithmetic, flat-buffer layout, the loop's step order."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture()
+def lib():
+    import graphical_gan_amd  # noqa: F401
+    import tflib
+    tflib.delete_all_params()
+    tflib.delete_param_aliases()
+    tflib.set_device('cpu')
+    yield tflib
+    tflib.delete_all_params()
+    tflib.delete_param_aliases()
+    tflib._device[0] = None
+
+
+def test_tflib_alias_resolves_reference_import_paths():
+    import graphical_gan_amd
+    import tflib
+    import tflib.ops.linear, tflib.ops.conv2d, tflib.ops.deconv2d, tflib.ops.batchnorm, tflib.objs.gan_inference, tflib.plot
+    assert tflib is graphical_gan_amd.tflib
+    for fn in ('Linear',):
+        assert hasattr(tflib.ops.linear, fn)
+    assert all(hasattr(tflib.objs.gan_inference, f) for f in ('ali', 'local_ep', 'weighted_local_epce', 'wali_gp'))
+    assert all(hasattr(tflib.plot, f) for f in ('plot', 'tick', 'flush'))
+
+
+def test_param_create_once_share_after(lib):
+    a = lib.param('Generator.Input.W', np.ones((2, 3), 'float32'))
+    b = lib.param('Generator.Input.W', np.zeros((2, 3), 'float32'))     # second init value is ignored
+    assert a is b and float(a.detach().sum()) == 6.0 and a.requires_grad
+    mv = lib.param('Generator.BN2.moving_mean', np.zeros(4, 'float32'), trainable=False)
+    assert not mv.requires_grad
+    lib.param('Extractor.1.Filters', np.zeros((5, 5, 3, 4), 'float32'))
+    lib.param('Discriminator.HyperInput.W', np.zeros((3, 4), 'float32'))
+    assert len(lib.params_with_name('Generator')) == 2                   # substring match incl. moving stats
+    assert len(lib.params_with_name('Discriminator')) == 1
+    assert lib.params_with_name('Hyper')[0] is lib.param('Discriminator.HyperInput.W', None)
+    lib.delete_all_params()
+    assert lib.params_with_name('Generator') == []
+
+
+def test_param_aliases(lib):
+    a = lib.param('A.W', np.ones(2, 'float32'))
+    b = lib.param('B.W', np.zeros(2, 'float32'))
+    lib.alias_params({a: b})
+    assert lib.param('A.W', None) is b
+    lib.delete_param_aliases()
+    assert lib.param('A.W', None) is a
+
+
+def test_initialisers_consume_rng_like_the_reference(lib):
+    """conv2d.py:75-88 draws filter values on EVERY call, even when the param exists."""
+    import torch
+    from graphical_gan_amd import _lib
+    np.random.seed(0)
+    s0 = np.random.get_state()[1][:4].copy()
+    x = torch.zeros(1, 3, 8, 8)
+    for _ in range(2):
+        with pytest.raises(_lib.GganError):       # op refuses CPU tensors, after creating/looking up the params
+            lib.ops.conv2d.Conv2D('Extractor.1', 3, 4, 5, x, stride=2)
+    w = lib.param('Extractor.1.Filters', None)
+    assert tuple(w.shape) == (5, 5, 3, 4)
+    bound = np.sqrt(4. / (3 * 25 + 4 * 25 / 4.)) * np.sqrt(3)
+    assert float(w.abs().max()) <= bound + 1e-6
+    np.random.seed(0)
+    np.random.uniform(size=(5, 5, 3, 4)); np.random.uniform(size=(5, 5, 3, 4))
+    expect = np.random.get_state()[1][:4]
+    np.random.seed(0)
+    with pytest.raises(_lib.GganError):
+        lib.ops.conv2d.Conv2D('Extractor.1', 3, 4, 5, x, stride=2)
+    with pytest.raises(_lib.GganError):
+        lib.ops.conv2d.Conv2D('Extractor.1', 3, 4, 5, x, stride=2)
+    assert np.array_equal(np.random.get_state()[1][:4], expect)
+    assert lib.ops.deconv2d.Deconv2D.__defaults__ is not None
+    with pytest.raises(Exception, match='Unsupported configuration'):
+        lib.ops.deconv2d.Deconv2D('G.2', 4, 2, 5, x, mask_type=('a', 1))
+    with pytest.raises(Exception, match='Invalid initialization!'):
+        lib.ops.linear.Linear('L', 3, 4, torch.zeros(2, 3), initialization=('bogus', 1))
+
+
+def test_same_padding_table():
+    """k=5,s=2: 64/32/28/16/14/8 -> pad (1,2); 7 -> (2,2)."""
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    for size in (64, 32, 28, 16, 14, 8):
+        assert F.same_geometry(size, 5, 2) == (size // 2, 1)
+        assert O.conv_geometry(size, 5, 2) == (size // 2, 1, 2)
+    assert F.same_geometry(7, 5, 2) == (4, 2) and O.conv_geometry(7, 5, 2) == (4, 2, 2)
+    assert F.same_geometry(12, 5, 1, 'VALID') == (8, 0)
+    g = F.conv_geom(64, 3, 32, 32, 64, 5, 2)
+    assert g == (64, 3, 32, 32, 64, 16, 16, 5, 2, 1, 1)
+
+
+def test_flat_layout_is_aligned():
+    from graphical_gan_amd.optim import layout_slots
+    slots, total = layout_slots([5, 64, 100, 1])
+    assert slots == [(0, 5), (64, 64), (128, 100), (256, 1)] and total == 320
+    assert all(o % 64 == 0 for o, _ in slots)
+
+
+def test_loop_step_order():
+    """gmgan_inference_cifar10.py:480-494: iteration 0 = critic steps only; then 1 gen + CRITIC_ITERS critic."""
+    from graphical_gan_amd.engine import Trainer
+    from graphical_gan_amd.models import Config
+
+    class Fake(Trainer):
+        def __init__(self, cfg):
+            self.cfg, self.log = cfg, []
+
+        def set_batch(self, b):
+            self.log.append(('load', b))
+
+        def step(self, which):
+            self.log.append(which)
+            return 0.0
+    for mode, ci in (('ali', 1), ('wali-gp', 5)):
+        t = Fake(Config('cifar10', mode=mode))
+        assert t.cfg.critic_iters == ci
+        t.iteration(0, iter(range(100)))
+        assert [x for x in t.log if isinstance(x, str)] == ['disc'] * ci
+        t.log = []
+        t.iteration(1, iter(range(100)))
+        assert [x for x in t.log if isinstance(x, str)] == ['gen'] + ['disc'] * ci
+        assert [x[1] for x in t.log if not isinstance(x, str)] == list(range(1 + ci))    # fresh minibatch per run
+
+
+def test_plot_shim(tmp_path, capsys):
+    import graphical_gan_amd  # noqa: F401
+    import tflib.plot as plot
+    plot.plot('time', 1.0); plot.tick(); plot.plot('time', 3.0)
+    logfile = tmp_path / 'log.txt'
+    plot.flush(str(tmp_path), str(logfile))
+    assert 'time\t2.0' in capsys.readouterr().out and 'time\t2.0' in logfile.read_text()

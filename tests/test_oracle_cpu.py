@@ -1,0 +1,201 @@
+"""not-gpu: pins the CPU oracle (PARITY UNPINNED at the TF boundary -- SURVEY.md 8c) by
+ (i) analytic known answers, (ii) float64 finite differences incl. the GP double backward,
+ (iii) an independent PyTorch-CPU cross-check composed to TF semantics, (iv) the committed goldens."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ops as O, tape as tp, nets as N, step as S, objs as J
+from _golden import load, traj_feeds, digest
+
+
+# ---- (i) known answers ------------------------------------------------------------------------------
+def test_conv_delta_exposes_same_alignment():
+    x = np.zeros((1, 1, 8, 8)); x[0, 0, 3, 4] = 1.0
+    w = np.arange(25, dtype=np.float64).reshape(5, 5, 1, 1) + 1
+    y = O.conv2d(x, w, 2, 'SAME')[0, 0]
+    ref = np.zeros((4, 4))
+    for oh in range(4):
+        for ow in range(4):
+            kh, kw = 3 - 2 * oh + 1, 4 - 2 * ow + 1        # ih = 2*oh + kh - 1
+            if 0 <= kh < 5 and 0 <= kw < 5:
+                ref[oh, ow] = w[kh, kw, 0, 0]
+    assert np.array_equal(y, ref)
+
+
+def test_deconv_is_full_transposed_conv_cropped_at_1():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    x, w = rng.standard_normal((2, 6, 4, 4)), rng.standard_normal((5, 5, 3, 6))
+    y = O.deconv2d(x, w)
+    full = F.conv_transpose2d(torch.tensor(x), torch.tensor(w).permute(3, 2, 0, 1), stride=2).numpy()
+    assert np.abs(y - full[:, :, 1:9, 1:9]).max() < 1e-12
+    wrong = F.conv_transpose2d(torch.tensor(x), torch.tensor(w).permute(3, 2, 0, 1), stride=2, padding=2, output_padding=1).numpy()
+    assert np.abs(y - wrong).max() > 0.1            # the "obvious" torch recipe is a different alignment (A.2)
+
+
+def test_bn_known_answer():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((6, 3, 4, 4)) * 3 + 2
+    y = O.batchnorm_train(x, np.ones(3), np.zeros(3), (0, 2, 3))
+    assert np.abs(y.mean(axis=(0, 2, 3))).max() < 1e-12
+    var = x.var(axis=(0, 2, 3))                       # biased
+    assert np.abs(y.var(axis=(0, 2, 3)) - var / (var + 1e-5)).max() < 1e-12
+
+
+def test_adam_step1_closed_form():
+    g = np.array([1e-3, -2.0, 5.0, -1e-6])
+    th, m, v = O.adam_update(np.zeros(4), g, np.zeros(4), np.zeros(4), 1, 2e-4, 0.5, 0.999)
+    assert np.allclose(th, -2e-4 * g / (np.abs(g) + 1e-8 / np.sqrt(1 - 0.999)), rtol=1e-12)
+
+
+def test_ali_is_local_ep_with_one_factor_and_ratios_sum_to_one():
+    rng = np.random.default_rng(2)
+    f, r = tp.T(rng.standard_normal(8)), tp.T(rng.standard_normal(8))
+    a, b = J.ali_costs(f, r), J.local_ep_costs([f], [r])
+    assert float(a[0].v) == float(b[0].v) and float(a[1].v) == float(b[1].v)
+    LEN = 16
+    ratio = np.array([1] * (LEN - 1) + [1, LEN], dtype=np.float64)
+    ratio = ratio / (len(ratio) + LEN - 1)            # ssgan_inference_moving_mnist.py:78-79
+    assert abs(ratio.sum() - 1.0) < 1e-12 and ratio[-1] == 0.5
+    x = rng.standard_normal(5)
+    assert np.allclose(O.bce_with_logits(x, 1.0), -np.log(O.sigmoid(x)))
+    assert np.allclose(O.bce_with_logits(x, 0.0), -np.log(1 - O.sigmoid(x)))
+
+
+# ---- (iii) torch-CPU cross-check ----------------------------------------------------------------------------
+@pytest.mark.parametrize('H,cin,cout', [(16, 4, 6), (7, 3, 5), (28, 1, 4), (8, 5, 3), (64, 2, 3)])
+def test_conv_family_vs_torch(H, cin, cout):
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(H)
+    x, w = rng.standard_normal((2, cin, H, H)), rng.standard_normal((5, 5, cin, cout))
+    ho, pt, pb = O.conv_geometry(H, 5, 2)
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    yt = F.conv2d(F.pad(xt, (pt, pb, pt, pb)), wt.permute(3, 2, 0, 1), stride=2)
+    assert np.abs(O.conv2d(x, w, 2) - yt.detach().numpy()).max() < 1e-12
+    gy = rng.standard_normal(yt.shape)
+    gx, gw = torch.autograd.grad(yt, [xt, wt], grad_outputs=torch.tensor(gy))
+    assert np.abs(O.conv2d_bwd_data(gy, w, (H, H), 2) - gx.numpy()).max() < 1e-12
+    assert np.abs(O.conv2d_bwd_filter(x, gy, 5, 2) - gw.numpy()).max() < 1e-11
+
+
+def test_full_step_vs_torch_autograd():
+    """The whole gen/disc cost graph (cifar ali, small dims) rebuilt with torch-CPU float64 ops + autograd."""
+    import torch
+    import torch.nn.functional as F
+    cfg = N.Cfg('cifar10', batch_size=4, dim=4, dim_latent=8)
+    P0 = {k: v.astype(np.float64) for k, v in N.init_params(cfg, 3).items()}
+    feed = S.make_feed(cfg, np.random.default_rng(5))
+    Pt = {k: tp.T(v) for k, v in P0.items()}
+    out = S.forward(cfg, Pt, feed, 'ali')
+    T = {k: torch.tensor(v, requires_grad=True) for k, v in P0.items()}
+
+    def conv(x, name):
+        return F.conv2d(F.pad(x, (1, 2, 1, 2)), T[name + '.Filters'].permute(3, 2, 0, 1), T[name + '.Biases'], stride=2)
+
+    def deconv(x, name):
+        H = x.shape[2]
+        y = F.conv_transpose2d(x, T[name + '.Filters'].permute(3, 2, 0, 1), stride=2)[:, :, 1:1 + 2 * H, 1:1 + 2 * H]
+        return y + T[name + '.Biases'].view(1, -1, 1, 1)
+
+    def bn(x, name, axes):
+        m = x.mean(axes, keepdim=True)
+        v = ((x - m) ** 2).mean(axes, keepdim=True)
+        shp = [1 if i in axes else s for i, s in enumerate(x.shape)]
+        return T[name + '.scale'].view(shp) * (x - m) / torch.sqrt(v + 1e-5) + T[name + '.offset'].view(shp)
+    lrelu = lambda x: torch.maximum(0.2 * x, x)
+    real = torch.tensor(S.real_x_from_feed(cfg, feed, np.float64)).view(-1, 3, 32, 32)
+    e = lrelu(conv(real, 'Extractor.1'))
+    e = lrelu(bn(conv(e, 'Extractor.2'), 'Extractor.BN2', (0, 2, 3)))
+    e = lrelu(bn(conv(e, 'Extractor.3'), 'Extractor.BN3', (0, 2, 3)))
+    q_z = e.reshape(4, -1) @ T['Extractor.Output.W'] + T['Extractor.Output.b']
+    p_z = torch.tensor(feed['p_z_noise'].astype(np.float64))
+    g = torch.relu(bn(p_z @ T['Generator.Input.W'] + T['Generator.Input.b'], 'Generator.BN1', (0,)))
+    g = g.view(-1, 16, 4, 4)
+    g = torch.relu(bn(deconv(g, 'Generator.2'), 'Generator.BN2', (0, 2, 3)))
+    g = torch.relu(bn(deconv(g, 'Generator.3'), 'Generator.BN3', (0, 2, 3)))
+    fake = torch.tanh(deconv(g, 'Generator.5'))
+
+    def D(x, z):
+        o = x
+        for i in (1, 2, 3):
+            o = lrelu(conv(o, 'Discriminator.%d' % i))
+        zo = lrelu(z @ T['Discriminator.z1.W'] + T['Discriminator.z1.b'])
+        o = torch.cat([o.reshape(4, -1), zo], 1)
+        o = lrelu(o @ T['Discriminator.zx1.W'] + T['Discriminator.zx1.b'])
+        return (o @ T['Discriminator.Output.W'] + T['Discriminator.Output.b']).view(-1)
+    df, dr = D(fake, p_z), D(real, q_z)
+    bce = F.binary_cross_entropy_with_logits
+    gen = bce(df, torch.ones_like(df)) + bce(dr, torch.zeros_like(dr))
+    disc = bce(df, torch.zeros_like(df)) + bce(dr, torch.ones_like(dr))
+    assert abs(float(gen) - float(out['gen_cost'].v)) < 1e-12
+    assert abs(float(disc) - float(out['disc_cost'].v)) < 1e-12
+    for cost_t, cost_o, sub in ((gen, out['gen_cost'], ('Generator', 'Extractor')), (disc, out['disc_cost'], ('Discriminator',))):
+        names = [n for n in N.trainable(list(P0)) if any(s in n for s in sub)]
+        tg = torch.autograd.grad(cost_t, [T[n] for n in names], retain_graph=True, allow_unused=True)
+        og = tp.grad(cost_o, [Pt[n] for n in names])
+        for n, a, b in zip(names, tg, og):
+            assert np.abs(a.numpy() - b.v).max() < 1e-10, n
+
+
+# ---- (ii) finite differences ---------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode,K,dataset', [('ali', 0, 'cifar10'), ('wali-gp', 0, 'cifar10'), ('ali', 5, 'cifar10'),
+                                            ('ali', 3, 'mnist'), ('ali', 3, 'face')])
+def test_costs_finite_differences(mode, K, dataset):
+    cfg = N.Cfg(dataset, batch_size=3, n_coms=K, dim=4, dim_latent=6, temp=1.0)
+    rng = np.random.default_rng(2)
+    P = {k: v.astype(np.float64) + (0.1 * rng.standard_normal(v.shape) if v.ndim <= 2 else 0) for k, v in N.init_params(cfg, 0).items()}
+    feed = S.make_feed(cfg, np.random.default_rng(1), mode)
+
+    def costs(Pd):
+        Pt = {k: tp.T(v) for k, v in Pd.items()}
+        return S.forward(cfg, Pt, feed, mode), Pt
+    out, Pt = costs(P)
+    names = N.trainable(list(P))
+    for which in ('gen', 'disc'):
+        gs = tp.grad(out[which + '_cost'], [Pt[n] for n in names])
+        gmax = max(np.abs(g.v).max() for g in gs if g is not None)
+        for n, g in zip(names, gs):
+            if g is None:
+                continue
+            idx = tuple(np.random.default_rng(3).integers(0, s) for s in P[n].shape)
+            e = 1e-6
+            Pp = {k: v.copy() for k, v in P.items()}; Pp[n][idx] += e
+            Pm = {k: v.copy() for k, v in P.items()}; Pm[n][idx] -= e
+            fd = (float(costs(Pp)[0][which + '_cost'].v) - float(costs(Pm)[0][which + '_cost'].v)) / (2 * e)
+            assert abs(fd - g.v[idx]) <= 1e-6 * max(abs(fd), gmax) + 1e-9, (which, n, fd, g.v[idx])
+
+
+# ---- (iv) committed goldens ------------------------------------------------------------------------------------
+def test_oracle_reproduces_op_goldens():
+    z = load('ops_small')
+    for tag, h in (('a', 8), ('b', 7), ('c', 28)):
+        x, w, gy = (z['conv_%s_%s' % (tag, k)].astype(np.float64) for k in ('x', 'w', 'gy'))
+        assert np.abs(O.conv2d(x, w, 2) - z['conv_%s_y' % tag]).max() < 1e-12
+        assert np.abs(O.conv2d_bwd_data(gy, w, (h, h), 2) - z['conv_%s_gx' % tag]).max() < 1e-12
+        assert np.abs(O.conv2d_bwd_filter(x, gy, 5, 2) - z['conv_%s_gw' % tag]).max() < 1e-11
+    assert np.abs(O.deconv2d(z['deconv_x'].astype(np.float64), z['deconv_w'].astype(np.float64)) - z['deconv_y']).max() < 1e-12
+    assert np.abs(O.bce_with_logits(z['bce_x'].astype(np.float64), 1.0) - z['bce_1']).max() < 1e-14
+
+
+@pytest.mark.parametrize('name', ['traj_cifar_ali', 'traj_cifar_wali_gp'])
+def test_oracle_reproduces_trajectory_goldens(name):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import make_golden as MG
+    dataset, B, K, mode, dim, dl, iters = MG.TRAJ[name]
+    z = load(name)
+    cfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl)
+    tr = S.Trainer(cfg, MG.perturbed_params(cfg), mode, np.float64)
+    feeds = iter(traj_feeds(z))
+    for it in range(iters):
+        r = tr.iteration(it, feeds)
+        if it > 0:
+            assert abs(r['gen_cost'] - z['costs'][it, 0]) < 1e-10
+        assert abs(r['disc_cost'] - z['costs'][it, 1]) < 1e-10
+    for k, v in tr.P.items():
+        assert np.abs(digest(v) - z['p1/' + k]).max() < 1e-7 * max(1.0, np.abs(z['p1/' + k]).max()), k
