@@ -2,6 +2,7 @@
 // (5x5 stride-2 hot path) and the plain kernels (everything else, or ggan_set_naive(1)).
 #include "common.h"
 #include "conv.h"
+#include <stdlib.h>
 using namespace ggan;
 
 namespace {
@@ -33,7 +34,7 @@ int ggan_conv2d_fwd(const ggan_conv_geom* g, const float* x, const float* w, con
     if (check_geom(g)) return -1;
     GGAN_CHECK_ARG(x && w && y, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (!g_force_naive) {
+    if (!g_force_naive && !getenv("GGAN_NAIVE_FWD")) {
         int r = conv_fwd_mfma(*g, x, w, bias, y, act, alpha, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
     }
@@ -45,7 +46,7 @@ int ggan_conv2d_bwd_data(const ggan_conv_geom* g, const float* gy, const float* 
     if (check_geom(g)) return -1;
     GGAN_CHECK_ARG(gy && w && gx, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (!g_force_naive) {
+    if (!g_force_naive && !getenv("GGAN_NAIVE_DGRAD")) {
         int r = conv_dgrad_mfma(*g, gy, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
     }
@@ -61,7 +62,7 @@ int ggan_conv2d_bwd_filter(const ggan_conv_geom* g, const float* x, const float*
         int r = ggan_chansum(gy, gbias, g->N, g->Co, g->Ho * g->Wo, stream);
         if (r) return r;
     }
-    if (!g_force_naive) {
+    if (!g_force_naive && !getenv("GGAN_NAIVE_WGRAD")) {
         int r = conv_wgrad_mfma(*g, x, gy, gw, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
     }

@@ -1,0 +1,533 @@
+// fp32-MFMA "strided correlation" kernel for gfx950 (CDNA4): Conv2D / Deconv2D forward and data-gradients.
+//
+//   out[n,cn,U,V] = sum_{ck,i,j} in[n,ck, SU*u+DI*i+.., SU*v+DI*j+..] * w[i,j,ck,cn]
+//
+//   fwd    (Conv2D forward, Deconv2D data-gradient): SU=2, DI=+1, 5x5 taps, ck=Ci, cn=Co, filter rows contiguous in cn.
+//   dgrad  (Conv2D data-gradient, Deconv2D FORWARD): the stride-2 transposed conv is split into its 4 output parity
+//          classes; each is a dense stride-1 correlation (DI=-1) with a 3x3 / 3x2 / 2x3 / 2x2 sub-filter, so no MFMA
+//          multiplies the structural zeros of a zero-insertion formulation.  One workgroup computes a PAIR of classes
+//          {3x3 + 2x2} or {3x2 + 2x3} (13 / 12 taps: balanced) from ONE staged gy slab.
+//
+// Implicit GEMM with v_mfma_f32_32x32x2_f32 (exact fp32).  Per workgroup (4 waves, one per SIMD):
+//   * LDS slab = raw input patch of the pixel tile for CK reduction channels, zero halo (= TF SAME padding) so the
+//     MFMA loop has no bounds checks: fragment address = per-lane base + wave-uniform tap offset;
+//   * LDS filter slice [tap][ck][cn]; the FILTER is the MFMA A operand (rows -> accumulator registers), pixels are the
+//     B operand (cols -> lanes), so every accumulator store is a coalesced run of NCHW floats;
+//   * staging = raw buffer loads (hardware bounds check returns 0 for the halo: no branches, no selects) issued into
+//     registers BEFORE the MFMA block of the current chunk and committed to LDS after it (async-STAGE split);
+//   * wave layout WM x WN x KS: KS > 1 splits the reduction channels of each chunk across waves and combines the
+//     accumulators through LDS at the end.  The problems here are small GEMMs (1024..16384 pixels x 32..256 channels);
+//     picking (2,2,1) / (2,1,2) / (1,1,4) per layer yields >= 256 workgroups (one per CU) WITHOUT a global split-K pass.
+//     A deterministic global split-K (partial slabs + reduce) remains as a fallback for even smaller problems.
+#include "common.h"
+#include "conv.h"
+#include <stdlib.h>
+using namespace ggan;
+
+namespace {
+
+constexpr int XE_MAX = 12;                 // slab elements staged per thread per chunk
+constexpr unsigned OOB = 0x7FFFFFF0u;      // voffset >= num_records: the buffer load returns 0
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct CorrClass {
+    int Hu, Wv;        // pixel grid of this class
+    int roff, coff;    // slab row/col of tap (0,0) for pixel (0,0)
+    int or0, oc0;      // output row = or0 + ors*u
+    int wbase;         // filter offset of tap (0,0) (floats)
+    int pad_;
+};
+
+struct CorrParams {
+    const float* in;
+    const float* w;
+    const float* bias;
+    float* out;
+    int N, CKtot, Hin, Win;
+    int CNtot, Hout, Wout;
+    int ors, ocs;
+    int w_si, w_sj, w_sk, w_sn;
+    int TR, TC, TI;
+    int SR, SCp, CS;
+    int row0, col0;
+    FastDiv d_CS, d_SRSC, d_SCp, d_TRTC, d_TC;
+    int img_groups, tiles_r, tiles_c;
+    int cps, SK;
+    int act;
+    float alpha;
+    unsigned in_bytes, w_bytes;
+    int dbg;
+    size_t out_elems;
+    CorrClass cls[4];
+};
+
+// One chunk's MFMAs for one class (the compiler interleaves the LDS fragment reads with the MFMAs; explicit
+// row-ahead prefetch pinned with sched_barrier measured SLOWER: 28.9 vs 25.7 us on the 64->128 @16 layer).
+template <int TH, int TW, int DI, int PW, int CK, int TNW>
+__device__ __forceinline__ void mma_taps(const float* __restrict__ xs, const float* __restrict__ ws, int xfrag, int wfrag,
+                                         int CS, int SCp, f32x16& acc) {
+#pragma unroll
+    for (int i = 0; i < TH; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int p = 0; p < PW; ++p) {
+                const float a = ws[((i * TW + j) * CK + p * 2) * TNW + wfrag];
+                const float b = xs[p * 2 * CS + xfrag + DI * (i * SCp + j)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+}
+
+// NC classes (1 for fwd, 2 for a dgrad pair) with tap grids (TH0,TW0) / (TH1,TW1).
+template <int NC, int TH0, int TW0, int TH1, int TW1, int SU, int DI, int WM, int WN, int KS, int PW>
+__device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& c0, const CorrClass& c1, const int split,
+                                          float* smem) {
+    constexpr int CK = 2 * KS * PW;
+    constexpr int TNW = 32 * WN;
+    constexpr int NT0 = TH0 * TW0, NT1 = NC > 1 ? TH1 * TW1 : 0, NTT = NT0 + NT1;
+    constexpr int WUNITS = NTT * CK * (TNW / 4);
+    constexpr int WE = (WUNITS + 255) / 256;
+    static_assert(WM * WN * KS == 4, "4 waves per workgroup");
+    static_assert(CK % 4 == 0, "chunk must hold whole float4 groups");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = (wave / WM) % WN, ks = wave / (WM * WN);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // ---- which tile ---------------------------------------------------------------------------------
+    const int tiles_per_img = P.tiles_r * P.tiles_c;
+    const int ig = blockIdx.x / tiles_per_img;
+    const int tt = blockIdx.x - ig * tiles_per_img;
+    const int tr = tt / P.tiles_c, tc = tt - tr * P.tiles_c;
+    const int n0 = ig * P.TI, u0 = tr * P.TR, v0 = tc * P.TC;
+    const int cn0 = blockIdx.y * TNW;
+    const int ck_begin = split * P.cps;
+    const int ck_end = min(ck_begin + P.cps, P.CKtot);
+    const int in_row0 = SU * u0 + P.row0, in_col0 = SU * v0 + P.col0;
+    const int HWin = P.Hin * P.Win;
+
+    // two staging buffers: [CK][CS] slab + [NTT][CK][TNW] filter slice each
+    const int XS_SZ = (CK * P.CS + 3) & ~3;
+    const int STAGE = XS_SZ + NTT * CK * TNW;
+
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, (short)0, (int)P.in_bytes, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)P.w_bytes, 0x00020000);
+
+    // ---- per-thread staging descriptors (fixed across chunks) ---------------------------------------------
+    unsigned xvo[XE_MAX];
+    const int xe_cnt = CK * P.CS;
+#pragma unroll
+    for (int j = 0; j < XE_MAX; ++j) {
+        const int e = tid + j * 256;
+        unsigned off = OOB;
+        if (e < xe_cnt) {
+            const int ckl = fdiv(e, P.d_CS);
+            const int r1 = e - ckl * P.CS;
+            const int img = fdiv(r1, P.d_SRSC);
+            const int r2 = r1 - img * (P.SR * P.SCp);
+            const int r = fdiv(r2, P.d_SCp);
+            const int cc = r2 - r * P.SCp;
+            const int ih = in_row0 + r, iw = in_col0 + cc, n = n0 + img;
+            if (n < P.N && ih >= 0 && ih < P.Hin && iw >= 0 && iw < P.Win)
+                off = (unsigned)(((n * P.CKtot + ckl) * P.Hin + ih) * P.Win + iw) * 4u;
+        }
+        xvo[j] = off;
+    }
+    unsigned wvo[WE];
+    int wlds[WE], wck[WE];
+#pragma unroll
+    for (int q = 0; q < WE; ++q) {
+        const int u = tid + q * 256;
+        unsigned off = OOB;
+        int l = 0, ckl = 0;
+        if (u < WUNITS) {
+            // unit = (tap, ck, cn4): 4 consecutive cn in memory => every wave-load is a run of whole 128-B filter rows
+            const int cn = (u % (TNW / 4)) * 4;
+            ckl = (u / (TNW / 4)) % CK;
+            const int tapg = u / (CK * (TNW / 4));
+            const bool second = NC > 1 && tapg >= NT0;
+            const int tap = second ? tapg - NT0 : tapg;
+            const int tw = second ? TW1 : TW0;
+            const int i = tap / tw, j = tap - i * tw;
+            const int wb = second ? c1.wbase : c0.wbase;
+            if (cn0 + cn < P.CNtot)
+                off = (unsigned)(wb + i * P.w_si + j * P.w_sj + ckl * P.w_sk + (cn0 + cn) * P.w_sn) * 4u;
+            l = (tapg * CK + ckl) * TNW + cn;
+        }
+        wvo[q] = off;
+        wlds[q] = l;
+        wck[q] = ckl;
+    }
+
+    // ---- per-lane MFMA fragment bases ----------------------------------------------------------------------
+    int xfrag0, xfrag1 = 0, o_off0 = 0, o_off1 = 0;
+    bool ok0, ok1 = false;
+    {
+        const int p = wm * 32 + l31;
+        const int img = fdiv(p, P.d_TRTC);
+        const int rem = p - img * (P.TR * P.TC);
+        const int ur = fdiv(rem, P.d_TC);
+        const int vc = rem - ur * P.TC;
+        const bool in_tile = img < P.TI && (n0 + img) < P.N;
+        const int kbase = (ks * PW * 2 + half) * P.CS;
+        const int b = in_tile ? img * (P.SR * P.SCp) + SU * ur * P.SCp + SU * vc : 0;
+        ok0 = in_tile && (u0 + ur) < c0.Hu && (v0 + vc) < c0.Wv;
+        xfrag0 = kbase + b + c0.roff * P.SCp + c0.coff;
+        if (ok0) o_off0 = (((n0 + img) * P.CNtot) * P.Hout + (c0.or0 + P.ors * (u0 + ur))) * P.Wout + (c0.oc0 + P.ocs * (v0 + vc));
+        if (NC > 1) {
+            ok1 = in_tile && (u0 + ur) < c1.Hu && (v0 + vc) < c1.Wv;
+            xfrag1 = kbase + b + c1.roff * P.SCp + c1.coff;
+            if (ok1) o_off1 = (((n0 + img) * P.CNtot) * P.Hout + (c1.or0 + P.ors * (u0 + ur))) * P.Wout + (c1.oc0 + P.ocs * (v0 + vc));
+        }
+    }
+    const int wfrag = (ks * PW * 2 + half) * TNW + wn * 32 + l31;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    unsigned xreg[XE_MAX];
+    u32x4 wreg[WE];
+
+    auto prefetch = [&](int ck0) {
+        const int soff_x = ck0 * HWin * 4;
+        const int soff_w = ck0 * P.w_sk * 4;
+#pragma unroll
+        for (int j = 0; j < XE_MAX; ++j) xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, xvo[j], soff_x, 0);
+#pragma unroll
+        for (int q = 0; q < WE; ++q) {
+            const unsigned vo = (ck0 + wck[q] < ck_end) ? wvo[q] : OOB;     // reduction-channel tail -> zero filter rows
+            wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, vo, soff_w, 0);
+        }
+    };
+
+    auto commit = [&](int buf) {
+        float* xsb = smem + buf * STAGE;
+        float* wsb = xsb + XS_SZ;
+#pragma unroll
+        for (int j = 0; j < XE_MAX; ++j) {
+            const int e = tid + j * 256;
+            if (e < xe_cnt) xsb[e] = __uint_as_float(xreg[j]);
+        }
+#pragma unroll
+        for (int q = 0; q < WE; ++q) {
+            const int u = tid + q * 256;
+            if (u < WUNITS) {
+                *reinterpret_cast<u32x4*>(wsb + wlds[q]) = wreg[q];
+            }
+        }
+    };
+
+    // ---- main loop over reduction-channel chunks: chunk c is multiplied out of buffer c&1 while chunk c+1 is committed
+    //      to the other buffer and chunk c+2's global loads are in flight; ONE barrier per chunk ---------------------
+    prefetch(ck_begin);
+    commit(0);
+    if (ck_begin + CK < ck_end) prefetch(ck_begin + CK);
+    __syncthreads();
+    int buf = 0;
+    for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
+        if (ck0 + CK < ck_end && !(P.dbg & 1)) {
+            commit(buf ^ 1);
+            if (ck0 + 2 * CK < ck_end) prefetch(ck0 + 2 * CK);
+        }
+        if (!(P.dbg & 2)) {
+            const float* xs = smem + ((P.dbg & 1) ? 0 : buf * STAGE);
+            const float* ws = xs + XS_SZ;
+            mma_taps<TH0, TW0, DI, PW, CK, TNW>(xs, ws, xfrag0, wfrag, P.CS, P.SCp, acc0);
+            if (NC > 1) mma_taps<TH1, TW1, DI, PW, CK, TNW>(xs, ws + NT0 * CK * TNW, xfrag1, wfrag, P.CS, P.SCp, acc1);
+        }
+        __syncthreads();
+    }
+
+    // ---- combine the k-split waves through LDS ---------------------------------------------------------------
+    if (KS > 1) {
+        float* red = smem;     // [(KS-1)][NC][16][64 * WM * WN]
+        constexpr int LANES = 64 * WM * WN;
+        const int slot = lane + 64 * (wm + WM * wn);
+        if (ks > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[(((ks - 1) * NC + 0) * 16 + r) * LANES + slot] = acc0[r];
+                if (NC > 1) red[(((ks - 1) * NC + 1) * 16 + r) * LANES + slot] = acc1[r];
+            }
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] += red[((k * NC + 0) * 16 + r) * LANES + slot];
+                if (NC > 1) acc1[r] += red[((k * NC + 1) * 16 + r) * LANES + slot];
+            }
+    }
+
+    // ---- epilogue: lanes run along pixels => coalesced NCHW stores ---------------------------------------------
+    const bool direct = P.SK == 1;
+    float* outp = direct ? P.out : P.out + (size_t)split * P.out_elems;   // P.out = partial slab when SK > 1
+    const int chw = P.Hout * P.Wout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cn = cn0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (cn < P.CNtot) {
+            const float bv = (direct && P.bias) ? P.bias[cn] : 0.f;
+            if (ok0) {
+                float v = acc0[r];
+                if (direct) v = act_apply(v + bv, P.act, P.alpha);
+                outp[(size_t)o_off0 + (size_t)cn * chw] = v;
+            }
+            if (NC > 1 && ok1) {
+                float v = acc1[r];
+                if (direct) v = act_apply(v + bv, P.act, P.alpha);
+                outp[(size_t)o_off1 + (size_t)cn * chw] = v;
+            }
+        }
+    }
+}
+
+// MODE 0: fwd (one 5x5 class).  MODE 1: dgrad class pairs, blockIdx.z = pair * SK + split.
+template <int MODE, int WM, int WN, int KS, int PW>
+__global__ __launch_bounds__(256) void corr_kernel(const CorrParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = blockIdx.z / P.SK, split = blockIdx.z - grp * P.SK;
+    if (MODE == 0) {
+        corr_body<1, 5, 5, 1, 1, 2, 1, WM, WN, KS, PW>(P, P.cls[0], P.cls[0], split, smem);
+    } else if (grp == 0) {
+        corr_body<2, 3, 3, 2, 2, 1, -1, WM, WN, KS, PW>(P, P.cls[0], P.cls[3], split, smem);
+    } else {
+        corr_body<2, 3, 2, 2, 3, 1, -1, WM, WN, KS, PW>(P, P.cls[1], P.cls[2], split, smem);
+    }
+}
+
+// out[idx] = act(sum_s partial[s][idx] + bias[c])
+__global__ void splitk_reduce_k(const float* __restrict__ partial, int SK, size_t elems, float* __restrict__ out,
+                                const float* __restrict__ bias, int C, int HW, int act, float alpha) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < SK; ++k) s += partial[(size_t)k * elems + i];
+        if (bias) s += bias[(i / (size_t)HW) % (size_t)C];
+        out[i] = act_apply(s, act, alpha);
+    }
+}
+
+// wT[t][co][cip] = w[t][ci][co] (cip = Ci rounded up to 4, zero filled): gives the data-gradient the same
+// "rows contiguous in the output-channel index" filter layout the forward pass has.
+__global__ void filter_transpose_k(const float* __restrict__ w, float* __restrict__ wT, int Ci, int Co, int Cip) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < Ci && co < Co) ? w[((size_t)t * Ci + ci) * Co + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < Co && ci < Cip) wT[((size_t)t * Co + co) * Cip + ci] = tile[tx][r];
+    }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+struct WaveCfg { int WM, WN, KS, PW; };
+const WaveCfg kCfgs[3] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}};
+
+// pixel tile TI x TR x TC <= TM whose CK-channel slab fits the per-thread staging budget
+bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r, int ext_c) {
+    P.TC = Wv < TM ? Wv : TM;
+    P.TR = TM / P.TC; if (P.TR < 1) P.TR = 1; if (P.TR > Hu) P.TR = Hu;
+    P.TI = TM / (P.TR * P.TC); if (P.TI < 1) P.TI = 1; if (P.TI > P.N) P.TI = P.N;
+    for (;;) {
+        P.SR = su * (P.TR - 1) + ext_r;
+        P.SCp = su * (P.TC - 1) + ext_c;
+        P.CS = P.TI * P.SR * P.SCp;
+        if (CK * P.CS <= XE_MAX * 256) return true;
+        if (P.TI > 1) P.TI = (P.TI + 1) / 2;
+        else if (P.TR > 1) P.TR = (P.TR + 1) / 2;
+        else return false;
+    }
+}
+
+void finish_tile(CorrParams& P, int Hu, int Wv) {
+    P.d_CS = make_fastdiv(P.CS); P.d_SRSC = make_fastdiv(P.SR * P.SCp); P.d_SCp = make_fastdiv(P.SCp);
+    P.d_TRTC = make_fastdiv(P.TR * P.TC); P.d_TC = make_fastdiv(P.TC);
+    P.img_groups = cdiv(P.N, P.TI);
+    P.tiles_r = cdiv(Hu, P.TR); P.tiles_c = cdiv(Wv, P.TC);
+}
+
+template <int MODE>
+int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_t s, const char* name, double fl) {
+    switch (cfg) {
+        case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
+        case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
+        default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+    }
+    return 0;
+}
+
+// common tail: wave-config choice, split-K fallback, launch
+template <int MODE>
+int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c, int ntaps, int groups, float* dst,
+                    const float* bias, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s, const char* name,
+                    double fl, const char* sk_env, const char* cfg_env) {
+    const int target = env_int("GGAN_TARGET_WGS", 200);
+    int cfg = env_int(cfg_env, -1);
+    if (cfg < 0 || cfg > 2) {
+        cfg = 2;
+        for (int c = 0; c < 3; ++c) {
+            const WaveCfg& wc = kCfgs[c];
+            const int CK = 2 * wc.KS * wc.PW, TM = 32 * wc.WM, TNW = 32 * wc.WN;
+            if (c < 2 && P.CNtot <= 32 && TNW > 32 && c == 0) continue;          // don't pad tiny channel counts to 64
+            if (P.CKtot < CK && c > 0) continue;                                   // tiny reductions: smallest chunk
+            CorrParams T = P;
+            if (!pick_tile(T, Hu, Wv, TM, CK, su, ext_r, ext_c)) continue;
+            if (c < 2 && T.TI * T.TR * T.TC * 2 <= TM && Hu * Wv * P.N >= TM) continue;   // staging budget forced a half-empty tile
+            const int wgs = cdiv(P.N, T.TI) * cdiv(Hu, T.TR) * cdiv(Wv, T.TC) * cdiv(P.CNtot, TNW) * groups;
+            if (wgs >= target || c == 2) { cfg = c; break; }
+        }
+        if (P.CKtot < 8) cfg = 0;
+    }
+    const WaveCfg& wc = kCfgs[cfg];
+    const int CK = 2 * wc.KS * wc.PW, TM = 32 * wc.WM, TNW = 32 * wc.WN;
+    if (!pick_tile(P, Hu, Wv, TM, CK, su, ext_r, ext_c)) return 1;
+    finish_tile(P, Hu, Wv);
+    const int gx = P.img_groups * P.tiles_r * P.tiles_c, gy = cdiv(P.CNtot, TNW);
+    int sk = env_int(sk_env, 0);
+    if (sk <= 0) {
+        sk = 1;
+        const int base = gx * gy * groups;
+        if (base < target / 2) {            // still far from one workgroup per CU: global split-K
+            sk = target / base;
+            const int max_sk = P.CKtot / (2 * CK);
+            if (sk > max_sk) sk = max_sk;
+            if (sk > 16) sk = 16;
+        }
+    }
+    if (sk < 1) sk = 1;
+    P.cps = cdiv(cdiv(P.CKtot, sk), CK) * CK;
+    P.SK = cdiv(P.CKtot, P.cps);
+    if (P.SK > 1 && (size_t)P.SK * P.out_elems * sizeof(float) > ws_bytes) {
+        P.SK = 1;
+        P.cps = cdiv(P.CKtot, CK) * CK;
+    }
+    P.out = P.SK > 1 ? (float*)ws : dst;
+    P.bias = bias; P.act = act; P.alpha = alpha;
+    P.dbg = env_int("GGAN_DBG", 0);
+    size_t stage = 2 * ((size_t)((CK * P.CS + 3) & ~3) + (size_t)ntaps * CK * TNW);
+    size_t red = (size_t)(wc.KS - 1) * (groups > 1 ? 2 : 1) * 16 * 64 * wc.WM * wc.WN;
+    const size_t shmem = (stage > red ? stage : red) * sizeof(float);
+    int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
+    if (rc) return rc;
+    if (P.SK > 1)
+        return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, dst, bias, P.CNtot, P.Hout * P.Wout, act, alpha, s);
+    return 0;
+}
+
+}  // namespace
+
+namespace ggan {
+
+int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,
+                         float alpha, hipStream_t s) {
+    size_t b = (elems + 255) / 256;
+    if (b > 2048) b = 2048;
+    GGAN_LAUNCH("conv_splitk_reduce", 0, 4.0 * elems * (SK + 1), splitk_reduce_k, dim3((int)b), dim3(256), 0, s, partial,
+                SK, elems, out, bias, C, HW, act, alpha);
+    return 0;
+}
+
+size_t conv_workspace_bytes(const ggan_conv_geom& g) {
+    // upper bound over the three ops: 16 split-K slabs of the largest result / 64 filter-gradient slabs
+    size_t big = (size_t)g.N * g.Ci * g.H * g.W, small_ = (size_t)g.N * g.Co * g.Ho * g.Wo;
+    size_t wsz = (size_t)g.k * g.k * g.Ci * g.Co;
+    size_t m = big > small_ ? big : small_;
+    size_t a = 16 * m * sizeof(float), b = 64 * wsz * sizeof(float);
+    return a > b ? a : b;
+}
+
+static bool hot_geometry(const ggan_conv_geom& g) { return g.k == 5 && g.stride == 2; }
+static bool fits32(size_t bytes) { return bytes < 0x7FFFFFF0ull; }
+
+int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
+                  float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!hot_geometry(g) || (g.Co & 3)) return 1;
+    const size_t in_bytes = (size_t)g.N * g.Ci * g.H * g.W * 4, w_bytes = (size_t)25 * g.Ci * g.Co * 4;
+    if (!fits32(in_bytes) || !fits32(w_bytes) || !fits32((size_t)g.N * g.Co * g.Ho * g.Wo * 4)) return 1;
+    if (((uintptr_t)w & 15) != 0) return 1;
+    CorrParams P;
+    memset(&P, 0, sizeof(P));
+    P.in = x; P.w = w;
+    P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
+    P.N = g.N; P.CKtot = g.Ci; P.Hin = g.H; P.Win = g.W;
+    P.CNtot = g.Co; P.Hout = g.Ho; P.Wout = g.Wo;
+    P.ors = 1; P.ocs = 1;
+    P.w_si = g.k * g.Ci * g.Co; P.w_sj = g.Ci * g.Co; P.w_sk = g.Co; P.w_sn = 1;
+    P.row0 = -g.pad_t; P.col0 = -g.pad_l;
+    CorrClass& c = P.cls[0];
+    c.Hu = g.Ho; c.Wv = g.Wo; c.roff = 0; c.coff = 0; c.or0 = 0; c.oc0 = 0; c.wbase = 0;
+    P.out_elems = (size_t)g.N * g.Co * g.Ho * g.Wo;
+    const double fl = 2.0 * P.out_elems * g.Ci * 25.0;
+    return plan_and_launch<0>(P, g.Ho, g.Wo, 2, 5, 5, 25, 1, y, bias, act, alpha, ws, ws_bytes, s, "conv_fwd_mfma", fl,
+                              "GGAN_FWD_SK", "GGAN_FWD_CFG");
+}
+
+int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
+                    float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!hot_geometry(g)) return 1;
+    const int Cip = (g.Ci + 3) & ~3;
+    const size_t in_bytes = (size_t)g.N * g.Co * g.Ho * g.Wo * 4, w_bytes = (size_t)25 * g.Co * Cip * 4;
+    if (!fits32(in_bytes) || !fits32(w_bytes) || !fits32((size_t)g.N * g.Ci * g.H * g.W * 4)) return 1;
+    const size_t wT_bytes = (w_bytes + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < wT_bytes) return 1;
+    float* wT = (float*)ws;
+    {
+        const double by = 2.0 * 25 * g.Ci * g.Co * 4;
+        GGAN_LAUNCH("conv_filter_transpose", 0, by, filter_transpose_k, dim3(cdiv(Cip, 32), cdiv(g.Co, 32), 25), dim3(32, 8), 0, s,
+                    w, wT, g.Ci, g.Co, Cip);
+    }
+    ws = (char*)ws + wT_bytes;
+    ws_bytes -= wT_bytes;
+    const int S = 2;
+    CorrParams P;
+    memset(&P, 0, sizeof(P));
+    P.in = gy; P.w = wT;
+    P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
+    P.N = g.N; P.CKtot = g.Co; P.Hin = g.Ho; P.Win = g.Wo;
+    P.CNtot = g.Ci; P.Hout = g.H; P.Wout = g.W;
+    P.ors = S; P.ocs = S;
+    P.w_si = S * g.k * g.Co * Cip; P.w_sj = S * g.Co * Cip; P.w_sk = Cip; P.w_sn = 1;
+    // per dimension and parity p (kh = p + S*i): output positions ih = off + S*a, input row oh = a + base - i
+    int offs[2][2], bases[2][2], cnt[2][2], th[2][2], lo[2], hi[2];
+    for (int d = 0; d < 2; ++d) {
+        const int pad = d == 0 ? g.pad_t : g.pad_l, L = d == 0 ? g.H : g.W;
+        lo[d] = 1 << 30; hi[d] = -(1 << 30);
+        for (int p = 0; p < S; ++p) {
+            const int off = ((p - pad) % S + S) % S;
+            offs[d][p] = off;
+            bases[d][p] = (off + pad - p) / S;
+            cnt[d][p] = off < L ? (L - off + S - 1) / S : 0;
+            th[d][p] = (g.k - p + S - 1) / S;
+            if (bases[d][p] - (th[d][p] - 1) < lo[d]) lo[d] = bases[d][p] - (th[d][p] - 1);
+            if (bases[d][p] > hi[d]) hi[d] = bases[d][p];
+        }
+    }
+    const int Hu = cnt[0][0] > cnt[0][1] ? cnt[0][0] : cnt[0][1];
+    const int Wv = cnt[1][0] > cnt[1][1] ? cnt[1][0] : cnt[1][1];
+    P.row0 = lo[0]; P.col0 = lo[1];
+    for (int ph = 0; ph < S; ++ph)
+        for (int pw = 0; pw < S; ++pw) {
+            CorrClass& c = P.cls[ph * 2 + pw];
+            c.Hu = cnt[0][ph]; c.Wv = cnt[1][pw];
+            c.roff = bases[0][ph] - lo[0]; c.coff = bases[1][pw] - lo[1];
+            c.or0 = offs[0][ph]; c.oc0 = offs[1][pw];
+            c.wbase = (ph * g.k + pw) * g.Co * Cip;
+        }
+    P.out_elems = (size_t)g.N * g.Ci * g.H * g.W;
+    const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
+    return plan_and_launch<1>(P, Hu, Wv, 1, hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, 13, 2, gx, bias, act, alpha, ws, ws_bytes,
+                              s, "conv_dgrad_mfma", fl, "GGAN_DGRAD_SK", "GGAN_DGRAD_CFG");
+}
+
+}  // namespace ggan

@@ -1,0 +1,285 @@
+// fp32-MFMA filter-gradient kernel for gfx950 (CDNA4): Conv2DBackpropFilter of the 5x5 stride-2 layers (and, with the
+// roles of the two tensors swapped, of Deconv2D).
+//
+//   gw[kh,kw,ci,co] = sum_{n,oh,ow} x[n,ci,2*oh+kh-pt,2*ow+kw-pl] * gy[n,co,oh,ow]
+//
+// GEMM per tap: M = ci, N = co, K = pixels.  v_mfma_f32_16x16x4_f32 so that ONE wave holds all 25 taps of a 16x16 (ci,co)
+// tile in 100 accumulator registers; a k-step is 4 consecutive pixels along ow: 1 gy-fragment read + 25 x-fragment reads
+// (lane base + immediate tap offset into the zero-haloed x slab) + 25 MFMAs.  The 4 waves of a workgroup take different
+// pixel quads of the staged chunk (in-workgroup split-K) and combine through LDS at the end, so only a light global
+// split-K over image groups is needed to reach one workgroup per CU (deterministic partial slabs, no atomics).
+//
+// LDS x slab: [16 ci][TI images][SR rows][even cols | odd cols]; de-interleaving the columns by parity turns the stride-2
+// pixel walk into stride-1 LDS addresses, and a channel stride == 2 (mod 32) makes the 16ci x 2px half-wave fragment read
+// conflict-free.  Staging = 16-byte raw buffer loads of whole image rows (hardware bounds check supplies the zero rows),
+// prefetched into registers under the MFMA block of the previous chunk; halo columns are zeroed once.
+#include "common.h"
+#include "conv.h"
+#include <stdlib.h>
+using namespace ggan;
+
+namespace {
+
+constexpr int TCI = 16, TCO = 16;
+constexpr int XU_MAX = 8;                  // float4 slab units per thread per chunk
+constexpr unsigned OOB = 0x7FFFFFF0u;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct WgradParams {
+    const float* x;
+    const float* gy;
+    float* out;          // gw, or the partial slabs when SK > 1
+    int N, Ci, H, W, Co, Ho, Wo;
+    int pad_t;
+    int TR, TI;          // pixel chunk = TI images x TR rows x Wo cols (<= 64 pixels, multiple of 4)
+    int SR, SCp, SCh, CS;
+    int PC, PCp;
+    FastDiv d_F4, d_SR, d_TI, d_PC4, d_TRWo, d_Wo;
+    int row_tiles, chunks_total, chunks_per_split, SK;
+    int xunits;
+    unsigned x_bytes, gy_bytes;
+    size_t out_elems;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 5, NT = 25;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, qq = lane >> 4;
+    const int ci0 = blockIdx.x * TCI, co0 = blockIdx.y * TCO, split = blockIdx.z;
+
+    float* xs = smem;                      // [TCI][CS]
+    float* gs = smem + TCI * P.CS;         // [TCO][PCp]
+    const int HW = P.H * P.W, HoWo = P.Ho * P.Wo, F4 = P.W >> 2;
+
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, (int)P.x_bytes, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)P.gy, (short)0, (int)P.gy_bytes, 0x00020000);
+
+    // ---- staging descriptors -----------------------------------------------------------------------------
+    int xrel[XU_MAX], xinfo[XU_MAX], xlds[XU_MAX];
+#pragma unroll
+    for (int j = 0; j < XU_MAX; ++j) {
+        const int u = tid + j * 256;
+        int rel = 0, info = -1, l = 0;
+        if (u < P.xunits) {
+            const int row = fdiv(u, P.d_F4);
+            const int f4 = u - row * F4;
+            const int t = fdiv(row, P.d_SR);
+            const int r = row - t * P.SR;
+            const int cil = fdiv(t, P.d_TI);
+            const int img = t - cil * P.TI;
+            rel = (img * P.Ci + cil) * HW + r * P.W + f4 * 4;
+            info = (ci0 + cil < P.Ci) ? (r | (img << 8)) : -1;
+            l = cil * P.CS + (img * P.SR + r) * P.SCp + 2 * f4 + 2;     // even-plane index of slab col 4*f4+4
+        }
+        xrel[j] = rel; xinfo[j] = info; xlds[j] = l;
+    }
+    // gy tile: one float4 (4 consecutive pixels) per thread
+    const int gcol = fdiv(tid, P.d_PC4);
+    const int gp4 = tid - gcol * (P.PC >> 2);
+    int grel, gimg, gr;
+    {
+        const int p = gp4 * 4;
+        gimg = fdiv(p, P.d_TRWo);
+        const int rem = p - gimg * (P.TR * P.Wo);
+        gr = fdiv(rem, P.d_Wo);
+        const int c = rem - gr * P.Wo;
+        grel = (gimg * P.Co + gcol) * HoWo + gr * P.Wo + c;
+    }
+    const bool gvalid = gcol < TCO && (co0 + gcol) < P.Co;
+
+    // zero the slab once: halo columns and padded channels are never written again
+    for (int e = tid; e < TCI * P.CS; e += 256) xs[e] = 0.f;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int xa = l15 * P.CS + qq;        // x-fragment lane base
+    const int gb = l15 * P.PCp + qq;       // gy-fragment lane base
+
+    u32x4 xreg[XU_MAX];
+    u32x4 greg;
+
+    auto prefetch = [&](int ch) {
+        const int ig = ch / P.row_tiles, rt = ch - ig * P.row_tiles;
+        const int n0 = ig * P.TI, oh0 = rt * P.TR;
+        const int in_row0 = 2 * oh0 - P.pad_t;
+        const int xbase = (n0 * P.Ci + ci0) * HW + in_row0 * P.W;
+#pragma unroll
+        for (int j = 0; j < XU_MAX; ++j) {
+            const int r = xinfo[j] & 255, img = (xinfo[j] >> 8) & 255;
+            const bool ok = xinfo[j] >= 0 && (unsigned)(in_row0 + r) < (unsigned)P.H && (n0 + img) < P.N;
+            const unsigned vo = ok ? (unsigned)(xbase + xrel[j]) * 4u : OOB;
+            xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+        }
+        const bool gok = gvalid && (n0 + gimg) < P.N && (oh0 + gr) < P.Ho;
+        const unsigned gvo = gok ? (unsigned)((n0 * P.Co + co0) * HoWo + oh0 * P.Wo + grel) * 4u : OOB;
+        greg = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo, 0, 0);
+    };
+
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < XU_MAX; ++j) {
+            if (tid + j * 256 < P.xunits) {
+                u32x2 ev = {xreg[j].x, xreg[j].z}, od = {xreg[j].y, xreg[j].w};
+                *reinterpret_cast<u32x2*>(xs + xlds[j]) = ev;
+                *reinterpret_cast<u32x2*>(xs + xlds[j] + P.SCh) = od;
+            }
+        }
+        if (gcol < TCO) *reinterpret_cast<u32x4*>(gs + gcol * P.PCp + gp4 * 4) = greg;
+    };
+
+    const int c_begin = split * P.chunks_per_split;
+    const int c_end = min(c_begin + P.chunks_per_split, P.chunks_total);
+    if (c_begin < c_end) prefetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (ch + 1 < c_end) prefetch(ch + 1);
+        // ---- MFMA: this wave's pixel quads; the 26 fragment reads of the NEXT quad are issued before the 25 MFMAs
+        //      of the current one (one wave per SIMD: nothing else hides the LDS latency) ---------------------------
+        const int nq = P.PC >> 2;
+        float av[2][NT], bv[2];
+        auto load_quad = [&](int qd, float* a, float& b) {
+            const int p0 = qd * 4;
+            const int img = fdiv(p0, P.d_TRWo);
+            const int rem = p0 - img * (P.TR * P.Wo);
+            const int r = fdiv(rem, P.d_Wo);
+            const int c0 = rem - r * P.Wo;
+            b = gs[gb + p0];
+            const float* xp = xs + xa + (img * P.SR + 2 * r) * P.SCp + c0;
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)   // slab col = 2*ow+kw+3 -> parity plane (kw+3)&1, index ow+((kw+3)>>1)
+                    a[kh * KS + kw] = xp[kh * P.SCp + ((kw + 3) & 1) * P.SCh + ((kw + 3) >> 1)];
+        };
+        if (wave < nq) load_quad(wave, av[0], bv[0]);
+        for (int qd = wave; qd < nq; qd += 8) {
+            if (qd + 4 < nq) load_quad(qd + 4, av[1], bv[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][t], bv[0], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (qd + 4 < nq) {
+                if (qd + 8 < nq) load_quad(qd + 8, av[0], bv[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][t], bv[1], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- combine the 4 pixel-split waves: (2,3)->(0,1), then 1->0 -------------------------------------------------
+    __syncthreads();
+    float* red = smem;                     // [2][NT*4][64]
+    if (wave >= 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave - 2) * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += red[(wave * NT * 4 + t * 4 + r) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- store: D col = lane&15 -> co (contiguous), row = 4*(lane>>4)+reg -> ci -------------------------------------
+    float* outp = P.out + (size_t)split * P.out_elems;
+    const int co = co0 + l15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[t][r] + red[(t * 4 + r) * 64 + lane];
+            const int ci = ci0 + qq * 4 + r;
+            if (co < P.Co && ci < P.Ci) outp[((size_t)t * P.Ci + ci) * P.Co + co] = v;
+        }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+namespace ggan {
+
+int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, void* ws, size_t ws_bytes,
+                    hipStream_t s) {
+    if (g.k != 5 || g.stride != 2 || (g.Wo & 3) || (g.W & 3) || g.pad_l != 1 || g.Wo > 64) return 1;
+    const size_t xb = (size_t)g.N * g.Ci * g.H * g.W * 4, gb = (size_t)g.N * g.Co * g.Ho * g.Wo * 4;
+    if (xb >= 0x7FFFFFF0ull || gb >= 0x7FFFFFF0ull) return 1;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)gy) & 15)) return 1;
+    WgradParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.gy = gy;
+    P.x_bytes = (unsigned)xb; P.gy_bytes = (unsigned)gb;
+    P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo;
+    P.pad_t = g.pad_t;
+    P.TR = 64 / g.Wo; if (P.TR > g.Ho) P.TR = g.Ho;
+    P.TI = 64 / (P.TR * g.Wo); if (P.TI < 1) P.TI = 1; if (P.TI > g.N) P.TI = g.N;
+    for (;;) {
+        P.SR = 2 * (P.TR - 1) + 5;
+        P.SCp = g.W + 8;
+        P.xunits = TCI * P.TI * P.SR * (g.W / 4);
+        if (P.xunits <= XU_MAX * 256 && P.TI < 256 && P.SR < 256) break;
+        if (P.TI > 1) P.TI = (P.TI + 1) / 2;
+        else if (P.TR > 1) P.TR = (P.TR + 1) / 2;
+        else return 1;
+    }
+    P.SCh = P.SCp / 2;
+    P.CS = P.TI * P.SR * P.SCp;
+    while ((P.CS & 31) != 2) P.CS += 1;     // == 2 (mod 32): conflict-free 16ci x 2px fragment reads; even for b64 stores
+    P.PC = P.TI * P.TR * g.Wo;
+    P.PCp = P.PC + 4;
+    if ((P.PC & 3) || TCO * (P.PC / 4) > 256) return 1;
+    P.d_F4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR); P.d_TI = make_fastdiv(P.TI);
+    P.d_PC4 = make_fastdiv(P.PC / 4); P.d_TRWo = make_fastdiv(P.TR * g.Wo); P.d_Wo = make_fastdiv(g.Wo);
+    P.row_tiles = cdiv(g.Ho, P.TR);
+    P.chunks_total = cdiv(g.N, P.TI) * P.row_tiles;
+    const int gx = cdiv(g.Ci, TCI), gy_ = cdiv(g.Co, TCO);
+    int sk = env_int("GGAN_WGRAD_SK", 0);
+    if (sk <= 0) {
+        sk = cdiv(env_int("GGAN_WGRAD_WGS", 256), gx * gy_);
+        if (sk > P.chunks_total / 2) sk = P.chunks_total / 2;
+        if (sk > 64) sk = 64;
+    }
+    if (sk < 1) sk = 1;
+    P.out_elems = (size_t)25 * g.Ci * g.Co;
+    while (sk > 1 && (size_t)sk * P.out_elems * sizeof(float) > ws_bytes) sk /= 2;
+    P.chunks_per_split = cdiv(P.chunks_total, sk);
+    P.SK = cdiv(P.chunks_total, P.chunks_per_split);
+    P.out = P.SK > 1 ? (float*)ws : gw;
+    size_t stage = (size_t)TCI * P.CS + (size_t)TCO * P.PCp;
+    size_t red = (size_t)2 * 100 * 64;
+    const size_t shmem = (stage > red ? stage : red) * sizeof(float);
+    if (shmem > 160 * 1024) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
+    GGAN_LAUNCH("conv_wgrad_mfma", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(256), shmem, s, P);
+    if (P.SK > 1) return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s);
+    return 0;
+}
+
+}  // namespace ggan
