@@ -59,7 +59,7 @@ int ggan_conv2d_bwd_filter(const ggan_conv_geom* g, const float* x, const float*
     GGAN_CHECK_ARG(x && gy && gw, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (gbias) {
-        int r = ggan_chansum(gy, gbias, g->N, g->Co, g->Ho * g->Wo, stream);
+        int r = ggan_chansum(gy, gbias, g->N, g->Co, g->Ho * g->Wo, ws, ws_bytes, stream);
         if (r) return r;
     }
     if (!g_force_naive && !getenv("GGAN_NAIVE_WGRAD")) {
@@ -85,7 +85,7 @@ int ggan_deconv2d_bwd_filter(const ggan_conv_geom* g, const float* gy_big, const
     if (check_geom(g)) return -1;
     if (gbias) {
         GGAN_CHECK_ARG(gy_big, "null pointer");
-        int r = ggan_chansum(gy_big, gbias, g->N, g->Ci, g->H * g->W, stream);
+        int r = ggan_chansum(gy_big, gbias, g->N, g->Ci, g->H * g->W, ws, ws_bytes, stream);
         if (r) return r;
     }
     return ggan_conv2d_bwd_filter(g, gy_big, x_small, gw, nullptr, ws, ws_bytes, stream);

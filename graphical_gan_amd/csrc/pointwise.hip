@@ -101,18 +101,37 @@ __global__ void colsum_k(const float* __restrict__ x, float* __restrict__ out, i
     out[c] = s;
 }
 
-// per-channel sum over (n, hw) of NCHW: one block per channel
-__global__ void chansum_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW) {
+// per-channel sum over (n, hw) of NCHW: block (c, p) sums images p, p+P, ... of channel c (each image-channel plane is HW
+// contiguous floats: float4 loads when HW % 4 == 0) into part[c*P + p]; launched with P = 1 (one block per channel).
+__global__ void chansum_part_k(const float* __restrict__ x, float* __restrict__ part, int N, int C, int HW, int P) {
     __shared__ float sm[32];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, p = blockIdx.y;
     float s = 0.f;
-    const int total = N * HW;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        int n = i / HW, p = i - n * HW;
-        s += x[((size_t)n * C + c) * HW + p];
+    if ((HW & 3) == 0) {
+        const int hw4 = HW >> 2;
+        for (int n = p; n < N; n += P) {
+            const float4* pl = reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * HW);
+            for (int i = threadIdx.x; i < hw4; i += blockDim.x) {
+                const float4 v = pl[i];
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+    } else {
+        for (int n = p; n < N; n += P) {
+            const float* pl = x + ((size_t)n * C + c) * HW;
+            for (int i = threadIdx.x; i < HW; i += blockDim.x) s += pl[i];
+        }
     }
     s = block_sum(s, sm);
-    if (threadIdx.x == 0) out[c] = s;
+    if (threadIdx.x == 0) part[(size_t)c * P + p] = s;
+}
+
+__global__ void chansum_final_k(const float* __restrict__ part, float* __restrict__ out, int C, int P) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(size_t)c * P + p];
+    out[c] = s;
 }
 
 // ---- losses (single block: n is a minibatch of logits) ---------------------------------------------
@@ -230,14 +249,22 @@ struct PackTable {
     int count;
 };
 
-// blockIdx.y = tensor, blockIdx.x grid-strides inside it
+// blockIdx.y = tensor, blockIdx.x grid-strides inside it (16-byte copies when both sides are aligned)
 __global__ void pack_k(PackTable t, float* __restrict__ flat) {
     const int k = blockIdx.y;
     const float* s = t.src[k];
     float* d = flat + t.off[k];
     const size_t n = t.size[k];
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        d[i] = s ? s[i] : 0.f;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if (s && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+        const size_t n4 = n >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        float4* d4 = reinterpret_cast<float4*>(d);
+        for (size_t i = i0; i < n4; i += stride) d4[i] = s4[i];
+        for (size_t i = (n4 << 2) + i0; i < n; i += stride) d[i] = s[i];
+    } else {
+        for (size_t i = i0; i < n; i += stride) d[i] = s ? s[i] : 0.f;
+    }
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -298,9 +325,23 @@ int ggan_colsum(const float* x, float* out, int rows, int cols, ggan_stream_t st
     return 0;
 }
 
-int ggan_chansum(const float* x, float* out, int N, int C, int HW, ggan_stream_t stream) {
+int ggan_chansum(const float* x, float* out, int N, int C, int HW, void* ws, size_t ws_bytes, ggan_stream_t stream) {
     GGAN_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "bad argument");
-    GGAN_LAUNCH("chansum", 0, 4.0 * N * C * HW, chansum_k, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, HW);
+    hipStream_t s = (hipStream_t)stream;
+    // stage 1 over ~1024 workgroups (C x P, each sums every P-th image plane of one channel), stage 2 adds the P
+    // partials per channel in a fixed order: chip-wide bandwidth, deterministic, scratch supplied by the caller
+    int P = 1024 / C;
+    if (P > N) P = N;
+    if (!ws || (size_t)C * P * sizeof(float) > ws_bytes) P = 1;
+    if (P <= 1) {
+        const int threads = (size_t)N * HW >= 16384 ? 1024 : 256;
+        GGAN_LAUNCH("chansum", 0, 4.0 * N * C * HW, chansum_part_k, dim3(C, 1), dim3(threads), 0, s, x, out, N, C, HW, 1);
+        return 0;
+    }
+    const int threads = HW >= 1024 ? 256 : (HW >= 256 ? 128 : 64);
+    float* part = (float*)ws;
+    GGAN_LAUNCH("chansum", 0, 4.0 * N * C * HW, chansum_part_k, dim3(C, P), dim3(threads), 0, s, x, part, N, C, HW, P);
+    GGAN_LAUNCH("chansum_final", 0, 4.0 * C * P, chansum_final_k, dim3(cdiv(C, 64)), dim3(64), 0, s, (const float*)part, out, C, P);
     return 0;
 }
 
@@ -368,9 +409,9 @@ int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offse
         tot += sizes[i];
     }
     t.count = count;
-    int gx = (int)cdivz(mx, (size_t)kBlock * 8);
+    int gx = (int)cdivz(mx, (size_t)kBlock * 16);
     if (gx < 1) gx = 1;
-    if (gx > 256) gx = 256;
+    if (gx > 512) gx = 512;
     GGAN_LAUNCH("pack", 0, 8.0 * tot, pack_k, dim3(gx, count), dim3(kBlock), 0, (hipStream_t)stream, t, flat);
     return 0;
 }

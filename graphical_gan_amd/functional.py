@@ -186,7 +186,8 @@ class ChanSum(Function):
         N, Cc = x.shape[0], x.shape[1]
         HW = x.numel() // (N * Cc)
         out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-        check(_L().ggan_chansum(_p(x), _p(out), N, Cc, HW, _stream()), 'ggan_chansum')
+        ws = workspace(x.device)
+        check(_L().ggan_chansum(_p(x), _p(out), N, Cc, HW, _p(ws), ws.numel(), _stream()), 'ggan_chansum')
         ctx.shape = tuple(x.shape)
         return out
 

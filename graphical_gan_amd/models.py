@@ -20,7 +20,7 @@ from .tflib.ops.act import LRELU, RELU, TANH, SIGMOID
 
 class Config(object):
     def __init__(self, dataset='cifar10', batch_size=64, n_coms=0, mode=None, dim=None, dim_latent=128, bn=None,
-                 temp=0.1, fuse=True, lr=None):
+                 temp=0.1, fuse=True, lr=None, batch_critic=True):
         self.dataset, self.B, self.K, self.dim_latent, self.temp, self.fuse = dataset, batch_size, n_coms, dim_latent, temp, fuse
         if dataset == 'cifar10':
             self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, True, 'tanh'
@@ -42,6 +42,10 @@ class Config(object):
         self.critic_iters = 5 if self.mode == 'wali-gp' else 1          # gan_inference_cifar10.py:53-59
         self.lr = lr if lr is not None else (1e-4 if self.mode == 'wali-gp' else 2e-4)
         self.beta1 = 0.5
+        # critic steps evaluate the critic ONCE on [fake; real] (the critics of these scripts have no BatchNorm, so
+        # rows are independent and the result is identical); generator steps keep the two branches separate because
+        # only the fake branch needs the conv data-gradients
+        self.batch_critic = batch_critic
 
 
 class GraphicalGAN(object):
@@ -189,20 +193,36 @@ class GraphicalGAN(object):
         fake_x = self.Generator(p_z)
         out.update(p_z=p_z, fake_x=fake_x)
         J = lib.objs.gan_inference
+        batched = c.batch_critic and which == 'disc'
+        if batched:
+            # the critic step needs no gradient w.r.t. the generator/extractor outputs (TF prunes those paths too)
+            fx, pz, qz = fake_x.detach(), p_z.detach(), q_z.detach()
+            B = fx.shape[0]
+            x_cat, z_cat = torch.cat([fx, real_x], 0), torch.cat([pz, qz], 0)
         if c.K:
-            d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)]
-            d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)]
+            if batched:
+                h = self.HyperDiscriminator(z_cat, torch.cat([onehot, q_k.detach()], 0))
+                d = self.Discriminator(x_cat, z_cat)
+                d_fake, d_real = [h[:B], d[:B]], [h[B:], d[B:]]
+            else:
+                d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)]
+                d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)]
             gen_params, disc_params = self._var_lists()
             res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
         else:
-            d_fake = self.Discriminator(fake_x, p_z)
-            d_real = self.Discriminator(real_x, q_z)
+            if batched:
+                d = self.Discriminator(x_cat, z_cat)
+                d_fake, d_real = d[:B], d[B:]
+            else:
+                d_fake = self.Discriminator(fake_x, p_z)
+                d_real = self.Discriminator(real_x, q_z)
             gen_params, disc_params = self._var_lists()
             if c.mode == 'wali-gp':
                 if which == 'gen':
                     gp = torch.zeros((), device=d_fake.device)
                 else:
-                    gp = J.gradient_penalty(self.Discriminator, real_x, fake_x, q_z, p_z, feed['alpha'])
+                    gp = J.gradient_penalty(self.Discriminator, real_x, fake_x.detach() if batched else fake_x,
+                                            q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
                 res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
                 out['gradient_penalty'] = gp
             else:

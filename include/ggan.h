@@ -80,8 +80,9 @@ int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* 
               float* C, int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
 /* out[c] = sum_r x[r,c] over a [rows,cols] matrix (BiasAddGrad of Linear). */
 int ggan_colsum(const float* x, float* out, int rows, int cols, ggan_stream_t stream);
-/* out[c] = sum_{n,hw} x[n,c,hw] (BiasAddGrad NCHW). */
-int ggan_chansum(const float* x, float* out, int N, int C, int HW, ggan_stream_t stream);
+/* out[c] = sum_{n,hw} x[n,c,hw] (BiasAddGrad NCHW).  ws: optional scratch (>= 4 KiB * C) enabling a chip-wide
+ * two-stage reduction; with ws == NULL one workgroup per channel is used. */
+int ggan_chansum(const float* x, float* out, int N, int C, int HW, void* ws, size_t ws_bytes, ggan_stream_t stream);
 
 /* ---- batch normalisation, training mode, batch statistics, biased variance -------------------
  * tf.nn.fused_batch_norm(NCHW, eps) (tflib/ops/batchnorm.py:29-30) for HW>1 and the

@@ -78,6 +78,8 @@ def test_trajectory_vs_goldens(gpu, name):
         if ocfg.bn and (n.endswith('.Biases') or n == 'Generator.Input.b') and not n.startswith('Discriminator') \
                 and n not in ('Extractor.1.Biases', 'Generator.5.Biases'):
             continue
+        if mode == 'wali-gp' and n == 'Discriminator.Output.b':
+            continue   # d(mean(D_fake) - mean(D_real) + GP)/d(output bias) == 0 exactly: Adam walks on rounding noise
         d, ref = digest(P[n]), z[k]
         numel = P[n].size
         assert abs(d[1] - ref[1]) <= 1e-3 * ref[1] + 3e-4 * numel * 0.02 + 1e-6, (n, d[1], ref[1])

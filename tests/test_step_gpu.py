@@ -118,6 +118,8 @@ def test_trajectory(gpu, case, graph):
         if cfg.bn and (n.endswith('.Biases') or n == 'Generator.Input.b') and not n.startswith('Discriminator') \
                 and n not in ('Extractor.1.Biases', 'Generator.5.Biases'):
             continue   # bias feeding BatchNorm: true gradient is 0, Adam random-walks on rounding noise (fp64 too)
+        if mode == 'wali-gp' and n == 'Discriminator.Output.b':
+            continue   # Wasserstein critic cost: the output bias cancels exactly, same random walk
         d = np.abs(P[n].reshape(ref.shape) - ref)
         assert d.max() <= 2.5 * lr * steps, (n, d.max())
         assert (d > 2e-5).mean() <= 0.02, (n, (d > 2e-5).mean())
