@@ -15,6 +15,99 @@ namespace {
 
 constexpr int kThreads = 512;
 
+// Register-resident variants: when a channel's N*HW values fit 32 per thread the activation is read from HBM/L2 ONCE
+// (mean, centred variance and the normalised write all come from registers): 2 passes of traffic instead of 4.
+constexpr int kRegE = 32;
+
+__global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ offset, float* __restrict__ y,
+                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                              int N, int C, int HW, float eps, int act, float alpha) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x;
+    const int total = N * HW;
+    const float inv_cnt = 1.f / (float)total;
+    float v[kRegE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kRegE; ++j) {
+        const int i = threadIdx.x + j * kThreads;
+        float t = 0.f;
+        if (i < total) {
+            const int n = i / HW, p = i - n * HW;
+            t = x[((size_t)n * C + c) * HW + p];
+        }
+        v[j] = t;
+        s += t;
+    }
+    const float mean = block_sum(s, sm) * inv_cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kRegE; ++j) {
+        const int i = threadIdx.x + j * kThreads;
+        const float d = v[j] - mean;
+        if (i < total) q += d * d;
+    }
+    const float var = block_sum(q, sm) * inv_cnt;
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float g = scale[c], b = offset[c];
+#pragma unroll
+    for (int j = 0; j < kRegE; ++j) {
+        const int i = threadIdx.x + j * kThreads;
+        if (i < total) {
+            const int n = i / HW, p = i - n * HW;
+            y[((size_t)n * C + c) * HW + p] = act_apply(g * ((v[j] - mean) * invstd) + b, act, alpha);
+        }
+    }
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __restrict__ x, const float* __restrict__ gy,
+                                                              const float* __restrict__ scale, const float* __restrict__ save_mean,
+                                                              const float* __restrict__ save_invstd, float* __restrict__ gx,
+                                                              float* __restrict__ gscale, float* __restrict__ goffset, int N,
+                                                              int C, int HW) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x;
+    const int total = N * HW;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    float xh[kRegE], g[kRegE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kRegE; ++j) {
+        const int i = threadIdx.x + j * kThreads;
+        float a = 0.f, b = 0.f;
+        if (i < total) {
+            const int n = i / HW, p = i - n * HW;
+            const size_t idx = ((size_t)n * C + c) * HW + p;
+            b = gy[idx];
+            a = (x[idx] - mean) * invstd;
+        }
+        xh[j] = a; g[j] = b;
+        s1 += b;
+        s2 += b * a;
+    }
+    const float sum_g = block_sum(s1, sm);
+    const float sum_gx = block_sum(s2, sm);
+    const float inv_cnt = 1.f / (float)total;
+    const float k = scale[c] * invstd, mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
+#pragma unroll
+    for (int j = 0; j < kRegE; ++j) {
+        const int i = threadIdx.x + j * kThreads;
+        if (i < total) {
+            const int n = i / HW, p = i - n * HW;
+            gx[((size_t)n * C + c) * HW + p] = k * (g[j] - mg - xh[j] * mgx);
+        }
+    }
+    if (threadIdx.x == 0) {
+        gscale[c] = sum_gx;
+        goffset[c] = sum_g;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_k(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ offset, float* __restrict__ y,
                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
@@ -167,7 +260,9 @@ int ggan_bn_fwd_train(const float* x, const float* scale, const float* offset, f
     GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
     hipStream_t s = (hipStream_t)stream;
     const double bytes = 12.0 * N * C * HW;
-    if (HW > 1) {
+    if (HW > 1 && N * HW <= kRegE * kThreads) {
+        GGAN_LAUNCH("bn_fwd_nchw", 0, 8.0 * N * C * HW, bn_fwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, HW, eps, act, alpha);
+    } else if (HW > 1) {
         GGAN_LAUNCH("bn_fwd_nchw", 0, bytes, bn_fwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, HW, eps, act, alpha);
     } else {
         GGAN_LAUNCH("bn_fwd_rows", 0, bytes, bn_fwd_rows_k, dim3(cdiv(C, kCols)), dim3(kCols, kSlices), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, eps, act, alpha);
@@ -181,7 +276,9 @@ int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float
     GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
     hipStream_t s = (hipStream_t)stream;
     const double bytes = 20.0 * N * C * HW;
-    if (HW > 1) {
+    if (HW > 1 && N * HW <= kRegE * kThreads) {
+        GGAN_LAUNCH("bn_bwd_nchw", 0, 12.0 * N * C * HW, bn_bwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
+    } else if (HW > 1) {
         GGAN_LAUNCH("bn_bwd_nchw", 0, bytes, bn_bwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
     } else {
         GGAN_LAUNCH("bn_bwd_rows", 0, bytes, bn_bwd_rows_k, dim3(cdiv(C, kCols)), dim3(kCols, kSlices), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C);

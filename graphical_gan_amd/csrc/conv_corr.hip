@@ -332,7 +332,10 @@ int env_int(const char* name, int dflt) {
 }
 
 struct WaveCfg { int WM, WN, KS, PW; };
-const WaveCfg kCfgs[3] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}};
+// fwd: 25 taps per chunk-channel-pair; dgrad class pairs carry only 12-13 taps, so they stage twice as many channels per
+// chunk (PW doubled) to keep ~25+ MFMAs per wave between barriers
+const WaveCfg kCfgsFwd[3] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}};
+const WaveCfg kCfgsDgrad[3] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}};
 
 // pixel tile TI x TR x TC <= TM whose CK-channel slab fits the per-thread staging budget
 bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r, int ext_c) {
@@ -357,12 +360,32 @@ void finish_tile(CorrParams& P, int Hu, int Wv) {
     P.tiles_r = cdiv(Hu, P.TR); P.tiles_c = cdiv(Wv, P.TC);
 }
 
+template <typename K>
+void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 template <int MODE>
 int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_t s, const char* name, double fl) {
-    switch (cfg) {
-        case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
-        case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
-        default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+    static bool once = false;
+    if (!once) {   // double-buffered staging can exceed the 64 KiB default dynamic-LDS limit
+        allow_big_lds(corr_kernel<0, 2, 2, 1, 2>); allow_big_lds(corr_kernel<0, 2, 1, 2, 2>); allow_big_lds(corr_kernel<0, 1, 1, 4, 1>);
+        allow_big_lds(corr_kernel<1, 2, 2, 1, 4>); allow_big_lds(corr_kernel<1, 2, 1, 2, 4>); allow_big_lds(corr_kernel<1, 1, 1, 4, 2>);
+        once = true;
+    }
+    if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
+    if (MODE == 0) {
+        switch (cfg) {
+            case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
+            case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
+            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+        }
+    } else {
+        switch (cfg) {
+            case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 2, 1, 4>), grid, dim3(256), shmem, s, P); break;
+            case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 1, 2, 4>), grid, dim3(256), shmem, s, P); break;
+            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+        }
     }
     return 0;
 }
@@ -373,6 +396,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
                     const float* bias, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s, const char* name,
                     double fl, const char* sk_env, const char* cfg_env) {
     const int target = env_int("GGAN_TARGET_WGS", 200);
+    const WaveCfg* kCfgs = MODE == 0 ? kCfgsFwd : kCfgsDgrad;
     int cfg = env_int(cfg_env, -1);
     if (cfg < 0 || cfg > 2) {
         cfg = 2;

@@ -101,7 +101,9 @@ class Trainer(object):
 
     def _capture(self, which):
         # warm-up eagerly on a side stream (allocator + lazy init), restoring optimizer state afterwards
-        s = torch.cuda.Stream(device=self.device)
+        if getattr(self, '_cap_stream', None) is None:
+            self._cap_stream = torch.cuda.Stream(device=self.device)    # warm-up AND capture run on this stream, so the
+        s = self._cap_stream                                            # per-stream scratch buffers exist before capture
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
             # (the optimizers exist: the first call of each kind ran eagerly)
@@ -114,14 +116,14 @@ class Trainer(object):
         torch.cuda.synchronize(self.device)
         g1 = torch.cuda.CUDAGraph()
         if self.world == 1:
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, stream=s):
                 cost, opt, keep = self._fwd_bwd(which)
                 opt.update()
             return dict(g1=g1, g2=None, cost=cost, opt=opt, keep=keep)
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, stream=s):
             cost, opt, keep = self._fwd_bwd(which)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
+        with torch.cuda.graph(g2, stream=s):
             opt.update()
         return dict(g1=g1, g2=g2, cost=cost, opt=opt, keep=keep)
 

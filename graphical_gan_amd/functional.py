@@ -46,9 +46,56 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def workspace(device):
-    """Persistent split-K scratch, one per device (kernels on a stream are serialised, so it is shared)."""
+# Backward of a layer = two independent kernels (data-gradient and filter-gradient).  With OVERLAP_BWD they are issued
+# on two HIP streams (fork after gy is ready, join before anything downstream runs), so the chip holds one workgroup
+# of each per CU and each kernel's prologue / staging latency hides under the other's MFMA phase.  The fork/join is
+# captured into the step's HIP graph as parallel branches.
+OVERLAP_BWD = False   # measured: cross-queue graph dependencies cost 6-11 us each on ROCm 7.2, cancelling the overlap gain
+_SIDE = {}
+
+
+def _side_stream(device):
     key = (device.type, device.index)
+    s = _SIDE.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE[key] = s
+    return s
+
+
+class _fork(object):
+    """with _fork(dev) as side: ... kernels issued on the side stream; joined back into the current stream on exit."""
+
+    def __init__(self, device, enabled=True):
+        self.enabled = enabled and OVERLAP_BWD and not torch.is_grad_enabled()
+        self.device = device
+
+    def __enter__(self):
+        if not self.enabled:
+            return None
+        self.main = torch.cuda.current_stream(self.device)
+        self.side = _side_stream(self.device)
+        self.side.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self.side
+
+    def __exit__(self, *a):
+        if self.enabled:
+            self.ctx.__exit__(*a)
+
+    def join(self, *tensors):
+        """call after the main-stream kernel has been issued"""
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+
+
+def workspace(device):
+    """Persistent split-K / filter-transpose scratch, one per (device, stream): kernels on one stream are serialised."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
@@ -108,12 +155,16 @@ class ConvFwd(Function):
             ref = y if ctx.act in (ACT_TANH, ACT_SIGMOID) else y   # lrelu/relu: sign(y) == sign(pre-activation)
             gy = ActBwd.apply(gy, ref, ctx.act, ctx.alpha)
         gx = gw = gb = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        fork = _fork(gy.device, ctx.needs_input_grad[0] and need_w)
+        with fork:
+            if ctx.needs_input_grad[1]:
+                gw = ConvWgrad.apply(x, gy, ctx.geom)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = ChanSum.apply(gy)
         if ctx.needs_input_grad[0]:
             gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
-        if ctx.needs_input_grad[1]:
-            gw = ConvWgrad.apply(x, gy, ctx.geom)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = ChanSum.apply(gy)
+        fork.join(gw, gb)
         return gx, gw, gb, None, None, None
 
 
@@ -140,12 +191,16 @@ class ConvDgrad(Function):
         if ctx.act != ACT_NONE:
             h = ActBwd.apply(h, out, ctx.act, ctx.alpha)
         d_gy = d_w = d_b = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        fork = _fork(h.device, ctx.needs_input_grad[0] and need_w)
+        with fork:
+            if ctx.needs_input_grad[1]:
+                d_w = ConvWgrad.apply(h, gy, ctx.geom)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                d_b = ChanSum.apply(h)
         if ctx.needs_input_grad[0]:
             d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
-        if ctx.needs_input_grad[1]:
-            d_w = ConvWgrad.apply(h, gy, ctx.geom)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            d_b = ChanSum.apply(h)
+        fork.join(d_w, d_b)
         return d_gy, d_w, d_b, None, None, None
 
 
@@ -241,18 +296,22 @@ class Gemm(Function):
         if ctx.act != ACT_NONE:
             g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
         da = db = dbias = None
+        need_b = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        fork = _fork(g.device, ctx.needs_input_grad[0] and need_b)
+        with fork:
+            if ctx.needs_input_grad[1]:
+                if not tb:
+                    db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0)      # op(A)^T g
+                else:
+                    db = Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)           # g^T op(A)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                dbias = ColSum.apply(g)
         if ctx.needs_input_grad[0]:
             if not ta:
                 da = Gemm.apply(g, b, None, False, not tb, ACT_NONE, 0.0)      # g op(B)^T
             else:
                 da = Gemm.apply(b, g, None, tb, True, ACT_NONE, 0.0)           # op(B) g^T
-        if ctx.needs_input_grad[1]:
-            if not tb:
-                db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0)      # op(A)^T g
-            else:
-                db = Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)           # g^T op(A)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = ColSum.apply(g)
+        fork.join(db, dbias)
         return da, db, dbias, None, None, None, None
 
 

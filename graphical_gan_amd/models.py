@@ -193,6 +193,7 @@ class GraphicalGAN(object):
         fake_x = self.Generator(p_z)
         out.update(p_z=p_z, fake_x=fake_x)
         J = lib.objs.gan_inference
+        J.ONLY[0] = which            # TF prunes the cost a session.run does not fetch; so do we
         batched = c.batch_critic and which == 'disc'
         if batched:
             # the critic step needs no gradient w.r.t. the generator/extractor outputs (TF prunes those paths too)
@@ -219,7 +220,7 @@ class GraphicalGAN(object):
             gen_params, disc_params = self._var_lists()
             if c.mode == 'wali-gp':
                 if which == 'gen':
-                    gp = torch.zeros((), device=d_fake.device)
+                    gp = None                # not part of gen_cost; TF prunes the third critic pass
                 else:
                     gp = J.gradient_penalty(self.Discriminator, real_x, fake_x.detach() if batched else fake_x,
                                             q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
@@ -227,6 +228,7 @@ class GraphicalGAN(object):
                 out['gradient_penalty'] = gp
             else:
                 res = J.ali(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        J.ONLY[0] = None
         out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=res[0], disc_cost=res[1],
                    gen_train_op=res[2], disc_train_op=res[3])
         return out

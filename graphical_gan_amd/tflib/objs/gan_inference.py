@@ -8,6 +8,9 @@ from ... import functional as F
 from ...optim import TrainOp, get_optimizer
 
 
+ONLY = [None]   # 'gen' | 'disc': build just that cost (what one session.run fetches); None builds both
+
+
 def _bce_costs(fakes, reals, ratios):
     """gen: fake->1, real->0 ; disc: fake->0, real->1 (sigmoid cross-entropy, mean over the batch)."""
     logits, gl, dl, w = [], [], [], []
@@ -16,14 +19,14 @@ def _bce_costs(fakes, reals, ratios):
         gl += [1.0, 0.0]
         dl += [0.0, 1.0]
         w += [float(ratio), float(ratio)]
-    gen_cost = F.BceSum.apply(tuple(gl), tuple(w), *logits)
-    disc_cost = F.BceSum.apply(tuple(dl), tuple(w), *logits)
+    gen_cost = F.BceSum.apply(tuple(gl), tuple(w), *logits) if ONLY[0] != 'disc' else None
+    disc_cost = F.BceSum.apply(tuple(dl), tuple(w), *logits) if ONLY[0] != 'gen' else None
     return gen_cost, disc_cost
 
 
 def ali(disc_fake, disc_real, gen_params, disc_params, lr=2e-4, beta1=0.5, beta2=0.999, s_f=None):
     gen_cost, disc_cost = _bce_costs([disc_fake], [disc_real], [1.0])
-    if s_f is not None:
+    if s_f is not None and gen_cost is not None:
         gen_cost = gen_cost + s_f
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
@@ -36,8 +39,8 @@ def local_ep(disc_fake_list, disc_real_list, gen_params, disc_params, lr=2e-4, b
         gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0 / n] * len(disc_fake_list))
     else:   # (sum + s_f) / n, as gan_inference.py:102-106
         gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0] * len(disc_fake_list))
-        gen_cost = (gen_cost + s_f) / n
-        disc_cost = disc_cost / n
+        gen_cost = (gen_cost + s_f) / n if gen_cost is not None else None
+        disc_cost = disc_cost / n if disc_cost is not None else None
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
@@ -49,7 +52,7 @@ def weighted_local_epce(disc_fake_list, disc_real_list, ratio_list, gen_params, 
     assert len(disc_fake_list) == ratio_list.shape[0]
     gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, list(ratio_list))
     gen_debug_list, disc_debug_list = [], []   # per-factor terms are debug-only in the reference (:321-343)
-    if rec_penalty is not None:
+    if rec_penalty is not None and gen_cost is not None:
         gen_cost = gen_cost + rec_penalty
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
@@ -58,9 +61,12 @@ def weighted_local_epce(disc_fake_list, disc_real_list, ratio_list, gen_params, 
 
 
 def wali_gp(disc_fake, disc_real, gradient_penalty, gen_params, disc_params, lr=1e-4):
-    gen_cost = F.MeanSum.apply((-1.0, 1.0), disc_fake, disc_real)
-    disc_cost = F.MeanSum.apply((1.0, -1.0), disc_fake, disc_real)
-    disc_cost = disc_cost + gradient_penalty
+    gen_cost = F.MeanSum.apply((-1.0, 1.0), disc_fake, disc_real) if ONLY[0] != 'disc' else None
+    disc_cost = None
+    if ONLY[0] != 'gen':
+        disc_cost = F.MeanSum.apply((1.0, -1.0), disc_fake, disc_real)
+        if gradient_penalty is not None:
+            disc_cost = disc_cost + gradient_penalty
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=0.5, beta2=0.9)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=0.5, beta2=0.9)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
