@@ -45,6 +45,7 @@ SIGNATURES = {
     'ggan_deconv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_gemm_workspace': (_Z, [_I, _I, _I]),
     'ggan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_gemm_colsum': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_colsum': (_I, [_P, _P, _I, _I, _P]),
     'ggan_chansum': (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     'ggan_bn_fwd_train': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),

@@ -39,6 +39,15 @@ int check_launch(const char* name);
     if (ggan::check_launch(name)) return -2
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Workspace convention (include/ggan.h): the first GGAN_WS_RESERVED bytes of every caller workspace are arrival counters
+// for in-kernel split-K combines.  They must be zero before the first call and every kernel leaves them zero.
+constexpr size_t kWsReserved = GGAN_WS_RESERVED;
+static inline void* ws_scratch(void* ws, size_t& bytes) {
+    if (!ws || bytes <= kWsReserved) { bytes = 0; return nullptr; }
+    bytes -= kWsReserved;
+    return (char*)ws + kWsReserved;
+}
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 
 // ---- device helpers ---------------------------------------------------------------------------

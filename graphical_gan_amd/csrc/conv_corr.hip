@@ -477,6 +477,7 @@ static bool fits32(size_t bytes) { return bytes < 0x7FFFFFF0ull; }
 int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                   float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!hot_geometry(g) || (g.Co & 3)) return 1;
+    ws = ws_scratch(ws, ws_bytes);
     const size_t in_bytes = (size_t)g.N * g.Ci * g.H * g.W * 4, w_bytes = (size_t)25 * g.Ci * g.Co * 4;
     if (!fits32(in_bytes) || !fits32(w_bytes) || !fits32((size_t)g.N * g.Co * g.Ho * g.Wo * 4)) return 1;
     if (((uintptr_t)w & 15) != 0) return 1;
@@ -500,6 +501,7 @@ int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const
 int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
                     float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!hot_geometry(g)) return 1;
+    ws = ws_scratch(ws, ws_bytes);
     const int Cip = (g.Ci + 3) & ~3;
     const size_t in_bytes = (size_t)g.N * g.Co * g.Ho * g.Wo * 4, w_bytes = (size_t)25 * g.Co * Cip * 4;
     if (!fits32(in_bytes) || !fits32(w_bytes) || !fits32((size_t)g.N * g.Ci * g.H * g.W * 4)) return 1;

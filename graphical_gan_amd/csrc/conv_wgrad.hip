@@ -224,6 +224,7 @@ namespace ggan {
 int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, void* ws, size_t ws_bytes,
                     hipStream_t s) {
     if (g.k != 5 || g.stride != 2 || (g.Wo & 3) || (g.W & 3) || g.pad_l != 1 || g.Wo > 64) return 1;
+    ws = ws_scratch(ws, ws_bytes);
     const size_t xb = (size_t)g.N * g.Ci * g.H * g.W * 4, gb = (size_t)g.N * g.Co * g.Ho * g.Wo * 4;
     if (xb >= 0x7FFFFFF0ull || gb >= 0x7FFFFFF0ull) return 1;
     if ((((uintptr_t)x) & 15) || (((uintptr_t)gy) & 15)) return 1;

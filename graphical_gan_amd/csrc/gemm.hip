@@ -29,6 +29,7 @@ struct GemmParams {
     int act;
     float alpha;
     size_t out_elems;
+    float* colsum;     // optional: column sums of op(B) (SK == 1, tb == 0), from the B tiles staged anyway
 };
 
 // Load a [64 rows(r) x 16 k] tile of a matrix into LDS as T[k][r].
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool do_colsum = P.colsum != nullptr && blockIdx.y == 0 && tid < BN;   // rows beyond K are zero in the tile
+    float csum = 0.f;
     float4 ra, rb;
     load_tile<!TA>(P.A, P.lda, P.M, m0, kb, ke, P.vecA, ra);
     load_tile<TB>(P.B, P.ldb, P.N, n0, kb, ke, P.vecB, rb);
@@ -108,6 +111,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
             load_tile<!TA>(P.A, P.lda, P.M, m0, k0 + BK, ke, P.vecA, ra);
             load_tile<TB>(P.B, P.ldb, P.N, n0, k0 + BK, ke, P.vecB, rb);
         }
+        if (do_colsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) csum += Bs[kk * LDP + tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a = As[(kk + half) * LDP + wm * 32 + l31];
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     }
+    if (do_colsum && n0 + tid < P.N) P.colsum[n0 + tid] = csum;
     const int n = n0 + wn * 32 + l31;
     if (n >= P.N) return;
     const bool direct = P.SK == 1;
@@ -142,11 +150,8 @@ size_t ggan_gemm_workspace(int M, int N, int K) {
     return (size_t)64 * M * N * sizeof(float);
 }
 
-int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C, int act,
-              float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
-    GGAN_CHECK_ARG(A && B && C, "null pointer");
-    GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
-    hipStream_t s = (hipStream_t)stream;
+static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C,
+                       float* colsum, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
     GemmParams P;
     memset(&P, 0, sizeof(P));
     P.A = A; P.B = B; P.bias = bias; P.C = C;
@@ -158,9 +163,11 @@ int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* 
     P.vecB = al16(B) && (P.ldb % 4 == 0);
     P.act = act; P.alpha = alpha;
     P.out_elems = (size_t)M * N;
+    P.colsum = colsum;
+    ws = ws_scratch(ws, ws_bytes);
     const int gx = cdiv(N, BN), gy = cdiv(M, BM);
     int sk = 1;
-    {
+    if (!colsum && ws) {       // (a fused column sum needs the whole K range in one workgroup)
         const char* e = getenv("GGAN_GEMM_SK");
         if (e) sk = atoi(e);
         else {
@@ -171,8 +178,8 @@ int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* 
             if (sk > 64) sk = 64;
         }
         if (sk < 1) sk = 1;
+        while (sk > 1 && (size_t)sk * P.out_elems * sizeof(float) > ws_bytes) sk /= 2;
     }
-    while (sk > 1 && (size_t)sk * P.out_elems * sizeof(float) > ws_bytes) sk /= 2;
     P.kps = cdiv(cdiv(K, sk), BK) * BK;
     P.SK = cdiv(K, P.kps);
     if (P.SK > 1) P.C = (float*)ws;
@@ -184,6 +191,20 @@ int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* 
     else { GGAN_LAUNCH("gemm_tt", fl, 0, (gemm_kernel<true, true>), grid, block, 0, s, P); }
     if (P.SK > 1) return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, C, bias, N, 1, act, alpha, s);
     return 0;
+}
+
+int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C, int act,
+              float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(A && B && C, "null pointer");
+    GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
+    return gemm_launch(ta, tb, M, N, K, A, B, bias, C, nullptr, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ggan_gemm_colsum(int ta, int M, int N, int K, const float* A, const float* B, float* C, float* colsum_b, void* ws,
+                     size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(A && B && C && colsum_b, "null pointer");
+    GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
+    return gemm_launch(ta, 0, M, N, K, A, B, nullptr, C, colsum_b, GGAN_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

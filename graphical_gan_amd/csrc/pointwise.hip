@@ -332,6 +332,7 @@ int ggan_chansum(const float* x, float* out, int N, int C, int HW, void* ws, siz
     // partials per channel in a fixed order: chip-wide bandwidth, deterministic, scratch supplied by the caller
     int P = 1024 / C;
     if (P > N) P = N;
+    ws = ws_scratch(ws, ws_bytes);
     if (!ws || (size_t)C * P * sizeof(float) > ws_bytes) P = 1;
     if (P <= 1) {
         const int threads = (size_t)N * HW >= 16384 ? 1024 : 256;

@@ -101,6 +101,7 @@ def workspace(device):
         if torch.cuda.is_current_stream_capturing():
             raise _lib.GganError('workspace must be created before graph capture (run one eager warm-up step)')
         ws = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+        ws[:65536].zero_()       # GGAN_WS_RESERVED: split-K arrival counters start (and are left) at zero
         _WS[key] = ws
     return ws
 
@@ -299,13 +300,17 @@ class Gemm(Function):
         need_b = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         fork = _fork(g.device, ctx.needs_input_grad[0] and need_b)
         with fork:
-            if ctx.needs_input_grad[1]:
-                if not tb:
-                    db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0)      # op(A)^T g
-                else:
-                    db = Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)           # g^T op(A)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                dbias = ColSum.apply(g)
+            if (ctx.needs_input_grad[1] and not tb and ctx.has_bias and ctx.needs_input_grad[2]
+                    and not torch.is_grad_enabled()):
+                db, dbias = gemm_colsum_(a, g, not ta)                             # dW and db in ONE launch
+            else:
+                if ctx.needs_input_grad[1]:
+                    if not tb:
+                        db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0)      # op(A)^T g
+                    else:
+                        db = Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)           # g^T op(A)
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    dbias = ColSum.apply(g)
         if ctx.needs_input_grad[0]:
             if not ta:
                 da = Gemm.apply(g, b, None, False, not tb, ACT_NONE, 0.0)      # g op(B)^T
@@ -313,6 +318,20 @@ class Gemm(Function):
                 da = Gemm.apply(b, g, None, tb, True, ACT_NONE, 0.0)           # op(B) g^T
         fork.join(db, dbias)
         return da, db, dbias, None, None, None, None
+
+
+def gemm_colsum_(a, g, ta):
+    """C = op(A) @ g and colsum[n] = sum_k g[k, n] in one kernel (no autograd: used inside plain backward passes)."""
+    a, g = _c(a), _c(g)
+    M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    K2, N = g.shape
+    assert K == K2
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    cs = torch.empty((N,), dtype=torch.float32, device=a.device)
+    ws = workspace(a.device)
+    check(_L().ggan_gemm_colsum(int(ta), M, N, K, _p(a), _p(g), _p(out), _p(cs), _p(ws), ws.numel(), _stream()),
+          'ggan_gemm_colsum')
+    return out, cs
 
 
 def linear(x, w, bias=None, act=ACT_NONE, alpha=0.0):

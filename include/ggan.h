@@ -14,7 +14,9 @@
  *   - Conv2D filters HWIO [k][k][Cin][Cout]; Deconv2D filters [k][k][Cout][Cin] (reference layouts);
  *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), allocates
  *     nothing, keeps no state between calls and is hipGraph-capturable;
- *   - `ws` is caller-provided scratch of at least ggan_*_workspace() bytes (may be NULL when 0);
+ *   - `ws` is caller-provided scratch of at least ggan_*_workspace() bytes (may be NULL when 0).  Its first
+ *     GGAN_WS_RESERVED bytes hold arrival counters of in-kernel split-K combines: the caller zeroes them ONCE when it
+ *     allocates the workspace, every kernel leaves them zero; calls sharing a workspace must be stream-ordered;
  *   - return value 0 = ok, negative = error; ggan_last_error() gives the message (thread-local).
  */
 #ifndef GGAN_H
@@ -27,6 +29,7 @@ extern "C" {
 #endif
 
 typedef void* ggan_stream_t; /* hipStream_t */
+#define GGAN_WS_RESERVED 16384
 
 /* activation codes for fused epilogues and ggan_act_* */
 enum { GGAN_ACT_NONE = 0, GGAN_ACT_LRELU = 1, GGAN_ACT_RELU = 2, GGAN_ACT_TANH = 3, GGAN_ACT_SIGMOID = 4 };
@@ -78,6 +81,10 @@ int ggan_deconv2d_bwd_filter(const ggan_conv_geom* g, const float* gy_big, const
 size_t ggan_gemm_workspace(int M, int N, int K);
 int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias,
               float* C, int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
+/* Same, plus colsum_b[n] = sum_k op(B)[k][n] from the B tiles the kernel stages anyway (tb must be 0): dW = X^T dY and
+ * db = sum_rows dY of the Linear backward in ONE launch. */
+int ggan_gemm_colsum(int ta, int M, int N, int K, const float* A, const float* B, float* C, float* colsum_b,
+                     void* ws, size_t ws_bytes, ggan_stream_t stream);
 /* out[c] = sum_r x[r,c] over a [rows,cols] matrix (BiasAddGrad of Linear). */
 int ggan_colsum(const float* x, float* out, int rows, int cols, ggan_stream_t stream);
 /* out[c] = sum_{n,hw} x[n,c,hw] (BiasAddGrad NCHW).  ws: optional scratch (>= 4 KiB * C) enabling a chip-wide

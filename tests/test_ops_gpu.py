@@ -278,3 +278,21 @@ def test_c_abi_error_reporting(gpu):
     g = _lib.ConvGeom(0, 1, 1, 1, 1, 1, 1, 5, 2, 1, 1)
     rc = L.ggan_conv2d_fwd(C.byref(g), None, None, None, None, 0, 0.0, None, 0, None)
     assert rc != 0 and b'geometry' in L.ggan_last_error()
+
+
+def test_gemm_colsum_and_splitk_is_deterministic(gpu):
+    """dW = X^T dY with the fused bias-gradient; the in-kernel split-K combine adds slices in a fixed order."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((64, 4608)).astype(np.float32)
+    gy = rng.standard_normal((64, 512)).astype(np.float32)
+    dw, db = F.gemm_colsum_(_t(x, gpu), _t(gy, gpu), True)
+    assert _rel(dw.cpu().numpy(), x.astype(np.float64).T @ gy.astype(np.float64)) < 2e-5
+    assert _rel(db.cpu().numpy(), gy.astype(np.float64).sum(0)) < 1e-5
+    w = rng.standard_normal((4608, 512)).astype(np.float32)
+    outs = [F.Gemm.apply(_t(x, gpu), _t(w, gpu), None, False, False, 0, 0.0).cpu().numpy() for _ in range(5)]
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])          # bitwise reproducible
+    assert _rel(outs[0], x.astype(np.float64) @ w.astype(np.float64)) < 2e-5
+    ws = F.workspace(gpu)
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0             # arrival counters left at zero
