@@ -40,6 +40,8 @@ SIGNATURES = {
     'ggan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_conv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_conv2d_bwd_data_act': (_I, [_G, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
+    'ggan_conv2d_bwd_filter_act': (_I, [_G, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_deconv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_deconv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _Z, _P]),
     'ggan_deconv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),

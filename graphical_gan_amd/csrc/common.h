@@ -61,6 +61,18 @@ __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
     }
 }
 
+// g * act'(.) given the reference value: forward INPUT or OUTPUT for lrelu/relu (only the sign matters, and
+// sign(output) == sign(input) for both), forward OUTPUT for tanh/sigmoid.
+__device__ __forceinline__ float act_grad(float g, float r, int act, float alpha) {
+    switch (act) {
+        case GGAN_ACT_LRELU: return r > 0.f ? g : alpha * g;
+        case GGAN_ACT_RELU: return r > 0.f ? g : 0.f;
+        case GGAN_ACT_TANH: return g * (1.f - r * r);
+        case GGAN_ACT_SIGMOID: return g * r * (1.f - r);
+        default: return g;
+    }
+}
+
 // wave64 all-reduce sum via DPP-free shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

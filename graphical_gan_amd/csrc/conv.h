@@ -6,22 +6,30 @@ namespace ggan {
 
 int conv_fwd_naive(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                    float alpha, hipStream_t s);
-int conv_dgrad_naive(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
-                     float alpha, hipStream_t s);
-int conv_wgrad_naive(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, hipStream_t s);
+// "gy mask": when m.act != GGAN_ACT_NONE the kernels consume gy[i] * act'(m.ref[i]) instead of gy[i] -- the activation
+// backward of a fused conv+bias+act layer applied while the operand is staged (no separate act_bwd pass / tensor).
+struct GyMask {
+    const float* ref;
+    int act;
+    float alpha;
+};
+int conv_dgrad_naive(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx,
+                     int act, float alpha, hipStream_t s);
+int conv_wgrad_naive(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, hipStream_t s);
 
 // MFMA paths: return 1 when the geometry is not covered (caller falls back to the naive kernel),
 // 0 on success, <0 on error.
 int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act,
                   float alpha, void* ws, size_t ws_bytes, hipStream_t s);
-int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
-                    float alpha, void* ws, size_t ws_bytes, hipStream_t s);
-int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, void* ws, size_t ws_bytes,
-                    hipStream_t s);
+int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx,
+                    int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s);
+// gbias (may be NULL): sum over n,oh,ow of the (masked) gy, produced from the gy tiles the kernel stages anyway
+int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
+                    size_t ws_bytes, hipStream_t s);
 size_t conv_workspace_bytes(const ggan_conv_geom& g);
 // out[i] = act(sum_s partial[s][i] + bias[(i/HW)%C]) -- deterministic split-K combine (conv + gemm)
 int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,
-                         float alpha, hipStream_t s);
+                         float alpha, hipStream_t s, size_t slab_stride = 0, float* tail_out = nullptr, size_t tail = 0);
 
 // exact n / d for n*d < 2^32 via one mulhi
 struct FastDiv {

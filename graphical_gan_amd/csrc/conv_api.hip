@@ -41,32 +41,55 @@ int ggan_conv2d_fwd(const ggan_conv_geom* g, const float* x, const float* w, con
     return conv_fwd_naive(*g, x, w, bias, y, act, alpha, s);
 }
 
-int ggan_conv2d_bwd_data(const ggan_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx, int act,
-                         float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+static int bwd_data(const ggan_conv_geom* g, const float* gy, GyMask m, const float* w, const float* bias, float* gx, int act,
+                    float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
     if (check_geom(g)) return -1;
-    GGAN_CHECK_ARG(gy && w && gx, "null pointer");
+    if (!(gy && w && gx)) { set_error("ggan_conv2d_bwd_data: null pointer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     if (!g_force_naive && !getenv("GGAN_NAIVE_DGRAD")) {
-        int r = conv_dgrad_mfma(*g, gy, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
+        int r = conv_dgrad_mfma(*g, gy, m, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
     }
-    return conv_dgrad_naive(*g, gy, w, bias, gx, act, alpha, s);
+    return conv_dgrad_naive(*g, gy, m, w, bias, gx, act, alpha, s);
+}
+
+static int bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
+                      size_t ws_bytes, ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    if (!(x && gy && gw)) { set_error("ggan_conv2d_bwd_filter: null pointer"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!g_force_naive && !getenv("GGAN_NAIVE_WGRAD")) {
+        int r = conv_wgrad_mfma(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
+        if (r <= 0) return r;
+    }
+    if (gbias) {   // plain path: separate reduction (needs the masked gradient materialised only when a mask is given)
+        if (m.act != GGAN_ACT_NONE) return 1;   // masked bias gradient only exists fused: caller uses act_bwd + the plain entry points
+        int r = ggan_chansum(gy, gbias, g->N, g->Co, g->Ho * g->Wo, ws, ws_bytes, stream);
+        if (r) return r;
+    }
+    return conv_wgrad_naive(*g, x, gy, m, gw, s);
+}
+
+int ggan_conv2d_bwd_data(const ggan_conv_geom* g, const float* gy, const float* w, const float* bias, float* gx, int act,
+                         float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    return bwd_data(g, gy, GyMask{nullptr, GGAN_ACT_NONE, 0.f}, w, bias, gx, act, alpha, ws, ws_bytes, stream);
 }
 
 int ggan_conv2d_bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, float* gw, float* gbias, void* ws,
                            size_t ws_bytes, ggan_stream_t stream) {
-    if (check_geom(g)) return -1;
-    GGAN_CHECK_ARG(x && gy && gw, "null pointer");
-    hipStream_t s = (hipStream_t)stream;
-    if (gbias) {
-        int r = ggan_chansum(gy, gbias, g->N, g->Co, g->Ho * g->Wo, ws, ws_bytes, stream);
-        if (r) return r;
-    }
-    if (!g_force_naive && !getenv("GGAN_NAIVE_WGRAD")) {
-        int r = conv_wgrad_mfma(*g, x, gy, gw, ws, ws ? ws_bytes : 0, s);
-        if (r <= 0) return r;
-    }
-    return conv_wgrad_naive(*g, x, gy, gw, s);
+    return bwd_filter(g, x, gy, GyMask{nullptr, GGAN_ACT_NONE, 0.f}, gw, gbias, ws, ws_bytes, stream);
+}
+
+int ggan_conv2d_bwd_data_act(const ggan_conv_geom* g, const float* gy, const float* y, int y_act, float y_alpha, const float* w,
+                             float* gx, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "null activation reference");
+    return bwd_data(g, gy, GyMask{y, y_act, y_alpha}, w, nullptr, gx, GGAN_ACT_NONE, 0.f, ws, ws_bytes, stream);
+}
+
+int ggan_conv2d_bwd_filter_act(const ggan_conv_geom* g, const float* x, const float* gy, const float* y, int y_act, float y_alpha,
+                               float* gw, float* gbias, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "null activation reference");
+    return bwd_filter(g, x, gy, GyMask{y, y_act, y_alpha}, gw, gbias, ws, ws_bytes, stream);
 }
 
 // Deconv2D = the adjoint family with the same filter bytes (see ggan.h)

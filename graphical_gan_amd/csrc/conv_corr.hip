@@ -26,7 +26,7 @@ using namespace ggan;
 
 namespace {
 
-constexpr int XE_MAX = 12;                 // slab elements staged per thread per chunk
+constexpr int XE_MAX = 16;                 // slab elements staged per thread per chunk
 constexpr unsigned OOB = 0x7FFFFFF0u;      // voffset >= num_records: the buffer load returns 0
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -57,6 +57,9 @@ struct CorrParams {
     float alpha;
     unsigned in_bytes, w_bytes;
     int dbg;
+    const float* in_ref;     // optional: slab values are in[i] * act'(in_ref[i]) (fused activation backward)
+    int in_act;
+    float in_alpha;
     size_t out_elems;
     CorrClass cls[4];
 };
@@ -86,8 +89,10 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
     constexpr int TNW = 32 * WN;
     constexpr int NT0 = TH0 * TW0, NT1 = NC > 1 ? TH1 * TW1 : 0, NTT = NT0 + NT1;
     constexpr int WUNITS = NTT * CK * (TNW / 4);
-    constexpr int WE = (WUNITS + 255) / 256;
-    static_assert(WM * WN * KS == 4, "4 waves per workgroup");
+    constexpr int NTHR = 64 * WM * WN * KS;
+    constexpr int WE = (WUNITS + NTHR - 1) / NTHR;
+    constexpr int XE = XE_MAX * 256 / NTHR;             // per-thread slab elements (same 4096-element budget)
+    static_assert(NTHR == 256 || NTHR == 512, "4 or 8 waves per workgroup");
     static_assert(CK % 4 == 0, "chunk must hold whole float4 groups");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = (wave / WM) % WN, ks = wave / (WM * WN);
@@ -111,13 +116,15 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
 
     const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, (short)0, (int)P.in_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)P.w_bytes, 0x00020000);
+    const bool masked = P.in_ref != nullptr;
+    const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(masked ? P.in_ref : P.in), (short)0, (int)P.in_bytes, 0x00020000);
 
     // ---- per-thread staging descriptors (fixed across chunks) ---------------------------------------------
-    unsigned xvo[XE_MAX];
+    unsigned xvo[XE];
     const int xe_cnt = CK * P.CS;
 #pragma unroll
-    for (int j = 0; j < XE_MAX; ++j) {
-        const int e = tid + j * 256;
+    for (int j = 0; j < XE; ++j) {
+        const int e = tid + j * NTHR;
         unsigned off = OOB;
         if (e < xe_cnt) {
             const int ckl = fdiv(e, P.d_CS);
@@ -136,7 +143,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
     int wlds[WE], wck[WE];
 #pragma unroll
     for (int q = 0; q < WE; ++q) {
-        const int u = tid + q * 256;
+        const int u = tid + q * NTHR;
         unsigned off = OOB;
         int l = 0, ckl = 0;
         if (u < WUNITS) {
@@ -185,14 +192,18 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-    unsigned xreg[XE_MAX];
+    unsigned xreg[XE], xref[XE];
     u32x4 wreg[WE];
 
     auto prefetch = [&](int ck0) {
         const int soff_x = ck0 * HWin * 4;
         const int soff_w = ck0 * P.w_sk * 4;
 #pragma unroll
-        for (int j = 0; j < XE_MAX; ++j) xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, xvo[j], soff_x, 0);
+        for (int j = 0; j < XE; ++j) xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, xvo[j], soff_x, 0);
+        if (masked) {
+#pragma unroll
+            for (int j = 0; j < XE; ++j) xref[j] = __builtin_amdgcn_raw_buffer_load_b32(rref, xvo[j], soff_x, 0);
+        }
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
             const unsigned vo = (ck0 + wck[q] < ck_end) ? wvo[q] : OOB;     // reduction-channel tail -> zero filter rows
@@ -204,13 +215,17 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
         float* xsb = smem + buf * STAGE;
         float* wsb = xsb + XS_SZ;
 #pragma unroll
-        for (int j = 0; j < XE_MAX; ++j) {
-            const int e = tid + j * 256;
-            if (e < xe_cnt) xsb[e] = __uint_as_float(xreg[j]);
+        for (int j = 0; j < XE; ++j) {
+            const int e = tid + j * NTHR;
+            if (e < xe_cnt) {
+                float v = __uint_as_float(xreg[j]);
+                if (masked) v = act_grad(v, __uint_as_float(xref[j]), P.in_act, P.in_alpha);
+                xsb[e] = v;
+            }
         }
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
-            const int u = tid + q * 256;
+            const int u = tid + q * NTHR;
             if (u < WUNITS) {
                 *reinterpret_cast<u32x4*>(wsb + wlds[q]) = wreg[q];
             }
@@ -286,7 +301,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
 
 // MODE 0: fwd (one 5x5 class).  MODE 1: dgrad class pairs, blockIdx.z = pair * SK + split.
 template <int MODE, int WM, int WN, int KS, int PW>
-__global__ __launch_bounds__(256) void corr_kernel(const CorrParams P) {
+__global__ __launch_bounds__(64 * WM * WN * KS) void corr_kernel(const CorrParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = blockIdx.z / P.SK, split = blockIdx.z - grp * P.SK;
     if (MODE == 0) {
@@ -298,14 +313,20 @@ __global__ __launch_bounds__(256) void corr_kernel(const CorrParams P) {
     }
 }
 
-// out[idx] = act(sum_s partial[s][idx] + bias[c])
-__global__ void splitk_reduce_k(const float* __restrict__ partial, int SK, size_t elems, float* __restrict__ out,
-                                const float* __restrict__ bias, int C, int HW, int act, float alpha) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+// out[idx] = act(sum_s partial[s*stride + idx] + bias[c]); entries idx >= elems (a "tail" of n2 extra sums, e.g. the bias
+// gradient riding along with the filter-gradient slabs) go to out2 unmodified.
+__global__ void splitk_reduce_k(const float* __restrict__ partial, int SK, size_t elems, size_t stride, float* __restrict__ out,
+                                const float* __restrict__ bias, int C, int HW, int act, float alpha, float* __restrict__ out2,
+                                size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems + n2; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < SK; ++k) s += partial[(size_t)k * elems + i];
-        if (bias) s += bias[(i / (size_t)HW) % (size_t)C];
-        out[i] = act_apply(s, act, alpha);
+        for (int k = 0; k < SK; ++k) s += partial[(size_t)k * stride + i];
+        if (i < elems) {
+            if (bias) s += bias[(i / (size_t)HW) % (size_t)C];
+            out[i] = act_apply(s, act, alpha);
+        } else {
+            out2[i - elems] = s;
+        }
     }
 }
 
@@ -334,8 +355,8 @@ int env_int(const char* name, int dflt) {
 struct WaveCfg { int WM, WN, KS, PW; };
 // fwd: 25 taps per chunk-channel-pair; dgrad class pairs carry only 12-13 taps, so they stage twice as many channels per
 // chunk (PW doubled) to keep ~25+ MFMAs per wave between barriers
-const WaveCfg kCfgsFwd[3] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}};
-const WaveCfg kCfgsDgrad[3] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}};
+const WaveCfg kCfgsFwd[7] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}, {1, 1, 4, 2}, {2, 1, 4, 1}, {1, 1, 8, 1}, {2, 2, 2, 1}};
+const WaveCfg kCfgsDgrad[7] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}, {1, 1, 4, 4}, {2, 1, 4, 2}, {1, 1, 8, 1}, {2, 2, 2, 2}};
 
 // pixel tile TI x TR x TC <= TM whose CK-channel slab fits the per-thread staging budget
 bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r, int ext_c) {
@@ -371,6 +392,10 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
     if (!once) {   // double-buffered staging can exceed the 64 KiB default dynamic-LDS limit
         allow_big_lds(corr_kernel<0, 2, 2, 1, 2>); allow_big_lds(corr_kernel<0, 2, 1, 2, 2>); allow_big_lds(corr_kernel<0, 1, 1, 4, 1>);
         allow_big_lds(corr_kernel<1, 2, 2, 1, 4>); allow_big_lds(corr_kernel<1, 2, 1, 2, 4>); allow_big_lds(corr_kernel<1, 1, 1, 4, 2>);
+        allow_big_lds(corr_kernel<0, 1, 1, 4, 2>); allow_big_lds(corr_kernel<1, 1, 1, 4, 4>);
+        allow_big_lds(corr_kernel<0, 2, 1, 4, 1>); allow_big_lds(corr_kernel<0, 1, 1, 8, 1>);
+        allow_big_lds(corr_kernel<1, 2, 1, 4, 2>); allow_big_lds(corr_kernel<1, 1, 1, 8, 1>);
+        allow_big_lds(corr_kernel<0, 2, 2, 2, 1>); allow_big_lds(corr_kernel<1, 2, 2, 2, 2>);
         once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
@@ -378,13 +403,21 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         switch (cfg) {
             case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
             case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
-            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+            case 2: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+            case 3: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 4: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
+            case 5: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
         }
     } else {
         switch (cfg) {
             case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 2, 1, 4>), grid, dim3(256), shmem, s, P); break;
             case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 1, 2, 4>), grid, dim3(256), shmem, s, P); break;
-            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 2: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 3: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 4, 4>), grid, dim3(256), shmem, s, P); break;
+            case 4: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
+            case 5: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 2, 2, 2>), grid, dim3(512), shmem, s, P); break;
         }
     }
     return 0;
@@ -398,20 +431,23 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const int target = env_int("GGAN_TARGET_WGS", 200);
     const WaveCfg* kCfgs = MODE == 0 ? kCfgsFwd : kCfgsDgrad;
     int cfg = env_int(cfg_env, -1);
-    if (cfg < 0 || cfg > 2) {
-        cfg = 2;
-        for (int c = 0; c < 3; ++c) {
+    if (cfg < 0 || cfg > 6) {
+        // 8 waves per workgroup (two per SIMD: one wave's LDS / barrier stalls hide under the other's MFMAs; measured
+        // 12-19 % faster than the 4-wave layouts).  Largest tile that still yields ~one workgroup per CU.
+        static const int order[3] = {6, 4, 5};          // 64x64, 64x32, 32x32 (pixels x channels)
+        cfg = 5;
+        for (int oi = 0; oi < 3; ++oi) {
+            const int c = order[oi];
             const WaveCfg& wc = kCfgs[c];
             const int CK = 2 * wc.KS * wc.PW, TM = 32 * wc.WM, TNW = 32 * wc.WN;
-            if (c < 2 && P.CNtot <= 32 && TNW > 32 && c == 0) continue;          // don't pad tiny channel counts to 64
-            if (P.CKtot < CK && c > 0) continue;                                   // tiny reductions: smallest chunk
+            if (P.CNtot <= 32 && TNW > 32) continue;                               // don't pad tiny channel counts to 64
             CorrParams T = P;
             if (!pick_tile(T, Hu, Wv, TM, CK, su, ext_r, ext_c)) continue;
-            if (c < 2 && T.TI * T.TR * T.TC * 2 <= TM && Hu * Wv * P.N >= TM) continue;   // staging budget forced a half-empty tile
+            if (oi < 2 && T.TI * T.TR * T.TC * 2 <= TM && Hu * Wv * P.N >= TM) continue;   // staging budget forced a half-empty tile
             const int wgs = cdiv(P.N, T.TI) * cdiv(Hu, T.TR) * cdiv(Wv, T.TC) * cdiv(P.CNtot, TNW) * groups;
-            if (wgs >= target || c == 2) { cfg = c; break; }
+            if (wgs >= target || oi == 2) { cfg = c; break; }
         }
-        if (P.CKtot < 8) cfg = 0;
+        if (P.CKtot < 8) cfg = P.CNtot <= 32 ? 1 : 6;                              // 3-channel inputs: smallest chunks
     }
     const WaveCfg& wc = kCfgs[cfg];
     const int CK = 2 * wc.KS * wc.PW, TM = 32 * wc.WM, TNW = 32 * wc.WN;
@@ -454,11 +490,13 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
 namespace ggan {
 
 int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,
-                         float alpha, hipStream_t s) {
-    size_t b = (elems + 255) / 256;
+                         float alpha, hipStream_t s, size_t slab_stride, float* tail_out, size_t tail) {
+    if (slab_stride == 0) slab_stride = elems;
+    if (!tail_out) tail = 0;
+    size_t b = (elems + tail + 255) / 256;
     if (b > 2048) b = 2048;
-    GGAN_LAUNCH("conv_splitk_reduce", 0, 4.0 * elems * (SK + 1), splitk_reduce_k, dim3((int)b), dim3(256), 0, s, partial,
-                SK, elems, out, bias, C, HW, act, alpha);
+    GGAN_LAUNCH("conv_splitk_reduce", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_k, dim3((int)b), dim3(256), 0, s, partial,
+                SK, elems, slab_stride, out, bias, C, HW, act, alpha, tail_out, tail);
     return 0;
 }
 
@@ -498,8 +536,8 @@ int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const
                               "GGAN_FWD_SK", "GGAN_FWD_CFG");
 }
 
-int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
-                    float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
+int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx,
+                    int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!hot_geometry(g)) return 1;
     ws = ws_scratch(ws, ws_bytes);
     const int Cip = (g.Ci + 3) & ~3;
@@ -519,6 +557,7 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, const float* w, co
     CorrParams P;
     memset(&P, 0, sizeof(P));
     P.in = gy; P.w = wT;
+    if (m.act != GGAN_ACT_NONE) { P.in_ref = m.ref; P.in_act = m.act; P.in_alpha = m.alpha; }
     P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
     P.N = g.N; P.CKtot = g.Co; P.Hin = g.Ho; P.Win = g.Wo;
     P.CNtot = g.Ci; P.Hout = g.H; P.Wout = g.W;

@@ -35,7 +35,7 @@ __global__ void conv_fwd_naive_k(ggan_conv_geom g, const float* __restrict__ x, 
     }
 }
 
-__global__ void conv_dgrad_naive_k(ggan_conv_geom g, const float* __restrict__ gy, const float* __restrict__ w,
+__global__ void conv_dgrad_naive_k(ggan_conv_geom g, const float* __restrict__ gy, GyMask mk, const float* __restrict__ w,
                                    const float* __restrict__ bias, float* __restrict__ gx, int act, float alpha) {
     const size_t total = (size_t)g.N * g.Ci * g.H * g.W;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -56,8 +56,13 @@ __global__ void conv_dgrad_naive_k(ggan_conv_geom g, const float* __restrict__ g
                 int ow = tw / g.stride;
                 if (ow >= g.Wo) continue;
                 const float* wp = w + (((size_t)kh * g.k + kw) * g.Ci + ci) * g.Co;
-                const float* gp = gy + (size_t)n * g.Co * g.Ho * g.Wo + (size_t)oh * g.Wo + ow;
-                for (int co = 0; co < g.Co; ++co) acc = fmaf(gp[(size_t)co * g.Ho * g.Wo], wp[co], acc);
+                const size_t gb = (size_t)n * g.Co * g.Ho * g.Wo + (size_t)oh * g.Wo + ow;
+                for (int co = 0; co < g.Co; ++co) {
+                    const size_t gi = gb + (size_t)co * g.Ho * g.Wo;
+                    float gv = gy[gi];
+                    if (mk.act) gv = act_grad(gv, mk.ref[gi], mk.act, mk.alpha);
+                    acc = fmaf(gv, wp[co], acc);
+                }
             }
         }
         if (bias) acc += bias[ci];
@@ -65,7 +70,7 @@ __global__ void conv_dgrad_naive_k(ggan_conv_geom g, const float* __restrict__ g
     }
 }
 
-__global__ void conv_wgrad_naive_k(ggan_conv_geom g, const float* __restrict__ x, const float* __restrict__ gy,
+__global__ void conv_wgrad_naive_k(ggan_conv_geom g, const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
                                    float* __restrict__ gw) {
     const size_t total = (size_t)g.k * g.k * g.Ci * g.Co;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -77,14 +82,16 @@ __global__ void conv_wgrad_naive_k(ggan_conv_geom g, const float* __restrict__ x
         float acc = 0.f;
         for (int n = 0; n < g.N; ++n) {
             const float* xp = x + ((size_t)n * g.Ci + ci) * g.H * g.W;
-            const float* gp = gy + ((size_t)n * g.Co + co) * g.Ho * g.Wo;
+            const size_t gb = ((size_t)n * g.Co + co) * g.Ho * g.Wo;
             for (int oh = 0; oh < g.Ho; ++oh) {
                 int ih = oh * g.stride + kh - g.pad_t;
                 if (ih < 0 || ih >= g.H) continue;
                 for (int ow = 0; ow < g.Wo; ++ow) {
                     int iw = ow * g.stride + kw - g.pad_l;
                     if (iw < 0 || iw >= g.W) continue;
-                    acc = fmaf(xp[ih * g.W + iw], gp[oh * g.Wo + ow], acc);
+                    float gv = gy[gb + oh * g.Wo + ow];
+                    if (mk.act) gv = act_grad(gv, mk.ref[gb + oh * g.Wo + ow], mk.act, mk.alpha);
+                    acc = fmaf(xp[ih * g.W + iw], gv, acc);
                 }
             }
         }
@@ -111,18 +118,18 @@ int conv_fwd_naive(const ggan_conv_geom& g, const float* x, const float* w, cons
     return 0;
 }
 
-int conv_dgrad_naive(const ggan_conv_geom& g, const float* gy, const float* w, const float* bias, float* gx, int act,
-                     float alpha, hipStream_t s) {
+int conv_dgrad_naive(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx,
+                     int act, float alpha, hipStream_t s) {
     size_t total = (size_t)g.N * g.Ci * g.H * g.W;
     double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * g.k * g.k;
-    GGAN_LAUNCH("conv_dgrad_naive", fl, 0, conv_dgrad_naive_k, dim3(grid_for(total)), dim3(256), 0, s, g, gy, w, bias, gx, act, alpha);
+    GGAN_LAUNCH("conv_dgrad_naive", fl, 0, conv_dgrad_naive_k, dim3(grid_for(total)), dim3(256), 0, s, g, gy, m, w, bias, gx, act, alpha);
     return 0;
 }
 
-int conv_wgrad_naive(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, hipStream_t s) {
+int conv_wgrad_naive(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, hipStream_t s) {
     size_t total = (size_t)g.k * g.k * g.Ci * g.Co;
     double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * g.k * g.k;
-    GGAN_LAUNCH("conv_wgrad_naive", fl, 0, conv_wgrad_naive_k, dim3(grid_for(total)), dim3(256), 0, s, g, x, gy, gw);
+    GGAN_LAUNCH("conv_wgrad_naive", fl, 0, conv_wgrad_naive_k, dim3(grid_for(total)), dim3(256), 0, s, g, x, gy, m, gw);
     return 0;
 }
 

@@ -39,7 +39,12 @@ struct WgradParams {
     int row_tiles, chunks_total, chunks_per_split, SK;
     int xunits;
     unsigned x_bytes, gy_bytes;
-    size_t out_elems;
+    size_t out_elems;      // 25*Ci*Co
+    size_t slab_stride;    // out_elems (+ Co when the bias gradient rides along)
+    const float* gy_ref;   // optional fused activation backward: gy[i] * act'(gy_ref[i])
+    int gy_act;
+    float gy_alpha;
+    float* gbias;          // optional: sum over n,oh,ow of the (masked) gy
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
@@ -55,6 +60,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
 
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, (int)P.x_bytes, 0x00020000);
     const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)P.gy, (short)0, (int)P.gy_bytes, 0x00020000);
+    const bool masked = P.gy_ref != nullptr;
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)(masked ? P.gy_ref : P.gy), (short)0, (int)P.gy_bytes, 0x00020000);
+    const bool do_bias = P.gbias != nullptr && blockIdx.x == 0;
+    float bsum = 0.f;
 
     // ---- staging descriptors -----------------------------------------------------------------------------
     int xrel[XU_MAX], xinfo[XU_MAX], xlds[XU_MAX];
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     const int gb = l15 * P.PCp + qq;       // gy-fragment lane base
 
     u32x4 xreg[XU_MAX];
-    u32x4 greg;
+    u32x4 greg, gref;
 
     auto prefetch = [&](int ch) {
         const int ig = ch / P.row_tiles, rt = ch - ig * P.row_tiles;
@@ -117,6 +126,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
         const bool gok = gvalid && (n0 + gimg) < P.N && (oh0 + gr) < P.Ho;
         const unsigned gvo = gok ? (unsigned)((n0 * P.Co + co0) * HoWo + oh0 * P.Wo + grel) * 4u : OOB;
         greg = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo, 0, 0);
+        if (masked) gref = __builtin_amdgcn_raw_buffer_load_b128(rr, gvo, 0, 0);
     };
 
     auto commit = [&]() {
@@ -128,7 +138,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
                 *reinterpret_cast<u32x2*>(xs + xlds[j] + P.SCh) = od;
             }
         }
-        if (gcol < TCO) *reinterpret_cast<u32x4*>(gs + gcol * P.PCp + gp4 * 4) = greg;
+        if (gcol < TCO) {
+            float4 gv = make_float4(__uint_as_float(greg.x), __uint_as_float(greg.y), __uint_as_float(greg.z), __uint_as_float(greg.w));
+            if (masked) {
+                gv.x = act_grad(gv.x, __uint_as_float(gref.x), P.gy_act, P.gy_alpha);
+                gv.y = act_grad(gv.y, __uint_as_float(gref.y), P.gy_act, P.gy_alpha);
+                gv.z = act_grad(gv.z, __uint_as_float(gref.z), P.gy_act, P.gy_alpha);
+                gv.w = act_grad(gv.w, __uint_as_float(gref.w), P.gy_act, P.gy_alpha);
+            }
+            *reinterpret_cast<float4*>(gs + gcol * P.PCp + gp4 * 4) = gv;
+            // bias gradient: this thread's 4 pixels; the PC/4 threads of a channel are contiguous lanes (power of two <= 16)
+            if (do_bias) bsum += (gv.x + gv.y) + (gv.z + gv.w);
+        }
     };
 
     const int c_begin = split * P.chunks_per_split;
@@ -174,6 +195,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
         }
     }
 
+    if (do_bias) {
+        // threads gcol*(PC/4) .. +PC/4-1 hold the partial sums of channel gcol: xor-shuffle within that lane group
+        const int grp = P.PC >> 2;
+        for (int o = grp >> 1; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o, 64);
+        if (gcol < TCO && gp4 == 0 && co0 + gcol < P.Co) {
+            if (P.SK == 1) P.gbias[co0 + gcol] = bsum;
+            else P.out[(size_t)split * P.slab_stride + P.out_elems + co0 + gcol] = bsum;
+        }
+    }
+
     // ---- combine the 4 pixel-split waves: (2,3)->(0,1), then 1->0 -------------------------------------------------
     __syncthreads();
     float* red = smem;                     // [2][NT*4][64]
@@ -200,7 +231,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     __syncthreads();
     if (wave != 0) return;
     // ---- store: D col = lane&15 -> co (contiguous), row = 4*(lane>>4)+reg -> ci -------------------------------------
-    float* outp = P.out + (size_t)split * P.out_elems;
+    float* outp = P.out + (size_t)split * P.slab_stride;
     const int co = co0 + l15;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -221,8 +252,8 @@ int env_int(const char* name, int dflt) {
 
 namespace ggan {
 
-int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, float* gw, void* ws, size_t ws_bytes,
-                    hipStream_t s) {
+int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
     if (g.k != 5 || g.stride != 2 || (g.Wo & 3) || (g.W & 3) || g.pad_l != 1 || g.Wo > 64) return 1;
     ws = ws_scratch(ws, ws_bytes);
     const size_t xb = (size_t)g.N * g.Ci * g.H * g.W * 4, gb = (size_t)g.N * g.Co * g.Ho * g.Wo * 4;
@@ -231,6 +262,8 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, fl
     WgradParams P;
     memset(&P, 0, sizeof(P));
     P.x = x; P.gy = gy;
+    if (m.act != GGAN_ACT_NONE) { P.gy_ref = m.ref; P.gy_act = m.act; P.gy_alpha = m.alpha; }
+    P.gbias = gbias;
     P.x_bytes = (unsigned)xb; P.gy_bytes = (unsigned)gb;
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo;
     P.pad_t = g.pad_t;
@@ -251,6 +284,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, fl
     P.PC = P.TI * P.TR * g.Wo;
     P.PCp = P.PC + 4;
     if ((P.PC & 3) || TCO * (P.PC / 4) > 256) return 1;
+    if (gbias && ((P.PC / 4) & (P.PC / 4 - 1))) return 1;      // lane-group shuffle needs a power-of-two group
     P.d_F4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR); P.d_TI = make_fastdiv(P.TI);
     P.d_PC4 = make_fastdiv(P.PC / 4); P.d_TRWo = make_fastdiv(P.TR * g.Wo); P.d_Wo = make_fastdiv(g.Wo);
     P.row_tiles = cdiv(g.Ho, P.TR);
@@ -264,7 +298,8 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, fl
     }
     if (sk < 1) sk = 1;
     P.out_elems = (size_t)25 * g.Ci * g.Co;
-    while (sk > 1 && (size_t)sk * P.out_elems * sizeof(float) > ws_bytes) sk /= 2;
+    P.slab_stride = P.out_elems + (gbias ? (size_t)g.Co : 0);
+    while (sk > 1 && (size_t)sk * P.slab_stride * sizeof(float) > ws_bytes) sk /= 2;
     P.chunks_per_split = cdiv(P.chunks_total, sk);
     P.SK = cdiv(P.chunks_total, P.chunks_per_split);
     P.out = P.SK > 1 ? (float*)ws : gw;
@@ -279,7 +314,9 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, fl
     }
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     GGAN_LAUNCH("conv_wgrad_mfma", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(256), shmem, s, P);
-    if (P.SK > 1) return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s);
+    if (P.SK > 1)
+        return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s, P.slab_stride,
+                                    gbias, gbias ? (size_t)g.Co : 0);
     return 0;
 }
 

@@ -29,16 +29,6 @@ __global__ void act_fwd_k(const float* __restrict__ x, float* __restrict__ y, si
     for (size_t j = (n4 << 2) + i; j < n; j += stride) y[j] = act_apply(x[j], act, alpha);
 }
 
-__device__ __forceinline__ float act_grad(float g, float r, int act, float alpha) {
-    switch (act) {
-        case GGAN_ACT_LRELU: return r > 0.f ? g : alpha * g;      // ref = forward input
-        case GGAN_ACT_RELU: return r > 0.f ? g : 0.f;             // ref = forward input
-        case GGAN_ACT_TANH: return g * (1.f - r * r);             // ref = forward output
-        case GGAN_ACT_SIGMOID: return g * r * (1.f - r);          // ref = forward output
-        default: return g;
-    }
-}
-
 __global__ void act_bwd_k(const float* __restrict__ gy, const float* __restrict__ ref, float* __restrict__ gx,
                           size_t n, int act, float alpha) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;

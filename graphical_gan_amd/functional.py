@@ -50,6 +50,8 @@ def _c(t):
 # on two HIP streams (fork after gy is ready, join before anything downstream runs), so the chip holds one workgroup
 # of each per CU and each kernel's prologue / staging latency hides under the other's MFMA phase.  The fork/join is
 # captured into the step's HIP graph as parallel branches.
+import os as _os
+FUSED_CONV_BWD = _os.environ.get('GGAN_NO_FUSED_BWD') is None
 OVERLAP_BWD = False   # measured: cross-queue graph dependencies cost 6-11 us each on ROCm 7.2, cancelling the overlap gain
 _SIDE = {}
 
@@ -152,9 +154,14 @@ class ConvFwd(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
+        if not torch.is_grad_enabled() and FUSED_CONV_BWD:
+            # plain backward: two launches -- the activation derivative is applied while gy is staged and the bias
+            # gradient comes out of the filter-gradient kernel (no act_bwd / chansum passes, no intermediate tensor)
+            r = _fused_conv_backward(ctx, gy, x, w, y)
+            if r is not None:
+                return r
         if ctx.act != ACT_NONE:
-            ref = y if ctx.act in (ACT_TANH, ACT_SIGMOID) else y   # lrelu/relu: sign(y) == sign(pre-activation)
-            gy = ActBwd.apply(gy, ref, ctx.act, ctx.alpha)
+            gy = ActBwd.apply(gy, y, ctx.act, ctx.alpha)       # lrelu/relu: sign(y) == sign(pre-activation)
         gx = gw = gb = None
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         fork = _fork(gy.device, ctx.needs_input_grad[0] and need_w)
@@ -167,6 +174,33 @@ class ConvFwd(Function):
             gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
         fork.join(gw, gb)
         return gx, gw, gb, None, None, None
+
+
+def _fused_conv_backward(ctx, gy, x, w, y):
+    gy = _c(gy)
+    geom = ctx.geom
+    N, Ci, H, W, Co, Ho, Wo, k = geom[:8]
+    g = _geom(geom)
+    L = _L()
+    ws = workspace(gy.device)
+    act = ctx.act
+    yref = _p(y) if act != ACT_NONE else _p(None)
+    gx = gw = gb = None
+    if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=gy.device)
+        gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(x), _p(gy), yref, act, ctx.alpha, _p(gw), _p(gb), _p(ws), ws.numel(),
+                                          _stream())
+        if rc == 1:
+            return None          # geometry not covered by the fused kernels: caller takes the unfused path
+        check(rc, 'ggan_conv2d_bwd_filter_act')
+        if not ctx.needs_input_grad[1]:
+            gw = None
+    if ctx.needs_input_grad[0]:
+        gx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gy.device)
+        check(L.ggan_conv2d_bwd_data_act(C.byref(g), _p(gy), yref, act, ctx.alpha, _p(w), _p(gx), _p(ws), ws.numel(), _stream()),
+              'ggan_conv2d_bwd_data_act')
+    return gx, gw, gb, None, None, None
 
 
 class ConvDgrad(Function):

@@ -61,6 +61,13 @@ int ggan_conv2d_bwd_data(const ggan_conv_geom* g, const float* gy, const float* 
 /* Conv2DBackpropFilter: gw[k,k,Ci,Co]; gbias[Co] = sum over N,Ho,Wo of gy (BiasAddGrad), may be NULL. */
 int ggan_conv2d_bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, float* gw,
                            float* gbias, void* ws, size_t ws_bytes, ggan_stream_t stream);
+/* Backward of a FUSED conv+bias+activation layer: the two gradients above computed from gy[i]*act'(y[i]) where y is the
+ * layer's saved output, with the activation derivative applied while gy is staged (no separate pointwise pass and no
+ * intermediate tensor) and the bias gradient produced by the filter-gradient kernel from the tiles it stages anyway. */
+int ggan_conv2d_bwd_data_act(const ggan_conv_geom* g, const float* gy, const float* y, int y_act, float y_alpha,
+                             const float* w, float* gx, void* ws, size_t ws_bytes, ggan_stream_t stream);
+int ggan_conv2d_bwd_filter_act(const ggan_conv_geom* g, const float* x, const float* gy, const float* y, int y_act,
+                               float y_alpha, float* gw, float* gbias, void* ws, size_t ws_bytes, ggan_stream_t stream);
 
 /* tf.nn.conv2d_transpose + bias_add (tflib/ops/deconv2d.py:101-114) computed natively in NCHW (the two
  * layout transposes at :91/:116 are mathematically no-ops).  g describes the forward conv whose
