@@ -347,6 +347,24 @@ __global__ void filter_transpose_k(const float* __restrict__ w, float* __restric
     }
 }
 
+// Many slabs, few outputs (filter gradients of the 3-channel layers: 64 slabs x 4.8 K floats): 64 outputs per block,
+// the slabs dealt to 4 thread groups, combined through LDS in group order (deterministic).
+__global__ void splitk_reduce_small_k(const float* __restrict__ partial, int SK, size_t elems, size_t stride, float* __restrict__ out,
+                                      float* __restrict__ out2, size_t n2) {
+    __shared__ float sm[4][64];
+    const int o = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (i < elems + n2)
+        for (int k = kg; k < SK; k += 4) s += partial[(size_t)k * stride + i];
+    sm[kg][o] = s;
+    __syncthreads();
+    if (kg == 0 && i < elems + n2) {
+        const float v = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+        if (i < elems) out[i] = v; else out2[i - elems] = v;
+    }
+}
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -493,6 +511,11 @@ int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out,
                          float alpha, hipStream_t s, size_t slab_stride, float* tail_out, size_t tail) {
     if (slab_stride == 0) slab_stride = elems;
     if (!tail_out) tail = 0;
+    if (!bias && act == GGAN_ACT_NONE && SK >= 8 && elems + tail <= 65536) {
+        GGAN_LAUNCH("conv_splitk_reduce", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_small_k,
+                    dim3((int)((elems + tail + 63) / 64)), dim3(256), 0, s, partial, SK, elems, slab_stride, out, tail_out, tail);
+        return 0;
+    }
     size_t b = (elems + tail + 255) / 256;
     if (b > 2048) b = 2048;
     GGAN_LAUNCH("conv_splitk_reduce", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_k, dim3((int)b), dim3(256), 0, s, partial,

@@ -21,7 +21,9 @@ using namespace ggan;
 namespace {
 
 constexpr int TCI = 16, TCO = 16;
-constexpr int XU_MAX = 8;                  // float4 slab units per thread per chunk
+constexpr int NW = 8;                      // waves per workgroup: two per SIMD, pixel quads dealt round-robin
+constexpr int NTHR = 64 * NW;
+constexpr int XU_MAX = 4;                  // float4 slab units per thread per chunk (2048 per workgroup)
 constexpr unsigned OOB = 0x7FFFFFF0u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -47,7 +49,7 @@ struct WgradParams {
     float* gbias;          // optional: sum over n,oh,ow of the (masked) gy
 };
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
+__global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 5, NT = 25;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     int xrel[XU_MAX], xinfo[XU_MAX], xlds[XU_MAX];
 #pragma unroll
     for (int j = 0; j < XU_MAX; ++j) {
-        const int u = tid + j * 256;
+        const int u = tid + j * NTHR;
         int rel = 0, info = -1, l = 0;
         if (u < P.xunits) {
             const int row = fdiv(u, P.d_F4);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     const bool gvalid = gcol < TCO && (co0 + gcol) < P.Co;
 
     // zero the slab once: halo columns and padded channels are never written again
-    for (int e = tid; e < TCI * P.CS; e += 256) xs[e] = 0.f;
+    for (int e = tid; e < TCI * P.CS; e += NTHR) xs[e] = 0.f;
 
     f32x4 acc[NT];
 #pragma unroll
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < XU_MAX; ++j) {
-            if (tid + j * 256 < P.xunits) {
+            if (tid + j * NTHR < P.xunits) {
                 u32x2 ev = {xreg[j].x, xreg[j].z}, od = {xreg[j].y, xreg[j].w};
                 *reinterpret_cast<u32x2*>(xs + xlds[j]) = ev;
                 *reinterpret_cast<u32x2*>(xs + xlds[j] + P.SCh) = od;
@@ -179,14 +181,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
                     a[kh * KS + kw] = xp[kh * P.SCp + ((kw + 3) & 1) * P.SCh + ((kw + 3) >> 1)];
         };
         if (wave < nq) load_quad(wave, av[0], bv[0]);
-        for (int qd = wave; qd < nq; qd += 8) {
-            if (qd + 4 < nq) load_quad(qd + 4, av[1], bv[1]);
+        for (int qd = wave; qd < nq; qd += 2 * NW) {
+            if (qd + NW < nq) load_quad(qd + NW, av[1], bv[1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][t], bv[0], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (qd + 4 < nq) {
-                if (qd + 8 < nq) load_quad(qd + 8, av[0], bv[0]);
+            if (qd + NW < nq) {
+                if (qd + 2 * NW < nq) load_quad(qd + 2 * NW, av[0], bv[0]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][t], bv[1], acc[t], 0, 0, 0);
@@ -205,30 +207,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
         }
     }
 
-    // ---- combine the 4 pixel-split waves: (2,3)->(0,1), then 1->0 -------------------------------------------------
+    // ---- combine the NW pixel-split waves by halving: waves [h, 2h) hand their accumulators to waves [0, h) through LDS ------
     __syncthreads();
-    float* red = smem;                     // [2][NT*4][64]
-    if (wave >= 2) {
+    float* red = smem;                     // [NW/2][NT*4][64]
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+    for (int h = NW / 2; h >= 1; h >>= 1) {
+        if (wave >= h && wave < 2 * h) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[((wave - 2) * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((wave - h) * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (wave < h) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] += red[(wave * NT * 4 + t * 4 + r) * 64 + lane];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (wave < 2) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] += red[(wave * NT * 4 + t * 4 + r) * 64 + lane];
-    }
-    __syncthreads();
-    if (wave == 1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(t * 4 + r) * 64 + lane] = acc[t][r];
-    }
-    __syncthreads();
     if (wave != 0) return;
     // ---- store: D col = lane&15 -> co (contiguous), row = 4*(lane>>4)+reg -> ci -------------------------------------
     float* outp = P.out + (size_t)split * P.slab_stride;
@@ -237,7 +235,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = acc[t][r] + red[(t * 4 + r) * 64 + lane];
+            const float v = acc[t][r];
             const int ci = ci0 + qq * 4 + r;
             if (co < P.Co && ci < P.Ci) outp[((size_t)t * P.Ci + ci) * P.Co + co] = v;
         }
@@ -273,7 +271,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         P.SR = 2 * (P.TR - 1) + 5;
         P.SCp = g.W + 8;
         P.xunits = TCI * P.TI * P.SR * (g.W / 4);
-        if (P.xunits <= XU_MAX * 256 && P.TI < 256 && P.SR < 256) break;
+        if (P.xunits <= XU_MAX * NTHR && P.TI < 256 && P.SR < 256) break;
         if (P.TI > 1) P.TI = (P.TI + 1) / 2;
         else if (P.TR > 1) P.TR = (P.TR + 1) / 2;
         else return 1;
@@ -304,7 +302,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     P.SK = cdiv(P.chunks_total, P.chunks_per_split);
     P.out = P.SK > 1 ? (float*)ws : gw;
     size_t stage = (size_t)TCI * P.CS + (size_t)TCO * P.PCp;
-    size_t red = (size_t)2 * 100 * 64;
+    size_t red = (size_t)(NW / 2) * 100 * 64;
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     if (shmem > 160 * 1024) return 1;
     static bool attr_set = false;
@@ -313,7 +311,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         attr_set = true;
     }
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
-    GGAN_LAUNCH("conv_wgrad_mfma", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(256), shmem, s, P);
+    GGAN_LAUNCH("conv_wgrad_mfma", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P);
     if (P.SK > 1)
         return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s, P.slab_stride,
                                     gbias, gbias ? (size_t)g.Co : 0);
