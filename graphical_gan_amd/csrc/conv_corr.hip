@@ -57,6 +57,7 @@ struct CorrParams {
     float alpha;
     unsigned in_bytes, w_bytes;
     int dbg;
+    unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
     const float* in_ref;     // optional: slab values are in[i] * act'(in_ref[i]) (fused activation backward)
     int in_act;
     float in_alpha;
@@ -81,21 +82,43 @@ __device__ __forceinline__ void mma_taps(const float* __restrict__ xs, const flo
             }
 }
 
-// NC classes (1 for fwd, 2 for a dgrad pair) with tap grids (TH0,TW0) / (TH1,TW1).
-template <int NC, int TH0, int TW0, int TH1, int TW1, int SU, int DI, int WM, int WN, int KS, int PW>
-__device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& c0, const CorrClass& c1, const int split,
-                                          float* smem) {
+// Class lists.  KIND 0: forward, one 5x5 class.  KIND 1 / 2: data-gradient class pairs {0,3} / {1,2} (13 / 12 taps).
+// KIND 3: all four parity classes in one workgroup (25 taps): each lane then owns the 2x2 output block of its class pixel
+// and the epilogue writes FULL output rows as float2 (the pair kinds leave every 128-B line half-written by two different
+// workgroups -- measured 29 % of the workgroup's lifetime in the store tail).
+template <int KIND> struct ClassList;
+template <> struct ClassList<0> { static constexpr int NC = 1; static constexpr int cls(int) { return 0; }
+                                  static constexpr int th(int) { return 5; } static constexpr int tw(int) { return 5; } };
+template <> struct ClassList<1> { static constexpr int NC = 2; static constexpr int cls(int i) { return i == 0 ? 0 : 3; }
+                                  static constexpr int th(int i) { return i == 0 ? 3 : 2; } static constexpr int tw(int i) { return i == 0 ? 3 : 2; } };
+template <> struct ClassList<2> { static constexpr int NC = 2; static constexpr int cls(int i) { return i == 0 ? 1 : 2; }
+                                  static constexpr int th(int i) { return i == 0 ? 3 : 2; } static constexpr int tw(int i) { return i == 0 ? 2 : 3; } };
+template <> struct ClassList<3> { static constexpr int NC = 4; static constexpr int cls(int i) { return i; }
+                                  static constexpr int th(int i) { return i < 2 ? 3 : 2; } static constexpr int tw(int i) { return (i & 1) ? 2 : 3; } };
+
+template <int KIND, int SU, int DI, int WM, int WN, int KS, int PW>
+__device__ __forceinline__ void corr_body(const CorrParams& P, const int split, float* smem) {
+    using CL = ClassList<KIND>;
+    constexpr int NC = CL::NC;
     constexpr int CK = 2 * KS * PW;
     constexpr int TNW = 32 * WN;
-    constexpr int NT0 = TH0 * TW0, NT1 = NC > 1 ? TH1 * TW1 : 0, NTT = NT0 + NT1;
+    constexpr int NT0 = CL::th(0) * CL::tw(0);
+    constexpr int NT1 = NC > 1 ? CL::th(1) * CL::tw(1) : 0;
+    constexpr int NT2 = NC > 2 ? CL::th(2) * CL::tw(2) : 0;
+    constexpr int NT3 = NC > 3 ? CL::th(3) * CL::tw(3) : 0;
+    constexpr int NTT = NT0 + NT1 + NT2 + NT3;
     constexpr int WUNITS = NTT * CK * (TNW / 4);
     constexpr int NTHR = 64 * WM * WN * KS;
     constexpr int WE = (WUNITS + NTHR - 1) / NTHR;
-    constexpr int XE = XE_MAX * 256 / NTHR;             // per-thread slab elements (same 4096-element budget)
+    constexpr int XE = (KIND == 0 ? XE_MAX : XE_MAX / 2) * 256 / NTHR;   // per-thread slab elements (4096 / 2048 budget)
     static_assert(NTHR == 256 || NTHR == 512, "4 or 8 waves per workgroup");
     static_assert(CK % 4 == 0, "chunk must hold whole float4 groups");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = (wave / WM) % WN, ks = wave / (WM * WN);
+    const bool stamping = (P.dbg & 4) && P.stamps && tid == 0;
+    const int wg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    auto stamp = [&](int i) { if (stamping) P.stamps[(size_t)wg_lin * 16 + i] = __builtin_readcyclecounter(); };
+    stamp(0);
     const int half = lane >> 5, l31 = lane & 31;
 
     // ---- which tile ---------------------------------------------------------------------------------
@@ -140,34 +163,32 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
         xvo[j] = off;
     }
     unsigned wvo[WE];
-    int wlds[WE], wck[WE];
+    auto w_ck = [](int u) { return (u / (TNW / 4)) % CK; };
+    auto w_lds = [](int u) { return ((u / (CK * (TNW / 4))) * CK + (u / (TNW / 4)) % CK) * TNW + (u % (TNW / 4)) * 4; };
 #pragma unroll
     for (int q = 0; q < WE; ++q) {
         const int u = tid + q * NTHR;
         unsigned off = OOB;
-        int l = 0, ckl = 0;
         if (u < WUNITS) {
             // unit = (tap, ck, cn4): 4 consecutive cn in memory => every wave-load is a run of whole 128-B filter rows
             const int cn = (u % (TNW / 4)) * 4;
-            ckl = (u / (TNW / 4)) % CK;
+            const int ckl = w_ck(u);
             const int tapg = u / (CK * (TNW / 4));
-            const bool second = NC > 1 && tapg >= NT0;
-            const int tap = second ? tapg - NT0 : tapg;
-            const int tw = second ? TW1 : TW0;
+            int ci_ = 0, tap = tapg;                     // which class of the list, tap index inside it
+            if (NC > 1 && tap >= NT0) { tap -= NT0; ci_ = 1; }
+            if (NC > 2 && ci_ == 1 && tap >= NT1) { tap -= NT1; ci_ = 2; }
+            if (NC > 3 && ci_ == 2 && tap >= NT2) { tap -= NT2; ci_ = 3; }
+            const int tw = CL::tw(ci_);
             const int i = tap / tw, j = tap - i * tw;
-            const int wb = second ? c1.wbase : c0.wbase;
+            const int wb = P.cls[CL::cls(ci_)].wbase;
             if (cn0 + cn < P.CNtot)
                 off = (unsigned)(wb + i * P.w_si + j * P.w_sj + ckl * P.w_sk + (cn0 + cn) * P.w_sn) * 4u;
-            l = (tapg * CK + ckl) * TNW + cn;
         }
         wvo[q] = off;
-        wlds[q] = l;
-        wck[q] = ckl;
     }
 
     // ---- per-lane MFMA fragment bases ----------------------------------------------------------------------
-    int xfrag0, xfrag1 = 0, o_off0 = 0, o_off1 = 0;
-    bool ok0, ok1 = false;
+    int xfrag[NC];
     {
         const int p = wm * 32 + l31;
         const int img = fdiv(p, P.d_TRTC);
@@ -177,20 +198,19 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
         const bool in_tile = img < P.TI && (n0 + img) < P.N;
         const int kbase = (ks * PW * 2 + half) * P.CS;
         const int b = in_tile ? img * (P.SR * P.SCp) + SU * ur * P.SCp + SU * vc : 0;
-        ok0 = in_tile && (u0 + ur) < c0.Hu && (v0 + vc) < c0.Wv;
-        xfrag0 = kbase + b + c0.roff * P.SCp + c0.coff;
-        if (ok0) o_off0 = (((n0 + img) * P.CNtot) * P.Hout + (c0.or0 + P.ors * (u0 + ur))) * P.Wout + (c0.oc0 + P.ocs * (v0 + vc));
-        if (NC > 1) {
-            ok1 = in_tile && (u0 + ur) < c1.Hu && (v0 + vc) < c1.Wv;
-            xfrag1 = kbase + b + c1.roff * P.SCp + c1.coff;
-            if (ok1) o_off1 = (((n0 + img) * P.CNtot) * P.Hout + (c1.or0 + P.ors * (u0 + ur))) * P.Wout + (c1.oc0 + P.ocs * (v0 + vc));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const CorrClass& cc = P.cls[CL::cls(c)];
+            xfrag[c] = kbase + b + cc.roff * P.SCp + cc.coff;
         }
     }
     const int wfrag = (ks * PW * 2 + half) * TNW + wn * 32 + l31;
 
-    f32x16 acc0, acc1;
+    f32x16 acc[NC];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     unsigned xreg[XE], xref[XE];
     u32x4 wreg[WE];
@@ -206,7 +226,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
         }
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
-            const unsigned vo = (ck0 + wck[q] < ck_end) ? wvo[q] : OOB;     // reduction-channel tail -> zero filter rows
+            const unsigned vo = (ck0 + w_ck(tid + q * NTHR) < ck_end) ? wvo[q] : OOB;     // reduction-channel tail -> zero filter rows
             wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, vo, soff_w, 0);
         }
     };
@@ -226,19 +246,21 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
             const int u = tid + q * NTHR;
-            if (u < WUNITS) {
-                *reinterpret_cast<u32x4*>(wsb + wlds[q]) = wreg[q];
-            }
+            if (u < WUNITS) *reinterpret_cast<u32x4*>(wsb + w_lds(u)) = wreg[q];
         }
     };
 
     // ---- main loop over reduction-channel chunks: chunk c is multiplied out of buffer c&1 while chunk c+1 is committed
     //      to the other buffer and chunk c+2's global loads are in flight; ONE barrier per chunk ---------------------
+    stamp(1);
     prefetch(ck_begin);
     commit(0);
+    stamp(2);
     if (ck_begin + CK < ck_end) prefetch(ck_begin + CK);
     __syncthreads();
+    stamp(3);
     int buf = 0;
+    int it_ = 0;
     for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
         if (ck0 + CK < ck_end && !(P.dbg & 1)) {
             commit(buf ^ 1);
@@ -247,69 +269,130 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const CorrClass& 
         if (!(P.dbg & 2)) {
             const float* xs = smem + ((P.dbg & 1) ? 0 : buf * STAGE);
             const float* ws = xs + XS_SZ;
-            mma_taps<TH0, TW0, DI, PW, CK, TNW>(xs, ws, xfrag0, wfrag, P.CS, P.SCp, acc0);
-            if (NC > 1) mma_taps<TH1, TW1, DI, PW, CK, TNW>(xs, ws + NT0 * CK * TNW, xfrag1, wfrag, P.CS, P.SCp, acc1);
+            mma_taps<CL::th(0), CL::tw(0), DI, PW, CK, TNW>(xs, ws, xfrag[0], wfrag, P.CS, P.SCp, acc[0]);
+            if constexpr (NC > 1) mma_taps<CL::th(1), CL::tw(1), DI, PW, CK, TNW>(xs, ws + NT0 * CK * TNW, xfrag[1], wfrag, P.CS, P.SCp, acc[1]);
+            if constexpr (NC > 2) mma_taps<CL::th(2), CL::tw(2), DI, PW, CK, TNW>(xs, ws + (NT0 + NT1) * CK * TNW, xfrag[2], wfrag, P.CS, P.SCp, acc[2]);
+            if constexpr (NC > 3) mma_taps<CL::th(3), CL::tw(3), DI, PW, CK, TNW>(xs, ws + (NT0 + NT1 + NT2) * CK * TNW, xfrag[3], wfrag, P.CS, P.SCp, acc[3]);
         }
         __syncthreads();
+        if (it_ < 8) stamp(4 + it_);
+        ++it_;
     }
+    stamp(12);
 
-    // ---- combine the k-split waves through LDS ---------------------------------------------------------------
-    if (KS > 1) {
-        float* red = smem;     // [(KS-1)][NC][16][64 * WM * WN]
-        constexpr int LANES = 64 * WM * WN;
-        const int slot = lane + 64 * (wm + WM * wn);
-        if (ks > 0) {
+    // ---- epilogue.  Global stores are issue-bound (~500 cycles per wave-instruction when the whole chip stores at once), so
+    //      the tile is not written by the accumulator owners (16-64 dword stores per lane, and only the ks==0 waves after a
+    //      k-split combine) but re-distributed through LDS: every wave parks its partial accumulators as
+    //      red[ks][class][cn][pixel], then EVERY thread adds the KS partials of 4 consecutive pixels of one channel and
+    //      writes them as float4 (forward / all-class data-gradient: two float4 = 8 consecutive output floats).
+    constexpr int TMW = 32 * WM;
+    float* red = smem;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                red[(((ks - 1) * NC + 0) * 16 + r) * LANES + slot] = acc0[r];
-                if (NC > 1) red[(((ks - 1) * NC + 1) * 16 + r) * LANES + slot] = acc1[r];
-            }
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cnl = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[((ks * NC + c) * TNW + cnl) * TMW + wm * 32 + l31] = acc[c][r];
         }
-        __syncthreads();
-        if (ks > 0) return;
-#pragma unroll
-        for (int k = 0; k < KS - 1; ++k)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc0[r] += red[((k * NC + 0) * 16 + r) * LANES + slot];
-                if (NC > 1) acc1[r] += red[((k * NC + 1) * 16 + r) * LANES + slot];
-            }
-    }
-
-    // ---- epilogue: lanes run along pixels => coalesced NCHW stores ---------------------------------------------
+    __syncthreads();
+    stamp(13);
+    if (P.dbg & 8) return;      // (timing experiment: skip the output stores)
     const bool direct = P.SK == 1;
     float* outp = direct ? P.out : P.out + (size_t)split * P.out_elems;   // P.out = partial slab when SK > 1
     const int chw = P.Hout * P.Wout;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cn = cn0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (cn < P.CNtot) {
-            const float bv = (direct && P.bias) ? P.bias[cn] : 0.f;
-            if (ok0) {
-                float v = acc0[r];
-                if (direct) v = act_apply(v + bv, P.act, P.alpha);
-                outp[(size_t)o_off0 + (size_t)cn * chw] = v;
+    constexpr int GROUPS = NC == 4 ? 2 : NC;           // stores per (channel, pixel quad): classes, or row parities
+    constexpr int UNITS = GROUPS * TNW * (TMW / 4);
+    const bool quad_rows = (P.TC & 3) == 0;            // 4 consecutive tile pixels share (image, row)
+    for (int u = tid; u < UNITS; u += NTHR) {
+        const int p4 = u % (TMW / 4);
+        const int cnl = (u / (TMW / 4)) % TNW;
+        const int gsel = u / ((TMW / 4) * TNW);
+        const int cn = cn0 + cnl;
+        if (cn >= P.CNtot) continue;
+        const int ca = NC == 4 ? 2 * gsel : gsel, cb = NC == 4 ? 2 * gsel + 1 : gsel;
+        float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int k = 0; k < KS; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(red + ((k * NC + ca) * TNW + cnl) * TMW + 4 * p4);
+            va[0] += t.x; va[1] += t.y; va[2] += t.z; va[3] += t.w;
+            if (NC == 4) {
+                const float4 t2 = *reinterpret_cast<const float4*>(red + ((k * NC + cb) * TNW + cnl) * TMW + 4 * p4);
+                vb[0] += t2.x; vb[1] += t2.y; vb[2] += t2.z; vb[3] += t2.w;
             }
-            if (NC > 1 && ok1) {
-                float v = acc1[r];
-                if (direct) v = act_apply(v + bv, P.act, P.alpha);
-                outp[(size_t)o_off1 + (size_t)cn * chw] = v;
+        }
+        if (direct) {
+            const float bv = P.bias ? P.bias[cn] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                va[j] = act_apply(va[j] + bv, P.act, P.alpha);
+                if (NC == 4) vb[j] = act_apply(vb[j] + bv, P.act, P.alpha);
+            }
+        }
+        const CorrClass& A = P.cls[CL::cls(ca)];
+        const CorrClass& B = P.cls[CL::cls(cb)];
+        // first pixel of the quad
+        const int p = 4 * p4;
+        const int img = fdiv(p, P.d_TRTC);
+        const int rem = p - img * (P.TR * P.TC);
+        const int ur = fdiv(rem, P.d_TC);
+        const int vc = rem - ur * P.TC;
+        const bool img_ok = img < P.TI && (n0 + img) < P.N;
+        const size_t cbase = ((size_t)(n0 + img) * P.CNtot + cn) * chw;
+        bool done = false;
+        if (quad_rows && img_ok && (P.Wout & 3) == 0) {
+            if (NC != 4 && P.ocs == 1 && (A.Wv & 3) == 0 && (u0 + ur) < A.Hu && (v0 + vc + 3) < A.Wv) {
+                const int off = (A.or0 + P.ors * (u0 + ur)) * P.Wout + A.oc0 + v0 + vc;
+                if ((off & 3) == 0) {
+                    *reinterpret_cast<float4*>(outp + cbase + off) = make_float4(va[0], va[1], va[2], va[3]);
+                    done = true;
+                }
+            }
+            if (NC == 4 && A.Wv == B.Wv && A.Hu == B.Hu && (A.Wv & 3) == 0 && (u0 + ur) < A.Hu && (v0 + vc + 3) < A.Wv) {
+                // the two column parities interleave into 8 consecutive floats of output row or0 + 2*(u0+ur)
+                const bool a_even = A.oc0 < B.oc0;
+                const int off = (A.or0 + P.ors * (u0 + ur)) * P.Wout + (a_even ? A.oc0 : B.oc0) + P.ocs * (v0 + vc);
+                if ((off & 3) == 0 && P.ocs == 2) {
+                    const float* e = a_even ? va : vb;
+                    const float* o = a_even ? vb : va;
+                    *reinterpret_cast<float4*>(outp + cbase + off) = make_float4(e[0], o[0], e[1], o[1]);
+                    *reinterpret_cast<float4*>(outp + cbase + off + 4) = make_float4(e[2], o[2], e[3], o[3]);
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pj = p + j;
+                const int im = fdiv(pj, P.d_TRTC);
+                const int rm = pj - im * (P.TR * P.TC);
+                const int urj = fdiv(rm, P.d_TC);
+                const int vcj = rm - urj * P.TC;
+                if (!(im < P.TI && (n0 + im) < P.N)) continue;
+                const size_t cb2 = ((size_t)(n0 + im) * P.CNtot + cn) * chw;
+                if ((u0 + urj) < A.Hu && (v0 + vcj) < A.Wv)
+                    outp[cb2 + (A.or0 + P.ors * (u0 + urj)) * P.Wout + A.oc0 + P.ocs * (v0 + vcj)] = va[j];
+                if (NC == 4 && (u0 + urj) < B.Hu && (v0 + vcj) < B.Wv)
+                    outp[cb2 + (B.or0 + P.ors * (u0 + urj)) * P.Wout + B.oc0 + P.ocs * (v0 + vcj)] = vb[j];
             }
         }
     }
+    stamp(14);
 }
 
-// MODE 0: fwd (one 5x5 class).  MODE 1: dgrad class pairs, blockIdx.z = pair * SK + split.
+// MODE 0: fwd.  MODE 1: dgrad class pairs, blockIdx.z = pair * SK + split.  MODE 2: dgrad, all four classes per workgroup.
 template <int MODE, int WM, int WN, int KS, int PW>
 __global__ __launch_bounds__(64 * WM * WN * KS) void corr_kernel(const CorrParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = blockIdx.z / P.SK, split = blockIdx.z - grp * P.SK;
     if (MODE == 0) {
-        corr_body<1, 5, 5, 1, 1, 2, 1, WM, WN, KS, PW>(P, P.cls[0], P.cls[0], split, smem);
+        corr_body<0, 2, 1, WM, WN, KS, PW>(P, split, smem);
+    } else if (MODE == 2) {
+        corr_body<3, 1, -1, WM, WN, KS, PW>(P, split, smem);
     } else if (grp == 0) {
-        corr_body<2, 3, 3, 2, 2, 1, -1, WM, WN, KS, PW>(P, P.cls[0], P.cls[3], split, smem);
+        corr_body<1, 1, -1, WM, WN, KS, PW>(P, split, smem);
     } else {
-        corr_body<2, 3, 2, 2, 3, 1, -1, WM, WN, KS, PW>(P, P.cls[1], P.cls[2], split, smem);
+        corr_body<2, 1, -1, WM, WN, KS, PW>(P, split, smem);
     }
 }
 
@@ -378,6 +461,7 @@ const WaveCfg kCfgsDgrad[7] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}, {1, 1, 
 
 // pixel tile TI x TR x TC <= TM whose CK-channel slab fits the per-thread staging budget
 bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r, int ext_c) {
+    const int budget = (su == 2 ? XE_MAX : XE_MAX / 2) * 256;     // staged slab elements per chunk (fwd / dgrad)
     P.TC = Wv < TM ? Wv : TM;
     P.TR = TM / P.TC; if (P.TR < 1) P.TR = 1; if (P.TR > Hu) P.TR = Hu;
     P.TI = TM / (P.TR * P.TC); if (P.TI < 1) P.TI = 1; if (P.TI > P.N) P.TI = P.N;
@@ -385,7 +469,7 @@ bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r,
         P.SR = su * (P.TR - 1) + ext_r;
         P.SCp = su * (P.TC - 1) + ext_c;
         P.CS = P.TI * P.SR * P.SCp;
-        if (CK * P.CS <= XE_MAX * 256) return true;
+        if (CK * P.CS <= budget) return true;
         if (P.TI > 1) P.TI = (P.TI + 1) / 2;
         else if (P.TR > 1) P.TR = (P.TR + 1) / 2;
         else return false;
@@ -414,18 +498,21 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         allow_big_lds(corr_kernel<0, 2, 1, 4, 1>); allow_big_lds(corr_kernel<0, 1, 1, 8, 1>);
         allow_big_lds(corr_kernel<1, 2, 1, 4, 2>); allow_big_lds(corr_kernel<1, 1, 1, 8, 1>);
         allow_big_lds(corr_kernel<0, 2, 2, 2, 1>); allow_big_lds(corr_kernel<1, 2, 2, 2, 2>);
+        allow_big_lds(corr_kernel<2, 2, 2, 1, 2>); allow_big_lds(corr_kernel<2, 2, 1, 2, 2>); allow_big_lds(corr_kernel<2, 1, 1, 4, 1>);
+        allow_big_lds(corr_kernel<2, 1, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 1>); allow_big_lds(corr_kernel<2, 1, 1, 8, 1>);
+        allow_big_lds(corr_kernel<2, 2, 2, 2, 1>);
         once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
-    if (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 2) {
         switch (cfg) {
-            case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
-            case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
-            case 2: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
-            case 3: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
-            case 4: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
-            case 5: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<0, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
+            case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
+            case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
+            case 2: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+            case 3: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 4: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
+            case 5: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
         }
     } else {
         switch (cfg) {
@@ -447,7 +534,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
                     const float* bias, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s, const char* name,
                     double fl, const char* sk_env, const char* cfg_env) {
     const int target = env_int("GGAN_TARGET_WGS", 200);
-    const WaveCfg* kCfgs = MODE == 0 ? kCfgsFwd : kCfgsDgrad;
+    const WaveCfg* kCfgs = MODE == 1 ? kCfgsDgrad : kCfgsFwd;
     int cfg = env_int(cfg_env, -1);
     if (cfg < 0 || cfg > 6) {
         // 8 waves per workgroup (two per SIMD: one wave's LDS / barrier stalls hide under the other's MFMAs; measured
@@ -493,8 +580,9 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     P.out = P.SK > 1 ? (float*)ws : dst;
     P.bias = bias; P.act = act; P.alpha = alpha;
     P.dbg = env_int("GGAN_DBG", 0);
+    if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     size_t stage = 2 * ((size_t)((CK * P.CS + 3) & ~3) + (size_t)ntaps * CK * TNW);
-    size_t red = (size_t)(wc.KS - 1) * (groups > 1 ? 2 : 1) * 16 * 64 * wc.WM * wc.WN;
+    size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
     if (rc) return rc;
@@ -614,6 +702,14 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
         }
     P.out_elems = (size_t)g.N * g.Ci * g.H * g.W;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
+    // all four parity classes in one workgroup (full-row float2 stores) when 32x32 tiles still give ~one workgroup per CU;
+    // otherwise balanced class pairs (twice the workgroups)
+    const long wgs_all = (long)cdiv(g.N * Hu * Wv, 32) * cdiv(g.Ci, 32);
+    int mode = env_int("GGAN_DGRAD_MODE", 0);
+    if (mode == 0) mode = wgs_all >= env_int("GGAN_TARGET_WGS", 200) ? 2 : 1;
+    if (mode == 2)
+        return plan_and_launch<2>(P, Hu, Wv, 1, hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, 25, 1, gx, bias, act, alpha, ws, ws_bytes,
+                                  s, "conv_dgrad_mfma", fl, "GGAN_DGRAD_SK", "GGAN_DGRAD_CFG");
     return plan_and_launch<1>(P, Hu, Wv, 1, hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, 13, 2, gx, bias, act, alpha, ws, ws_bytes,
                               s, "conv_dgrad_mfma", fl, "GGAN_DGRAD_SK", "GGAN_DGRAD_CFG");
 }

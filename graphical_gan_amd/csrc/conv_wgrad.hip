@@ -47,6 +47,7 @@ struct WgradParams {
     int gy_act;
     float gy_alpha;
     float* gbias;          // optional: sum over n,oh,ow of the (masked) gy
+    int dbg_nostore;
 };
 
 __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
@@ -207,11 +208,12 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
         }
     }
 
-    // ---- combine the NW pixel-split waves by halving: waves [h, 2h) hand their accumulators to waves [0, h) through LDS ------
+    // ---- combine the NW pixel-split waves: halve through LDS down to two partial tiles, then ALL waves add those two and
+    //      store float4 runs along co (one wave storing 100 dwords per lane is a ~50k-cycle issue-bound tail) -------------
     __syncthreads();
     float* red = smem;                     // [NW/2][NT*4][64]
 #pragma unroll
-    for (int h = NW / 2; h >= 1; h >>= 1) {
+    for (int h = NW / 2; h >= 2; h >>= 1) {
         if (wave >= h && wave < 2 * h) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -227,18 +229,35 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
         }
         __syncthreads();
     }
-    if (wave != 0) return;
-    // ---- store: D col = lane&15 -> co (contiguous), row = 4*(lane>>4)+reg -> ci -------------------------------------
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (P.dbg_nostore) return;
+    // element (t, ci_l, co_l) sits at red[w][(t*4 + (ci_l&3))*64 + (ci_l>>2)*16 + co_l]
     float* outp = P.out + (size_t)split * P.slab_stride;
-    const int co = co0 + l15;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = acc[t][r];
-            const int ci = ci0 + qq * 4 + r;
-            if (co < P.Co && ci < P.Ci) outp[((size_t)t * P.Ci + ci) * P.Co + co] = v;
+    const bool vec = (P.Co & 3) == 0;
+    for (int u = tid; u < NT * TCI * (TCO / 4); u += NTHR) {
+        const int c4 = u & 3, cil = (u >> 2) & 15, t = u >> 6;
+        const int idx = (t * 4 + (cil & 3)) * 64 + (cil >> 2) * 16 + c4 * 4;
+        const float4 a = *reinterpret_cast<const float4*>(red + idx);
+        const float4 b2 = *reinterpret_cast<const float4*>(red + NT * 4 * 64 + idx);
+        const float4 v = make_float4(a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w);
+        const int ci = ci0 + cil, co = co0 + c4 * 4;
+        if (ci >= P.Ci || co >= P.Co) continue;
+        float* dst = outp + ((size_t)t * P.Ci + ci) * P.Co + co;
+        if (vec && co + 3 < P.Co) {
+            *reinterpret_cast<float4*>(dst) = v;
+        } else {
+            dst[0] = v.x;
+            if (co + 1 < P.Co) dst[1] = v.y;
+            if (co + 2 < P.Co) dst[2] = v.z;
+            if (co + 3 < P.Co) dst[3] = v.w;
         }
+    }
 }
 
 int env_int(const char* name, int dflt) {
@@ -262,6 +281,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     P.x = x; P.gy = gy;
     if (m.act != GGAN_ACT_NONE) { P.gy_ref = m.ref; P.gy_act = m.act; P.gy_alpha = m.alpha; }
     P.gbias = gbias;
+    P.dbg_nostore = env_int("GGAN_DBG", 0) & 8;
     P.x_bytes = (unsigned)xb; P.gy_bytes = (unsigned)gb;
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo;
     P.pad_t = g.pad_t;
