@@ -197,8 +197,8 @@ def main():
             'value': round(images_per_s, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'gan_inference_%s.py MODE=%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
-                args.dataset if not K else args.dataset + ' (gmgan, N_COMS=%d)' % K, args.mode, cfg.B, cfg.S, cfg.S, cfg.C,
+            'config': {'workload': '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
+                'gmgan' if K else 'gan', args.dataset, args.mode, ' N_COMS=%d' % K if K else '', cfg.B, cfg.S, cfg.S, cfg.C,
                 cfg.critic_iters, '' if not args.no_graph else ', eager'),
                 'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world, 'hip_graph': not args.no_graph,
                 'fused_epilogues': not args.no_fuse, 'minibatches_per_step': 1 + cfg.critic_iters,

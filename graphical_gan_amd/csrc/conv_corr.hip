@@ -26,7 +26,7 @@ using namespace ggan;
 
 namespace {
 
-constexpr int XE_MAX = 16;                 // slab elements staged per thread per chunk
+constexpr int XE_MAX = 24;                 // slab elements staged per thread per chunk (x256 threads: 6144 budget)
 constexpr unsigned OOB = 0x7FFFFFF0u;      // voffset >= num_records: the buffer load returns 0
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -65,21 +65,32 @@ struct CorrParams {
     CorrClass cls[4];
 };
 
-// One chunk's MFMAs for one class (the compiler interleaves the LDS fragment reads with the MFMAs; explicit
-// row-ahead prefetch pinned with sched_barrier measured SLOWER: 28.9 vs 25.7 us on the 64->128 @16 layer).
+// One chunk's MFMAs for one class.  hipcc emits "ds_read; s_waitcnt lgkmcnt(0); v_mfma; v_mfma" for the straightforward loop
+// (operands fetched right before use into the same four registers), which leaves the matrix pipe idle for one LDS latency
+// per MFMA pair (measured: 5300 cycles per chunk where the MFMAs need 3200).  Here the operands of MFMA pair s+2,s+3 are
+// read BEFORE MFMA pair s,s+1 is issued, and sched_group_barrier pins that interleave (<= 4 LDS reads in flight).
 template <int TH, int TW, int DI, int PW, int CK, int TNW>
 __device__ __forceinline__ void mma_taps(const float* __restrict__ xs, const float* __restrict__ ws, int xfrag, int wfrag,
                                          int CS, int SCp, f32x16& acc) {
+    constexpr int NS = TH * TW * PW;
+    float a[NS], b[NS];
+    auto load = [&](int s) {
+        const int tap = s / PW, p = s - tap * PW;
+        const int i = tap / TW, j = tap - i * TW;
+        a[s] = ws[(tap * CK + p * 2) * TNW + wfrag];
+        b[s] = xs[p * 2 * CS + xfrag + DI * (i * SCp + j)];
+    };
+    load(0);
+    if (NS > 1) load(1);
 #pragma unroll
-    for (int i = 0; i < TH; ++i)
-#pragma unroll
-        for (int j = 0; j < TW; ++j)
-#pragma unroll
-            for (int p = 0; p < PW; ++p) {
-                const float a = ws[((i * TW + j) * CK + p * 2) * TNW + wfrag];
-                const float b = xs[p * 2 * CS + xfrag + DI * (i * SCp + j)];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
+    for (int s = 0; s < NS; s += 2) {
+        if (s + 2 < NS) load(s + 2);
+        if (s + 3 < NS) load(s + 3);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        if (s + 1 < NS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], b[s + 1], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS reads of the NEXT pair first
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // then this pair's two MFMAs
+    }
 }
 
 // Class lists.  KIND 0: forward, one 5x5 class.  KIND 1 / 2: data-gradient class pairs {0,3} / {1,2} (13 / 12 taps).
@@ -261,11 +272,20 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     stamp(3);
     int buf = 0;
     int it_ = 0;
-    for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
+    // The two waves that share a SIMD run the chunk in OPPOSITE order: waves of the first half stage chunk c+1 (LDS commit +
+    // global prefetch of c+2) and then multiply chunk c, waves of the second half multiply first and stage afterwards.  The
+    // vector-memory / LDS-write burst of one half therefore overlaps the MFMA phase of the other (with every wave in the
+    // same phase the staging burst saturates the CU's single texture-address path while the matrix pipes idle: measured
+    // staging 5.5 us + MFMA 13.1 us = 29 us kernel, i.e. zero overlap).
+    const bool stage_first = NTHR == 256 || wave < (NTHR / 128);
+    auto stage_next = [&](int ck0) {
         if (ck0 + CK < ck_end && !(P.dbg & 1)) {
-            commit(buf ^ 1);
-            if (ck0 + 2 * CK < ck_end) prefetch(ck0 + 2 * CK);
+            if (!(P.dbg & 16)) commit(buf ^ 1);
+            if (ck0 + 2 * CK < ck_end && !(P.dbg & 32)) prefetch(ck0 + 2 * CK);
         }
+    };
+    for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
+        if (stage_first) stage_next(ck0);
         if (!(P.dbg & 2)) {
             const float* xs = smem + ((P.dbg & 1) ? 0 : buf * STAGE);
             const float* ws = xs + XS_SZ;
@@ -274,6 +294,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
             if constexpr (NC > 2) mma_taps<CL::th(2), CL::tw(2), DI, PW, CK, TNW>(xs, ws + (NT0 + NT1) * CK * TNW, xfrag[2], wfrag, P.CS, P.SCp, acc[2]);
             if constexpr (NC > 3) mma_taps<CL::th(3), CL::tw(3), DI, PW, CK, TNW>(xs, ws + (NT0 + NT1 + NT2) * CK * TNW, xfrag[3], wfrag, P.CS, P.SCp, acc[3]);
         }
+        if (!stage_first) stage_next(ck0);
         __syncthreads();
         if (it_ < 8) stamp(4 + it_);
         ++it_;
@@ -456,7 +477,7 @@ int env_int(const char* name, int dflt) {
 struct WaveCfg { int WM, WN, KS, PW; };
 // fwd: 25 taps per chunk-channel-pair; dgrad class pairs carry only 12-13 taps, so they stage twice as many channels per
 // chunk (PW doubled) to keep ~25+ MFMAs per wave between barriers
-const WaveCfg kCfgsFwd[7] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}, {1, 1, 4, 2}, {2, 1, 4, 1}, {1, 1, 8, 1}, {2, 2, 2, 1}};
+const WaveCfg kCfgsFwd[8] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}, {1, 1, 4, 2}, {2, 1, 4, 1}, {1, 1, 8, 1}, {2, 2, 2, 1}, {2, 1, 4, 2}};
 const WaveCfg kCfgsDgrad[7] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}, {1, 1, 4, 4}, {2, 1, 4, 2}, {1, 1, 8, 1}, {2, 2, 2, 2}};
 
 // pixel tile TI x TR x TC <= TM whose CK-channel slab fits the per-thread staging budget
@@ -500,7 +521,7 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         allow_big_lds(corr_kernel<0, 2, 2, 2, 1>); allow_big_lds(corr_kernel<1, 2, 2, 2, 2>);
         allow_big_lds(corr_kernel<2, 2, 2, 1, 2>); allow_big_lds(corr_kernel<2, 2, 1, 2, 2>); allow_big_lds(corr_kernel<2, 1, 1, 4, 1>);
         allow_big_lds(corr_kernel<2, 1, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 1>); allow_big_lds(corr_kernel<2, 1, 1, 8, 1>);
-        allow_big_lds(corr_kernel<2, 2, 2, 2, 1>);
+        allow_big_lds(corr_kernel<2, 2, 2, 2, 1>); allow_big_lds(corr_kernel<0, 2, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 2>);
         once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
@@ -512,7 +533,8 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
             case 3: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
             case 4: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
             case 5: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
+            case 6: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
         }
     } else {
         switch (cfg) {
@@ -536,7 +558,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const int target = env_int("GGAN_TARGET_WGS", 200);
     const WaveCfg* kCfgs = MODE == 1 ? kCfgsDgrad : kCfgsFwd;
     int cfg = env_int(cfg_env, -1);
-    if (cfg < 0 || cfg > 6) {
+    if (cfg < 0 || cfg > 7) {
         // 8 waves per workgroup (two per SIMD: one wave's LDS / barrier stalls hide under the other's MFMAs; measured
         // 12-19 % faster than the 4-wave layouts).  Largest tile that still yields ~one workgroup per CU.
         static const int order[3] = {6, 4, 5};          // 64x64, 64x32, 32x32 (pixels x channels)

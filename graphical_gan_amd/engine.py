@@ -10,6 +10,8 @@ buffers (a device-resident ring of pre-staged minibatches feeds them with one d2
 device inside the graph.  With data parallelism the graph is split around the gradient all-reduce:
 [fwd+bwd+pack] -> RCCL all-reduce of the flat bucket -> [Adam].
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -47,6 +49,9 @@ class Trainer(object):
         self._graphs = {}
         self._calls = {'gen': 0, 'disc': 0}
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # data-parallel runs split the step graph around the gradient all-reduce; the flag lets a single GPU exercise
+        # exactly that code path (the collective is then a 1-rank no-op)
+        self.split_graph = self.world > 1 or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
         self._opts = None
 
     # ---- inputs ---------------------------------------------------------------------------------------
@@ -115,7 +120,7 @@ class Trainer(object):
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         g1 = torch.cuda.CUDAGraph()
-        if self.world == 1:
+        if not self.split_graph:
             with torch.cuda.graph(g1, stream=s):
                 cost, opt, keep = self._fwd_bwd(which)
                 opt.update()

@@ -123,3 +123,54 @@ def test_trajectory(gpu, case, graph):
         d = np.abs(P[n].reshape(ref.shape) - ref)
         assert d.max() <= 2.5 * lr * steps, (n, d.max())
         assert (d > 2e-5).mean() <= 0.02, (n, (d > 2e-5).mean())
+
+
+def test_split_graph_path_matches_single_graph(gpu, monkeypatch):
+    """The data-parallel step runs as [fwd+bwd+pack graph] -> all-reduce -> [Adam graph].  Exercise that exact code path
+    on one GPU (1-rank no-op collective) and require bit-identical weights vs the single-graph path."""
+    import torch
+    from oracle import step as S
+    res = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv('GGAN_FORCE_SPLIT_GRAPH', '1')
+        else:
+            monkeypatch.delenv('GGAN_FORCE_SPLIT_GRAPH', raising=False)
+        ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, 'ali', 8, 16, True, True, gpu)
+        assert tr.split_graph == force
+        feeds = iter([S.make_feed(ocfg, np.random.default_rng(300 + i), 'ali') for i in range(12)])
+        for it in range(5):
+            tr.iteration(it, feeds)
+        torch.cuda.synchronize()
+        res.append(tr.get_params())
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_fused_conv_backward_entry_points(gpu):
+    """ggan_conv2d_bwd_{data,filter}_act: gy*act'(y) applied on staging + bias gradient out of the filter kernel."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    rng = np.random.default_rng(21)
+    for (N, Ci, H, Co) in [(64, 64, 16, 128), (8, 3, 32, 64), (5, 128, 7, 256)]:
+        geom = F.conv_geom(N, Ci, H, H, Co, 5, 2)
+        Ho = geom[5]
+        x = rng.standard_normal((N, Ci, H, H)).astype(np.float32)
+        w = (rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci)).astype(np.float32)
+        b = rng.standard_normal(Co).astype(np.float32)
+        gy = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+        xd = torch.as_tensor(x, device=gpu).requires_grad_(True)
+        wd = torch.as_tensor(w, device=gpu).requires_grad_(True)
+        bd = torch.as_tensor(b, device=gpu).requires_grad_(True)
+        y = F.ConvFwd.apply(xd, wd, bd, geom, F.ACT_LRELU, 0.2)
+        gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], grad_outputs=torch.as_tensor(gy, device=gpu))
+        pre = O.conv2d(x.astype(np.float64), w.astype(np.float64), 2) + b.reshape(1, -1, 1, 1)
+        g2 = gy.astype(np.float64) * np.where(pre > 0, 1.0, 0.2)
+        assert _rel_(gx.cpu().numpy(), O.conv2d_bwd_data(g2, w.astype(np.float64), (H, H), 2)) < 3e-5
+        assert _rel_(gw.cpu().numpy(), O.conv2d_bwd_filter(x.astype(np.float64), g2, 5, 2)) < 3e-5
+        assert _rel_(gb.cpu().numpy(), g2.sum(axis=(0, 2, 3))) < 3e-5
+
+
+def _rel_(a, ref):
+    return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
