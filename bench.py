@@ -166,8 +166,18 @@ def main():
         dom = next((r for r in recs if r['flops'] > 0), None)
         if dom is not None:
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this same
+            # workload, committed by tools/prof_round.sh; counters cannot be read from inside the process
+            traffic, pmc = None, None
+            try:
+                tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')))
+                pmc = tab.get(dom['name'])
+                traffic = pmc['traffic_bytes'] if pmc else None
+            except (OSError, ValueError):
+                pass
             roofline = dict(bound='mfma', kernel=dom['name'], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
-                            unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                            unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic,
+                            traffic_unit='bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)', pmc=pmc,
                             avg_launch_us=round(1e3 * dom['total_ms'] / dom['launches'], 2),
                             flop_per_launch=dom['flops'] / dom['launches'],
                             whole_step_tflops=round(step_tflops, 2),

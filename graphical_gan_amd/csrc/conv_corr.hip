@@ -527,24 +527,24 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
     if constexpr (MODE == 0 || MODE == 2) {
         switch (cfg) {
-            case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
-            case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
-            case 2: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
-            case 3: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
-            case 4: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
-            case 5: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
-            case 6: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<MODE, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
+            case 0: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 1, 2>" : "corr_kernel<2, 2, 2, 1, 2>"), fl, 0, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
+            case 1: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 2, 2>" : "corr_kernel<2, 2, 1, 2, 2>"), fl, 0, (corr_kernel<MODE, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
+            case 2: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 4, 1>" : "corr_kernel<2, 1, 1, 4, 1>"), fl, 0, (corr_kernel<MODE, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+            case 3: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 4, 2>" : "corr_kernel<2, 1, 1, 4, 2>"), fl, 0, (corr_kernel<MODE, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 4: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 1>" : "corr_kernel<2, 2, 1, 4, 1>"), fl, 0, (corr_kernel<MODE, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
+            case 5: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 8, 1>" : "corr_kernel<2, 1, 1, 8, 1>"), fl, 0, (corr_kernel<MODE, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
+            case 6: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 2, 1>" : "corr_kernel<2, 2, 2, 2, 1>"), fl, 0, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 2>" : "corr_kernel<2, 2, 1, 4, 2>"), fl, 0, (corr_kernel<MODE, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
         }
     } else {
         switch (cfg) {
-            case 0: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 2, 1, 4>), grid, dim3(256), shmem, s, P); break;
-            case 1: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 1, 2, 4>), grid, dim3(256), shmem, s, P); break;
-            case 2: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
-            case 3: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 4, 4>), grid, dim3(256), shmem, s, P); break;
-            case 4: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
-            case 5: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH(name, fl, 0, (corr_kernel<1, 2, 2, 2, 2>), grid, dim3(512), shmem, s, P); break;
+            case 0: GGAN_LAUNCH("corr_kernel<1, 2, 2, 1, 4>", fl, 0, (corr_kernel<1, 2, 2, 1, 4>), grid, dim3(256), shmem, s, P); break;
+            case 1: GGAN_LAUNCH("corr_kernel<1, 2, 1, 2, 4>", fl, 0, (corr_kernel<1, 2, 1, 2, 4>), grid, dim3(256), shmem, s, P); break;
+            case 2: GGAN_LAUNCH("corr_kernel<1, 1, 1, 4, 2>", fl, 0, (corr_kernel<1, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 3: GGAN_LAUNCH("corr_kernel<1, 1, 1, 4, 4>", fl, 0, (corr_kernel<1, 1, 1, 4, 4>), grid, dim3(256), shmem, s, P); break;
+            case 4: GGAN_LAUNCH("corr_kernel<1, 2, 1, 4, 2>", fl, 0, (corr_kernel<1, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
+            case 5: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 1>", fl, 0, (corr_kernel<1, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH("corr_kernel<1, 2, 2, 2, 2>", fl, 0, (corr_kernel<1, 2, 2, 2, 2>), grid, dim3(512), shmem, s, P); break;
         }
     }
     return 0;
@@ -622,13 +622,13 @@ int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out,
     if (slab_stride == 0) slab_stride = elems;
     if (!tail_out) tail = 0;
     if (!bias && act == GGAN_ACT_NONE && SK >= 8 && elems + tail <= 65536) {
-        GGAN_LAUNCH("conv_splitk_reduce", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_small_k,
+        GGAN_LAUNCH("splitk_reduce_small_k", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_small_k,
                     dim3((int)((elems + tail + 63) / 64)), dim3(256), 0, s, partial, SK, elems, slab_stride, out, tail_out, tail);
         return 0;
     }
     size_t b = (elems + tail + 255) / 256;
     if (b > 2048) b = 2048;
-    GGAN_LAUNCH("conv_splitk_reduce", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_k, dim3((int)b), dim3(256), 0, s, partial,
+    GGAN_LAUNCH("splitk_reduce_k", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_k, dim3((int)b), dim3(256), 0, s, partial,
                 SK, elems, slab_stride, out, bias, C, HW, act, alpha, tail_out, tail);
     return 0;
 }
@@ -681,7 +681,7 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     float* wT = (float*)ws;
     {
         const double by = 2.0 * 25 * g.Ci * g.Co * 4;
-        GGAN_LAUNCH("conv_filter_transpose", 0, by, filter_transpose_k, dim3(cdiv(Cip, 32), cdiv(g.Co, 32), 25), dim3(32, 8), 0, s,
+        GGAN_LAUNCH("filter_transpose_k", 0, by, filter_transpose_k, dim3(cdiv(Cip, 32), cdiv(g.Co, 32), 25), dim3(32, 8), 0, s,
                     w, wT, g.Ci, g.Co, Cip);
     }
     ws = (char*)ws + wT_bytes;

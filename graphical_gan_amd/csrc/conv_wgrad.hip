@@ -331,7 +331,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         attr_set = true;
     }
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
-    GGAN_LAUNCH("conv_wgrad_mfma", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P);
+    GGAN_LAUNCH("wgrad_kernel", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P);
     if (P.SK > 1)
         return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s, P.slab_stride,
                                     gbias, gbias ? (size_t)g.Co : 0);

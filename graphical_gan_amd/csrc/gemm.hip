@@ -185,10 +185,10 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     if (P.SK > 1) P.C = (float*)ws;
     const double fl = 2.0 * M * N * (double)K;
     const dim3 grid(gx, gy, P.SK), block(256);
-    if (!ta && !tb) { GGAN_LAUNCH("gemm_nn", fl, 0, (gemm_kernel<false, false>), grid, block, 0, s, P); }
-    else if (!ta && tb) { GGAN_LAUNCH("gemm_nt", fl, 0, (gemm_kernel<false, true>), grid, block, 0, s, P); }
-    else if (ta && !tb) { GGAN_LAUNCH("gemm_tn", fl, 0, (gemm_kernel<true, false>), grid, block, 0, s, P); }
-    else { GGAN_LAUNCH("gemm_tt", fl, 0, (gemm_kernel<true, true>), grid, block, 0, s, P); }
+    if (!ta && !tb) { GGAN_LAUNCH("gemm_kernel<false, false>", fl, 0, (gemm_kernel<false, false>), grid, block, 0, s, P); }
+    else if (!ta && tb) { GGAN_LAUNCH("gemm_kernel<false, true>", fl, 0, (gemm_kernel<false, true>), grid, block, 0, s, P); }
+    else if (ta && !tb) { GGAN_LAUNCH("gemm_kernel<true, false>", fl, 0, (gemm_kernel<true, false>), grid, block, 0, s, P); }
+    else { GGAN_LAUNCH("gemm_kernel<true, true>", fl, 0, (gemm_kernel<true, true>), grid, block, 0, s, P); }
     if (P.SK > 1) return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, C, bias, N, 1, act, alpha, s);
     return 0;
 }

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 CSV output (--output-format csv): per kernel, mean counter value per dispatch and mean duration.
+usage: python tools/pmc_summary.py <dir with *_counter_collection.csv / *_kernel_trace.csv> [more dirs...]"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'^void ', '', n)
+    return re.sub(r'\(.*$', '', n)[:60]
+
+
+def main(dirs):
+    jout = None
+    if '--json' in dirs:
+        i = dirs.index('--json'); jout = dirs[i + 1]; dirs = dirs[:i] + dirs[i + 2:]
+    ctr = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))     # kernel -> counter -> [sum, dispatches]
+    dur = defaultdict(lambda: [0.0, 0])
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            per = defaultdict(float)                               # (dispatch, kernel, counter) -> summed over dimensions
+            span = {}
+            for r in csv.DictReader(open(f)):
+                k = short(r['Kernel_Name'])
+                per[(r['Dispatch_Id'], k, r['Counter_Name'])] += float(r['Counter_Value'])
+                if 'Start_Timestamp' in r and r.get('End_Timestamp'):
+                    span[(r['Dispatch_Id'], k)] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+            for (_, k, c), v in per.items():
+                a = ctr[k][c]; a[0] += v; a[1] += 1
+            for (_, k), v in span.items():
+                a = ctr[k]['_dur_ns_under_pmc']; a[0] += v; a[1] += 1
+        for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                a = dur[short(r['Kernel_Name'])]
+                a[0] += float(r['End_Timestamp']) - float(r['Start_Timestamp']); a[1] += 1
+    # derived columns (MI355X: 256 CUs x 4 SIMDs, 2.4 GHz; FETCH_SIZE / WRITE_SIZE are KiB)
+    for k in ctr:
+        c = ctr[k]
+        if c['SQ_VALU_MFMA_BUSY_CYCLES'][1] and c['_dur_ns_under_pmc'][1]:
+            busy = c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / c['SQ_VALU_MFMA_BUSY_CYCLES'][1]
+            ns = c['_dur_ns_under_pmc'][0] / c['_dur_ns_under_pmc'][1]
+            c['~MFMA_util_%'] = [100.0 * busy / (ns * 2.4 * 1024), 1]
+    names = sorted(set(c for k in ctr for c in ctr[k] if ctr[k][c][1]))
+    print('| kernel | dispatches | avg us (trace) | ' + ' | '.join(names) + ' |')
+    print('|---|---|---|' + '---|' * len(names))
+    keys = sorted(set(ctr) | set(dur), key=lambda k: -dur[k][0] if k in dur else 0)
+    for k in keys:
+        n = max([ctr[k][c][1] for c in ctr[k]] + [dur[k][1]])
+        us = '%.2f' % (dur[k][0] / dur[k][1] / 1e3) if dur[k][1] else ''
+        print('| %s | %d | %s | ' % (k, n, us) + ' | '.join(
+            ('%.4g' % (ctr[k][c][0] / ctr[k][c][1]) if ctr[k][c][1] else '') for c in names) + ' |')
+    if jout:
+        import json
+        # FETCH_SIZE under-reports 16 B/lane streaming reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section); the
+        # wgrad and pointwise kernels load float4, the corr kernels load dwords (uncalibrated -> raw value kept)
+        wide = ('wgrad_kernel', 'adam_k', 'pack_k', 'act_bwd_k', 'splitk_reduce_k')
+        tab = {}
+        for k in ctr:
+            c = ctr[k]
+            if not (c['FETCH_SIZE'][1] and c['WRITE_SIZE'][1]):
+                continue
+            f = 1024.0 * c['FETCH_SIZE'][0] / c['FETCH_SIZE'][1]
+            w = 1024.0 * c['WRITE_SIZE'][0] / c['WRITE_SIZE'][1]
+            corr = 2.0 if k.startswith(wide) else 1.0
+            tab[k] = dict(fetch_bytes_raw=round(f), write_bytes=round(w), fetch_correction=corr,
+                          traffic_bytes=round(f * corr + w),
+                          mfma_util_pct=round(c['~MFMA_util_%'][0], 2) if c['~MFMA_util_%'][1] else None)
+        json.dump(tab, open(jout, 'w'), indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])
