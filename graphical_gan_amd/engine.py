@@ -52,6 +52,9 @@ class Trainer(object):
         # data-parallel runs split the step graph around the gradient all-reduce; the flag lets a single GPU exercise
         # exactly that code path (the collective is then a 1-rank no-op)
         self.split_graph = self.world > 1 or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
+        # weight-gradient kernels on a second stream: needs one gradient contribution per parameter per backward pass
+        # (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
+        self.side_wgrad = bool(getattr(cfg, 'batch_critic', False)) and cfg.mode != 'wali-gp'
         self._opts = None
 
     # ---- inputs ---------------------------------------------------------------------------------------
@@ -90,7 +93,7 @@ class Trainer(object):
         out = self.model.forward(self.feed, which)
         op = out[which + '_train_op']
         opt = op.optimizer
-        grads = opt.compute_gradients(op.cost)
+        grads = opt.compute_gradients(op.cost, side_wgrad=self.side_wgrad)
         keep = opt.pack(grads)
         return out[which + '_cost'].detach(), opt, keep
 

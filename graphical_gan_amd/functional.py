@@ -46,14 +46,23 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Backward of a layer = two independent kernels (data-gradient and filter-gradient).  With OVERLAP_BWD they are issued
-# on two HIP streams (fork after gy is ready, join before anything downstream runs), so the chip holds one workgroup
-# of each per CU and each kernel's prologue / staging latency hides under the other's MFMA phase.  The fork/join is
-# captured into the step's HIP graph as parallel branches.
+# Backward of a layer = two independent kernels: the data-gradient (on the critical path: the next layer's backward needs
+# it) and the filter/weight-gradient (needed only when the gradients are packed for Adam).  Inside `side_chain` the
+# weight-gradient kernels are issued on a second HIP stream that only ever WAITS for the main stream (one event per
+# layer) and is joined once, when the backward pass is over.  The chip then holds workgroups of both kernels per CU and
+# one kernel's prologue / staging / epilogue latency hides under the other's MFMA phase.  Captured into the step's HIP
+# graph as a parallel branch.  Everything a side-stream kernel reads or writes is held until the join (the caching
+# allocator must not hand the memory to a main-stream kernel earlier).
+# Only valid when every parameter receives exactly ONE gradient contribution per backward pass (autograd would sum
+# several contributions on the main stream without waiting for the side stream) -- the caller guarantees that.
 import os as _os
 FUSED_CONV_BWD = _os.environ.get('GGAN_NO_FUSED_BWD') is None
-OVERLAP_BWD = False   # measured: cross-queue graph dependencies cost 6-11 us each on ROCm 7.2, cancelling the overlap gain
+# measured on MI355X / ROCm 7.2 (gan_inference_cifar10 ali bs=64, HIP graph): 2.32 ms with the side chain vs 2.01 ms without --
+# parallel graph branches cost more than the overlap wins, so it is opt-in
+SIDE_WGRAD = _os.environ.get('GGAN_SIDE_WGRAD') is not None
+OVERLAP_BWD = False   # per-layer fork AND join: measured no gain (cross-queue graph dependencies cost 6-11 us each)
 _SIDE = {}
+_CHAIN = None
 
 
 def _side_stream(device):
@@ -65,17 +74,46 @@ def _side_stream(device):
     return s
 
 
-class _fork(object):
-    """with _fork(dev) as side: ... kernels issued on the side stream; joined back into the current stream on exit."""
+class side_chain(object):
+    """with side_chain(device): <plain backward pass>   (see the comment above)"""
 
     def __init__(self, device, enabled=True):
-        self.enabled = enabled and OVERLAP_BWD and not torch.is_grad_enabled()
+        self.enabled = bool(enabled) and SIDE_WGRAD
+        self.device = device
+
+    def __enter__(self):
+        global _CHAIN
+        if self.enabled:
+            self.main = torch.cuda.current_stream(self.device)
+            self.side = _side_stream(self.device)
+            self.held, self.used = [], False
+            _CHAIN = self
+        return self
+
+    def __exit__(self, *a):
+        global _CHAIN
+        if self.enabled:
+            _CHAIN = None
+            if self.used:
+                self.main.wait_stream(self.side)
+            self.held = []
+
+
+class _fork(object):
+    """with _fork(dev) as side: ... kernels issued on the side stream.  join(): inside a side_chain only registers the
+    tensors the side kernels touch (joined at the end of the chain); with OVERLAP_BWD joins immediately."""
+
+    def __init__(self, device, enabled=True):
+        self.chain = _CHAIN
+        self.enabled = enabled and (OVERLAP_BWD or self.chain is not None) and not torch.is_grad_enabled()
         self.device = device
 
     def __enter__(self):
         if not self.enabled:
             return None
         self.main = torch.cuda.current_stream(self.device)
+        if self.chain is not None and self.main != self.chain.main:
+            raise _lib.GganError('side_chain entered on a different stream than the backward pass runs on')
         self.side = _side_stream(self.device)
         self.side.wait_stream(self.main)
         self.ctx = torch.cuda.stream(self.side)
@@ -87,12 +125,17 @@ class _fork(object):
             self.ctx.__exit__(*a)
 
     def join(self, *tensors):
-        """call after the main-stream kernel has been issued"""
-        if self.enabled:
-            self.main.wait_stream(self.side)
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self.main)
+        """call after the main-stream kernel has been issued; `tensors` = everything the side kernels read or wrote"""
+        if not self.enabled:
+            return
+        if self.chain is not None:
+            self.chain.held.extend(t for t in tensors if t is not None)
+            self.chain.used = True
+            return
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.main)
 
 
 def workspace(device):
@@ -172,7 +215,7 @@ class ConvFwd(Function):
                 gb = ChanSum.apply(gy)
         if ctx.needs_input_grad[0]:
             gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
-        fork.join(gw, gb)
+        fork.join(gw, gb, x, gy)
         return gx, gw, gb, None, None, None
 
 
@@ -187,10 +230,14 @@ def _fused_conv_backward(ctx, gy, x, w, y):
     yref = _p(y) if act != ACT_NONE else _p(None)
     gx = gw = gb = None
     if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-        gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=gy.device)
-        gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(x), _p(gy), yref, act, ctx.alpha, _p(gw), _p(gb), _p(ws), ws.numel(),
-                                          _stream())
+        fork = _fork(gy.device, ctx.needs_input_grad[0])
+        with fork:
+            ws_f = workspace(gy.device)
+            gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=gy.device)
+            gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(x), _p(gy), yref, act, ctx.alpha, _p(gw), _p(gb), _p(ws_f),
+                                              ws_f.numel(), _stream())
+        fork.join(gw, gb, x, gy, y)
         if rc == 1:
             return None          # geometry not covered by the fused kernels: caller takes the unfused path
         check(rc, 'ggan_conv2d_bwd_filter_act')
@@ -235,7 +282,7 @@ class ConvDgrad(Function):
                 d_b = ChanSum.apply(h)
         if ctx.needs_input_grad[0]:
             d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
-        fork.join(d_w, d_b)
+        fork.join(d_w, d_b, h, gy)
         return d_gy, d_w, d_b, None, None, None
 
 
@@ -350,7 +397,7 @@ class Gemm(Function):
                 da = Gemm.apply(g, b, None, False, not tb, ACT_NONE, 0.0)      # g op(B)^T
             else:
                 da = Gemm.apply(b, g, None, tb, True, ACT_NONE, 0.0)           # op(B) g^T
-        fork.join(db, dbias)
+        fork.join(db, dbias, a, g)
         return da, db, dbias, None, None, None, None
 
 

@@ -78,8 +78,11 @@ class AdamOptimizer(object):
         self.world = self.bucket.world
 
     # -- one optimizer step ---------------------------------------------------------------------------
-    def compute_gradients(self, cost):
-        return torch.autograd.grad(cost, self.params, allow_unused=True)
+    def compute_gradients(self, cost, side_wgrad=False):
+        """side_wgrad: run the weight-gradient kernels on a second stream (functional.side_chain); legal only when
+        every parameter is used once in the graph of `cost`."""
+        with F.side_chain(self.theta.device, side_wgrad):
+            return torch.autograd.grad(cost, self.params, allow_unused=True)
 
     def pack(self, grads):
         gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
