@@ -48,10 +48,13 @@ SIGNATURES = {
     'ggan_gemm_workspace': (_Z, [_I, _I, _I]),
     'ggan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_gemm_colsum': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_linear_bwd_data_act': (_I, [_I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
+    'ggan_linear_bwd_weight_act': (_I, [_I, _I, _I, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_colsum': (_I, [_P, _P, _I, _I, _P]),
     'ggan_chansum': (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     'ggan_bn_fwd_train': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),
     'ggan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'ggan_bn_bwd_act': (_I, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ggan_act_fwd': (_I, [_P, _P, _Z, _I, _F, _P]),
     'ggan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     'ggan_bias_add': (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -9,9 +9,17 @@
 //   HW == 1: [N, C] rows (Generator.BN1 over [B,4096]); lanes run along C so every row read is a
 //            coalesced 256-B segment; a 64x4 thread tile splits N four ways and combines through LDS.
 #include "common.h"
+#include "conv.h"
 using namespace ggan;
 
 namespace {
+
+// dL/d(bn output): the incoming gradient with the fused activation's derivative applied on load (GyMask, conv.h)
+__device__ __forceinline__ float ld_gy(const float* __restrict__ gy, const GyMask& mk, size_t idx) {
+    float g = gy[idx];
+    if (mk.act) g = act_grad(g, mk.ref[idx], mk.act, mk.alpha);
+    return g;
+}
 
 constexpr int kThreads = 512;
 
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __res
     }
 }
 
-__global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
                                                               const float* __restrict__ scale, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                               float* __restrict__ gscale, float* __restrict__ goffset, int N,
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
         if (i < total) {
             const int n = i / HW, p = i - n * HW;
             const size_t idx = ((size_t)n * C + c) * HW + p;
-            b = gy[idx];
+            b = ld_gy(gy, mk, idx);
             a = (x[idx] - mean) * invstd;
         }
         xh[j] = a; g[j] = b;
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_k(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
                                                           const float* __restrict__ scale, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                           float* __restrict__ gscale, float* __restrict__ goffset, int N,
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restric
     for (int i = threadIdx.x; i < total; i += kThreads) {
         int n = i / HW, p = i - n * HW;
         size_t idx = ((size_t)n * C + c) * HW + p;
-        float g = gy[idx];
+        float g = ld_gy(gy, mk, idx);
         s1 += g;
         s2 += g * ((x[idx] - mean) * invstd);
     }
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restric
         int n = i / HW, p = i - n * HW;
         size_t idx = ((size_t)n * C + c) * HW + p;
         float xh = (x[idx] - mean) * invstd;
-        gx[idx] = k * (gy[idx] - mg - xh * mgx);
+        gx[idx] = k * (ld_gy(gy, mk, idx) - mg - xh * mgx);
     }
     if (threadIdx.x == 0) {
         gscale[c] = sum_gx;
@@ -220,7 +228,7 @@ __global__ void bn_fwd_rows_k(const float* __restrict__ x, const float* __restri
     }
 }
 
-__global__ void bn_bwd_rows_k(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ scale,
+__global__ void bn_bwd_rows_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk, const float* __restrict__ scale,
                               const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                               float* __restrict__ gx, float* __restrict__ gscale, float* __restrict__ goffset, int N, int C) {
     __shared__ float sm[kSlices][kCols];
@@ -230,7 +238,7 @@ __global__ void bn_bwd_rows_k(const float* __restrict__ x, const float* __restri
     float s1 = 0.f, s2 = 0.f;
     if (ok) for (int n = threadIdx.y; n < N; n += kSlices) {
         size_t idx = (size_t)n * C + c;
-        float g = gy[idx];
+        float g = ld_gy(gy, mk, idx);
         s1 += g;
         s2 += g * ((x[idx] - mean) * invstd);
     }
@@ -242,7 +250,7 @@ __global__ void bn_bwd_rows_k(const float* __restrict__ x, const float* __restri
     for (int n = threadIdx.y; n < N; n += kSlices) {
         size_t idx = (size_t)n * C + c;
         float xh = (x[idx] - mean) * invstd;
-        gx[idx] = k * (gy[idx] - mg - xh * mgx);
+        gx[idx] = k * (ld_gy(gy, mk, idx) - mg - xh * mgx);
     }
     if (threadIdx.y == 0) {
         gscale[c] = sum_gx;
@@ -270,20 +278,29 @@ int ggan_bn_fwd_train(const float* x, const float* scale, const float* offset, f
     return 0;
 }
 
-int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float* save_mean, const float* save_invstd,
-                float* gx, float* gscale, float* goffset, int N, int C, int HW, ggan_stream_t stream) {
+int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* scale,
+                    const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset, int N, int C,
+                    int HW, ggan_stream_t stream) {
     GGAN_CHECK_ARG(x && gy && scale && save_mean && save_invstd && gx && gscale && goffset, "null pointer");
+    GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "activation mask needs the forward output");
     GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
     hipStream_t s = (hipStream_t)stream;
+    const GyMask mk{y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha};
     const double bytes = 20.0 * N * C * HW;
     if (HW > 1 && N * HW <= kRegE * kThreads) {
-        GGAN_LAUNCH("bn_bwd_nchw", 0, 12.0 * N * C * HW, bn_bwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
+        GGAN_LAUNCH("bn_bwd_nchw", 0, 12.0 * N * C * HW, bn_bwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
     } else if (HW > 1) {
-        GGAN_LAUNCH("bn_bwd_nchw", 0, bytes, bn_bwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
+        GGAN_LAUNCH("bn_bwd_nchw", 0, bytes, bn_bwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
     } else {
-        GGAN_LAUNCH("bn_bwd_rows", 0, bytes, bn_bwd_rows_k, dim3(cdiv(C, kCols)), dim3(kCols, kSlices), 0, s, x, gy, scale, save_mean, save_invstd, gx, gscale, goffset, N, C);
+        GGAN_LAUNCH("bn_bwd_rows", 0, bytes, bn_bwd_rows_k, dim3(cdiv(C, kCols)), dim3(kCols, kSlices), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, N, C);
     }
     return 0;
+}
+
+int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float* save_mean, const float* save_invstd,
+                float* gx, float* gscale, float* goffset, int N, int C, int HW, ggan_stream_t stream) {
+    return ggan_bn_bwd_act(x, gy, nullptr, GGAN_ACT_NONE, 0.f, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW,
+                           stream);
 }
 
 }  // extern "C"

@@ -30,6 +30,12 @@ struct GemmParams {
     float alpha;
     size_t out_elems;
     float* colsum;     // optional: column sums of op(B) (SK == 1, tb == 0), from the B tiles staged anyway
+    // optional activation-derivative mask on one operand: element e of A (or B) becomes act_grad(e, ref[e]); `ref` has the
+    // operand's own layout (the forward output of the layer whose gradient this is)
+    const float* a_ref;
+    const float* b_ref;
+    int ref_act;
+    float ref_alpha;
 };
 
 // Load a [64 rows(r) x 16 k] tile of a matrix into LDS as T[k][r].
@@ -68,6 +74,21 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, int ld
     reg = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// masked operand (compile-time): g * act'(ref), same addressing for both; the raw pair is kept in registers while the
+// MFMA block of the current tile runs and combined when it is committed to LDS
+template <bool KCONTIG, bool MASK>
+__device__ __forceinline__ void load_tile_m(const float* __restrict__ base, const float* __restrict__ ref, int ld, int R,
+                                            int r0, int k0, int kend, int vec, float4& reg, float4& rref) {
+    load_tile<KCONTIG>(base, ld, R, r0, k0, kend, vec, reg);
+    if (MASK) load_tile<KCONTIG>(ref, ld, R, r0, k0, kend, vec, rref);
+}
+template <bool MASK>
+__device__ __forceinline__ float4 apply_mask(const float4& g, const float4& r, int act, float alpha) {
+    if (!MASK) return g;
+    return make_float4(act_grad(g.x, r.x, act, alpha), act_grad(g.y, r.y, act, alpha), act_grad(g.z, r.z, act, alpha),
+                       act_grad(g.w, r.w, act, alpha));
+}
+
 template <bool KCONTIG>
 __device__ __forceinline__ void store_tile(float* T, const float4& reg) {
     const int tid = threadIdx.x;
@@ -85,7 +106,8 @@ __device__ __forceinline__ void store_tile(float* T, const float4& reg) {
 
 // TA: A stored [K,M] (transposed)  => element (m,k) at A[k*lda + m]  => !KCONTIG
 // TB: B stored [N,K] (transposed)  => element (n,k) at B[n*ldb + k]  =>  KCONTIG
-template <bool TA, bool TB>
+// MASK: 0 none, 1 activation-derivative mask on A, 2 on B
+template <bool TA, bool TB, int MASK = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     __shared__ __attribute__((aligned(16))) float As[BK * LDP];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDP];
@@ -99,17 +121,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool do_colsum = P.colsum != nullptr && blockIdx.y == 0 && tid < BN;   // rows beyond K are zero in the tile
     float csum = 0.f;
-    float4 ra, rb;
-    load_tile<!TA>(P.A, P.lda, P.M, m0, kb, ke, P.vecA, ra);
-    load_tile<TB>(P.B, P.ldb, P.N, n0, kb, ke, P.vecB, rb);
+    float4 ra, rb, rma, rmb;
+    load_tile_m<!TA, MASK == 1>(P.A, P.a_ref, P.lda, P.M, m0, kb, ke, P.vecA, ra, rma);
+    load_tile_m<TB, MASK == 2>(P.B, P.b_ref, P.ldb, P.N, n0, kb, ke, P.vecB, rb, rmb);
     for (int k0 = kb; k0 < ke; k0 += BK) {
         __syncthreads();
-        store_tile<!TA>(As, ra);
-        store_tile<TB>(Bs, rb);
+        store_tile<!TA>(As, apply_mask<MASK == 1>(ra, rma, P.ref_act, P.ref_alpha));
+        store_tile<TB>(Bs, apply_mask<MASK == 2>(rb, rmb, P.ref_act, P.ref_alpha));
         __syncthreads();
-        if (k0 + BK < ke) {
-            load_tile<!TA>(P.A, P.lda, P.M, m0, k0 + BK, ke, P.vecA, ra);
-            load_tile<TB>(P.B, P.ldb, P.N, n0, k0 + BK, ke, P.vecB, rb);
+        if (k0 + BK < ke) {   // register prefetch of the next tile under this tile's MFMA block
+            load_tile_m<!TA, MASK == 1>(P.A, P.a_ref, P.lda, P.M, m0, k0 + BK, ke, P.vecA, ra, rma);
+            load_tile_m<TB, MASK == 2>(P.B, P.b_ref, P.ldb, P.N, n0, k0 + BK, ke, P.vecB, rb, rmb);
         }
         if (do_colsum) {
 #pragma unroll
@@ -151,16 +173,18 @@ size_t ggan_gemm_workspace(int M, int N, int K) {
 }
 
 static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C,
-                       float* colsum, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
+                       float* colsum, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s,
+                       const float* a_ref = nullptr, const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f) {
     GemmParams P;
     memset(&P, 0, sizeof(P));
+    P.a_ref = a_ref; P.b_ref = b_ref; P.ref_act = ref_act; P.ref_alpha = ref_alpha;
     P.A = A; P.B = B; P.bias = bias; P.C = C;
     P.M = M; P.N = N; P.K = K;
     P.lda = ta ? M : K;
     P.ldb = tb ? K : N;
     // float4 legality: base aligned, leading dimension multiple of 4 (row starts stay aligned)
-    P.vecA = al16(A) && (P.lda % 4 == 0);
-    P.vecB = al16(B) && (P.ldb % 4 == 0);
+    P.vecA = al16(A) && (P.lda % 4 == 0) && (!a_ref || al16(a_ref));
+    P.vecB = al16(B) && (P.ldb % 4 == 0) && (!b_ref || al16(b_ref));
     P.act = act; P.alpha = alpha;
     P.out_elems = (size_t)M * N;
     P.colsum = colsum;
@@ -171,9 +195,11 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
         const char* e = getenv("GGAN_GEMM_SK");
         if (e) sk = atoi(e);
         else {
+            // a workgroup's k-step is latency-bound (~0.6 us measured), so spread K over the idle CUs down to one
+            // BK-step per split; measured optimum on the hot path's shapes (tools/bench_gemm.py)
             const int base = gx * gy;
             sk = 256 / base;
-            const int max_sk = K / (4 * BK);
+            const int max_sk = K / BK;
             if (sk > max_sk) sk = max_sk;
             if (sk > 64) sk = 64;
         }
@@ -185,6 +211,11 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     if (P.SK > 1) P.C = (float*)ws;
     const double fl = 2.0 * M * N * (double)K;
     const dim3 grid(gx, gy, P.SK), block(256);
+    if (a_ref || b_ref) {
+        if (a_ref && !b_ref && !ta && tb) { GGAN_LAUNCH("gemm_kernel<false, true, 1>", fl, 0, (gemm_kernel<false, true, 1>), grid, block, 0, s, P); }
+        else if (b_ref && !a_ref && ta && !tb) { GGAN_LAUNCH("gemm_kernel<true, false, 2>", fl, 0, (gemm_kernel<true, false, 2>), grid, block, 0, s, P); }
+        else { set_error("gemm: unsupported mask/transposition combination"); return -1; }
+    } else
     if (!ta && !tb) { GGAN_LAUNCH("gemm_kernel<false, false>", fl, 0, (gemm_kernel<false, false>), grid, block, 0, s, P); }
     else if (!ta && tb) { GGAN_LAUNCH("gemm_kernel<false, true>", fl, 0, (gemm_kernel<false, true>), grid, block, 0, s, P); }
     else if (ta && !tb) { GGAN_LAUNCH("gemm_kernel<true, false>", fl, 0, (gemm_kernel<true, false>), grid, block, 0, s, P); }
@@ -205,6 +236,24 @@ int ggan_gemm_colsum(int ta, int M, int N, int K, const float* A, const float* B
     GGAN_CHECK_ARG(A && B && C && colsum_b, "null pointer");
     GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
     return gemm_launch(ta, 0, M, N, K, A, B, nullptr, C, colsum_b, GGAN_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ggan_linear_bwd_data_act(int M, int N, int K, const float* g, const float* y, int y_act, float y_alpha, const float* w,
+                             float* dx, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(g && w && dx && (y || y_act == GGAN_ACT_NONE), "null pointer");
+    GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
+    // dx[M,K] = (g * act'(y))[M,N] @ w[K,N]^T
+    return gemm_launch(0, 1, M, K, N, g, w, nullptr, dx, nullptr, GGAN_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream,
+                       y_act != GGAN_ACT_NONE ? y : nullptr, nullptr, y_act, y_alpha);
+}
+
+int ggan_linear_bwd_weight_act(int M, int N, int K, const float* x, const float* g, const float* y, int y_act, float y_alpha,
+                               float* dw, float* db, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && g && dw && (y || y_act == GGAN_ACT_NONE), "null pointer");
+    GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
+    // dw[K,N] = x[M,K]^T @ (g * act'(y))[M,N];  db[N] = column sums of the masked g (from the tiles staged anyway)
+    return gemm_launch(1, 0, K, N, M, x, g, nullptr, dw, db, GGAN_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream, nullptr,
+                       y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha);
 }
 
 }  // extern "C"

@@ -375,6 +375,11 @@ class Gemm(Function):
     def backward(ctx, g):
         a, b, out = ctx.saved_tensors
         ta, tb = ctx.ta, ctx.tb
+        if (ctx.act != ACT_NONE and not ta and not tb and not torch.is_grad_enabled() and FUSED_CONV_BWD
+                and a.shape[1] <= 1024):
+            # (measured, tools/bench_gemm.py: for the long-K layers the masked operand loads cost more than the separate
+            # act_bwd pass they replace, 27-48 us vs 26-39 us; for K <= 1024 the fused pair wins)
+            return _fused_linear_backward(ctx, g, a, b, out)
         if ctx.act != ACT_NONE:
             g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
         da = db = dbias = None
@@ -399,6 +404,28 @@ class Gemm(Function):
                 da = Gemm.apply(b, g, None, tb, True, ACT_NONE, 0.0)           # op(B) g^T
         fork.join(db, dbias, a, g)
         return da, db, dbias, None, None, None, None
+
+
+def _fused_linear_backward(ctx, g, x, w, y):
+    """Linear(+activation) backward in two launches: the activation derivative is applied while g is staged."""
+    g = _c(g)
+    M, K = x.shape
+    N = w.shape[1]
+    L = _L()
+    ws = workspace(g.device)
+    dx = dw = db = None
+    if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        dw = torch.empty((K, N), dtype=torch.float32, device=g.device)
+        db = torch.empty((N,), dtype=torch.float32, device=g.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        check(L.ggan_linear_bwd_weight_act(M, N, K, _p(x), _p(g), _p(y), ctx.act, ctx.alpha, _p(dw), _p(db), _p(ws), ws.numel(),
+                                           _stream()), 'ggan_linear_bwd_weight_act')
+        if not ctx.needs_input_grad[1]:
+            dw = None
+    if ctx.needs_input_grad[0]:
+        dx = torch.empty((M, K), dtype=torch.float32, device=g.device)
+        check(L.ggan_linear_bwd_data_act(M, N, K, _p(g), _p(y), ctx.act, ctx.alpha, _p(w), _p(dx), _p(ws), ws.numel(), _stream()),
+              'ggan_linear_bwd_data_act')
+    return dx, dw, db, None, None, None, None
 
 
 def gemm_colsum_(a, g, ta):
@@ -508,16 +535,33 @@ class BatchNormTrain(Function):
         x, sc, mean, invstd, y = ctx.saved_tensors
         N, Cc, HW = ctx.dims
         gy = _c(gy)
-        if ctx.act != ACT_NONE:
-            g2 = torch.empty_like(gy)
-            check(_L().ggan_act_bwd(_p(gy), _p(y), _p(g2), gy.numel(), ctx.act, ctx.alpha, _stream()), 'ggan_act_bwd')
-            gy = g2
         gx = torch.empty_like(x)
         gs = torch.empty((Cc,), dtype=torch.float32, device=x.device)
         go = torch.empty_like(gs)
-        check(_L().ggan_bn_bwd(_p(x), _p(gy), _p(sc), _p(mean), _p(invstd), _p(gx), _p(gs), _p(go), N, Cc, HW, _stream()),
-              'ggan_bn_bwd')
+        check(_L().ggan_bn_bwd_act(_p(x), _p(gy), _p(y) if ctx.act != ACT_NONE else _p(None), ctx.act, ctx.alpha, _p(sc),
+                                   _p(mean), _p(invstd), _p(gx), _p(gs), _p(go), N, Cc, HW, _stream()), 'ggan_bn_bwd_act')
         return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None
+
+
+class SplitRows(Function):
+    """(x[:n], x[n:]) for the critic evaluated once on [fake; real]; the backward is ONE concatenation instead of two
+    zero-padded slice gradients and their sum."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.rows = n, x.shape[0]
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        like = ga if ga is not None else gb
+        if ga is None:
+            ga = like.new_zeros((ctx.n,) + tuple(like.shape[1:]))
+        if gb is None:
+            gb = like.new_zeros((ctx.rows - ctx.n,) + tuple(like.shape[1:]))
+        return torch.cat([ga, gb], 0), None
 
 
 class CastScaleI32(Function):

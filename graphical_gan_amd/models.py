@@ -204,7 +204,8 @@ class GraphicalGAN(object):
             if batched:
                 h = self.HyperDiscriminator(z_cat, torch.cat([onehot, q_k.detach()], 0))
                 d = self.Discriminator(x_cat, z_cat)
-                d_fake, d_real = [h[:B], d[:B]], [h[B:], d[B:]]
+                (hf, hr), (df, dr) = F.SplitRows.apply(h, B), F.SplitRows.apply(d, B)
+                d_fake, d_real = [hf, df], [hr, dr]
             else:
                 d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)]
                 d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)]
@@ -213,7 +214,7 @@ class GraphicalGAN(object):
         else:
             if batched:
                 d = self.Discriminator(x_cat, z_cat)
-                d_fake, d_real = d[:B], d[B:]
+                d_fake, d_real = F.SplitRows.apply(d, B)
             else:
                 d_fake = self.Discriminator(fake_x, p_z)
                 d_real = self.Discriminator(real_x, q_z)

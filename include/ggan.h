@@ -81,6 +81,16 @@ int ggan_deconv2d_bwd_filter(const ggan_conv_geom* g, const float* gy_big, const
                              float* gbias /* [Ci], sum of gy_big */, void* ws, size_t ws_bytes,
                              ggan_stream_t stream);
 
+/* Linear backward with the following activation's derivative folded into the operand load, so g' = g * act'(y) is never
+ * written (replaces tf.matmul's MatMul gradients + the script's tf.maximum/LeakyReLU gradient + BiasAddGrad,
+ * tflib/ops/linear.py:133-146).  x[M,K] layer input, w[K,N], y[M,N] the layer's activated output, g[M,N] = dL/dy.
+ *   ggan_linear_bwd_data_act:   dx[M,K] = g' w^T
+ *   ggan_linear_bwd_weight_act: dw[K,N] = x^T g',  db[N] = column sums of g' (db may be NULL) */
+int ggan_linear_bwd_data_act(int M, int N, int K, const float* g, const float* y, int y_act, float y_alpha,
+                             const float* w, float* dx, void* ws, size_t ws_bytes, ggan_stream_t stream);
+int ggan_linear_bwd_weight_act(int M, int N, int K, const float* x, const float* g, const float* y, int y_act,
+                               float y_alpha, float* dw, float* db, void* ws, size_t ws_bytes, ggan_stream_t stream);
+
 /* ---- dense -------------------------------------------------------------------------------
  * C[M,N] = op(A) * op(B) (+ bias[N]) (+act), row-major, ta/tb = 1 reads the operand transposed
  * (A stored [K,M] / B stored [N,K]).  tf.matmul + bias_add of tflib/ops/linear.py:133-146 is
@@ -108,6 +118,11 @@ int ggan_bn_fwd_train(const float* x, const float* scale, const float* offset, f
 int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float* save_mean,
                 const float* save_invstd, float* gx, float* gscale, float* goffset,
                 int N, int C, int HW, ggan_stream_t stream);
+/* same, with the activation fused into the forward (ggan_bn_fwd_train act != NONE) differentiated on load: gy is
+ * dL/d(activated output y); no separate ggan_act_bwd pass. */
+int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* scale,
+                    const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset,
+                    int N, int C, int HW, ggan_stream_t stream);
 
 /* ---- pointwise -------------------------------------------------------------------------------
  * LeakyReLU = tf.maximum(alpha*x, x) (gmgan_inference_cifar10.py:122-123), tf.nn.relu, tf.tanh,
