@@ -42,6 +42,7 @@ SIGNATURES = {
     'ggan_conv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_conv2d_bwd_data_act': (_I, [_G, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_conv2d_bwd_filter_act': (_I, [_G, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
+    'ggan_conv2d_bwd_filter_parts': (_I, [_G, _P, _P, _P, _I, _F, _I, _P, _Z, C.POINTER(_I), C.POINTER(_Z), _P]),
     'ggan_deconv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_deconv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _Z, _P]),
     'ggan_deconv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     'ggan_adam_step': (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P]),
     'ggan_adam_advance': (_I, [_P, _P]),
     'ggan_pack': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), _I, _P, _P]),
+    'ggan_pack_parts': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), _I, _P, _P]),
     'ggan_prof_enable': (_I, [_I]),
     'ggan_prof_reset': (_I, []),
     'ggan_prof_report': (_I, [C.POINTER(ProfRec), _I]),

@@ -24,8 +24,17 @@ int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const
 int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx,
                     int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s);
 // gbias (may be NULL): sum over n,oh,ow of the (masked) gy, produced from the gy tiles the kernel stages anyway
+// parts != NULL: the split-K slabs stay in parts->buf ([n][stride], bias-gradient tail after each slab) for a consumer that
+// sums them (ggan_pack_parts); no reduce kernel is launched and gw/gbias/ws are ignored.
+struct WgradParts {
+    float* buf;
+    size_t cap_floats;
+    int with_bias;
+    int n;            // out: number of slabs
+    size_t stride;    // out: floats between slabs
+};
 int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
-                    size_t ws_bytes, hipStream_t s);
+                    size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
 size_t conv_workspace_bytes(const ggan_conv_geom& g);
 // out[i] = act(sum_s partial[s][i] + bias[(i/HW)%C]) -- deterministic split-K combine (conv + gemm)
 int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,

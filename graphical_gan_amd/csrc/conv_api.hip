@@ -92,6 +92,19 @@ int ggan_conv2d_bwd_filter_act(const ggan_conv_geom* g, const float* x, const fl
     return bwd_filter(g, x, gy, GyMask{y, y_act, y_alpha}, gw, gbias, ws, ws_bytes, stream);
 }
 
+int ggan_conv2d_bwd_filter_parts(const ggan_conv_geom* g, const float* x, const float* gy, const float* y, int y_act,
+                                 float y_alpha, int with_bias, float* part, size_t part_cap, int* n_parts, size_t* stride,
+                                 ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    GGAN_CHECK_ARG(x && gy && part && n_parts && stride, "null pointer");
+    GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "null activation reference");
+    if (g_force_naive || getenv("GGAN_NAIVE_WGRAD")) return 1;
+    WgradParts po{part, part_cap, with_bias, 0, 0};
+    int r = conv_wgrad_mfma(*g, x, gy, GyMask{y, y_act, y_alpha}, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, &po);
+    if (r == 0) { *n_parts = po.n; *stride = po.stride; }
+    return r;
+}
+
 // Deconv2D = the adjoint family with the same filter bytes (see ggan.h)
 int ggan_deconv2d_fwd(const ggan_conv_geom* g, const float* x_small, const float* w, const float* bias, float* y_big,
                       int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {

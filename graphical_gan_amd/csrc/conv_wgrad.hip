@@ -270,9 +270,16 @@ int env_int(const char* name, int dflt) {
 namespace ggan {
 
 int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
-                    size_t ws_bytes, hipStream_t s) {
+                    size_t ws_bytes, hipStream_t s, WgradParts* parts) {
     if (g.k != 5 || g.stride != 2 || (g.Wo & 3) || (g.W & 3) || g.pad_l != 1 || g.Wo > 64) return 1;
-    ws = ws_scratch(ws, ws_bytes);
+    if (parts) {   // leave the split-K slabs (bias-gradient tail after each) in the caller's buffer: no reduce launch
+        ws = parts->buf;
+        ws_bytes = parts->cap_floats * sizeof(float);
+        gw = parts->buf;
+        gbias = parts->with_bias ? parts->buf + (size_t)25 * g.Ci * g.Co : nullptr;
+    } else {
+        ws = ws_scratch(ws, ws_bytes);
+    }
     const size_t xb = (size_t)g.N * g.Ci * g.H * g.W * 4, gb = (size_t)g.N * g.Co * g.Ho * g.Wo * 4;
     if (xb >= 0x7FFFFFF0ull || gb >= 0x7FFFFFF0ull) return 1;
     if ((((uintptr_t)x) & 15) || (((uintptr_t)gy) & 15)) return 1;
@@ -331,7 +338,13 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         attr_set = true;
     }
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
+    if (parts && ws_bytes < P.slab_stride * sizeof(float)) { set_error("conv_wgrad: partial-slab buffer too small"); return -1; }
     GGAN_LAUNCH("wgrad_kernel", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P);
+    if (parts) {
+        parts->n = P.SK;
+        parts->stride = P.slab_stride;
+        return 0;
+    }
     if (P.SK > 1)
         return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s, P.slab_stride,
                                     gbias, gbias ? (size_t)g.Co : 0);

@@ -236,24 +236,46 @@ struct PackTable {
     const float* src[GGAN_PACK_MAX];
     size_t size[GGAN_PACK_MAX];
     size_t off[GGAN_PACK_MAX];
+    size_t pstride[GGAN_PACK_MAX];   // floats between the partial slabs of source k
+    int parts[GGAN_PACK_MAX];        // number of slabs to sum (1 = plain copy)
     int count;
 };
 
-// blockIdx.y = tensor, blockIdx.x grid-strides inside it (16-byte copies when both sides are aligned)
+// blockIdx.y = tensor, blockIdx.x grid-strides inside it (16-byte accesses when every side is aligned); a source made of
+// several split-K slabs is summed in slab order on the way
 __global__ void pack_k(PackTable t, float* __restrict__ flat) {
     const int k = blockIdx.y;
     const float* s = t.src[k];
     float* d = flat + t.off[k];
     const size_t n = t.size[k];
+    const int np = t.parts[k];
+    const size_t ps = t.pstride[k];
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-    if (s && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+    if (s && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0 && (np == 1 || (ps & 3) == 0)) {
         const size_t n4 = n >> 2;
-        const float4* s4 = reinterpret_cast<const float4*>(s);
         float4* d4 = reinterpret_cast<float4*>(d);
-        for (size_t i = i0; i < n4; i += stride) d4[i] = s4[i];
-        for (size_t i = (n4 << 2) + i0; i < n; i += stride) d[i] = s[i];
+        for (size_t i = i0; i < n4; i += stride) {
+            float4 a = reinterpret_cast<const float4*>(s)[i];
+            for (int p = 1; p < np; ++p) {
+                const float4 b = reinterpret_cast<const float4*>(s + (size_t)p * ps)[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            d4[i] = a;
+        }
+        for (size_t i = (n4 << 2) + i0; i < n; i += stride) {
+            float a = s[i];
+            for (int p = 1; p < np; ++p) a += s[(size_t)p * ps + i];
+            d[i] = a;
+        }
     } else {
-        for (size_t i = i0; i < n; i += stride) d[i] = s ? s[i] : 0.f;
+        for (size_t i = i0; i < n; i += stride) {
+            float a = 0.f;
+            if (s) {
+                a = s[i];
+                for (int p = 1; p < np; ++p) a += s[(size_t)p * ps + i];
+            }
+            d[i] = a;
+        }
     }
 }
 
@@ -389,22 +411,30 @@ int ggan_adam_advance(int32_t* step, ggan_stream_t stream) {
     return 0;
 }
 
-int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count, float* flat, ggan_stream_t stream) {
+int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts,
+                    const size_t* strides, int count, float* flat, ggan_stream_t stream) {
     GGAN_CHECK_ARG(srcs && sizes && offsets && flat, "null pointer");
     GGAN_CHECK_ARG(count > 0 && count <= GGAN_PACK_MAX, "count out of range");
     PackTable t;
     size_t mx = 0, tot = 0;
     for (int i = 0; i < count; ++i) {
         t.src[i] = srcs[i]; t.size[i] = sizes[i]; t.off[i] = offsets[i];
+        t.parts[i] = parts ? parts[i] : 1;
+        t.pstride[i] = strides ? strides[i] : 0;
+        GGAN_CHECK_ARG(t.parts[i] >= 1, "parts must be >= 1");
         if (sizes[i] > mx) mx = sizes[i];
-        tot += sizes[i];
+        tot += sizes[i] * (size_t)t.parts[i];
     }
     t.count = count;
     int gx = (int)cdivz(mx, (size_t)kBlock * 16);
     if (gx < 1) gx = 1;
     if (gx > 512) gx = 512;
-    GGAN_LAUNCH("pack", 0, 8.0 * tot, pack_k, dim3(gx, count), dim3(kBlock), 0, (hipStream_t)stream, t, flat);
+    GGAN_LAUNCH("pack", 0, 4.0 * tot + 4.0 * mx, pack_k, dim3(gx, count), dim3(kBlock), 0, (hipStream_t)stream, t, flat);
     return 0;
+}
+
+int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count, float* flat, ggan_stream_t stream) {
+    return ggan_pack_parts(srcs, sizes, offsets, nullptr, nullptr, count, flat, stream);
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import tflib as lib
+from . import functional as F
 from .models import GraphicalGAN
 
 
@@ -54,7 +55,7 @@ class Trainer(object):
         self.split_graph = self.world > 1 or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
         # weight-gradient kernels on a second stream: needs one gradient contribution per parameter per backward pass
         # (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
-        self.side_wgrad = bool(getattr(cfg, 'batch_critic', False)) and cfg.mode != 'wali-gp'
+        self.single_contrib = bool(getattr(cfg, 'batch_critic', False)) and cfg.mode != 'wali-gp'
         self._opts = None
 
     # ---- inputs ---------------------------------------------------------------------------------------
@@ -93,8 +94,10 @@ class Trainer(object):
         out = self.model.forward(self.feed, which)
         op = out[which + '_train_op']
         opt = op.optimizer
-        grads = opt.compute_gradients(op.cost, side_wgrad=self.side_wgrad)
-        keep = opt.pack(grads)
+        # (the filter-gradient slabs are summed by the pack kernel: legal under the same one-contribution condition)
+        with F.defer_wgrad_reduce(self.single_contrib):
+            grads = opt.compute_gradients(op.cost, side_wgrad=self.single_contrib)
+            keep = opt.pack(grads)
         return out[which + '_cost'].detach(), opt, keep
 
     def _eager(self, which):

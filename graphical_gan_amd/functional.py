@@ -138,6 +138,57 @@ class _fork(object):
                 t.record_stream(self.main)
 
 
+# Filter gradients as split-K partial slabs: inside `defer_wgrad_reduce` the filter-gradient kernels leave their slabs in a
+# private buffer and return slab 0 (+ a registry entry); `pack_` sums the slabs while it gathers the gradient bucket, so the
+# per-layer reduce launches disappear.  Only legal when the returned tensors go straight to pack_ (one gradient
+# contribution per parameter, no other consumer) -- pack_ raises if a registered tensor never reached it.
+_DEFER = [None]
+
+
+class defer_wgrad_reduce(object):
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled) and _os.environ.get('GGAN_NO_DEFER_WGRAD') is None
+
+    def __enter__(self):
+        if self.enabled:
+            _DEFER[0] = {}
+        return self
+
+    def __exit__(self, et, ev, tb):
+        reg, _DEFER[0] = _DEFER[0], None
+        if self.enabled and et is None and reg:
+            raise _lib.GganError('%d deferred filter-gradient slab sets were never packed' % len(reg))
+
+
+def _wgrad_parts(x, gy, y, act, alpha, geom, with_bias):
+    """Filter gradient via ggan_conv2d_bwd_filter_parts; None when deferral is off or the geometry is not covered."""
+    reg = _DEFER[0]
+    if reg is None:
+        return None
+    N, Ci, H, W, Co, Ho, Wo, k = geom[:8]
+    if k != 5:
+        return None
+    elems = k * k * Ci * Co
+    stride = elems + (Co if with_bias else 0)
+    tiles = -(-Ci // 16) * -(-Co // 16)
+    cap = min(64, max(1, -(-256 // tiles))) * stride
+    part = torch.empty((cap,), dtype=torch.float32, device=x.device)
+    n, st = C.c_int(0), C.c_size_t(0)
+    g = _geom(geom)
+    rc = _L().ggan_conv2d_bwd_filter_parts(C.byref(g), _p(x), _p(gy), _p(y) if act != ACT_NONE else _p(None), act, alpha,
+                                           1 if with_bias else 0, _p(part), cap, C.byref(n), C.byref(st), _stream())
+    if rc == 1:
+        return None
+    check(rc, 'ggan_conv2d_bwd_filter_parts')
+    gw = part[:elems].view(k, k, Ci, Co)
+    gb = part[elems:elems + Co] if with_bias else None
+    if n.value > 1:
+        reg[gw.data_ptr()] = (n.value, st.value, part)
+        if gb is not None:
+            reg[gb.data_ptr()] = (n.value, st.value, part)
+    return gw, gb
+
+
 def workspace(device):
     """Persistent split-K / filter-transpose scratch, one per (device, stream): kernels on one stream are serialised."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -230,17 +281,22 @@ def _fused_conv_backward(ctx, gy, x, w, y):
     yref = _p(y) if act != ACT_NONE else _p(None)
     gx = gw = gb = None
     if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-        fork = _fork(gy.device, ctx.needs_input_grad[0])
-        with fork:
-            ws_f = workspace(gy.device)
-            gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=gy.device)
-            gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(x), _p(gy), yref, act, ctx.alpha, _p(gw), _p(gb), _p(ws_f),
-                                              ws_f.numel(), _stream())
-        fork.join(gw, gb, x, gy, y)
-        if rc == 1:
-            return None          # geometry not covered by the fused kernels: caller takes the unfused path
-        check(rc, 'ggan_conv2d_bwd_filter_act')
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        parts = _wgrad_parts(x, gy, y, act, ctx.alpha, geom, want_b)
+        if parts is not None:
+            gw, gb = parts
+        else:
+            fork = _fork(gy.device, ctx.needs_input_grad[0])
+            with fork:
+                ws_f = workspace(gy.device)
+                gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=gy.device)
+                gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if want_b else None
+                rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(x), _p(gy), yref, act, ctx.alpha, _p(gw), _p(gb), _p(ws_f),
+                                                  ws_f.numel(), _stream())
+            fork.join(gw, gb, x, gy, y)
+            if rc == 1:
+                return None          # geometry not covered by the fused kernels: caller takes the unfused path
+            check(rc, 'ggan_conv2d_bwd_filter_act')
         if not ctx.needs_input_grad[1]:
             gw = None
     if ctx.needs_input_grad[0]:
@@ -277,7 +333,8 @@ class ConvDgrad(Function):
         fork = _fork(h.device, ctx.needs_input_grad[0] and need_w)
         with fork:
             if ctx.needs_input_grad[1]:
-                d_w = ConvWgrad.apply(h, gy, ctx.geom)
+                parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None
+                d_w = parts[0] if parts is not None else ConvWgrad.apply(h, gy, ctx.geom)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 d_b = ChanSum.apply(h)
         if ctx.needs_input_grad[0]:
@@ -716,12 +773,20 @@ def adam_step_(theta, g, m, v, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0)
 
 
 def pack_(tensors, offsets, flat):
-    """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros)."""
+    """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros); tensors registered by `defer_wgrad_reduce` are
+    summed over their split-K slabs on the way."""
     L = _L()
+    reg = _DEFER[0]
     for i0 in range(0, len(tensors), _lib.PACK_MAX):
         chunk = tensors[i0:i0 + _lib.PACK_MAX]
         n = len(chunk)
         srcs = (C.c_void_p * n)(*[t.data_ptr() if t is not None else 0 for t in chunk])
         sizes = (C.c_size_t * n)(*[int(s) for s in [o[1] for o in offsets[i0:i0 + n]]])
         offs = (C.c_size_t * n)(*[int(o[0]) for o in offsets[i0:i0 + n]])
-        check(L.ggan_pack(srcs, sizes, offs, n, _p(flat), _stream()), 'ggan_pack')
+        info = [reg.pop(t.data_ptr(), None) if (reg and t is not None) else None for t in chunk]
+        if any(info):
+            parts = (C.c_int * n)(*[(e[0] if e else 1) for e in info])
+            strides = (C.c_size_t * n)(*[(e[1] if e else 0) for e in info])
+            check(L.ggan_pack_parts(srcs, sizes, offs, parts, strides, n, _p(flat), _stream()), 'ggan_pack_parts')
+        else:
+            check(L.ggan_pack(srcs, sizes, offs, n, _p(flat), _stream()), 'ggan_pack')

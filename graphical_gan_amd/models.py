@@ -195,6 +195,30 @@ class GraphicalGAN(object):
         J = lib.objs.gan_inference
         J.ONLY[0] = which            # TF prunes the cost a session.run does not fetch; so do we
         batched = c.batch_critic and which == 'disc'
+        # a generator step owns only Generator/Extractor variables: hand the critic its weights without gradient edges
+        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
+            d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None)
+        gen_params, disc_params = self._var_lists()
+        if c.K:
+            res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        elif c.mode == 'wali-gp':
+            if which == 'gen':
+                gp = None                # not part of gen_cost; TF prunes the third critic pass
+            else:
+                gp = J.gradient_penalty(self.Discriminator, real_x, fake_x.detach() if batched else fake_x,
+                                        q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
+            res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
+            out['gradient_penalty'] = gp
+        else:
+            res = J.ali(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        J.ONLY[0] = None
+        out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=res[0], disc_cost=res[1],
+                   gen_train_op=res[2], disc_train_op=res[3])
+        return out
+
+    def _critic(self, batched, real_x, q_z, p_z, fake_x, onehot, q_k):
+        """critic logits of the fake and the real pair; critic steps evaluate the critic ONCE on [fake; real]"""
+        c = self.cfg
         if batched:
             # the critic step needs no gradient w.r.t. the generator/extractor outputs (TF prunes those paths too)
             fx, pz, qz = fake_x.detach(), p_z.detach(), q_z.detach()
@@ -209,8 +233,6 @@ class GraphicalGAN(object):
             else:
                 d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)]
                 d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)]
-            gen_params, disc_params = self._var_lists()
-            res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
         else:
             if batched:
                 d = self.Discriminator(x_cat, z_cat)
@@ -218,18 +240,4 @@ class GraphicalGAN(object):
             else:
                 d_fake = self.Discriminator(fake_x, p_z)
                 d_real = self.Discriminator(real_x, q_z)
-            gen_params, disc_params = self._var_lists()
-            if c.mode == 'wali-gp':
-                if which == 'gen':
-                    gp = None                # not part of gen_cost; TF prunes the third critic pass
-                else:
-                    gp = J.gradient_penalty(self.Discriminator, real_x, fake_x.detach() if batched else fake_x,
-                                            q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
-                res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
-                out['gradient_penalty'] = gp
-            else:
-                res = J.ali(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
-        J.ONLY[0] = None
-        out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=res[0], disc_cost=res[1],
-                   gen_train_op=res[2], disc_train_op=res[3])
-        return out
+        return d_fake, d_real

@@ -43,7 +43,30 @@ def param(name, *args, **kwargs):
     result = _params[name]
     while id(result) in _param_aliases:
         result = _param_aliases[id(result)]
+    if _frozen and any(f in name for f in _frozen):
+        return result.detach()
     return result
+
+
+_frozen = []
+
+
+class frozen(object):
+    """with frozen('Discriminator'): ...   parameters whose name contains the substring are handed to the ops without
+    a gradient edge.  Eager counterpart of the reference's `var_list=` (tflib/objs/gan_inference.py:108-117): TF prunes
+    the gradients of variables a train op does not own; an eager tape must be told before the forward pass, otherwise
+    it computes (and throws away) the critic's weight gradients during every generator step."""
+
+    def __init__(self, *substrings):
+        self.subs = list(substrings)
+
+    def __enter__(self):
+        _frozen.extend(self.subs)
+        return self
+
+    def __exit__(self, *a):
+        for s_ in self.subs:
+            _frozen.remove(s_)
 
 
 def params_with_name(name):

@@ -68,6 +68,13 @@ int ggan_conv2d_bwd_data_act(const ggan_conv_geom* g, const float* gy, const flo
                              const float* w, float* gx, void* ws, size_t ws_bytes, ggan_stream_t stream);
 int ggan_conv2d_bwd_filter_act(const ggan_conv_geom* g, const float* x, const float* gy, const float* y, int y_act,
                                float y_alpha, float* gw, float* gbias, void* ws, size_t ws_bytes, ggan_stream_t stream);
+/* Filter gradient left as its split-K partial slabs, for a consumer that sums them anyway (ggan_pack_parts): saves the
+ * reduce launch.  part[s*stride + i], s < *n_parts, i < 25*Ci*Co is slab s of gw; with_bias != 0 appends the Co
+ * bias-gradient partials to every slab (i in [25*Ci*Co, 25*Ci*Co+Co)).  part_cap (floats) bounds the number of slabs.
+ * Returns 1 when the geometry is not covered by the MFMA kernel (nothing written; use ggan_conv2d_bwd_filter_act). */
+int ggan_conv2d_bwd_filter_parts(const ggan_conv_geom* g, const float* x, const float* gy, const float* y, int y_act,
+                                 float y_alpha, int with_bias, float* part, size_t part_cap, int* n_parts,
+                                 size_t* stride, ggan_stream_t stream);
 
 /* tf.nn.conv2d_transpose + bias_add (tflib/ops/deconv2d.py:101-114) computed natively in NCHW (the two
  * layout transposes at :91/:116 are mathematically no-ops).  g describes the forward conv whose
@@ -174,6 +181,9 @@ int ggan_adam_advance(int32_t* step, ggan_stream_t stream);
 #define GGAN_PACK_MAX 64
 int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count,
               float* flat, ggan_stream_t stream);
+/* same, where source i is the sum of parts[i] slabs strides[i] floats apart (summed in slab order: deterministic) */
+int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts,
+                    const size_t* strides, int count, float* flat, ggan_stream_t stream);
 
 /* ---- per-kernel timing (bench.py roofline leg) -----------------------------------------------
  * When enabled every launch is bracketed by hipEvents on its own stream.  ggan_prof_report
