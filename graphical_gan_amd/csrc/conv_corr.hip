@@ -69,7 +69,7 @@ struct CorrParams {
 // (operands fetched right before use into the same four registers), which leaves the matrix pipe idle for one LDS latency
 // per MFMA pair (measured: 5300 cycles per chunk where the MFMAs need 3200).  Here the operands of MFMA pair s+2,s+3 are
 // read BEFORE MFMA pair s,s+1 is issued, and sched_group_barrier pins that interleave (<= 4 LDS reads in flight).
-template <int TH, int TW, int DI, int PW, int CK, int TNW>
+template <int TH, int TW, int DI, int PW, int CK, int RS>
 __device__ __forceinline__ void mma_taps(const float* __restrict__ xs, const float* __restrict__ ws, int xfrag, int wfrag,
                                          int CS, int SCp, f32x16& acc) {
     constexpr int NS = TH * TW * PW;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void mma_taps(const float* __restrict__ xs, const flo
     auto load = [&](int s) {
         const int tap = s / PW, p = s - tap * PW;
         const int i = tap / TW, j = tap - i * TW;
-        a[s] = ws[(tap * CK + p * 2) * TNW + wfrag];
+        a[s] = ws[(tap * CK + p * 2) * RS + wfrag];
         b[s] = xs[p * 2 * CS + xfrag + DI * (i * SCp + j)];
     };
     load(0);
@@ -113,6 +113,11 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     constexpr int NC = CL::NC;
     constexpr int CK = 2 * KS * PW;
     constexpr int TNW = 32 * WN;
+    // The data-gradient kinds read the filter in its own HWIO layout, where the REDUCTION channel (co) is the contiguous
+    // one: a staging unit is then 4 consecutive k of one output channel, scattered into 4 LDS rows; rows are padded by 2
+    // floats so that scatter (lanes = 8 channels x 8 k-quads) and the fragment reads are both bank-conflict free.
+    constexpr bool WK = KIND != 0;
+    constexpr int RS = TNW + (WK ? 2 : 0);
     constexpr int NT0 = CL::th(0) * CL::tw(0);
     constexpr int NT1 = NC > 1 ? CL::th(1) * CL::tw(1) : 0;
     constexpr int NT2 = NC > 2 ? CL::th(2) * CL::tw(2) : 0;
@@ -146,7 +151,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 
     // two staging buffers: [CK][CS] slab + [NTT][CK][TNW] filter slice each
     const int XS_SZ = (CK * P.CS + 3) & ~3;
-    const int STAGE = XS_SZ + NTT * CK * TNW;
+    const int STAGE = XS_SZ + ((NTT * CK * RS + 3) & ~3);
 
     const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, (short)0, (int)P.in_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)P.w_bytes, 0x00020000);
@@ -174,17 +179,21 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         xvo[j] = off;
     }
     unsigned wvo[WE];
-    auto w_ck = [](int u) { return (u / (TNW / 4)) % CK; };
-    auto w_lds = [](int u) { return ((u / (CK * (TNW / 4))) * CK + (u / (TNW / 4)) % CK) * TNW + (u % (TNW / 4)) * 4; };
+    // unit -> (tap group, first reduction channel, output channel) and its LDS float index
+    //   !WK: unit = (tap, ck, cn4): 4 consecutive cn in memory => every wave-load is a run of whole 128-B filter rows
+    //    WK: unit = (tap, cn, ck4): 4 consecutive ck in memory; 8 lanes cover one 128-B run of a channel's filter row
+    auto w_tap = [](int u) { return u / (CK * (TNW / 4)); };
+    auto w_ck = [](int u) { return WK ? (u % (CK / 4)) * 4 : (u / (TNW / 4)) % CK; };
+    auto w_cn = [](int u) { return WK ? (u / (CK / 4)) % TNW : (u % (TNW / 4)) * 4; };
+    auto w_lds = [&](int u) { return (w_tap(u) * CK + w_ck(u)) * RS + w_cn(u); };
 #pragma unroll
     for (int q = 0; q < WE; ++q) {
         const int u = tid + q * NTHR;
         unsigned off = OOB;
         if (u < WUNITS) {
-            // unit = (tap, ck, cn4): 4 consecutive cn in memory => every wave-load is a run of whole 128-B filter rows
-            const int cn = (u % (TNW / 4)) * 4;
+            const int cn = w_cn(u);
             const int ckl = w_ck(u);
-            const int tapg = u / (CK * (TNW / 4));
+            const int tapg = w_tap(u);
             int ci_ = 0, tap = tapg;                     // which class of the list, tap index inside it
             if (NC > 1 && tap >= NT0) { tap -= NT0; ci_ = 1; }
             if (NC > 2 && ci_ == 1 && tap >= NT1) { tap -= NT1; ci_ = 2; }
@@ -215,7 +224,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
             xfrag[c] = kbase + b + cc.roff * P.SCp + cc.coff;
         }
     }
-    const int wfrag = (ks * PW * 2 + half) * TNW + wn * 32 + l31;
+    const int wfrag = (ks * PW * 2 + half) * RS + wn * 32 + l31;
 
     f32x16 acc[NC];
 #pragma unroll
@@ -257,7 +266,14 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
             const int u = tid + q * NTHR;
-            if (u < WUNITS) *reinterpret_cast<u32x4*>(wsb + w_lds(u)) = wreg[q];
+            if (u < WUNITS) {
+                if (WK) {
+                    unsigned* d = reinterpret_cast<unsigned*>(wsb + w_lds(u));
+                    d[0] = wreg[q][0]; d[RS] = wreg[q][1]; d[2 * RS] = wreg[q][2]; d[3 * RS] = wreg[q][3];
+                } else {
+                    *reinterpret_cast<u32x4*>(wsb + w_lds(u)) = wreg[q];
+                }
+            }
         }
     };
 
@@ -289,10 +305,10 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         if (!(P.dbg & 2)) {
             const float* xs = smem + ((P.dbg & 1) ? 0 : buf * STAGE);
             const float* ws = xs + XS_SZ;
-            mma_taps<CL::th(0), CL::tw(0), DI, PW, CK, TNW>(xs, ws, xfrag[0], wfrag, P.CS, P.SCp, acc[0]);
-            if constexpr (NC > 1) mma_taps<CL::th(1), CL::tw(1), DI, PW, CK, TNW>(xs, ws + NT0 * CK * TNW, xfrag[1], wfrag, P.CS, P.SCp, acc[1]);
-            if constexpr (NC > 2) mma_taps<CL::th(2), CL::tw(2), DI, PW, CK, TNW>(xs, ws + (NT0 + NT1) * CK * TNW, xfrag[2], wfrag, P.CS, P.SCp, acc[2]);
-            if constexpr (NC > 3) mma_taps<CL::th(3), CL::tw(3), DI, PW, CK, TNW>(xs, ws + (NT0 + NT1 + NT2) * CK * TNW, xfrag[3], wfrag, P.CS, P.SCp, acc[3]);
+            mma_taps<CL::th(0), CL::tw(0), DI, PW, CK, RS>(xs, ws, xfrag[0], wfrag, P.CS, P.SCp, acc[0]);
+            if constexpr (NC > 1) mma_taps<CL::th(1), CL::tw(1), DI, PW, CK, RS>(xs, ws + NT0 * CK * RS, xfrag[1], wfrag, P.CS, P.SCp, acc[1]);
+            if constexpr (NC > 2) mma_taps<CL::th(2), CL::tw(2), DI, PW, CK, RS>(xs, ws + (NT0 + NT1) * CK * RS, xfrag[2], wfrag, P.CS, P.SCp, acc[2]);
+            if constexpr (NC > 3) mma_taps<CL::th(3), CL::tw(3), DI, PW, CK, RS>(xs, ws + (NT0 + NT1 + NT2) * CK * RS, xfrag[3], wfrag, P.CS, P.SCp, acc[3]);
         }
         if (!stage_first) stage_next(ck0);
         __syncthreads();
@@ -431,23 +447,6 @@ __global__ void splitk_reduce_k(const float* __restrict__ partial, int SK, size_
         } else {
             out2[i - elems] = s;
         }
-    }
-}
-
-// wT[t][co][cip] = w[t][ci][co] (cip = Ci rounded up to 4, zero filled): gives the data-gradient the same
-// "rows contiguous in the output-channel index" filter layout the forward pass has.
-__global__ void filter_transpose_k(const float* __restrict__ w, float* __restrict__ wT, int Ci, int Co, int Cip) {
-    __shared__ float tile[32][33];
-    const int t = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-    const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
-    for (int r = ty; r < 32; r += 8) {
-        const int ci = ci0 + r, co = co0 + tx;
-        tile[r][tx] = (ci < Ci && co < Co) ? w[((size_t)t * Ci + ci) * Co + co] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int co = co0 + r, ci = ci0 + tx;
-        if (co < Co && ci < Cip) wT[((size_t)t * Co + co) * Cip + ci] = tile[tx][r];
     }
 }
 
@@ -603,7 +602,8 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     P.bias = bias; P.act = act; P.alpha = alpha;
     P.dbg = env_int("GGAN_DBG", 0);
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
-    size_t stage = 2 * ((size_t)((CK * P.CS + 3) & ~3) + (size_t)ntaps * CK * TNW);
+    const int RS = TNW + (MODE != 0 ? 2 : 0);     // filter row stride in LDS (corr_body: padded for the k-contiguous staging)
+    size_t stage = 2 * ((size_t)((CK * P.CS + 3) & ~3) + (size_t)((ntaps * CK * RS + 3) & ~3));
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
@@ -673,29 +673,20 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
                     int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!hot_geometry(g)) return 1;
     ws = ws_scratch(ws, ws_bytes);
-    const int Cip = (g.Ci + 3) & ~3;
-    const size_t in_bytes = (size_t)g.N * g.Co * g.Ho * g.Wo * 4, w_bytes = (size_t)25 * g.Co * Cip * 4;
+    // the filter is read in place (HWIO: the reduction channel co is the contiguous one, staged k-contiguously by corr_body)
+    if ((g.Co & 3) || ((uintptr_t)w & 15)) return 1;
+    const size_t in_bytes = (size_t)g.N * g.Co * g.Ho * g.Wo * 4, w_bytes = (size_t)25 * g.Ci * g.Co * 4;
     if (!fits32(in_bytes) || !fits32(w_bytes) || !fits32((size_t)g.N * g.Ci * g.H * g.W * 4)) return 1;
-    const size_t wT_bytes = (w_bytes + 255) & ~(size_t)255;
-    if (!ws || ws_bytes < wT_bytes) return 1;
-    float* wT = (float*)ws;
-    {
-        const double by = 2.0 * 25 * g.Ci * g.Co * 4;
-        GGAN_LAUNCH("filter_transpose_k", 0, by, filter_transpose_k, dim3(cdiv(Cip, 32), cdiv(g.Co, 32), 25), dim3(32, 8), 0, s,
-                    w, wT, g.Ci, g.Co, Cip);
-    }
-    ws = (char*)ws + wT_bytes;
-    ws_bytes -= wT_bytes;
     const int S = 2;
     CorrParams P;
     memset(&P, 0, sizeof(P));
-    P.in = gy; P.w = wT;
+    P.in = gy; P.w = w;
     if (m.act != GGAN_ACT_NONE) { P.in_ref = m.ref; P.in_act = m.act; P.in_alpha = m.alpha; }
     P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
     P.N = g.N; P.CKtot = g.Co; P.Hin = g.Ho; P.Win = g.Wo;
     P.CNtot = g.Ci; P.Hout = g.H; P.Wout = g.W;
     P.ors = S; P.ocs = S;
-    P.w_si = S * g.k * g.Co * Cip; P.w_sj = S * g.Co * Cip; P.w_sk = Cip; P.w_sn = 1;
+    P.w_si = S * g.k * g.Ci * g.Co; P.w_sj = S * g.Ci * g.Co; P.w_sk = 1; P.w_sn = g.Co;
     // per dimension and parity p (kh = p + S*i): output positions ih = off + S*a, input row oh = a + base - i
     int offs[2][2], bases[2][2], cnt[2][2], th[2][2], lo[2], hi[2];
     for (int d = 0; d < 2; ++d) {
@@ -720,7 +711,7 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
             c.Hu = cnt[0][ph]; c.Wv = cnt[1][pw];
             c.roff = bases[0][ph] - lo[0]; c.coff = bases[1][pw] - lo[1];
             c.or0 = offs[0][ph]; c.oc0 = offs[1][pw];
-            c.wbase = (ph * g.k + pw) * g.Co * Cip;
+            c.wbase = (ph * g.k + pw) * g.Ci * g.Co;
         }
     P.out_elems = (size_t)g.N * g.Ci * g.H * g.W;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
