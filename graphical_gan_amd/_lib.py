@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'libggan.so')
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PACK_MAX = 64
+BCE_MAX = 16
 
 
 class ConvGeom(C.Structure):
@@ -55,7 +56,7 @@ SIGNATURES = {
     'ggan_chansum': (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     'ggan_bn_fwd_train': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),
     'ggan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'ggan_bn_bwd_act': (_I, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'ggan_bn_bwd_act': (_I, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ggan_act_fwd': (_I, [_P, _P, _Z, _I, _F, _P]),
     'ggan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     'ggan_bias_add': (_I, [_P, _P, _P, _I, _I, _I, _P]),
@@ -64,14 +65,17 @@ SIGNATURES = {
     'ggan_row_lerp': (_I, [_P, _P, _P, _P, _I, _I, _P]),
     'ggan_bce_logits_fwd': (_I, [_P, _F, _F, _P, _I, _I, _P]),
     'ggan_bce_logits_bwd': (_I, [_P, _F, _F, _P, _P, _I, _P]),
+    'ggan_bce_logits_multi_fwd': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _I, _P, _P]),
+    'ggan_bce_logits_multi_bwd': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _I, _P, C.POINTER(_P), _P]),
     'ggan_mean_fwd': (_I, [_P, _F, _P, _I, _I, _P]),
     'ggan_mean_bwd': (_I, [_P, _F, _P, _I, _P]),
     'ggan_gp_penalty_fwd': (_I, [_P, _P, _P, _I, _I, _F, _P]),
     'ggan_gp_penalty_bwd': (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     'ggan_adam_step': (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P]),
     'ggan_adam_advance': (_I, [_P, _P]),
+    'ggan_adam_step_counted': (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P]),
     'ggan_pack': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), _I, _P, _P]),
-    'ggan_pack_parts': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), _I, _P, _P]),
+    'ggan_pack_parts': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), _I, _P, _P, _P]),
     'ggan_prof_enable': (_I, [_I]),
     'ggan_prof_reset': (_I, []),
     'ggan_prof_report': (_I, [C.POINTER(ProfRec), _I]),

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __res
 __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
                                                               const float* __restrict__ scale, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ gx,
-                                                              float* __restrict__ gscale, float* __restrict__ goffset, int N,
+                                                              float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ gx_sum, int N,
                                                               int C, int HW) {
     __shared__ float sm[32];
     const int c = blockIdx.x;
@@ -102,13 +102,20 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
     const float sum_gx = block_sum(s2, sm);
     const float inv_cnt = 1.f / (float)total;
     const float k = scale[c] * invstd, mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
+    float s3 = 0.f;
 #pragma unroll
     for (int j = 0; j < kRegE; ++j) {
         const int i = threadIdx.x + j * kThreads;
         if (i < total) {
             const int n = i / HW, p = i - n * HW;
-            gx[((size_t)n * C + c) * HW + p] = k * (g[j] - mg - xh[j] * mgx);
+            const float o = k * (g[j] - mg - xh[j] * mgx);
+            gx[((size_t)n * C + c) * HW + p] = o;
+            s3 += o;
         }
+    }
+    if (gx_sum) {   // channel sum of the result: the bias gradient of the layer below (mathematically 0, kept for parity)
+        const float t = block_sum(s3, sm);
+        if (threadIdx.x == 0) gx_sum[c] = t;
     }
     if (threadIdx.x == 0) {
         gscale[c] = sum_gx;
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_k(const float* __restric
 __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
                                                           const float* __restrict__ scale, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, float* __restrict__ gx,
-                                                          float* __restrict__ gscale, float* __restrict__ goffset, int N,
+                                                          float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ gx_sum, int N,
                                                           int C, int HW) {
     __shared__ float sm[32];
     const int c = blockIdx.x;
@@ -173,11 +180,18 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restric
     const float inv_cnt = 1.f / (float)total;
     const float k = scale[c] * invstd;
     const float mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
+    float s3 = 0.f;
     for (int i = threadIdx.x; i < total; i += kThreads) {
         int n = i / HW, p = i - n * HW;
         size_t idx = ((size_t)n * C + c) * HW + p;
         float xh = (x[idx] - mean) * invstd;
-        gx[idx] = k * (ld_gy(gy, mk, idx) - mg - xh * mgx);
+        const float o = k * (ld_gy(gy, mk, idx) - mg - xh * mgx);
+        gx[idx] = o;
+        s3 += o;
+    }
+    if (gx_sum) {
+        const float t = block_sum(s3, sm);
+        if (threadIdx.x == 0) gx_sum[c] = t;
     }
     if (threadIdx.x == 0) {
         gscale[c] = sum_gx;
@@ -279,8 +293,8 @@ int ggan_bn_fwd_train(const float* x, const float* scale, const float* offset, f
 }
 
 int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* scale,
-                    const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset, int N, int C,
-                    int HW, ggan_stream_t stream) {
+                    const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset,
+                    float* gx_chansum, int N, int C, int HW, ggan_stream_t stream) {
     GGAN_CHECK_ARG(x && gy && scale && save_mean && save_invstd && gx && gscale && goffset, "null pointer");
     GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "activation mask needs the forward output");
     GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
@@ -288,10 +302,11 @@ int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, 
     const GyMask mk{y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha};
     const double bytes = 20.0 * N * C * HW;
     if (HW > 1 && N * HW <= kRegE * kThreads) {
-        GGAN_LAUNCH("bn_bwd_nchw", 0, 12.0 * N * C * HW, bn_bwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
+        GGAN_LAUNCH("bn_bwd_nchw", 0, 12.0 * N * C * HW, bn_bwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, gx_chansum, N, C, HW);
     } else if (HW > 1) {
-        GGAN_LAUNCH("bn_bwd_nchw", 0, bytes, bn_bwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW);
+        GGAN_LAUNCH("bn_bwd_nchw", 0, bytes, bn_bwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, gx_chansum, N, C, HW);
     } else {
+        GGAN_CHECK_ARG(!gx_chansum, "gx_chansum is only produced for NCHW inputs (HW > 1)");
         GGAN_LAUNCH("bn_bwd_rows", 0, bytes, bn_bwd_rows_k, dim3(cdiv(C, kCols)), dim3(kCols, kSlices), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, N, C);
     }
     return 0;
@@ -299,8 +314,8 @@ int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, 
 
 int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float* save_mean, const float* save_invstd,
                 float* gx, float* gscale, float* goffset, int N, int C, int HW, ggan_stream_t stream) {
-    return ggan_bn_bwd_act(x, gy, nullptr, GGAN_ACT_NONE, 0.f, scale, save_mean, save_invstd, gx, gscale, goffset, N, C, HW,
-                           stream);
+    return ggan_bn_bwd_act(x, gy, nullptr, GGAN_ACT_NONE, 0.f, scale, save_mean, save_invstd, gx, gscale, goffset, nullptr, N, C,
+                           HW, stream);
 }
 
 }  // extern "C"

@@ -150,6 +150,47 @@ __global__ void bce_bwd_k(const float* __restrict__ x, float z, float weight, co
     }
 }
 
+// all BCE terms of one cost in ONE launch: loss = sum_i w_i * mean(bce(x_i, z_i))
+struct BceTable {
+    const float* x[GGAN_BCE_MAX];
+    float* gx[GGAN_BCE_MAX];
+    float z[GGAN_BCE_MAX];
+    float w[GGAN_BCE_MAX];
+    int n[GGAN_BCE_MAX];
+    int count;
+};
+
+__global__ void bce_multi_fwd_k(BceTable t, float* __restrict__ loss) {
+    __shared__ float sm[32];
+    float tot = 0.f;
+    for (int k = 0; k < t.count; ++k) {      // terms in order: the same summation order as one launch per term
+        const float* x = t.x[k];
+        const float z = t.z[k];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < t.n[k]; i += blockDim.x) {
+            float v = x[i];
+            s += fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)));
+        }
+        s = block_sum(s, sm);
+        const float r = t.w[k] * (s / (float)t.n[k]);
+        tot = k ? tot + r : r;
+    }
+    if (threadIdx.x == 0) loss[0] = tot;
+}
+
+__global__ void bce_multi_bwd_k(BceTable t, const float* __restrict__ gloss) {
+    const int k = blockIdx.y;
+    const int n = t.n[k];
+    const float g = gloss[0] * t.w[k] / (float)n, z = t.z[k];
+    const float* x = t.x[k];
+    float* gx = t.gx[k];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float v = x[i];
+        float sg = 1.f / (1.f + expf(-v));
+        gx[i] = g * (sg - z);
+    }
+}
+
 __global__ void mean_fwd_k(const float* __restrict__ x, float weight, float* __restrict__ loss, int n, int accumulate) {
     __shared__ float sm[32];
     float s = 0.f;
@@ -198,10 +239,12 @@ __global__ void gp_bwd_k(const float* __restrict__ g, const float* __restrict__ 
 }
 
 // ---- Adam (TF flavour) ------------------------------------------------------------------------
+// PRE: step[0] already holds this update's ordinal (the gradient-pack kernel of the same optimizer step incremented it)
+template <bool PRE>
 __global__ void adam_k(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, size_t n, const int32_t* __restrict__ step, float lr, float b1,
                        float b2, float eps, float gscale) {
-    const float t = (float)(step[0] + 1);
+    const float t = (float)(step[0] + (PRE ? 0 : 1));
     const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     size_t n4 = n >> 2;
@@ -239,6 +282,7 @@ struct PackTable {
     size_t pstride[GGAN_PACK_MAX];   // floats between the partial slabs of source k
     int parts[GGAN_PACK_MAX];        // number of slabs to sum (1 = plain copy)
     int count;
+    int32_t* bump;                   // optional: counter incremented once per launch (the optimizer's step ordinal)
 };
 
 // blockIdx.y = tensor, blockIdx.x grid-strides inside it (16-byte accesses when every side is aligned); a source made of
@@ -251,6 +295,7 @@ __global__ void pack_k(PackTable t, float* __restrict__ flat) {
     const int np = t.parts[k];
     const size_t ps = t.pstride[k];
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if (t.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) t.bump[0] += 1;
     if (s && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0 && (np == 1 || (ps & 3) == 0)) {
         const size_t n4 = n >> 2;
         float4* d4 = reinterpret_cast<float4*>(d);
@@ -370,6 +415,41 @@ int ggan_bce_logits_bwd(const float* x, float label, float weight, const float* 
     return 0;
 }
 
+static int bce_table(BceTable& t, const float* const* xs, float* const* gxs, const float* labels, const float* weights,
+                     const int* ns, int count, int* max_n) {
+    *max_n = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!xs[i] || ns[i] <= 0 || (gxs && !gxs[i])) return -1;
+        t.x[i] = xs[i]; t.gx[i] = gxs ? gxs[i] : nullptr; t.z[i] = labels[i]; t.w[i] = weights[i]; t.n[i] = ns[i];
+        if (ns[i] > *max_n) *max_n = ns[i];
+    }
+    t.count = count;
+    return 0;
+}
+
+int ggan_bce_logits_multi_fwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count,
+                              float* loss, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(xs && labels && weights && ns && loss, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_BCE_MAX, "count out of range");
+    BceTable t;
+    int mx;
+    GGAN_CHECK_ARG(bce_table(t, xs, nullptr, labels, weights, ns, count, &mx) == 0, "bad term");
+    GGAN_LAUNCH("bce_logits_fwd", 0, 4.0 * mx * count, bce_multi_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, t, loss);
+    return 0;
+}
+
+int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count,
+                              const float* gloss, float* const* gxs, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(xs && labels && weights && ns && gloss && gxs, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_BCE_MAX, "count out of range");
+    BceTable t;
+    int mx;
+    GGAN_CHECK_ARG(bce_table(t, xs, gxs, labels, weights, ns, count, &mx) == 0, "bad term");
+    GGAN_LAUNCH("bce_logits_bwd", 0, 8.0 * mx * count, bce_multi_bwd_k, dim3(cdiv(mx, 256), count), dim3(256), 0,
+                (hipStream_t)stream, t, gloss);
+    return 0;
+}
+
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream) {
     GGAN_CHECK_ARG(x && loss && n > 0, "bad argument");
     GGAN_LAUNCH("mean_fwd", 0, 4.0 * n, mean_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, x, weight, loss, n, accumulate);
@@ -401,7 +481,16 @@ int ggan_adam_step(float* theta, const float* g, float* m, float* v, size_t n, c
     GGAN_CHECK_ARG(theta && g && m && v && step, "null pointer");
     if (n == 0) return 0;
     GGAN_CHECK_ARG(aligned16(theta) && aligned16(g) && aligned16(m) && aligned16(v), "buffers must be 16-byte aligned");
-    GGAN_LAUNCH("adam_step", 0, 28.0 * n, adam_k, dim3(grid_for(n, 8)), dim3(kBlock), 0, (hipStream_t)stream, theta, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale);
+    GGAN_LAUNCH("adam_step", 0, 28.0 * n, adam_k<false>, dim3(grid_for(n, 8)), dim3(kBlock), 0, (hipStream_t)stream, theta, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale);
+    return 0;
+}
+
+int ggan_adam_step_counted(float* theta, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr,
+                           float beta1, float beta2, float eps, float grad_scale, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(theta && g && m && v && step, "null pointer");
+    if (n == 0) return 0;
+    GGAN_CHECK_ARG(aligned16(theta) && aligned16(g) && aligned16(m) && aligned16(v), "buffers must be 16-byte aligned");
+    GGAN_LAUNCH("adam_step", 0, 28.0 * n, adam_k<true>, dim3(grid_for(n, 8)), dim3(kBlock), 0, (hipStream_t)stream, theta, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale);
     return 0;
 }
 
@@ -412,7 +501,7 @@ int ggan_adam_advance(int32_t* step, ggan_stream_t stream) {
 }
 
 int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts,
-                    const size_t* strides, int count, float* flat, ggan_stream_t stream) {
+                    const size_t* strides, int count, float* flat, int32_t* bump, ggan_stream_t stream) {
     GGAN_CHECK_ARG(srcs && sizes && offsets && flat, "null pointer");
     GGAN_CHECK_ARG(count > 0 && count <= GGAN_PACK_MAX, "count out of range");
     PackTable t;
@@ -426,6 +515,7 @@ int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t*
         tot += sizes[i] * (size_t)t.parts[i];
     }
     t.count = count;
+    t.bump = bump;
     int gx = (int)cdivz(mx, (size_t)kBlock * 16);
     if (gx < 1) gx = 1;
     if (gx > 512) gx = 512;
@@ -434,7 +524,7 @@ int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t*
 }
 
 int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count, float* flat, ggan_stream_t stream) {
-    return ggan_pack_parts(srcs, sizes, offsets, nullptr, nullptr, count, flat, stream);
+    return ggan_pack_parts(srcs, sizes, offsets, nullptr, nullptr, count, flat, nullptr, stream);
 }
 
 }  // extern "C"

@@ -336,7 +336,8 @@ class ConvDgrad(Function):
                 parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None
                 d_w = parts[0] if parts is not None else ConvWgrad.apply(h, gy, ctx.geom)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                d_b = ChanSum.apply(h)
+                pre = getattr(h, '_ggan_chansum', None) if not torch.is_grad_enabled() else None
+                d_b = pre if (pre is not None and pre.numel() == h.shape[1]) else ChanSum.apply(h)
         if ctx.needs_input_grad[0]:
             d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
         fork.join(d_w, d_b, h, gy)
@@ -595,8 +596,12 @@ class BatchNormTrain(Function):
         gx = torch.empty_like(x)
         gs = torch.empty((Cc,), dtype=torch.float32, device=x.device)
         go = torch.empty_like(gs)
+        csum = torch.empty_like(gs) if HW > 1 else None
         check(_L().ggan_bn_bwd_act(_p(x), _p(gy), _p(y) if ctx.act != ACT_NONE else _p(None), ctx.act, ctx.alpha, _p(sc),
-                                   _p(mean), _p(invstd), _p(gx), _p(gs), _p(go), N, Cc, HW, _stream()), 'ggan_bn_bwd_act')
+                                   _p(mean), _p(invstd), _p(gx), _p(gs), _p(go), _p(csum), N, Cc, HW, _stream()),
+              'ggan_bn_bwd_act')
+        if csum is not None:
+            gx._ggan_chansum = csum      # picked up by the producing layer's backward if gx reaches it unchanged
         return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None
 
 
@@ -618,6 +623,11 @@ class SplitRows(Function):
             ga = like.new_zeros((ctx.n,) + tuple(like.shape[1:]))
         if gb is None:
             gb = like.new_zeros((ctx.rows - ctx.n,) + tuple(like.shape[1:]))
+        if (ga.is_contiguous() and gb.is_contiguous() and ga.dtype == gb.dtype
+                and ga.untyped_storage().data_ptr() == gb.untyped_storage().data_ptr()
+                and gb.storage_offset() == ga.storage_offset() + ga.numel()):
+            # the two halves already sit back to back in one buffer (BceSum.backward): no copy
+            return torch.as_strided(ga, (ctx.rows,) + tuple(ga.shape[1:]), ga.stride(), ga.storage_offset()), None
         return torch.cat([ga, gb], 0), None
 
 
@@ -683,15 +693,22 @@ class RowLerp(Function):
 # losses
 # ---------------------------------------------------------------------------------------------------
 class BceSum(Function):
-    """sum_i weight_i * mean(sigmoid_cross_entropy_with_logits(x_i, label_i)) -> 0-dim tensor."""
+    """sum_i weight_i * mean(sigmoid_cross_entropy_with_logits(x_i, label_i)) -> 0-dim tensor; one launch forward and one
+    backward for all terms."""
+
+    @staticmethod
+    def _tables(logits, labels, weights):
+        n = len(logits)
+        assert n <= _lib.BCE_MAX, 'too many BCE terms for one launch'
+        return ((C.c_void_p * n)(*[x.data_ptr() for x in logits]), (C.c_float * n)(*[float(z) for z in labels]),
+                (C.c_float * n)(*[float(w) for w in weights]), (C.c_int * n)(*[x.numel() for x in logits]), n)
 
     @staticmethod
     def forward(ctx, labels, weights, *logits):
         logits = [_c(x).reshape(-1) for x in logits]
         loss = torch.empty((1,), dtype=torch.float32, device=logits[0].device)
-        for i, (x, z, w) in enumerate(zip(logits, labels, weights)):
-            check(_L().ggan_bce_logits_fwd(_p(x), float(z), float(w), _p(loss), x.numel(), int(i > 0), _stream()),
-                  'ggan_bce_logits_fwd')
+        xs, zs, ws, ns, n = BceSum._tables(logits, labels, weights)
+        check(_L().ggan_bce_logits_multi_fwd(xs, zs, ws, ns, n, _p(loss), _stream()), 'ggan_bce_logits_multi_fwd')
         ctx.labels, ctx.weights = labels, weights
         ctx.save_for_backward(*logits)
         return loss.reshape(())
@@ -700,12 +717,18 @@ class BceSum(Function):
     @once_differentiable
     def backward(ctx, g):
         g = _c(g.reshape(1))
-        outs = []
-        for x, z, w in zip(ctx.saved_tensors, ctx.labels, ctx.weights):
-            gx = torch.empty_like(x)
-            check(_L().ggan_bce_logits_bwd(_p(x), float(z), float(w), _p(g), _p(gx), x.numel(), _stream()),
-                  'ggan_bce_logits_bwd')
-            outs.append(gx)
+        logits = ctx.saved_tensors
+        # one gradient buffer; terms that are adjacent rows of one tensor (the critic evaluated on [fake; real]) get adjacent
+        # slices, so SplitRows.backward can hand the buffer on without a concatenation
+        sizes = [x.numel() for x in logits]
+        buf = torch.empty((sum(sizes),), dtype=torch.float32, device=g.device)
+        outs, o = [], 0
+        for nn in sizes:
+            outs.append(buf[o:o + nn])
+            o += nn
+        xs, zs, ws, ns, n = BceSum._tables(logits, ctx.labels, ctx.weights)
+        gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+        check(_L().ggan_bce_logits_multi_bwd(xs, zs, ws, ns, n, _p(g), gxs, _stream()), 'ggan_bce_logits_multi_bwd')
         return (None, None) + tuple(outs)
 
 
@@ -763,18 +786,23 @@ class GradPenalty(Function):
 # ---------------------------------------------------------------------------------------------------
 # optimiser primitives (no autograd)
 # ---------------------------------------------------------------------------------------------------
-def adam_step_(theta, g, m, v, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0):
+def adam_step_(theta, g, m, v, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0, counted=False):
+    """counted=True: `step` was already advanced to this update's ordinal (pack_(..., bump=step))."""
     n = theta.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n and step.dtype == torch.int32
     L = _L()
+    if counted:
+        check(L.ggan_adam_step_counted(_p(theta), _p(g), _p(m), _p(v), n, _p(step), lr, beta1, beta2, eps, grad_scale,
+                                       _stream()), 'ggan_adam_step_counted')
+        return
     check(L.ggan_adam_step(_p(theta), _p(g), _p(m), _p(v), n, _p(step), lr, beta1, beta2, eps, grad_scale, _stream()),
           'ggan_adam_step')
     check(L.ggan_adam_advance(_p(step), _stream()), 'ggan_adam_advance')
 
 
-def pack_(tensors, offsets, flat):
+def pack_(tensors, offsets, flat, bump=None):
     """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros); tensors registered by `defer_wgrad_reduce` are
-    summed over their split-K slabs on the way."""
+    summed over their split-K slabs on the way.  bump: int32 device counter incremented once (the Adam step ordinal)."""
     L = _L()
     reg = _DEFER[0]
     for i0 in range(0, len(tensors), _lib.PACK_MAX):
@@ -784,9 +812,7 @@ def pack_(tensors, offsets, flat):
         sizes = (C.c_size_t * n)(*[int(s) for s in [o[1] for o in offsets[i0:i0 + n]]])
         offs = (C.c_size_t * n)(*[int(o[0]) for o in offsets[i0:i0 + n]])
         info = [reg.pop(t.data_ptr(), None) if (reg and t is not None) else None for t in chunk]
-        if any(info):
-            parts = (C.c_int * n)(*[(e[0] if e else 1) for e in info])
-            strides = (C.c_size_t * n)(*[(e[1] if e else 0) for e in info])
-            check(L.ggan_pack_parts(srcs, sizes, offs, parts, strides, n, _p(flat), _stream()), 'ggan_pack_parts')
-        else:
-            check(L.ggan_pack(srcs, sizes, offs, n, _p(flat), _stream()), 'ggan_pack')
+        parts = (C.c_int * n)(*[(e[0] if e else 1) for e in info])
+        strides = (C.c_size_t * n)(*[(e[1] if e else 0) for e in info])
+        check(L.ggan_pack_parts(srcs, sizes, offs, parts, strides, n, _p(flat), _p(bump if i0 == 0 else None), _stream()),
+              'ggan_pack_parts')

@@ -67,7 +67,7 @@ class AdamOptimizer(object):
         self.m = torch.zeros_like(self.theta)
         self.v = torch.zeros_like(self.theta)
         self.g = torch.zeros_like(self.theta)
-        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)      # advanced by the pack kernel of each step
         with torch.no_grad():
             for p, (o, n) in zip(self.params, self.slots):
                 view = self.theta[o:o + n].view(p.shape)
@@ -75,18 +75,21 @@ class AdamOptimizer(object):
                 p.data = view
                 p._flat_owner = self
         self.bucket = GradBucket(self.g)
+        self._one = None
         self.world = self.bucket.world
 
     # -- one optimizer step ---------------------------------------------------------------------------
     def compute_gradients(self, cost, side_wgrad=False):
         """side_wgrad: run the weight-gradient kernels on a second stream (functional.side_chain); legal only when
         every parameter is used once in the graph of `cost`."""
+        if self._one is None or self._one.shape != cost.shape:
+            self._one = torch.ones_like(cost)            # persistent d(cost)/d(cost) seed (no fill launch per step)
         with F.side_chain(self.theta.device, side_wgrad):
-            return torch.autograd.grad(cost, self.params, allow_unused=True)
+            return torch.autograd.grad(cost, self.params, grad_outputs=self._one, allow_unused=True)
 
     def pack(self, grads):
         gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
-        F.pack_(gs, self.slots, self.g)
+        F.pack_(gs, self.slots, self.g, bump=self.step)     # also advances the step counter (read by update())
         return gs  # keep alive until the kernel ran (stream-ordered)
 
     def all_reduce(self):
@@ -95,7 +98,7 @@ class AdamOptimizer(object):
 
     def update(self):
         F.adam_step_(self.theta, self.g, self.m, self.v, self.step, self.lr, self.beta1, self.beta2, self.eps,
-                     self.bucket.scale)
+                     self.bucket.scale, counted=True)
 
     def apply_gradients(self, grads):
         keep = self.pack(grads)

@@ -126,10 +126,11 @@ int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float
                 const float* save_invstd, float* gx, float* gscale, float* goffset,
                 int N, int C, int HW, ggan_stream_t stream);
 /* same, with the activation fused into the forward (ggan_bn_fwd_train act != NONE) differentiated on load: gy is
- * dL/d(activated output y); no separate ggan_act_bwd pass. */
+ * dL/d(activated output y); no separate ggan_act_bwd pass.  gx_chansum (may be NULL; HW > 1 only) receives
+ * sum_{n,h,w} gx per channel = the BiasAddGrad of the layer that feeds this BatchNorm, from the values in registers. */
 int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* scale,
                     const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset,
-                    int N, int C, int HW, ggan_stream_t stream);
+                    float* gx_chansum, int N, int C, int HW, ggan_stream_t stream);
 
 /* ---- pointwise -------------------------------------------------------------------------------
  * LeakyReLU = tf.maximum(alpha*x, x) (gmgan_inference_cifar10.py:122-123), tf.nn.relu, tf.tanh,
@@ -159,6 +160,13 @@ int ggan_bce_logits_fwd(const float* x, float label, float weight, float* loss, 
 /* gx[i] = gloss[0]*weight*(sigmoid(x[i]) - z)/n */
 int ggan_bce_logits_bwd(const float* x, float label, float weight, const float* gloss, float* gx, int n,
                         ggan_stream_t stream);
+/* every term of one cost in a single launch: loss = sum_i weights[i] * mean(bce(xs[i], labels[i])), terms added in index
+ * order (same result as one ggan_bce_logits_fwd per term with accumulate); the backward writes gxs[i] for every term. */
+#define GGAN_BCE_MAX 16
+int ggan_bce_logits_multi_fwd(const float* const* xs, const float* labels, const float* weights, const int* ns,
+                              int count, float* loss, ggan_stream_t stream);
+int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns,
+                              int count, const float* gloss, float* const* gxs, ggan_stream_t stream);
 /* loss[0] (+)= weight*mean(x); bwd gx[i] = gloss[0]*weight/n  (wali_gp, gan_inference.py:29-30). */
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
@@ -177,13 +185,18 @@ int ggan_gp_penalty_bwd(const float* g, const float* slopes, const float* gpen, 
 int ggan_adam_step(float* theta, const float* g, float* m, float* v, size_t n, const int32_t* step,
                    float lr, float beta1, float beta2, float eps, float grad_scale, ggan_stream_t stream);
 int ggan_adam_advance(int32_t* step, ggan_stream_t stream);
+/* Adam step whose counter was already advanced: *step holds THIS update's ordinal t (>= 1), e.g. incremented by the
+ * ggan_pack_parts launch of the same optimizer step (its `bump` argument) -- no separate ggan_adam_advance launch. */
+int ggan_adam_step_counted(float* theta, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr,
+                           float beta1, float beta2, float eps, float grad_scale, ggan_stream_t stream);
 /* gather up to GGAN_PACK_MAX scattered tensors into one flat buffer (gradient bucket for RCCL). */
 #define GGAN_PACK_MAX 64
 int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count,
               float* flat, ggan_stream_t stream);
-/* same, where source i is the sum of parts[i] slabs strides[i] floats apart (summed in slab order: deterministic) */
+/* same, where source i is the sum of parts[i] slabs strides[i] floats apart (summed in slab order: deterministic);
+ * bump (may be NULL): an int32 incremented once by this launch. */
 int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts,
-                    const size_t* strides, int count, float* flat, ggan_stream_t stream);
+                    const size_t* strides, int count, float* flat, int32_t* bump, ggan_stream_t stream);
 
 /* ---- per-kernel timing (bench.py roofline leg) -----------------------------------------------
  * When enabled every launch is bracketed by hipEvents on its own stream.  ggan_prof_report
