@@ -120,11 +120,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    tr.flush()
     fence()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = tr.iteration(it, bi); it += 1
+    tr.flush()                                         # (DP: the last critic step's exchange + Adam belong to the timed work)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -57,6 +57,7 @@ class Trainer(object):
         # (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
         self.single_contrib = bool(getattr(cfg, 'batch_critic', False)) and cfg.mode != 'wali-gp'
         self._opts = None
+        self._pending = None         # (work handle, Adam graph) of a critic-step exchange still in flight (see step())
 
     # ---- inputs ---------------------------------------------------------------------------------------
     def set_feed(self, feed):
@@ -88,10 +89,13 @@ class Trainer(object):
             f['dequant_u'].uniform_(0., 1. / 128)
 
     # ---- one session.run ------------------------------------------------------------------------------
-    def _fwd_bwd(self, which):
+    def _nets(self):
         if not self.inject_noise:
             self._sample_noise()
-        out = self.model.forward(self.feed, which)
+        return self.model.forward_nets(self.feed)
+
+    def _fwd_bwd(self, which, nets=None):
+        out = self.model.forward(self.feed, which, nets if nets is not None else self._nets())
         op = out[which + '_train_op']
         opt = op.optimizer
         # (the filter-gradient slabs are summed by the pack kernel: legal under the same one-contribution condition)
@@ -101,6 +105,7 @@ class Trainer(object):
         return out[which + '_cost'].detach(), opt, keep
 
     def _eager(self, which):
+        self.flush()
         cost, opt, _ = self._fwd_bwd(which)
         opt.all_reduce()
         opt.update()
@@ -130,13 +135,30 @@ class Trainer(object):
             with torch.cuda.graph(g1, stream=s):
                 cost, opt, keep = self._fwd_bwd(which)
                 opt.update()
-            return dict(g1=g1, g2=None, cost=cost, opt=opt, keep=keep)
-        with torch.cuda.graph(g1, stream=s):
-            cost, opt, keep = self._fwd_bwd(which)
+            return dict(g0=None, g1=g1, g2=None, cost=cost, opt=opt, keep=keep)
+        # data parallel: [forward + backward + pack] -> all-reduce -> [Adam].  A generator step is cut once more, after
+        # the Extractor/Generator passes (g0): they read no critic variable, so they run while the previous critic step's
+        # gradient exchange is still on the wire (step()).
+        g0, nets = None, None
+        if which == 'gen':
+            g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0, stream=s):
+                nets = self._nets()
+        with torch.cuda.graph(g1, stream=s, pool=g0.pool() if g0 is not None else None):
+            cost, opt, keep = self._fwd_bwd(which, nets)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=s):
             opt.update()
-        return dict(g1=g1, g2=g2, cost=cost, opt=opt, keep=keep)
+        return dict(g0=g0, g1=g1, g2=g2, cost=cost, opt=opt, keep=(keep, nets))
+
+    def flush(self):
+        """Finish a critic step whose gradient exchange was left in flight: wait for it, apply its Adam update."""
+        if self._pending is not None:
+            work, g2 = self._pending
+            self._pending = None
+            if work is not None:
+                work.wait()              # the current stream waits; the host does not block
+            g2.replay()
 
     def step(self, which):
         """One gen or disc session.run on the current contents of the static buffers -> 0-dim cost tensor."""
@@ -148,11 +170,22 @@ class Trainer(object):
             if self._calls[which] == 1:
                 # the very first call of each kind runs eagerly AND counts as a real step
                 return self._eager(which)
+            self.flush()
             rec = self._capture(which)
             self._graphs[which] = rec
+        if rec['g2'] is None:            # single GPU: the whole step is one graph
+            rec['g1'].replay()
+            return rec['cost']
+        if rec['g0'] is not None:
+            rec['g0'].replay()           # overlaps the pending critic-gradient all-reduce
+        self.flush()
         rec['g1'].replay()
-        if rec['g2'] is not None:
-            rec['opt'].all_reduce()
+        work = rec['opt'].all_reduce(async_op=True)
+        if which == 'disc':
+            self._pending = (work, rec['g2'])    # finished by the next step (or flush()): nothing before that reads it
+        else:
+            if work is not None:
+                work.wait()
             rec['g2'].replay()
         return rec['cost']
 
@@ -186,6 +219,7 @@ class Trainer(object):
     # ---- parameters -------------------------------------------------------------------------------------
     def load_params(self, params):
         """name -> numpy array (e.g. oracle.nets.init_params) into the registry, creating entries as needed."""
+        self.flush()
         with torch.no_grad():
             for name, v in params.items():
                 trainable = not (name.endswith('.moving_mean') or name.endswith('.moving_variance'))
@@ -193,6 +227,7 @@ class Trainer(object):
                 p.data.copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(p.shape))
 
     def get_params(self):
+        self.flush()
         return {n: p.detach().cpu().numpy().copy() for n, p in lib.named_params().items()}
 
 

@@ -176,22 +176,29 @@ class GraphicalGAN(object):
             return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'])
         return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2.)
 
-    def forward(self, feed, which=None):
-        """which='gen'|'disc' builds only what that session.run fetches (TF prunes the rest: the gradient penalty
-        is not part of gen_cost); None builds everything."""
+    def forward_nets(self, feed):
+        """Extractor and Generator passes: everything of a session.run that does not read a critic variable."""
         c = self.cfg
         real_x = self.real_x(feed)
         q_z = self.Extractor(real_x)
         out = dict(real_x=real_x, q_z=q_z)
         if c.K:
-            onehot = feed['k_onehot']
             _, q_k = self.HyperExtractor(q_z, feed['gumbel_u'])
-            p_z = self.HyperGenerator(onehot, feed['p_z_noise'])
+            out['p_z'] = self.HyperGenerator(feed['k_onehot'], feed['p_z_noise'])
             out['q_k'] = q_k
         else:
-            p_z = feed['p_z_noise']
-        fake_x = self.Generator(p_z)
-        out.update(p_z=p_z, fake_x=fake_x)
+            out['p_z'] = feed['p_z_noise']
+        out['fake_x'] = self.Generator(out['p_z'])
+        return out
+
+    def forward(self, feed, which=None, nets=None):
+        """which='gen'|'disc' builds only what that session.run fetches (TF prunes the rest: the gradient penalty
+        is not part of gen_cost); None builds everything.  nets: a forward_nets() result to continue from."""
+        c = self.cfg
+        out = dict(nets) if nets is not None else self.forward_nets(feed)
+        real_x, q_z, p_z, fake_x = out['real_x'], out['q_z'], out['p_z'], out['fake_x']
+        if c.K:
+            onehot, q_k = feed['k_onehot'], out['q_k']
         J = lib.objs.gan_inference
         J.ONLY[0] = which            # TF prunes the cost a session.run does not fetch; so do we
         batched = c.batch_critic and which == 'disc'

@@ -8,6 +8,8 @@ keeps its identity and shape; its storage becomes a 256-byte aligned view), so t
     (12.5 MB generator side / 16.25 MB critic side on CIFAR -- SURVEY.md 8e), issued right after backward.
 The step counter lives in device memory so a captured HIP graph advances it on replay.
 """
+import os as _os
+
 import torch
 import torch.distributed as dist
 
@@ -38,10 +40,13 @@ class GradBucket(object):
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.scale = 1.0 / self.world
 
-    def all_reduce(self):
-        if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        return self.flat
+    def all_reduce(self, async_op=False):
+        """async_op: returns the torch.distributed work handle (None when there is nothing to exchange); the caller
+        calls .wait() before the bucket is read -- lets the exchange overlap kernels issued in between."""
+        if self.world > 1 or (_os.environ.get('GGAN_FORCE_ALLREDUCE') and dist.is_available() and dist.is_initialized()):
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            return work if async_op else None
+        return None
 
 
 class AdamOptimizer(object):
@@ -92,9 +97,9 @@ class AdamOptimizer(object):
         F.pack_(gs, self.slots, self.g, bump=self.step)     # also advances the step counter (read by update())
         return gs  # keep alive until the kernel ran (stream-ordered)
 
-    def all_reduce(self):
+    def all_reduce(self, async_op=False):
         """Sum the flat gradient bucket over the data-parallel replicas (RCCL over xGMI)."""
-        self.bucket.all_reduce()
+        return self.bucket.all_reduce(async_op)
 
     def update(self):
         F.adam_step_(self.theta, self.g, self.m, self.v, self.step, self.lr, self.beta1, self.beta2, self.eps,
