@@ -232,10 +232,14 @@ class ConvFwd(Function):
     """y = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) + bias  (tf.nn.conv2d + bias_add; also the Deconv2D data-gradient)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, geom, act, alpha):
+    def forward(ctx, x, w, bias, geom, act, alpha, grad_rows=None):
+        """grad_rows (optional): only images [0, grad_rows) of x need a gradient (the rest of the batch is data); a plain
+        backward pass with frozen weights then runs the data-gradient on that sub-batch and leaves the other rows of
+        the returned gradient unwritten -- the caller promises nothing reads them."""
         x, w = _c(x), _c(w)
         N, Ci, H, W, Co, Ho, Wo = geom[:7]
         assert tuple(x.shape) == (N, Ci, H, W) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (x.shape, w.shape, geom)
+        ctx.grad_rows = int(grad_rows) if grad_rows else None
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         ws = workspace(x.device)
         g = _geom(geom)
@@ -253,7 +257,7 @@ class ConvFwd(Function):
             # gradient comes out of the filter-gradient kernel (no act_bwd / chansum passes, no intermediate tensor)
             r = _fused_conv_backward(ctx, gy, x, w, y)
             if r is not None:
-                return r
+                return r + (None,)
         if ctx.act != ACT_NONE:
             gy = ActBwd.apply(gy, y, ctx.act, ctx.alpha)       # lrelu/relu: sign(y) == sign(pre-activation)
         gx = gw = gb = None
@@ -267,7 +271,7 @@ class ConvFwd(Function):
         if ctx.needs_input_grad[0]:
             gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
         fork.join(gw, gb, x, gy)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def _fused_conv_backward(ctx, gy, x, w, y):
@@ -301,6 +305,8 @@ def _fused_conv_backward(ctx, gy, x, w, y):
             gw = None
     if ctx.needs_input_grad[0]:
         gx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gy.device)
+        if ctx.grad_rows and ctx.grad_rows < N and gw is None and gb is None:
+            g = _geom((ctx.grad_rows,) + tuple(geom[1:]))      # leading images only (contiguous NCHW prefix of gy, y, gx)
         check(L.ggan_conv2d_bwd_data_act(C.byref(g), _p(gy), yref, act, ctx.alpha, _p(w), _p(gx), _p(ws), ws.numel(), _stream()),
               'ggan_conv2d_bwd_data_act')
     return gx, gw, gb, None, None, None

@@ -55,10 +55,10 @@ class GraphicalGAN(object):
         self.cfg = cfg
 
     # ---- small helpers: an op followed by its pointwise, fused or not -------------------------------------
-    def _conv(self, name, cin, cout, x, act):
+    def _conv(self, name, cin, cout, x, act, grad_rows=None):
         if self.cfg.fuse:
-            return lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, activation=act)
-        return F.ActFwd.apply(lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2), act, 0.2)
+            return lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, activation=act, grad_rows=grad_rows)
+        return F.ActFwd.apply(lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, grad_rows=grad_rows), act, 0.2)
 
     def _lin(self, name, nin, nout, x, act):
         if self.cfg.fuse:
@@ -118,13 +118,14 @@ class GraphicalGAN(object):
         out = out.reshape(-1, c.flat)
         return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out)
 
-    def Discriminator(self, x, z):
+    def Discriminator(self, x, z, grad_rows=None):
+        """grad_rows: only the first grad_rows images of x carry a gradient (generator steps: [fake; real])"""
         c = self.cfg
         out = x.reshape(-1, c.C, c.S, c.S)
         ch = c.C
         for i in range(c.nl):
             cout = c.dim * 2 ** i
-            out = self._conv('Discriminator.%d' % (i + 1), ch, cout, out, LRELU)   # dropout == identity
+            out = self._conv('Discriminator.%d' % (i + 1), ch, cout, out, LRELU, grad_rows)   # dropout == identity
             ch = cout
         out = out.reshape(-1, c.flat)
         z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
@@ -201,10 +202,11 @@ class GraphicalGAN(object):
             onehot, q_k = feed['k_onehot'], out['q_k']
         J = lib.objs.gan_inference
         J.ONLY[0] = which            # TF prunes the cost a session.run does not fetch; so do we
-        batched = c.batch_critic and which == 'disc'
+        batched = c.batch_critic and which in ('gen', 'disc')
         # a generator step owns only Generator/Extractor variables: hand the critic its weights without gradient edges
         with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
-            d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None)
+            d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None,
+                                          detach=which == 'disc')
         gen_params, disc_params = self._var_lists()
         if c.K:
             res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
@@ -223,28 +225,25 @@ class GraphicalGAN(object):
                    gen_train_op=res[2], disc_train_op=res[3])
         return out
 
-    def _critic(self, batched, real_x, q_z, p_z, fake_x, onehot, q_k):
-        """critic logits of the fake and the real pair; critic steps evaluate the critic ONCE on [fake; real]"""
+    def _critic(self, batched, real_x, q_z, p_z, fake_x, onehot, q_k, detach=True):
+        """critic logits of the fake and the real pair.  batched: the critic is evaluated ONCE on [fake; real] (its rows
+        are independent: no BatchNorm in the critics).  detach=True (critic steps): no gradient w.r.t. the
+        generator/extractor outputs (TF prunes those paths too); detach=False (generator steps): gradients flow to fake_x,
+        p_z, q_z, q_k, and the conv stack's data-gradient is needed for the fake half only (grad_rows)."""
         c = self.cfg
-        if batched:
-            # the critic step needs no gradient w.r.t. the generator/extractor outputs (TF prunes those paths too)
-            fx, pz, qz = fake_x.detach(), p_z.detach(), q_z.detach()
-            B = fx.shape[0]
-            x_cat, z_cat = torch.cat([fx, real_x], 0), torch.cat([pz, qz], 0)
+        if not batched:
+            if c.K:
+                return ([self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)],
+                        [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)])
+            return self.Discriminator(fake_x, p_z), self.Discriminator(real_x, q_z)
+        if detach:
+            fake_x, p_z, q_z = fake_x.detach(), p_z.detach(), q_z.detach()
+            q_k = q_k.detach() if c.K else None
+        B = fake_x.shape[0]
+        x_cat, z_cat = torch.cat([fake_x, real_x], 0), torch.cat([p_z, q_z], 0)
+        d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B)
         if c.K:
-            if batched:
-                h = self.HyperDiscriminator(z_cat, torch.cat([onehot, q_k.detach()], 0))
-                d = self.Discriminator(x_cat, z_cat)
-                (hf, hr), (df, dr) = F.SplitRows.apply(h, B), F.SplitRows.apply(d, B)
-                d_fake, d_real = [hf, df], [hr, dr]
-            else:
-                d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake_x, p_z)]
-                d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real_x, q_z)]
-        else:
-            if batched:
-                d = self.Discriminator(x_cat, z_cat)
-                d_fake, d_real = F.SplitRows.apply(d, B)
-            else:
-                d_fake = self.Discriminator(fake_x, p_z)
-                d_real = self.Discriminator(real_x, q_z)
-        return d_fake, d_real
+            h = self.HyperDiscriminator(z_cat, torch.cat([onehot, q_k], 0))
+            (hf, hr), (df, dr) = F.SplitRows.apply(h, B), F.SplitRows.apply(d, B)
+            return [hf, df], [hr, dr]
+        return F.SplitRows.apply(d, B)

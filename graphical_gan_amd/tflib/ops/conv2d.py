@@ -45,9 +45,10 @@ def _mask(mask_type, filter_size, input_dim, output_dim):
 
 
 def Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, mask_type=None, stride=1, weightnorm=None,
-           biases=True, gain=1., padding='SAME', activation=None, alpha=0.2):
+           biases=True, gain=1., padding='SAME', activation=None, alpha=0.2, grad_rows=None):
     """inputs: (batch, channels, height, width) -> (batch, output_dim, ceil(h/stride), ceil(w/stride)).
-    `activation`/`alpha` are an optional fused epilogue (extension; default = reference behaviour)."""
+    `activation`/`alpha` are an optional fused epilogue and `grad_rows` an optional backward pruning hint (see
+    functional.ConvFwd) -- extensions; the defaults give the reference behaviour."""
     fan_in = input_dim * filter_size ** 2
     fan_out = output_dim * filter_size ** 2 / (stride ** 2)
     if mask_type is not None:
@@ -73,4 +74,4 @@ def Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, mask_
     assert C == input_dim, (name, inputs.shape, input_dim)
     geom = F.conv_geom(N, input_dim, H, W, output_dim, filter_size, stride, padding)
     act = F.ACT_NONE if activation is None else activation
-    return F.ConvFwd.apply(inputs, filters, b, geom, act, float(alpha))
+    return F.ConvFwd.apply(inputs, filters, b, geom, act, float(alpha), grad_rows)
