@@ -453,6 +453,7 @@ __global__ void splitk_reduce_k(const float* __restrict__ partial, int SK, size_
 // Many slabs, few outputs (filter gradients of the 3-channel layers: 64 slabs x 4.8 K floats): 64 outputs per block,
 // the slabs dealt to 4 thread groups, combined through LDS in group order (deterministic).
 __global__ void splitk_reduce_small_k(const float* __restrict__ partial, int SK, size_t elems, size_t stride, float* __restrict__ out,
+                                      const float* __restrict__ bias, int C, int HW, int act, float alpha,
                                       float* __restrict__ out2, size_t n2) {
     __shared__ float sm[4][64];
     const int o = threadIdx.x & 63, kg = threadIdx.x >> 6;
@@ -463,8 +464,13 @@ __global__ void splitk_reduce_small_k(const float* __restrict__ partial, int SK,
     sm[kg][o] = s;
     __syncthreads();
     if (kg == 0 && i < elems + n2) {
-        const float v = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
-        if (i < elems) out[i] = v; else out2[i - elems] = v;
+        float v = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+        if (i < elems) {
+            if (bias) v += bias[(i / (size_t)HW) % (size_t)C];
+            out[i] = act_apply(v, act, alpha);
+        } else {
+            out2[i - elems] = v;
+        }
     }
 }
 
@@ -621,9 +627,10 @@ int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out,
                          float alpha, hipStream_t s, size_t slab_stride, float* tail_out, size_t tail) {
     if (slab_stride == 0) slab_stride = elems;
     if (!tail_out) tail = 0;
-    if (!bias && act == GGAN_ACT_NONE && SK >= 8 && elems + tail <= 65536) {
+    if (SK >= 8 && elems + tail <= 65536) {
         GGAN_LAUNCH("splitk_reduce_small_k", 0, 4.0 * (elems + tail) * (SK + 1), splitk_reduce_small_k,
-                    dim3((int)((elems + tail + 63) / 64)), dim3(256), 0, s, partial, SK, elems, slab_stride, out, tail_out, tail);
+                    dim3((int)((elems + tail + 63) / 64)), dim3(256), 0, s, partial, SK, elems, slab_stride, out, bias, C, HW, act,
+                    alpha, tail_out, tail);
         return 0;
     }
     size_t b = (elems + tail + 255) / 256;

@@ -15,6 +15,8 @@ using namespace ggan;
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = 68;   // LDP: padded tile row (floats)
+constexpr int KSTEP = 32;        // k per main-loop step
+constexpr int LDPK = 66;         // tile row for k-contiguous operands (scalar scatter: 2 (mod 8) keeps it conflict free)
 
 struct GemmParams {
     const float* A;
@@ -89,6 +91,55 @@ __device__ __forceinline__ float4 apply_mask(const float4& g, const float4& r, i
                        act_grad(g.w, r.w, act, alpha));
 }
 
+// ---- one main-loop step (KSTEP = 32 k) of an operand: [64 rows x 32 k] -> LDS T[k][r] ------------------------------------
+// k-contiguous operands are read as 128-byte runs: 8 lanes x float4 cover 32 consecutive k of one row (the 64 rows of the
+// earlier row-per-lane mapping touched 64 different cache lines per wave-load, 16 useful bytes each).
+template <bool KCONTIG>
+__device__ __forceinline__ void load_step_tile(const float* __restrict__ base, int ld, int R, int r0, int k0, int kend,
+                                               int vec, float4 (&reg)[2]) {
+    const int tid = threadIdx.x;
+    if (KCONTIG) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int unit = tid + 256 * u, row = r0 + (unit >> 3), k = k0 + (unit & 7) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < R) {
+                const float* p = base + (size_t)row * ld + k;
+                if (vec && k + 3 < kend) {
+                    const float4 t = *reinterpret_cast<const float4*>(p);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < kend) v[j] = p[j];
+                }
+            }
+            reg[u] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) load_tile<false>(base, ld, R, r0, k0 + u * BK, kend, vec, reg[u]);
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_step_tile(float* T, const float4 (&reg)[2]) {
+    const int tid = threadIdx.x;
+    if (KCONTIG) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int unit = tid + 256 * u, row = unit >> 3, kq = unit & 7;
+            float* d = T + (kq * 4) * LDPK + row;
+            d[0] = reg[u].x; d[LDPK] = reg[u].y; d[2 * LDPK] = reg[u].z; d[3 * LDPK] = reg[u].w;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kk = tid >> 4, r = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(T + (u * BK + kk) * LDP + r) = reg[u];
+        }
+    }
+}
+
 template <bool KCONTIG>
 __device__ __forceinline__ void store_tile(float* T, const float4& reg) {
     const int tid = threadIdx.x;
@@ -109,8 +160,13 @@ __device__ __forceinline__ void store_tile(float* T, const float4& reg) {
 // MASK: 0 none, 1 activation-derivative mask on A, 2 on B
 template <bool TA, bool TB, int MASK = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
-    __shared__ __attribute__((aligned(16))) float As[BK * LDP];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDP];
+    // LDS double-buffered so a step costs ONE barrier: the next step's global loads are issued before the MFMA block, parked in
+    // registers, and committed to the other buffer after it
+    constexpr bool AK = !TA, BKc = TB;                     // operand is k-contiguous in memory
+    constexpr int LA = AK ? LDPK : LDP, LB = BKc ? LDPK : LDP;
+    constexpr int TSZ = KSTEP * LDP;                       // (sized for the wider row)
+    __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1, half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
@@ -121,42 +177,81 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool do_colsum = P.colsum != nullptr && blockIdx.y == 0 && tid < BN;   // rows beyond K are zero in the tile
     float csum = 0.f;
-    float4 ra, rb, rma, rmb;
-    load_tile_m<!TA, MASK == 1>(P.A, P.a_ref, P.lda, P.M, m0, kb, ke, P.vecA, ra, rma);
-    load_tile_m<TB, MASK == 2>(P.B, P.b_ref, P.ldb, P.N, n0, kb, ke, P.vecB, rb, rmb);
-    for (int k0 = kb; k0 < ke; k0 += BK) {
-        __syncthreads();
-        store_tile<!TA>(As, apply_mask<MASK == 1>(ra, rma, P.ref_act, P.ref_alpha));
-        store_tile<TB>(Bs, apply_mask<MASK == 2>(rb, rmb, P.ref_act, P.ref_alpha));
-        __syncthreads();
-        if (k0 + BK < ke) {   // register prefetch of the next tile under this tile's MFMA block
-            load_tile_m<!TA, MASK == 1>(P.A, P.a_ref, P.lda, P.M, m0, k0 + BK, ke, P.vecA, ra, rma);
-            load_tile_m<TB, MASK == 2>(P.B, P.b_ref, P.ldb, P.N, n0, k0 + BK, ke, P.vecB, rb, rmb);
+    float4 ra[2], rb[2], rma[2], rmb[2];
+    auto load_step = [&](int k0) {
+        load_step_tile<AK>(P.A, P.lda, P.M, m0, k0, ke, P.vecA, ra);
+        if (MASK == 1) load_step_tile<AK>(P.a_ref, P.lda, P.M, m0, k0, ke, P.vecA, rma);
+        load_step_tile<BKc>(P.B, P.ldb, P.N, n0, k0, ke, P.vecB, rb);
+        if (MASK == 2) load_step_tile<BKc>(P.b_ref, P.ldb, P.N, n0, k0, ke, P.vecB, rmb);
+    };
+    auto store_step = [&](int buf) {
+        if (MASK == 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ra[u] = apply_mask<true>(ra[u], rma[u], P.ref_act, P.ref_alpha);
         }
+        if (MASK == 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) rb[u] = apply_mask<true>(rb[u], rmb[u], P.ref_act, P.ref_alpha);
+        }
+        store_step_tile<AK>(As + buf * TSZ, ra);
+        store_step_tile<BKc>(Bs + buf * TSZ, rb);
+    };
+    load_step(kb);
+    store_step(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += KSTEP, buf ^= 1) {
+        const bool more = k0 + KSTEP < ke;
+        if (more) load_step(k0 + KSTEP);
+        const float* Ab = As + buf * TSZ;
+        const float* Bb = Bs + buf * TSZ;
         if (do_colsum) {
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) csum += Bs[kk * LDP + tid];
+            for (int kk = 0; kk < KSTEP; ++kk) csum += Bb[kk * LB + tid];
         }
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[(kk + half) * LDP + wm * 32 + l31];
-            const float b = Bs[(kk + half) * LDP + wn * 32 + l31];
+        for (int kk = 0; kk < KSTEP; kk += 2) {
+            const float a = Ab[(kk + half) * LA + wm * 32 + l31];
+            const float b = Bb[(kk + half) * LB + wn * 32 + l31];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
     }
     if (do_colsum && n0 + tid < P.N) P.colsum[n0 + tid] = csum;
-    const int n = n0 + wn * 32 + l31;
-    if (n >= P.N) return;
-    const bool direct = P.SK == 1;
-    float* Cp = direct ? P.C : P.C + (size_t)split * P.out_elems;
-    const float bv = (direct && P.bias) ? P.bias[n] : 0.f;
+    // epilogue: global stores are issue-bound (16 dword stores per lane took longer than the k-loop of the short-K layers), so
+    // the tile goes through LDS and leaves as one float4 row segment per thread and pass (4 passes)
+    constexpr int LC = BN + 4;
+    float* Cs = As;                                   // 64 x 68 floats <= 2 * TSZ (all waves are past the last barrier)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < P.M) {
-            float v = acc[r];
-            if (direct) v = act_apply(v + bv, P.act, P.alpha);
-            Cp[(size_t)m * P.N + n] = v;
+        const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        Cs[ml * LC + wn * 32 + l31] = acc[r];
+    }
+    __syncthreads();
+    const bool direct = P.SK == 1;
+    float* Cp = direct ? P.C : P.C + (size_t)split * P.out_elems;
+    const bool vec_out = (P.N & 3) == 0 && ((uintptr_t)Cp & 15) == 0;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int idx = tid + pass * 256, ml = idx >> 4, c4 = (idx & 15) * 4;
+        const int m = m0 + ml, n = n0 + c4;
+        if (m >= P.M || n >= P.N) continue;
+        float4 v = *reinterpret_cast<const float4*>(Cs + ml * LC + c4);
+        float* vv = reinterpret_cast<float*>(&v);
+        if (direct) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float bv = (P.bias && n + q < P.N) ? P.bias[n + q] : 0.f;
+                vv[q] = act_apply(vv[q] + bv, P.act, P.alpha);
+            }
+        }
+        float* dst = Cp + (size_t)m * P.N + n;
+        if (vec_out && n + 3 < P.N) {
+            *reinterpret_cast<float4*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n + q < P.N) dst[q] = vv[q];
         }
     }
 }
