@@ -131,7 +131,8 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     static_assert(CK % 4 == 0, "chunk must hold whole float4 groups");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = (wave / WM) % WN, ks = wave / (WM * WN);
-    const bool stamping = (P.dbg & 4) && P.stamps && tid == 0;
+    const bool stamping = (P.dbg & 4) && P.stamps && tid == ((P.dbg & 64) ? NTHR / 2 : 0);   // dbg 64: a second-half wave
+    const bool fine = (P.dbg & 128) != 0;   // dbg 128: stamps 4.. = phase boundaries inside the first chunks instead of chunk ends
     const int wg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     auto stamp = [&](int i) { if (stamping) P.stamps[(size_t)wg_lin * 16 + i] = __builtin_readcyclecounter(); };
     stamp(0);
@@ -150,12 +151,16 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     const int HWin = P.Hin * P.Win;
 
     // two staging buffers: [CK][CS] slab + [NTT][CK][TNW] filter slice each
-    const int XS_SZ = (CK * P.CS + 3) & ~3;
-    const int STAGE = XS_SZ + ((NTT * CK * RS + 3) & ~3);
+    // (+1 / +4 rows: trash slots that absorb the commit of staging elements beyond the tile, so commits are branch-free)
+    const int XS_SZ = (CK * P.CS + 1 + 3) & ~3;
+    constexpr int WS_USED = NTT * CK * RS;
+    const int STAGE = XS_SZ + ((WS_USED + 4 * RS + 3) & ~3);
 
     const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, (short)0, (int)P.in_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)P.w_bytes, 0x00020000);
-    const bool masked = P.in_ref != nullptr;
+    constexpr bool CAN_MASK = KIND != 0;              // only the data-gradient kinds consume gy * act'(y)
+    const bool masked = CAN_MASK && P.in_ref != nullptr;
+    const float mslope = P.in_act == GGAN_ACT_LRELU ? P.in_alpha : 0.f;   // lrelu / relu only (launcher checks)
     const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(masked ? P.in_ref : P.in), (short)0, (int)P.in_bytes, 0x00020000);
 
     // ---- per-thread staging descriptors (fixed across chunks) ---------------------------------------------
@@ -233,46 +238,50 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     unsigned xreg[XE], xref[XE];
+#pragma unroll
+    for (int j = 0; j < XE; ++j) xref[j] = 0x3f800000u;      // 1.0f: "positive" reference = identity mask when unmasked
     u32x4 wreg[WE];
 
     auto prefetch = [&](int ck0) {
         const int soff_x = ck0 * HWin * 4;
         const int soff_w = ck0 * P.w_sk * 4;
+        if (!(P.dbg & 512)) {
 #pragma unroll
         for (int j = 0; j < XE; ++j) xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, xvo[j], soff_x, 0);
+        }
         if (masked) {
 #pragma unroll
             for (int j = 0; j < XE; ++j) xref[j] = __builtin_amdgcn_raw_buffer_load_b32(rref, xvo[j], soff_x, 0);
         }
+        if (!(P.dbg & 256)) {
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
             const unsigned vo = (ck0 + w_ck(tid + q * NTHR) < ck_end) ? wvo[q] : OOB;     // reduction-channel tail -> zero filter rows
             wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, vo, soff_w, 0);
+        }
         }
     };
 
     auto commit = [&](int buf) {
         float* xsb = smem + buf * STAGE;
         float* wsb = xsb + XS_SZ;
+        // straight-line: elements beyond the tile (their loads returned 0) land in a trash slot instead of being predicated
 #pragma unroll
         for (int j = 0; j < XE; ++j) {
             const int e = tid + j * NTHR;
-            if (e < xe_cnt) {
-                float v = __uint_as_float(xreg[j]);
-                if (masked) v = act_grad(v, __uint_as_float(xref[j]), P.in_act, P.in_alpha);
-                xsb[e] = v;
-            }
+            float v = __uint_as_float(xreg[j]);
+            if (CAN_MASK) v = __uint_as_float(xref[j]) > 0.f ? v : v * mslope;
+            xsb[min(e, xe_cnt)] = v;
         }
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
             const int u = tid + q * NTHR;
-            if (u < WUNITS) {
-                if (WK) {
-                    unsigned* d = reinterpret_cast<unsigned*>(wsb + w_lds(u));
-                    d[0] = wreg[q][0]; d[RS] = wreg[q][1]; d[2 * RS] = wreg[q][2]; d[3 * RS] = wreg[q][3];
-                } else {
-                    *reinterpret_cast<u32x4*>(wsb + w_lds(u)) = wreg[q];
-                }
+            const int li = (q < WE - 1 || u < WUNITS) ? w_lds(u) : WS_USED;
+            if (WK) {
+                unsigned* d = reinterpret_cast<unsigned*>(wsb + li);
+                d[0] = wreg[q][0]; d[RS] = wreg[q][1]; d[2 * RS] = wreg[q][2]; d[3 * RS] = wreg[q][3];
+            } else {
+                *reinterpret_cast<u32x4*>(wsb + li) = wreg[q];
             }
         }
     };
@@ -302,6 +311,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     };
     for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
         if (stage_first) stage_next(ck0);
+        if (fine && it_ < 4) stamp(4 + 2 * it_);
         if (!(P.dbg & 2)) {
             const float* xs = smem + ((P.dbg & 1) ? 0 : buf * STAGE);
             const float* ws = xs + XS_SZ;
@@ -310,9 +320,11 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
             if constexpr (NC > 2) mma_taps<CL::th(2), CL::tw(2), DI, PW, CK, RS>(xs, ws + (NT0 + NT1) * CK * RS, xfrag[2], wfrag, P.CS, P.SCp, acc[2]);
             if constexpr (NC > 3) mma_taps<CL::th(3), CL::tw(3), DI, PW, CK, RS>(xs, ws + (NT0 + NT1 + NT2) * CK * RS, xfrag[3], wfrag, P.CS, P.SCp, acc[3]);
         }
+        if (fine && it_ < 4 && stage_first) stamp(5 + 2 * it_);
         if (!stage_first) stage_next(ck0);
+        if (fine && it_ < 4 && !stage_first) stamp(5 + 2 * it_);
         __syncthreads();
-        if (it_ < 8) stamp(4 + it_);
+        if (!fine && it_ < 8) stamp(4 + it_);
         ++it_;
     }
     stamp(12);
@@ -609,7 +621,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     P.dbg = env_int("GGAN_DBG", 0);
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     const int RS = TNW + (MODE != 0 ? 2 : 0);     // filter row stride in LDS (corr_body: padded for the k-contiguous staging)
-    size_t stage = 2 * ((size_t)((CK * P.CS + 3) & ~3) + (size_t)((ntaps * CK * RS + 3) & ~3));
+    size_t stage = 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
@@ -688,6 +700,7 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     CorrParams P;
     memset(&P, 0, sizeof(P));
     P.in = gy; P.w = w;
+    if (m.act != GGAN_ACT_NONE && m.act != GGAN_ACT_LRELU && m.act != GGAN_ACT_RELU) return 1;   // other masks: plain kernels
     if (m.act != GGAN_ACT_NONE) { P.in_ref = m.ref; P.in_act = m.act; P.in_alpha = m.alpha; }
     P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
     P.N = g.N; P.CKtot = g.Co; P.Hin = g.Ho; P.Win = g.Wo;

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, (int)P.x_bytes, 0x00020000);
     const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)P.gy, (short)0, (int)P.gy_bytes, 0x00020000);
     const bool masked = P.gy_ref != nullptr;
+    const float mslope = P.gy_act == GGAN_ACT_LRELU ? P.gy_alpha : 0.f;
     const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)(masked ? P.gy_ref : P.gy), (short)0, (int)P.gy_bytes, 0x00020000);
     const bool do_bias = P.gbias != nullptr && blockIdx.x == 0;
     float bsum = 0.f;
@@ -143,11 +144,11 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
         }
         if (gcol < TCO) {
             float4 gv = make_float4(__uint_as_float(greg.x), __uint_as_float(greg.y), __uint_as_float(greg.z), __uint_as_float(greg.w));
-            if (masked) {
-                gv.x = act_grad(gv.x, __uint_as_float(gref.x), P.gy_act, P.gy_alpha);
-                gv.y = act_grad(gv.y, __uint_as_float(gref.y), P.gy_act, P.gy_alpha);
-                gv.z = act_grad(gv.z, __uint_as_float(gref.z), P.gy_act, P.gy_alpha);
-                gv.w = act_grad(gv.w, __uint_as_float(gref.w), P.gy_act, P.gy_alpha);
+            if (masked) {       // lrelu / relu derivative (launcher admits no other mask): a select, no per-element branches
+                gv.x = __uint_as_float(gref.x) > 0.f ? gv.x : gv.x * mslope;
+                gv.y = __uint_as_float(gref.y) > 0.f ? gv.y : gv.y * mslope;
+                gv.z = __uint_as_float(gref.z) > 0.f ? gv.z : gv.z * mslope;
+                gv.w = __uint_as_float(gref.w) > 0.f ? gv.w : gv.w * mslope;
             }
             *reinterpret_cast<float4*>(gs + gcol * P.PCp + gp4 * 4) = gv;
             // bias gradient: this thread's 4 pixels; the PC/4 threads of a channel are contiguous lanes (power of two <= 16)
@@ -286,6 +287,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     WgradParams P;
     memset(&P, 0, sizeof(P));
     P.x = x; P.gy = gy;
+    if (m.act != GGAN_ACT_NONE && m.act != GGAN_ACT_LRELU && m.act != GGAN_ACT_RELU) return 1;   // other masks: plain path
     if (m.act != GGAN_ACT_NONE) { P.gy_ref = m.ref; P.gy_act = m.act; P.gy_alpha = m.alpha; }
     P.gbias = gbias;
     P.dbg_nostore = env_int("GGAN_DBG", 0) & 8;

@@ -1,6 +1,6 @@
 """Per-workgroup timeline of the corr kernel (GGAN_DBG=4): prints median cycle deltas between stamps."""
 import os, sys
-os.environ['GGAN_DBG'] = '4'
+os.environ['GGAN_DBG'] = os.environ.get('GGAN_DBG', '4')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from graphical_gan_amd import functional as F, _lib
