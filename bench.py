@@ -56,6 +56,30 @@ def algorithmic_gflop_per_iteration(cfg):
     return total / 1e9
 
 
+def ssgan_gflop_per_iteration(cfg):
+    """ssgan_inference_moving_mnist.py (MODE local_ep, mean-field posterior): GEMM-like layers, forward + exactly the
+    gradients each step needs (critic frozen in the generator step; no data-gradient into input frames)."""
+    B, L, d = cfg.B, cfg.LEN, cfg.dim
+    F = B * L
+    chans, sizes = [1, d, 2 * d, 4 * d, 8 * d], [32, 16, 8, 4]
+    conv = [2.0 * chans[i + 1] * sizes[i] ** 2 * chans[i] * 25 for i in range(4)]             # per image
+    convG1 = 2.0 * d * 32 ** 2 * L * 25                                                        # G_Extractor layer 1 (LEN channels)
+    lin = lambda n, i, o: 2.0 * n * i * o
+    zin = cfg.dim_g + cfg.dim_l + cfg.n_c
+    fE = F * sum(conv) + lin(F, cfg.flat + cfg.n_c, cfg.dim_l)
+    fEG = B * (convG1 + sum(conv[1:])) + lin(B, cfg.flat + cfg.n_c, cfg.dim_g)
+    fG = F * sum(conv) + lin(F, zin, cfg.flat)                                                 # the frame generator mirrors the extractor
+    fDc = F * sum(conv)
+    fDl = lin(F, zin, 512) + lin(F, cfg.flat + 512 + cfg.n_c, 512) + lin(F, 512, 1)
+    mlp = lambda n, i: lin(n, i, 512) + 2 * lin(n, 512, 512) + lin(n, 512, 1)
+    fDs = mlp((L - 1) * B, 2 * cfg.dim_l) + mlp(B, cfg.dim_g)
+    fdyn = (L - 1) * (lin(B, cfg.dim_l + cfg.dim_t, cfg.dim_op) + lin(B, cfg.dim_op, cfg.dim_op) + lin(B, cfg.dim_op, cfg.dim_l))
+    fwd = fE + fEG + fG + fdyn + 2 * (fDc + fDl + fDs)
+    gen_bwd = (2 * fE - F * conv[0]) + (2 * fEG - B * convG1) + 2 * fG + 2 * fdyn + fDc + 2 * fDl + 2 * fDs
+    disc_bwd = 2 * (2 * (fDc + fDl + fDs) - F * conv[0])
+    return ((fwd + gen_bwd) + cfg.critic_iters * (fwd + disc_bwd)) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -63,7 +87,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--dataset', default='cifar10')
     ap.add_argument('--mode', default='ali', help="ali | wali-gp | local_ep (gmgan, N_COMS=30)")
-    ap.add_argument('--batch-size', type=int, default=64)
+    ap.add_argument('--batch-size', type=int, default=None, help='per-GPU minibatch (default 64; 32 sequences for moving_mnist)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-fuse', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -94,12 +118,23 @@ def main():
     from graphical_gan_amd.engine import Trainer, synthetic_ring, broadcast_params
     from graphical_gan_amd.models import Config
 
-    K = 30 if args.mode == 'local_ep' else 0
-    cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse)
+    ssgan = args.dataset == 'moving_mnist'
+    if args.batch_size is None:
+        args.batch_size = 32 if ssgan else 64
     np.random.seed(0)                                  # reference initialisers draw from numpy's global RNG
-    tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
+    if ssgan:                                          # BASELINE configs[4]: ssgan_inference_moving_mnist.py, T=16
+        from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
+        K = 0
+        args.mode = 'local_ep'
+        cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse)
+        model = StateSpaceGAN(cfg)
+        tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank, model=model)
+    else:
+        K = 30 if args.mode == 'local_ep' else 0
+        cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse)
+        tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
     torch.manual_seed(1234 + rank)
-    ring = synthetic_ring(cfg, dev, n=8, seed=1234 + rank)
+    ring = tr.model.synthetic_ring(dev, n=4 if ssgan else 8, seed=1234 + rank)
 
     def batches():
         i = 0
@@ -137,7 +172,7 @@ def main():
 
     ms_per_step = 1e3 * dt / args.steps
     images_per_s = cfg.B * world * args.steps / dt
-    gflop_it = algorithmic_gflop_per_iteration(cfg)
+    gflop_it = ssgan_gflop_per_iteration(cfg) if ssgan else algorithmic_gflop_per_iteration(cfg)
     step_tflops = gflop_it * args.steps / dt / 1e3      # per GPU
 
     # ---- per-kernel timing of the same step with HIP events (eager, on the launch stream) ---------------------
@@ -189,7 +224,20 @@ def main():
 
     # ---- CPU baseline: the numpy oracle (a port; the reference is Python2+TF1 and cannot run) ------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and ssgan:
+        from oracle import ssgan as OSS
+        ob = 2                                         # bounded sample: 2 sequences per minibatch instead of cfg.B
+        ocfg = OSS.Cfg(batch_size=ob)
+        otr = OSS.Trainer(ocfg, OSS.init_params(ocfg, 0), np.float32)
+        feeds = iter([OSS.make_feed(ocfg, np.random.default_rng(i)) for i in range(8)])
+        otr.iteration(1, feeds)
+        t1 = time.perf_counter()
+        otr.iteration(2, feeds)
+        cdt = time.perf_counter() - t1
+        cpu = dict(value=round(ob / cdt, 3), unit='sequences/sec', cores=os.cpu_count(), kind='port',
+                   sample='1 iteration (gen step + critic step) at %d sequences x 16 frames per minibatch, numpy fp32 '
+                   'oracle with multi-threaded BLAS' % ob)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import nets as ON, step as OS
         ocfg = ON.Cfg(args.dataset, batch_size=cfg.B, n_coms=K)
         otr = OS.Trainer(ocfg, ON.init_params(ocfg, 0), 'wali-gp' if args.mode == 'wali-gp' else 'ali', np.float32)
@@ -205,16 +253,20 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'images/sec (G+D%s step) %s %dx%d bs=%d' % ('+GP' if args.mode == 'wali-gp' else '', args.dataset, cfg.S, cfg.S, cfg.B),
-            'value': round(images_per_s, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'metric': ('sequences/sec (G+D step) moving_mnist T=%d 64x64 bs=%d' % (cfg.LEN, cfg.B)) if ssgan else
+                      'images/sec (G+D%s step) %s %dx%d bs=%d' % ('+GP' if args.mode == 'wali-gp' else '', args.dataset, cfg.S, cfg.S, cfg.B),
+            'value': round(images_per_s, 1), 'unit': 'sequences/sec' if ssgan else 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
+            'config': {'workload': ('ssgan_inference_moving_mnist.py MODE=local_ep POS_MODE=%s LEN=%d BATCH_SIZE=%d sequences '
+                                    '(per GPU) of 64x64x1 frames%s' % (cfg.pos_mode, cfg.LEN, cfg.B, ', eager' if args.no_graph else ''))
+                       if ssgan else '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
                 'gmgan' if K else 'gan', args.dataset, args.mode, ' N_COMS=%d' % K if K else '', cfg.B, cfg.S, cfg.S, cfg.C,
                 cfg.critic_iters, '' if not args.no_graph else ', eager'),
                 'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world, 'hip_graph': not args.no_graph,
                 'fused_epilogues': not args.no_fuse, 'minibatches_per_step': 1 + cfg.critic_iters,
-                'algorithmic_gflop_per_step': round(gflop_it, 2), 'finite_costs': bool(finite)},
+                'algorithmic_gflop_per_step': round(gflop_it, 2), 'finite_costs': bool(finite),
+                **({'frames_per_sec': round(images_per_s * cfg.LEN, 1)} if ssgan else {})},
             'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
         }
         print(json.dumps(out))

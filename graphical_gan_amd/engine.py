@@ -22,31 +22,19 @@ from .models import GraphicalGAN
 
 
 class Trainer(object):
-    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False):
+    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None):
+        """model: an object with forward_nets / forward / feed_buffers / sample_noise / set_batch / single_contribution
+        (default: models.GraphicalGAN(cfg); models_ssgan.StateSpaceGAN for the state-space scripts)."""
         self.cfg = cfg
         self.device = torch.device(device) if device is not None else lib.get_device()
         lib.set_device(self.device)
-        self.model = GraphicalGAN(cfg)
+        self.model = model if model is not None else GraphicalGAN(cfg)
         self.graph_enabled = graph
         self.inject_noise = inject_noise
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
-        B, c = cfg.B, cfg
-        dev = self.device
         # static input buffers (what the reference feeds / samples per session.run)
-        self.feed = {}
-        if c.dataset == 'mnist':
-            self.feed['real_x'] = torch.zeros(B, c.output_dim, device=dev)
-        else:
-            self.feed['real_x_int'] = torch.zeros(B, c.output_dim, dtype=torch.int32, device=dev)
-        if c.dataset == 'face':
-            self.feed['dequant_u'] = torch.zeros(B, c.output_dim, device=dev)
-        self.feed['p_z_noise'] = torch.zeros(B, c.dim_latent, device=dev)
-        if c.K:
-            self.feed['k_onehot'] = torch.zeros(B, c.K, device=dev)
-            self.feed['gumbel_u'] = torch.zeros(B, c.K, device=dev)
-        if c.mode == 'wali-gp':
-            self.feed['alpha'] = torch.zeros(B, 1, device=dev)
+        self.feed = self.model.feed_buffers(self.device)
         self._graphs = {}
         self._calls = {'gen': 0, 'disc': 0}
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -55,7 +43,7 @@ class Trainer(object):
         self.split_graph = self.world > 1 or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
         # weight-gradient kernels on a second stream: needs one gradient contribution per parameter per backward pass
         # (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
-        self.single_contrib = bool(getattr(cfg, 'batch_critic', False)) and cfg.mode != 'wali-gp'
+        self.single_contrib = bool(self.model.single_contribution)
         self._opts = None
         self._pending = None         # (work handle, Adam graph) of a critic-step exchange still in flight (see step())
 
@@ -72,21 +60,10 @@ class Trainer(object):
                 self.feed[k].copy_(torch.as_tensor(np.asarray(v)))
 
     def set_batch(self, batch):
-        key = 'real_x' if self.cfg.dataset == 'mnist' else 'real_x_int'
-        self.feed[key].copy_(batch, non_blocking=True)
+        self.model.set_batch(self.feed, batch)
 
     def _sample_noise(self):
-        """Fresh noise for one session.run, drawn on device (graph-capturable)."""
-        c, f = self.cfg, self.feed
-        f['p_z_noise'].normal_()
-        if c.K:
-            idx = torch.randint(0, c.K, (c.B, 1), device=self.device)
-            f['k_onehot'].zero_().scatter_(1, idx, 1.0)
-            f['gumbel_u'].uniform_()
-        if c.mode == 'wali-gp':
-            f['alpha'].uniform_()
-        if c.dataset == 'face':
-            f['dequant_u'].uniform_(0., 1. / 128)
+        self.model.sample_noise(self.feed)
 
     # ---- one session.run ------------------------------------------------------------------------------
     def _nets(self):
@@ -239,14 +216,5 @@ def broadcast_params(src=0):
 
 
 def synthetic_ring(cfg, device, n=8, seed=1234):
-    """Device-resident ring of pre-staged synthetic minibatches: uniform integers 0..255
-    (int32, as the reference's placeholder) or U[0,1) floats for MNIST."""
-    rng = np.random.default_rng(seed)
-    ring = []
-    for _ in range(n):
-        if cfg.dataset == 'mnist':
-            b = torch.as_tensor(rng.random((cfg.B, cfg.output_dim), dtype=np.float32))
-        else:
-            b = torch.as_tensor(rng.integers(0, 256, size=(cfg.B, cfg.output_dim)).astype(np.int32))
-        ring.append(b.to(device))
-    return ring
+    """Device-resident ring of pre-staged synthetic minibatches for cfg's default model."""
+    return GraphicalGAN(cfg).synthetic_ring(device, n, seed)

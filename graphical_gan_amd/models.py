@@ -54,6 +54,57 @@ class GraphicalGAN(object):
     def __init__(self, cfg):
         self.cfg = cfg
 
+    # ---- engine hooks: the static inputs of one session.run (what the reference feeds / samples) -----------------
+    @property
+    def single_contribution(self):
+        """every parameter receives exactly one gradient contribution per backward pass (critic evaluated once on
+        [fake; real]; the wali-gp penalty re-enters the critic)"""
+        return bool(self.cfg.batch_critic) and self.cfg.mode != 'wali-gp'
+
+    def feed_buffers(self, device):
+        c, B, feed = self.cfg, self.cfg.B, {}
+        if c.dataset == 'mnist':
+            feed['real_x'] = torch.zeros(B, c.output_dim, device=device)
+        else:
+            feed['real_x_int'] = torch.zeros(B, c.output_dim, dtype=torch.int32, device=device)
+        if c.dataset == 'face':
+            feed['dequant_u'] = torch.zeros(B, c.output_dim, device=device)
+        feed['p_z_noise'] = torch.zeros(B, c.dim_latent, device=device)
+        if c.K:
+            feed['k_onehot'] = torch.zeros(B, c.K, device=device)
+            feed['gumbel_u'] = torch.zeros(B, c.K, device=device)
+        if c.mode == 'wali-gp':
+            feed['alpha'] = torch.zeros(B, 1, device=device)
+        return feed
+
+    def sample_noise(self, f):
+        """Fresh noise for one session.run, drawn on device (graph-capturable)."""
+        c = self.cfg
+        f['p_z_noise'].normal_()
+        if c.K:
+            idx = torch.randint(0, c.K, (c.B, 1), device=f['p_z_noise'].device)
+            f['k_onehot'].zero_().scatter_(1, idx, 1.0)
+            f['gumbel_u'].uniform_()
+        if c.mode == 'wali-gp':
+            f['alpha'].uniform_()
+        if c.dataset == 'face':
+            f['dequant_u'].uniform_(0., 1. / 128)
+
+    def set_batch(self, feed, batch):
+        feed['real_x' if self.cfg.dataset == 'mnist' else 'real_x_int'].copy_(batch, non_blocking=True)
+
+    def synthetic_ring(self, device, n=8, seed=1234):
+        """Device-resident ring of pre-staged synthetic minibatches: uniform integers 0..255 (int32, as the
+        reference's placeholder) or U[0,1) floats for MNIST."""
+        c, rng, ring = self.cfg, np.random.default_rng(seed), []
+        for _ in range(n):
+            if c.dataset == 'mnist':
+                b = torch.as_tensor(rng.random((c.B, c.output_dim), dtype=np.float32))
+            else:
+                b = torch.as_tensor(rng.integers(0, 256, size=(c.B, c.output_dim)).astype(np.int32))
+            ring.append(b.to(device))
+        return ring
+
     # ---- small helpers: an op followed by its pointwise, fused or not -------------------------------------
     def _conv(self, name, cin, cout, x, act, grad_rows=None):
         if self.cfg.fuse:

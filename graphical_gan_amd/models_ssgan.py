@@ -1,0 +1,242 @@
+"""State-space GAN on moving-MNIST sequences: the net + loss wiring of ssgan_inference_moving_mnist.py against this
+package's `tflib` (same layer names, so registry keys match the reference's checkpoints).
+
+  hyper-parameters   ssgan_inference_moving_mnist.py:27-56 (MODE='local_ep', POS_MODE, OP_DYN_MODE, BN flags off)
+  nets               :98-349      (ImplicitOperator, ConcatOperator, Dynamic{Generator,Extractor}, Generator, Extractor,
+                                   G_Extractor, Discriminator, DynamicDiscrminator, ZGDiscrminator)
+  losses             :510-547     weighted_local_epce over LEN+1 factors with ratio = [1]*(LEN-1)+[1,LEN] (:78-79)
+
+What is done differently from a literal transcription (same arithmetic):
+  * every frame net runs on all B*LEN frames at once (the reference does too) and the LEN-1 transition critics, which
+    share one set of weights, are evaluated in ONE call on the stacked pairs [(LEN-1)*B, 2*dim_l] instead of LEN-1 calls;
+    their equal-weight BCE terms collapse into one term (sum_i r*mean_B(.) == r*(LEN-1)*mean over the stack);
+  * generator steps hand the critics their weights without gradient edges (tflib.frozen), as TF's var_list does.
+"""
+import numpy as np
+import torch
+
+from . import functional as F
+from . import tflib as lib
+from .tflib.ops.act import LRELU, RELU, TANH
+
+
+class SSConfig(object):
+    dataset, K, mode = 'moving_mnist', 0, 'local_ep'
+
+    def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
+                 pos_mode='naive_mean_field', op_dyn_mode='res', lr=1e-4, fuse=True):
+        self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
+        self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
+        self.S, self.C, self.output_dim = 64, 1, 64 * 64
+        self.flat = 4 * 4 * 8 * dim
+        assert pos_mode in ('naive_mean_field', 'inverse', 'forward_inverse', 'gsp'), pos_mode
+        assert op_dyn_mode in ('res', 'res_w'), op_dyn_mode
+        self.pos_mode, self.op_dyn_mode = pos_mode, op_dyn_mode
+        self.lr, self.beta1 = lr, 0.5
+        self.critic_iters = 1
+        self.fuse = fuse
+
+    def ratio(self):
+        r = np.asarray([1.0] * (self.LEN - 1) + [1, self.LEN])
+        return r * 1.0 / (len(r) + self.LEN - 1)
+
+
+class StateSpaceGAN(object):
+    """forward_nets(feed) / forward(feed, which, nets): the interface engine.Trainer drives."""
+
+    single_contribution = False      # the frame critic is applied to the fake and the real sequence separately
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    # ---- engine hooks: static inputs of one session.run ---------------------------------------------------------------
+    def feed_buffers(self, device):
+        c = self.cfg
+        z = lambda *s: torch.zeros(*s, device=device)
+        return dict(real_x_unit=z(c.B, c.LEN, c.output_dim), real_y=z(c.B, c.n_c), p_z_l_0=z(c.B, c.dim_l),
+                    epsilon=z(c.B, c.dim_t), p_z_g=z(c.B, c.dim_g), p_y=z(c.B, c.n_c))
+
+    def sample_noise(self, feed):
+        c = self.cfg
+        feed['p_z_l_0'].normal_()
+        feed['epsilon'].normal_()
+        feed['p_z_g'].normal_()
+        idx = torch.randint(0, c.n_c, (c.B, 1), device=feed['p_y'].device)
+        feed['p_y'].zero_().scatter_(1, idx, 1.0)
+
+    def set_batch(self, feed, batch):
+        x, y = batch
+        feed['real_x_unit'].copy_(x.reshape(feed['real_x_unit'].shape), non_blocking=True)
+        feed['real_y'].copy_(y, non_blocking=True)
+
+    def synthetic_ring(self, device, n=4, seed=1234):
+        c, rng, ring = self.cfg, np.random.default_rng(seed), []
+        for _ in range(n):
+            x = torch.as_tensor(rng.random((c.B, c.LEN, c.output_dim), dtype=np.float32))
+            y = np.zeros((c.B, c.n_c), np.float32)
+            y[np.arange(c.B), rng.integers(0, c.n_c, size=c.B)] = 1
+            ring.append((x.to(device), torch.as_tensor(y).to(device)))
+        return ring
+
+    # ---- helpers --------------------------------------------------------------------------------------------------------
+    def _lin(self, name, nin, nout, x, act=None):
+        if act is None:
+            return lib.ops.linear.Linear(name, nin, nout, x)
+        if self.cfg.fuse:
+            return lib.ops.linear.Linear(name, nin, nout, x, activation=act)
+        return F.ActFwd.apply(lib.ops.linear.Linear(name, nin, nout, x), act, 0.2)
+
+    def _conv(self, name, cin, cout, x):
+        if self.cfg.fuse:
+            return lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, activation=LRELU)
+        return F.ActFwd.apply(lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2), LRELU, 0.2)
+
+    def _deconv(self, name, cin, cout, x, act):
+        if self.cfg.fuse:
+            return lib.ops.deconv2d.Deconv2D(name, cin, cout, 5, x, activation=act)
+        return F.ActFwd.apply(lib.ops.deconv2d.Deconv2D(name, cin, cout, 5, x), act, 0.0)
+
+    def expand_labels(self, y):
+        c = self.cfg
+        return y.unsqueeze(1).expand(c.B, c.LEN, c.n_c).reshape(c.B * c.LEN, c.n_c)
+
+    def _z_rows(self, z_g, z_l, labels):
+        c = self.cfg
+        zg = z_g.reshape(c.B, 1, c.dim_g).expand(c.B, c.LEN, c.dim_g)
+        lab = labels.reshape(c.B, 1, c.n_c).expand(c.B, c.LEN, c.n_c)
+        return torch.cat([zg, z_l.reshape(c.B, c.LEN, c.dim_l), lab], -1).reshape(c.B * c.LEN, c.dim_g + c.dim_l + c.n_c)
+
+    # ---- nets -----------------------------------------------------------------------------------------------------------
+    def _operator(self, name, a, b, res_src):
+        c = self.cfg
+        out = self._lin(name + '.Input', a.shape[1] + b.shape[1], c.dim_op, torch.cat([a, b], 1), LRELU)
+        out = self._lin(name + '.1', c.dim_op, c.dim_op, out, LRELU)
+        out = self._lin(name + '.Output', c.dim_op, c.dim_l, out)
+        if c.op_dyn_mode == 'res':
+            return out + res_src
+        return out + self._lin(name + '.ZW', c.dim_l, c.dim_l, res_src)
+
+    def ImplicitOperator(self, z_l, epsilon, name):
+        return self._operator(name, z_l, epsilon, z_l)
+
+    def ConcatOperator(self, z_l_0, z_l_1_pre, name):
+        return self._operator(name, z_l_0, z_l_1_pre, z_l_0)
+
+    def DynamicGenerator(self, z_l_0, epsilon):
+        c, zs = self.cfg, [z_l_0]
+        for _ in range(c.LEN - 1):
+            zs.append(self.ImplicitOperator(zs[-1], epsilon, 'Generator.Dynamic'))
+        return torch.stack(zs, 1)
+
+    def DynamicExtractor(self, z_pre):
+        c, L = self.cfg, self.cfg.LEN
+        if c.pos_mode == 'naive_mean_field':
+            return z_pre
+        if c.pos_mode == 'inverse':
+            zs = [z_pre[:, L - 1, :]]
+            for i in range(L - 1):
+                zs.insert(0, self.ConcatOperator(zs[0], z_pre[:, L - i - 2, :], 'Extractor.Dynamic.Backward'))
+        elif c.pos_mode == 'forward_inverse':
+            zs = [z_pre[:, 0, :]]
+            for i in range(L - 1):
+                zs.append(self.ConcatOperator(zs[-1], z_pre[:, i + 1, :], 'Extractor.Dynamic.Forward'))
+        else:   # gsp
+            tmp = [z_pre[:, L - 1, :]]
+            for i in range(L - 1):
+                tmp.insert(0, self.ConcatOperator(tmp[0], z_pre[:, L - i - 2, :], 'Extractor.Dynamic.Backward'))
+            zs = [tmp[0]]
+            for i in range(L - 1):
+                zs.append(self.ConcatOperator(zs[-1], tmp[i + 1], 'Extractor.Dynamic.Forward'))
+        return torch.stack(zs, 1)
+
+    def Generator(self, z_g, z_l, labels):
+        c, d = self.cfg, self.cfg.dim
+        out = self._lin('Generator.Input', c.dim_g + c.dim_l + c.n_c, c.flat, self._z_rows(z_g, z_l, labels), RELU)
+        out = out.reshape(c.B * c.LEN, 8 * d, 4, 4)
+        out = self._deconv('Generator.2', 8 * d, 4 * d, out, RELU)
+        out = self._deconv('Generator.3', 4 * d, 2 * d, out, RELU)
+        out = self._deconv('Generator.4', 2 * d, d, out, RELU)
+        out = self._deconv('Generator.5', d, 1, out, TANH)
+        return out.reshape(c.B, c.LEN, c.output_dim)
+
+    def _conv_stack(self, pre, x, cin):
+        d = self.cfg.dim
+        out = self._conv(pre + '.1', cin, d, x)
+        out = self._conv(pre + '.2', d, 2 * d, out)
+        out = self._conv(pre + '.3', 2 * d, 4 * d, out)
+        return self._conv(pre + '.4', 4 * d, 8 * d, out)
+
+    def Extractor(self, inputs, labels):
+        c = self.cfg
+        out = self._conv_stack('Extractor', inputs.reshape(c.B * c.LEN, 1, 64, 64), 1).reshape(c.B * c.LEN, c.flat)
+        out = torch.cat([out, self.expand_labels(labels)], 1)
+        return self._lin('Extractor.Output', c.flat + c.n_c, c.dim_l, out).reshape(c.B, c.LEN, c.dim_l)
+
+    def G_Extractor(self, inputs, labels):
+        c = self.cfg
+        out = self._conv_stack('Extractor.G', inputs.reshape(c.B, c.LEN, 64, 64), c.LEN).reshape(c.B, c.flat)
+        return self._lin('Extractor.G.Output', c.flat + c.n_c, c.dim_g, torch.cat([out, labels], 1))
+
+    def Discriminator(self, x, z_g, z_l, labels):
+        c = self.cfg
+        out = self._conv_stack('Discriminator', x.reshape(c.B * c.LEN, 1, 64, 64), 1).reshape(c.B * c.LEN, c.flat)
+        z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l + c.n_c, 512, self._z_rows(z_g, z_l, labels), LRELU)
+        out = torch.cat([out, z_out, self.expand_labels(labels)], 1)
+        out = self._lin('Discriminator.zx1', c.flat + 512 + c.n_c, 512, out, LRELU)
+        return self._lin('Discriminator.Output', 512, 1, out).reshape(-1)
+
+    def _mlp_critic(self, pre, x):
+        out = self._lin(pre + '.Input', x.shape[1], 512, x, LRELU)
+        out = self._lin(pre + '.2', 512, 512, out, LRELU)
+        out = self._lin(pre + '.3', 512, 512, out, LRELU)
+        return self._lin(pre + '.Output', 512, 1, out).reshape(-1)
+
+    def DynamicDiscrminator(self, z1, z2):
+        return self._mlp_critic('Discriminator.Dynamic', torch.cat([z1, z2], 1))
+
+    def ZGDiscrminator(self, z_g):
+        return self._mlp_critic('Discriminator.ZG', z_g)
+
+    def _transitions(self, z_l):
+        """all LEN-1 (z_t, z_t+1) pairs stacked time-major: [(LEN-1)*B, 2*dim_l] -> transition-critic logits"""
+        c = self.cfg
+        a = z_l[:, :-1, :].transpose(0, 1).reshape((c.LEN - 1) * c.B, c.dim_l)
+        b = z_l[:, 1:, :].transpose(0, 1).reshape((c.LEN - 1) * c.B, c.dim_l)
+        return self.DynamicDiscrminator(a, b)
+
+    @staticmethod
+    def _var_lists():
+        gen = lib.params_with_name('Generator') + lib.params_with_name('Extractor')      # gen_params + ext_params (:543-545)
+        return gen, lib.params_with_name('Discriminator')
+
+    # ---- loss wiring ------------------------------------------------------------------------------------------------------
+    def forward_nets(self, feed):
+        """everything that reads no critic variable (:515-527)"""
+        real_y, p_y = feed['real_y'], feed['p_y']
+        real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0, 0.0, -1.0)      # 2*(x-.5)
+        q_z_l = self.DynamicExtractor(self.Extractor(real_x, real_y))
+        q_z_g = self.G_Extractor(real_x, real_y)
+        p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
+        fake_x = self.Generator(feed['p_z_g'], p_z_l, p_y)
+        return dict(real_x=real_x, q_z_l=q_z_l, q_z_g=q_z_g, p_z_l=p_z_l, p_z_g=feed['p_z_g'], fake_x=fake_x)
+
+    def forward(self, feed, which=None, nets=None):
+        c = self.cfg
+        out = dict(nets) if nets is not None else self.forward_nets(feed)
+        real_y, p_y = feed['real_y'], feed['p_y']
+        real_x, fake_x, q_z_l, q_z_g, p_z_l, p_z_g = (out[k] for k in ('real_x', 'fake_x', 'q_z_l', 'q_z_g', 'p_z_l', 'p_z_g'))
+        if which == 'disc':      # the critic step needs no gradient w.r.t. the generator/extractor outputs
+            fake_x, q_z_l, q_z_g, p_z_l = fake_x.detach(), q_z_l.detach(), q_z_g.detach(), p_z_l.detach()
+        J = lib.objs.gan_inference
+        J.ONLY[0] = which
+        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
+            disc_fake = [self._transitions(p_z_l), self.ZGDiscrminator(p_z_g), self.Discriminator(fake_x, p_z_g, p_z_l, p_y)]
+            disc_real = [self._transitions(q_z_l), self.ZGDiscrminator(q_z_g), self.Discriminator(real_x, q_z_g, q_z_l, real_y)]
+        r = c.ratio()
+        ratios = [float(r[0]) * (c.LEN - 1), float(r[c.LEN - 1]), float(r[c.LEN])]      # the LEN-1 equal transition terms as one
+        gen_params, disc_params = self._var_lists()
+        res = J.weighted_local_epce(disc_fake, disc_real, ratios, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        J.ONLY[0] = None
+        out.update(disc_fake=disc_fake, disc_real=disc_real, gen_cost=res[0], disc_cost=res[1], gen_train_op=res[4],
+                   disc_train_op=res[5])
+        return out

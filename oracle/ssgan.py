@@ -1,0 +1,295 @@
+"""State-space GAN (ssgan_inference_moving_mnist.py) restated on the oracle tape.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED: the reference is Python 2 + TensorFlow 1.x and cannot
+run here; this file follows its net definitions and loss wiring line by line so the product model
+(graphical_gan_amd/models_ssgan.py, which batches the per-time-step factors) can be checked against it.
+
+Covered: MODE='local_ep' (the script default) with weighted_local_epce; POS_MODE 'naive_mean_field' (default),
+'inverse', 'forward_inverse', 'gsp'; OP_DYN_MODE 'res' / 'res_w'; BN flags off (default).
+  nets      ssgan_inference_moving_mnist.py:98-349
+  wiring    ssgan_inference_moving_mnist.py:510-547
+  ratios    ssgan_inference_moving_mnist.py:78-79
+"""
+import numpy as np
+
+from . import nets as N
+from . import objs as J
+from . import tape as tp
+
+
+class Cfg(object):
+    def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
+                 pos_mode='naive_mean_field', op_dyn_mode='res'):
+        self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
+        self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
+        self.S, self.output_dim = 64, 64 * 64
+        self.flat = 4 * 4 * 8 * dim
+        self.pos_mode, self.op_dyn_mode = pos_mode, op_dyn_mode
+        self.lr, self.beta1, self.beta2 = 1e-4, 0.5, 0.999          # :49-53 (weighted_local_epce pins beta2 = .999)
+        self.critic_iters = 1
+
+    def ratio(self):
+        """:78-79"""
+        r = np.asarray([1.0] * (self.LEN - 1) + [1, self.LEN])
+        return r * 1.0 / (len(r) + self.LEN - 1)
+
+
+def init_params(cfg, seed=0):
+    """Reference initialisers in creation order of the script's graph build (Extractor, G_Extractor, [Dynamic extractor],
+    Generator, Dynamic generator, critics)."""
+    rng = np.random.RandomState(seed)
+    P = {}
+
+    def lin(name, nin, nout):
+        P[name + '.W'] = N.linear_init(rng, nin, nout)
+        P[name + '.b'] = np.zeros(nout, np.float32)
+
+    def conv(name, cin, cout):
+        P[name + '.Filters'] = N.conv_init(rng, cin, cout)
+        P[name + '.Biases'] = np.zeros(cout, np.float32)
+
+    def deconv(name, cin, cout):
+        P[name + '.Filters'] = N.deconv_init(rng, cin, cout)
+        P[name + '.Biases'] = np.zeros(cout, np.float32)
+
+    d = cfg.dim
+    for pre, cin in (('Extractor', 1), ('Extractor.G', cfg.LEN)):
+        conv(pre + '.1', cin, d); conv(pre + '.2', d, 2 * d); conv(pre + '.3', 2 * d, 4 * d); conv(pre + '.4', 4 * d, 8 * d)
+    lin('Extractor.Output', cfg.flat + cfg.n_c, cfg.dim_l)
+    lin('Extractor.G.Output', cfg.flat + cfg.n_c, cfg.dim_g)
+    for nm in ('Extractor.Dynamic.Backward', 'Extractor.Dynamic.Forward'):
+        lin(nm + '.Input', 2 * cfg.dim_l, cfg.dim_op); lin(nm + '.1', cfg.dim_op, cfg.dim_op)
+        lin(nm + '.Output', cfg.dim_op, cfg.dim_l); lin(nm + '.ZW', cfg.dim_l, cfg.dim_l)
+    lin('Generator.Input', cfg.dim_g + cfg.dim_l + cfg.n_c, cfg.flat)
+    deconv('Generator.2', 8 * d, 4 * d); deconv('Generator.3', 4 * d, 2 * d); deconv('Generator.4', 2 * d, d)
+    deconv('Generator.5', d, 1)
+    nm = 'Generator.Dynamic'
+    lin(nm + '.Input', cfg.dim_l + cfg.dim_t, cfg.dim_op); lin(nm + '.1', cfg.dim_op, cfg.dim_op)
+    lin(nm + '.Output', cfg.dim_op, cfg.dim_l); lin(nm + '.ZW', cfg.dim_l, cfg.dim_l)
+    conv('Discriminator.1', 1, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
+    conv('Discriminator.4', 4 * d, 8 * d)
+    lin('Discriminator.z1', cfg.dim_g + cfg.dim_l + cfg.n_c, 512)
+    lin('Discriminator.zx1', cfg.flat + 512 + cfg.n_c, 512)
+    lin('Discriminator.Output', 512, 1)
+    for nm, nin in (('Discriminator.Dynamic', 2 * cfg.dim_l), ('Discriminator.ZG', cfg.dim_g)):
+        lin(nm + '.Input', nin, 512); lin(nm + '.2', 512, 512); lin(nm + '.3', 512, 512); lin(nm + '.Output', 512, 1)
+    return P
+
+
+def used_names(cfg):
+    """parameters the default configuration actually touches (the others never receive a gradient)"""
+    skip = []
+    if cfg.op_dyn_mode != 'res_w':
+        skip.append('.ZW')
+    if cfg.pos_mode in ('naive_mean_field',):
+        skip.append('Extractor.Dynamic')
+    elif cfg.pos_mode == 'inverse':
+        skip.append('Extractor.Dynamic.Forward')
+    elif cfg.pos_mode == 'forward_inverse':
+        skip.append('Extractor.Dynamic.Backward')
+    return skip
+
+
+# ---- nets ------------------------------------------------------------------------------------------------------------
+def _lrelu(x):
+    return tp.leaky_relu(x, 0.2)
+
+
+def expand_labels(cfg, y):
+    """:91-93  [B,N_C] -> [B*LEN,N_C] (each label repeated LEN times)"""
+    yb = tp.broadcast_to(tp.reshape(y, (cfg.B, 1, cfg.n_c)), (cfg.B, cfg.LEN, cfg.n_c))
+    return tp.reshape(yb, (cfg.B * cfg.LEN, cfg.n_c))
+
+
+def _operator(cfg, P, name, a, b, res_src):
+    out = tp.concat([a, b], axis=1)
+    out = _lrelu(N.Linear(P, name + '.Input', out))
+    out = _lrelu(N.Linear(P, name + '.1', out))
+    out = N.Linear(P, name + '.Output', out)
+    if cfg.op_dyn_mode == 'res':
+        out = out + res_src
+    elif cfg.op_dyn_mode == 'res_w':
+        out = out + N.Linear(P, name + '.ZW', res_src)
+    return out
+
+
+def ImplicitOperator(cfg, P, z_l, epsilon, name):            # :98-114
+    return _operator(cfg, P, name, z_l, epsilon, z_l)
+
+
+def ConcatOperator(cfg, P, z_l_0, z_l_1_pre, name):         # :116-132
+    return _operator(cfg, P, name, z_l_0, z_l_1_pre, z_l_0)
+
+
+def DynamicGenerator(cfg, P, z_l_0, epsilon):                # :134-141 (one epsilon for the whole sequence)
+    zs = [z_l_0]
+    for _ in range(cfg.LEN - 1):
+        zs.append(ImplicitOperator(cfg, P, zs[-1], epsilon, 'Generator.Dynamic'))
+    return tp.reshape(tp.concat(zs, axis=1), (cfg.B, cfg.LEN, cfg.dim_l))
+
+
+def _step(cfg, z, i):
+    return tp.reshape(tp.slice_axis(z, 1, i, i + 1), (cfg.B, cfg.dim_l))
+
+
+def DynamicExtractor(cfg, P, z_pre):                         # :143-169
+    L = cfg.LEN
+    if cfg.pos_mode == 'naive_mean_field':
+        return z_pre
+    if cfg.pos_mode == 'inverse':
+        zs = [_step(cfg, z_pre, L - 1)]
+        for i in range(L - 1):
+            zs.insert(0, ConcatOperator(cfg, P, zs[0], _step(cfg, z_pre, L - i - 2), 'Extractor.Dynamic.Backward'))
+    elif cfg.pos_mode == 'forward_inverse':
+        zs = [_step(cfg, z_pre, 0)]
+        for i in range(L - 1):
+            zs.append(ConcatOperator(cfg, P, zs[-1], _step(cfg, z_pre, i + 1), 'Extractor.Dynamic.Forward'))
+    elif cfg.pos_mode == 'gsp':
+        tmp = [_step(cfg, z_pre, L - 1)]
+        for i in range(L - 1):
+            tmp.insert(0, ConcatOperator(cfg, P, tmp[0], _step(cfg, z_pre, L - i - 2), 'Extractor.Dynamic.Backward'))
+        zs = [tmp[0]]
+        for i in range(L - 1):
+            zs.append(ConcatOperator(cfg, P, zs[-1], tmp[i + 1], 'Extractor.Dynamic.Forward'))
+    else:
+        raise NotImplementedError(cfg.pos_mode)
+    return tp.reshape(tp.concat(zs, axis=1), (cfg.B, L, cfg.dim_l))
+
+
+def _z_rows(cfg, z_g, z_l, labels):
+    """[B*LEN, G+L+N_C]: global code and label repeated over time, local code per step (:172-180, :278-284)"""
+    zg = tp.broadcast_to(tp.reshape(z_g, (cfg.B, 1, cfg.dim_g)), (cfg.B, cfg.LEN, cfg.dim_g))
+    lab = tp.reshape(expand_labels(cfg, labels), (cfg.B, cfg.LEN, cfg.n_c))
+    z = tp.concat([zg, tp.reshape(z_l, (cfg.B, cfg.LEN, cfg.dim_l)), lab], axis=2)
+    return tp.reshape(z, (cfg.B * cfg.LEN, cfg.dim_g + cfg.dim_l + cfg.n_c))
+
+
+def Generator(cfg, P, z_g, z_l, labels):                     # :171-204
+    out = tp.relu(N.Linear(P, 'Generator.Input', _z_rows(cfg, z_g, z_l, labels)))
+    out = tp.reshape(out, (cfg.B * cfg.LEN, 8 * cfg.dim, 4, 4))
+    for nm in ('2', '3', '4'):
+        out = tp.relu(N.Deconv2D(P, 'Generator.' + nm, out))
+    out = tp.tanh(N.Deconv2D(P, 'Generator.5', out))
+    return tp.reshape(out, (cfg.B, cfg.LEN, cfg.output_dim))
+
+
+def _conv_stack(cfg, P, pre, x):
+    out = x
+    for i in range(4):
+        out = _lrelu(N.Conv2D(P, '%s.%d' % (pre, i + 1), out))   # (dropout == identity; BN flags off)
+    return out
+
+
+def Extractor(cfg, P, x, labels):                            # :206-234
+    out = _conv_stack(cfg, P, 'Extractor', tp.reshape(x, (cfg.B * cfg.LEN, 1, 64, 64)))
+    out = tp.concat([tp.reshape(out, (cfg.B * cfg.LEN, cfg.flat)), expand_labels(cfg, labels)], axis=1)
+    return tp.reshape(N.Linear(P, 'Extractor.Output', out), (cfg.B, cfg.LEN, cfg.dim_l))
+
+
+def G_Extractor(cfg, P, x, labels):                          # :236-262
+    out = _conv_stack(cfg, P, 'Extractor.G', tp.reshape(x, (cfg.B, cfg.LEN, 64, 64)))
+    out = tp.concat([tp.reshape(out, (cfg.B, cfg.flat)), labels], axis=1)
+    return N.Linear(P, 'Extractor.G.Output', out)
+
+
+def Discriminator(cfg, P, x, z_g, z_l, labels):              # :265-315
+    out = _conv_stack(cfg, P, 'Discriminator', tp.reshape(x, (cfg.B * cfg.LEN, 1, 64, 64)))
+    out = tp.reshape(out, (cfg.B * cfg.LEN, cfg.flat))
+    z_out = _lrelu(N.Linear(P, 'Discriminator.z1', _z_rows(cfg, z_g, z_l, labels)))
+    out = tp.concat([out, z_out, expand_labels(cfg, labels)], axis=1)
+    out = _lrelu(N.Linear(P, 'Discriminator.zx1', out))
+    return tp.reshape(N.Linear(P, 'Discriminator.Output', out), (cfg.B * cfg.LEN,))
+
+
+def _mlp_critic(P, pre, x):
+    out = _lrelu(N.Linear(P, pre + '.Input', x))
+    out = _lrelu(N.Linear(P, pre + '.2', out))
+    out = _lrelu(N.Linear(P, pre + '.3', out))
+    return tp.reshape(N.Linear(P, pre + '.Output', out), (-1,))
+
+
+def DynamicDiscriminator(cfg, P, z1, z2):                    # :317-333
+    return _mlp_critic(P, 'Discriminator.Dynamic', tp.concat([z1, z2], axis=1))
+
+
+def ZGDiscriminator(cfg, P, z_g):                            # :335-349
+    return _mlp_critic(P, 'Discriminator.ZG', z_g)
+
+
+# ---- one session.run ---------------------------------------------------------------------------------------------------
+def make_feed(cfg, rng):
+    f = {'real_x_unit': rng.random((cfg.B, cfg.LEN, cfg.output_dim), dtype=np.float32)}
+    y = np.zeros((cfg.B, cfg.n_c), np.float32)
+    y[np.arange(cfg.B), rng.integers(0, cfg.n_c, size=cfg.B)] = 1
+    f['real_y'] = y
+    f['p_z_l_0'] = rng.standard_normal((cfg.B, cfg.dim_l), dtype=np.float32)
+    f['epsilon'] = rng.standard_normal((cfg.B, cfg.dim_t), dtype=np.float32)
+    f['p_z_g'] = rng.standard_normal((cfg.B, cfg.dim_g), dtype=np.float32)
+    py = np.zeros((cfg.B, cfg.n_c), np.float32)
+    py[np.arange(cfg.B), rng.integers(0, cfg.n_c, size=cfg.B)] = 1
+    f['p_y'] = py
+    return f
+
+
+def forward(cfg, P, feed):
+    """:510-547 -- P: name -> tape.T.  Returns dict incl. gen_cost / disc_cost (weighted_local_epce, MODE 'local_ep')."""
+    dt = next(iter(P.values())).v.dtype.type
+    T = lambda k: tp.T(np.asarray(feed[k], dtype=dt))
+    real_x = tp.T(dt(2) * (np.asarray(feed['real_x_unit'], dtype=dt) - dt(.5)))
+    real_y, p_y = T('real_y'), T('p_y')
+    q_z_l = DynamicExtractor(cfg, P, Extractor(cfg, P, real_x, real_y))
+    q_z_g = G_Extractor(cfg, P, real_x, real_y)
+    p_z_l = DynamicGenerator(cfg, P, T('p_z_l_0'), T('epsilon'))
+    p_z_g = T('p_z_g')
+    fake_x = Generator(cfg, P, p_z_g, p_z_l, p_y)
+    disc_fake, disc_real = [], []
+    for i in range(cfg.LEN - 1):
+        disc_fake.append(DynamicDiscriminator(cfg, P, _step(cfg, p_z_l, i), _step(cfg, p_z_l, i + 1)))
+        disc_real.append(DynamicDiscriminator(cfg, P, _step(cfg, q_z_l, i), _step(cfg, q_z_l, i + 1)))
+    disc_fake.append(ZGDiscriminator(cfg, P, p_z_g))
+    disc_real.append(ZGDiscriminator(cfg, P, q_z_g))
+    disc_fake.append(Discriminator(cfg, P, fake_x, p_z_g, p_z_l, p_y))
+    disc_real.append(Discriminator(cfg, P, real_x, q_z_g, q_z_l, real_y))
+    gen_cost, disc_cost = J.weighted_local_epce_costs(disc_fake, disc_real, list(cfg.ratio()))
+    return dict(real_x=real_x, q_z_l=q_z_l, q_z_g=q_z_g, p_z_l=p_z_l, fake_x=fake_x, disc_fake=disc_fake,
+                disc_real=disc_real, gen_cost=gen_cost, disc_cost=disc_cost)
+
+
+class Trainer(object):
+    """gen_step / disc_step = one session.run each (same loop as oracle.step.Trainer)."""
+
+    def __init__(self, cfg, params, dtype=np.float64):
+        self.cfg, self.dtype = cfg, dtype
+        self.P = {k: np.asarray(v, dtype=dtype).copy() for k, v in params.items()}
+        names = list(self.P)
+        gen_names = [n for n in names if 'Generator' in n] + [n for n in names if 'Extractor' in n]   # gen_params+ext_params
+        disc_names = [n for n in names if 'Discriminator' in n]
+        hp = dict(lr=cfg.lr, beta1=cfg.beta1, beta2=cfg.beta2)
+        self.gen_opt, self.disc_opt = J.Adam(gen_names, **hp), J.Adam(disc_names, **hp)
+        self.critic_iters = cfg.critic_iters
+
+    def _run(self, feed, which):
+        Pt = {k: tp.T(v) for k, v in self.P.items()}
+        out = forward(self.cfg, Pt, feed)
+        opt = self.gen_opt if which == 'gen' else self.disc_opt
+        cost = out[which + '_cost']
+        gs = tp.grad(cost, [Pt[n] for n in opt.names])
+        return float(cost.v), {n: (g.v if g is not None else None) for n, g in zip(opt.names, gs)}, out
+
+    def gen_step(self, feed):
+        cost, grads, _ = self._run(feed, 'gen')
+        self.gen_opt.apply(self.P, grads)
+        return cost
+
+    def disc_step(self, feed):
+        cost, grads, _ = self._run(feed, 'disc')
+        self.disc_opt.apply(self.P, grads)
+        return cost
+
+    def iteration(self, it, feeds):
+        res = {}
+        if it > 0:
+            res['gen_cost'] = self.gen_step(next(feeds))
+        for _ in range(self.critic_iters):
+            res['disc_cost'] = self.disc_step(next(feeds))
+        return res
