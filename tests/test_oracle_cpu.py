@@ -199,3 +199,33 @@ def test_oracle_reproduces_trajectory_goldens(name):
         assert abs(r['disc_cost'] - z['costs'][it, 1]) < 1e-10
     for k, v in tr.P.items():
         assert np.abs(digest(v) - z['p1/' + k]).max() < 1e-7 * max(1.0, np.abs(z['p1/' + k]).max()), k
+
+
+def test_ssgan_oracle_finite_differences():
+    """oracle/ssgan.py (state-space GAN, weighted_local_epce): tape gradients vs float64 central differences, and the cost at
+    initialisation ~ 2*ln2*sum(ratio) = 2*ln2."""
+    from oracle import ssgan as S, tape as tp
+    cfg = S.Cfg(batch_size=1, length=3, dim=2, dim_op=8, dim_g=4, dim_l=3, pos_mode='gsp', op_dyn_mode='res_w')
+    assert abs(cfg.ratio().sum() - 1.0) < 1e-12
+    P0 = {k: v.astype(np.float64) for k, v in S.init_params(cfg, 0).items()}
+    feed = S.make_feed(cfg, np.random.default_rng(1))
+
+    def cost(P, which):
+        return S.forward(cfg, {k: tp.T(v) for k, v in P.items()}, feed)[which + '_cost']
+
+    assert abs(float(cost(P0, 'gen').v) - 2 * np.log(2)) < 0.2
+    rng = np.random.default_rng(2)
+    for which, names in (('gen', ['Generator.Dynamic.ZW.W', 'Extractor.Dynamic.Forward.Input.W', 'Extractor.G.1.Filters',
+                                  'Generator.3.Filters']),
+                         ('disc', ['Discriminator.Dynamic.2.W', 'Discriminator.2.Filters', 'Discriminator.zx1.W'])):
+        Pt = {k: tp.T(v) for k, v in P0.items()}
+        c = S.forward(cfg, Pt, feed)[which + '_cost']
+        gs = tp.grad(c, [Pt[n] for n in names])
+        for n, g in zip(names, gs):
+            idx = tuple(rng.integers(0, s) for s in P0[n].shape)
+            eps = 1e-5
+            Pp = dict(P0); Pm = dict(P0)
+            Pp[n] = P0[n].copy(); Pp[n][idx] += eps
+            Pm[n] = P0[n].copy(); Pm[n][idx] -= eps
+            fd = (float(cost(Pp, which).v) - float(cost(Pm, which).v)) / (2 * eps)
+            assert abs(fd - g.v[idx]) <= 1e-6 + 1e-5 * abs(fd), (which, n, fd, g.v[idx])
