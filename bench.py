@@ -93,6 +93,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=2)
+    ap.add_argument('--host-feed', action='store_true',
+                    help='minibatches start in host memory (pinned double-buffered H->D copies): the PCIe-inclusive rate')
     args = ap.parse_args()
 
     import numpy as np
@@ -142,6 +144,10 @@ def main():
             yield ring[i % len(ring)]
             i += 1
     bi = batches()
+    if args.host_feed:                                 # same minibatches, but every one crosses PCIe (graphical_gan_amd/data.py)
+        from graphical_gan_amd.data import DevicePrefetcher
+        host_ring = [tuple(t.cpu().numpy() for t in b) if isinstance(b, tuple) else b.cpu().numpy() for b in ring]
+        bi = DevicePrefetcher(lambda: iter(host_ring), dev, depth=2)
     it = 0
     tr.iteration(it, bi); it += 1                      # creates parameters + optimizers (eager)
     tr.iteration(it, bi); it += 1
@@ -263,7 +269,7 @@ def main():
                        if ssgan else '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
                 'gmgan' if K else 'gan', args.dataset, args.mode, ' N_COMS=%d' % K if K else '', cfg.B, cfg.S, cfg.S, cfg.C,
                 cfg.critic_iters, '' if not args.no_graph else ', eager'),
-                'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world, 'hip_graph': not args.no_graph,
+                'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world, 'hip_graph': not args.no_graph, 'host_feed': bool(args.host_feed),
                 'fused_epilogues': not args.no_fuse, 'minibatches_per_step': 1 + cfg.critic_iters,
                 'algorithmic_gflop_per_step': round(gflop_it, 2), 'finite_costs': bool(finite),
                 **({'frames_per_sec': round(images_per_s * cfg.LEN, 1)} if ssgan else {})},

@@ -141,7 +141,23 @@ def get_optimizer(role, params, **hp):
     if opt is None:
         opt = AdamOptimizer(params, **hp)
         _optimizers[key] = opt
+        if role in _pending_state:                      # a checkpoint restored before this optimizer existed
+            load_adam_state(opt, _pending_state.pop(role))
     return opt
+
+
+_pending_state = {}
+
+
+def load_adam_state(opt, state):
+    """state: {'step': int32[1], '<param name>/m': array, '<param name>/v': array} (checkpoint.py)"""
+    with torch.no_grad():
+        opt.step.copy_(torch.as_tensor(state['step']).to(opt.step.device).reshape(opt.step.shape))
+        for p, (o, n) in zip(opt.params, opt.slots):
+            for which, buf in (('m', opt.m), ('v', opt.v)):
+                a = state.get('%s/%s' % (p.param_name, which))
+                if a is not None:
+                    buf[o:o + n].copy_(torch.as_tensor(a, dtype=torch.float32).reshape(-1))
 
 
 def reset_optimizers():
@@ -150,3 +166,4 @@ def reset_optimizers():
             p.data = p.data.clone()
             p._flat_owner = None
     _optimizers.clear()
+    _pending_state.clear()

@@ -1,0 +1,68 @@
+"""Data loaders of the hot path's callers (tflib/mnist.py, cifar10.py, celebA.py, simple_moving_mnist.py counterparts): interface,
+epoch semantics, and the vectorised moving-MNIST renderer against its literal restatement (same seed -> identical videos)."""
+import numpy as np
+
+
+def _fake_mnist(n=96, seed=0):
+    rng = np.random.default_rng(seed)
+    mk = lambda m: (rng.random((m, 784), dtype=np.float32), rng.integers(0, 10, size=m))
+    return mk(n), mk(n // 2), mk(n // 2)
+
+
+def test_mnist_loader_pairs_images_with_targets():
+    from graphical_gan_amd.tflib import mnist
+    data = _fake_mnist()
+    tag = {tuple(np.round(x[:4], 6)): int(t) for x, t in zip(*data[0])}
+    np.random.seed(3)
+    train, dev, test = mnist.load(16, 8, data=data)
+    seen = 0
+    for epoch in range(2):
+        for x, t in train():
+            assert x.shape == (16, 784) and x.dtype == np.float32 and t.shape == (16,)
+            for xi, ti in zip(x, t):
+                assert tag[tuple(np.round(xi[:4], 6))] == int(ti)       # the pair survived both shuffles
+            seen += 1
+    assert seen == 2 * (96 // 16)
+    assert sum(1 for _ in dev()) == 48 // 8
+
+
+def test_cifar_and_celeba_loaders():
+    from graphical_gan_amd.tflib import cifar10, celebA
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(0, 256, size=(50, 3072)).astype(np.uint8)
+    labs = np.arange(50)
+    imgs[:, 0] = labs                                                      # marker to check pairing
+    tr, te = cifar10.load(8, '/nonexistent', data=((imgs, labs), (imgs[:16], labs[:16])))
+    n = 0
+    for x, y in tr():
+        assert x.shape == (8, 3072) and np.array_equal(x[:, 0], y.astype(np.uint8))
+        n += 1
+    assert n == 50 // 8 and sum(1 for _ in te()) == 2
+    faces = rng.integers(0, 256, size=(40, 64, 64, 3)).astype(np.uint8)
+    tr, te = celebA.load(4, '/nonexistent', num_dev=8, data=faces)
+    assert sum(1 for _ in tr()) == 8 and sum(1 for _ in te()) == 2
+    assert next(iter(tr())).shape == (4, 12288)
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        cifar10.load(8, '/nonexistent')
+
+
+def test_moving_mnist_matches_literal_restatement():
+    from graphical_gan_amd.tflib import simple_moving_mnist as M
+    from oracle import moving_mnist as O
+    train, dev, test = _fake_mnist(40, seed=5)
+    np.random.seed(11)
+    ref = O.epoch(test[0], test[1], seq_length=6, batch_size=5)
+    np.random.seed(11)
+    gen = M.moving_mnist_generator_video(test, 6, 5)
+    got = list(gen())
+    assert len(got) == len(ref) == 4
+    for (v, y), (rv, ry) in zip(got, ref):
+        assert v.shape == (5, 6, 4096) and v.dtype == np.float32
+        assert np.array_equal(v, rv) and np.array_equal(y, ry)
+    # the digit stays inside the canvas and keeps its mass from frame to frame
+    v = got[0][0].reshape(5, 6, 64, 64)
+    assert np.allclose(v.sum(axis=(2, 3)), v.sum(axis=(2, 3))[:, :1], rtol=1e-6)
+    tr, te = M.load_video(6, 5, data=(train, dev, test))
+    x, y = next(iter(tr()))
+    assert x.shape == (5, 6, 4096) and y.shape == (5,)

@@ -135,3 +135,22 @@ def test_plot_shim(tmp_path, capsys):
     logfile = tmp_path / 'log.txt'
     plot.flush(str(tmp_path), str(logfile))
     assert 'time\t2.0' in capsys.readouterr().out and 'time\t2.0' in logfile.read_text()
+
+
+def test_save_images_grid_and_png(tmp_path):
+    import struct, zlib
+    from graphical_gan_amd.tflib import save_images as SI
+    X = np.linspace(0, 1, 12 * 3 * 4 * 4, dtype=np.float32).reshape(12, 3, 4, 4)
+    img = SI.large_image(X)
+    assert img.shape == (3 * 4, 4 * 4, 3) and img.dtype == np.uint8          # 12 samples -> 3 x 4 grid
+    assert np.array_equal(img[:4, 4:8], (255.99 * X[1]).astype('uint8').transpose(1, 2, 0))
+    assert SI.large_image(np.zeros((6, 49), np.float32)).shape == (2 * 7, 3 * 7)
+    p = str(tmp_path / 'g.png')
+    SI.save_images(X, p)
+    raw = open(p, 'rb').read()
+    assert raw[:8] == b'\x89PNG\r\n\x1a\n'
+    w, h, depth, ctype = struct.unpack('>IIBB', raw[16:26])
+    assert (w, h, depth, ctype) == (16, 12, 8, 2)
+    n = struct.unpack('>I', raw[33:37])[0]
+    rows = zlib.decompress(raw[41:41 + n])
+    assert len(rows) == 12 * (1 + 16 * 3) and rows[1:49] == img[0].tobytes()

@@ -174,3 +174,60 @@ def test_fused_conv_backward_entry_points(gpu):
 
 def _rel_(a, ref):
     return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def test_checkpoint_save_restore_resumes_bit_exact(gpu, tmp_path):
+    """train 3 iterations, save; (a) train 2 more; (b) fresh registry + restore + the same 2 iterations -> identical weights
+    (parameters, both Adam moments and step counters travel through the .npz keyed by registry names)."""
+    import torch
+    from graphical_gan_amd import checkpoint
+    from oracle import step as S
+    ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, 'ali', 8, 16, True, False, gpu)
+    feeds = [S.make_feed(ocfg, np.random.default_rng(500 + i), 'ali') for i in range(12)]
+    it_feeds = iter(feeds)
+    for it in range(3):
+        tr.iteration(it, it_feeds)
+    path = str(tmp_path / 'ck.npz')
+    keys = checkpoint.save(path, tr)
+    assert 'Generator.Input.W' in keys and 'adam/gen/step' in keys and 'adam/disc/Discriminator.1.Filters/m' in keys
+    used = 5                                             # it 0: 1 feed, it 1-2: 2 feeds each
+    rest = feeds[used:]
+    a = iter(rest)
+    for it in range(3, 5):
+        tr.iteration(it, a)
+    PA = tr.get_params()
+    ocfg, P0, cfg, tr2 = _mk('cifar10', 8, 0, 'ali', 8, 16, True, False, gpu)     # fresh registry, initial weights
+    checkpoint.restore(path, tr2)                        # optimizers do not exist yet: Adam state is parked
+    b = iter(rest)
+    for it in range(3, 5):
+        tr2.iteration(it, b)
+    PB = tr2.get_params()
+    for k in PA:
+        assert np.array_equal(PA[k], PB[k]), k
+
+
+def test_device_prefetcher_feeds_trainer(gpu):
+    """pinned double-buffered H->D staging (graphical_gan_amd/data.py): same minibatches, same order, same training result as
+    feeding device-resident tensors."""
+    import torch
+    from graphical_gan_amd.data import DevicePrefetcher
+    rng = np.random.default_rng(0)
+    host = [rng.integers(0, 256, size=(8, 3072)).astype(np.uint8) for _ in range(5)]
+    pf = DevicePrefetcher(lambda: iter(host), gpu, depth=3, dtypes=[np.int32])
+    for i in range(12):                                  # wraps around the 5-batch "epoch" and the 3-slot ring
+        t = next(pf)
+        assert t.dtype == torch.int32 and np.array_equal(t.cpu().numpy(), host[i % 5].astype(np.int32))
+    res = []
+    for use_pf in (False, True):
+        ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, 'ali', 8, 16, True, False, gpu)
+        tr.inject_noise = False
+        torch.manual_seed(77)
+        if use_pf:
+            src = DevicePrefetcher(lambda: iter(host), gpu, dtypes=[np.int32])
+        else:
+            src = iter([torch.as_tensor(h.astype(np.int32)).to(gpu) for h in host] * 3)
+        for it in range(3):
+            tr.iteration(it, src)
+        res.append(tr.get_params())
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
