@@ -191,6 +191,33 @@ __global__ void bce_multi_bwd_k(BceTable t, const float* __restrict__ gloss) {
     }
 }
 
+// reconstruction distances of tflib/utils/distance.py: mean(|x-y|^p), p = 1 | 2, one workgroup (n <= a few 100 K)
+__global__ void dist_fwd_k(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, size_t n, int p,
+                           float weight, int accumulate) {
+    __shared__ float sm[32];
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = x[i] - y[i];
+        s += p == 2 ? d * d : fabsf(d);
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) {
+        const float r = weight * (s / (float)n);
+        out[0] = accumulate ? out[0] + r : r;
+    }
+}
+
+__global__ void dist_bwd_k(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gout,
+                           float* __restrict__ gx, float* __restrict__ gy, size_t n, int p, float weight) {
+    const float g = gout[0] * weight / (float)n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = x[i] - y[i];
+        const float v = g * (p == 2 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+        if (gx) gx[i] = v;
+        if (gy) gy[i] = -v;
+    }
+}
+
 __global__ void mean_fwd_k(const float* __restrict__ x, float weight, float* __restrict__ loss, int n, int accumulate) {
     __shared__ float sm[32];
     float s = 0.f;
@@ -447,6 +474,19 @@ int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const
     GGAN_CHECK_ARG(bce_table(t, xs, gxs, labels, weights, ns, count, &mx) == 0, "bad term");
     GGAN_LAUNCH("bce_logits_bwd", 0, 8.0 * mx * count, bce_multi_bwd_k, dim3(cdiv(mx, 256), count), dim3(256), 0,
                 (hipStream_t)stream, t, gloss);
+    return 0;
+}
+
+int ggan_dist_fwd(const float* x, const float* y, float* out, size_t n, int p, float weight, int accumulate, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && y && out && n > 0 && (p == 1 || p == 2), "bad argument");
+    GGAN_LAUNCH("dist_fwd", 0, 8.0 * n, dist_fwd_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, y, out, n, p, weight, accumulate);
+    return 0;
+}
+
+int ggan_dist_bwd(const float* x, const float* y, const float* gout, float* gx, float* gy, size_t n, int p, float weight,
+                  ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && y && gout && (gx || gy) && n > 0 && (p == 1 || p == 2), "bad argument");
+    GGAN_LAUNCH("dist_bwd", 0, 16.0 * n, dist_bwd_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, gout, gx, gy, n, p, weight);
     return 0;
 }
 

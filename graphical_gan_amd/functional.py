@@ -738,6 +738,34 @@ class BceSum(Function):
         return (None, None) + tuple(outs)
 
 
+class Distance(Function):
+    """weight * mean(|x - y|^p), p = 1 | 2 -> 0-dim tensor (tflib/utils/distance.py)."""
+
+    @staticmethod
+    def forward(ctx, x, y, p, weight):
+        ctx.shapes = (tuple(x.shape), tuple(y.shape))
+        x, y = _c(x).reshape(-1), _c(y).reshape(-1)
+        assert x.numel() == y.numel()
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+        check(_L().ggan_dist_fwd(_p(x), _p(y), _p(out), x.numel(), int(p), float(weight), 0, _stream()), 'ggan_dist_fwd')
+        ctx.p, ctx.weight = int(p), float(weight)
+        ctx.save_for_backward(x, y)
+        return out.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = _c(g.reshape(1))
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is not None or gy is not None:
+            check(_L().ggan_dist_bwd(_p(x), _p(y), _p(g), _p(gx), _p(gy), x.numel(), ctx.p, ctx.weight, _stream()),
+                  'ggan_dist_bwd')
+        return (gx.reshape(ctx.shapes[0]) if gx is not None else None, gy.reshape(ctx.shapes[1]) if gy is not None else None,
+                None, None)
+
+
 class MeanSum(Function):
     """sum_i weight_i * mean(x_i) -> 0-dim tensor (Wasserstein costs)."""
 

@@ -35,7 +35,10 @@ class Config(object):
         if bn is not None:
             self.bn = bn
         self.mode = mode or ('local_ep' if n_coms else 'ali')
-        assert self.mode in ('ali', 'local_ep', 'wali-gp')
+        # reconstruction variants (gan_inference_cifar10.py:293-304, gmgan_inference_cifar10.py:399-403):
+        #   alice-z: + l2(real_x, G(q_z));  alice-x: + l2(p_z, E(fake_x));  alice: both;  local_epce: gmgan + l2(real_x, G(q_z))
+        assert self.mode in ('ali', 'local_ep', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce')
+        assert not (self.mode.startswith('alice') and n_coms) and not (self.mode == 'local_epce' and not n_coms)
         self.top = self.dim * 2 ** (self.nl - 1)
         self.flat = 16 * self.top
         self.output_dim = self.C * self.S * self.S
@@ -59,7 +62,7 @@ class GraphicalGAN(object):
     def single_contribution(self):
         """every parameter receives exactly one gradient contribution per backward pass (critic evaluated once on
         [fake; real]; the wali-gp penalty re-enters the critic)"""
-        return bool(self.cfg.batch_critic) and self.cfg.mode != 'wali-gp'
+        return bool(self.cfg.batch_critic) and self.cfg.mode in ('ali', 'local_ep')   # (reconstruction terms reuse G / E)
 
     def feed_buffers(self, device):
         c, B, feed = self.cfg, self.cfg.B, {}
@@ -259,7 +262,20 @@ class GraphicalGAN(object):
             d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None,
                                           detach=which == 'disc')
         gen_params, disc_params = self._var_lists()
-        if c.K:
+        rec_penalty = None
+        if which != 'disc' and c.mode in ('alice', 'alice-z', 'alice-x', 'local_epce'):
+            D = lib.utils.distance.distance
+            if c.mode != 'alice-x':
+                rec_penalty = 1. * D(real_x, self.Generator(q_z), 'l2')
+            if c.mode in ('alice', 'alice-x'):
+                rz = 1. * D(p_z, self.Extractor(fake_x), 'l2')
+                rec_penalty = rz if rec_penalty is None else rec_penalty + rz
+            out['rec_penalty'] = rec_penalty
+        if c.mode == 'local_epce':
+            res = J.local_epce(d_fake, d_real, rec_penalty, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        elif c.mode.startswith('alice'):
+            res = J.alice(d_fake, d_real, rec_penalty, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        elif c.K:
             res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
         elif c.mode == 'wali-gp':
             if which == 'gen':

@@ -116,4 +116,5 @@ def print_model_settings_dict(settings):
         print("\t{}: {}".format(var_name, var_value))
 
 
-from . import ops, objs, plot  # noqa: E402,F401
+from . import ops, objs, plot, utils  # noqa: E402,F401
+from . import mnist, cifar10, celebA, simple_moving_mnist, save_images  # noqa: E402,F401

@@ -1,5 +1,6 @@
-"""Objectives of tflib/objs/gan_inference.py on the hot path: ali (:47-79), local_ep (:81-119),
-weighted_local_epce (:307-358), wali_gp (:28-45).  Same signatures and return tuples; `*_train_op` are
+"""Objectives of tflib/objs/gan_inference.py: ali (:47-79), local_ep (:81-119), weighted_local_epce (:307-358),
+wali_gp (:28-45), and the reconstruction variants local_epce (:121-160), alice (:162-195), vegan (:197-225),
+vegan_wgan_gp (:227-244).  (wali = RMSProp + weight clipping, :4-26, is not built.)  Same signatures and return tuples; `*_train_op` are
 callables (TrainOp) that run backward + one TF-flavoured Adam step, the costs are 0-dim device tensors.
 Losses are single fused kernels (ggan_bce_logits_* / ggan_mean_*), not per-term pointwise graphs."""
 import numpy as np
@@ -43,6 +44,63 @@ def local_ep(disc_fake_list, disc_real_list, gen_params, disc_params, lr=2e-4, b
         disc_cost = disc_cost / n if disc_cost is not None else None
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def _plus(cost, *terms):
+    for t in terms:
+        if t is not None and cost is not None:
+            cost = cost + t
+    return cost
+
+
+def local_epce(disc_fake_list, disc_real_list, rec_penalty, gen_params, disc_params, lr=2e-4, beta1=0.5, s_f=None):
+    """tflib/objs/gan_inference.py:121-160: (sum of BCE terms (+ s_f)) / n, then + rec_penalty on the generator side."""
+    n = float(len(disc_fake_list))
+    if s_f is None:
+        gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0 / n] * len(disc_fake_list))
+    else:
+        gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0] * len(disc_fake_list))
+        gen_cost = (gen_cost + s_f) / n if gen_cost is not None else None
+        disc_cost = disc_cost / n if disc_cost is not None else None
+    gen_cost = _plus(gen_cost, rec_penalty)
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def alice(disc_fake, disc_real, rec_penalty, gen_params, disc_params, lr=2e-4, beta1=0.5, s_f=None):
+    """tflib/objs/gan_inference.py:162-195: the ali costs, generator side + s_f + rec_penalty."""
+    gen_cost, disc_cost = _bce_costs([disc_fake], [disc_real], [1.0])
+    gen_cost = _plus(gen_cost, s_f, rec_penalty)
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def vegan(disc_fake, disc_real, rec_penalty, gen_params, disc_params, lamb, lr=2e-4, beta1=.5, s_f=None):
+    """tflib/objs/gan_inference.py:197-225: gen = lamb*(BCE(fake,1) + s_f) + rec_penalty; disc = lamb/2 * ali critic cost."""
+    gen_cost = disc_cost = None
+    if ONLY[0] != 'disc':
+        gen_cost = F.BceSum.apply((1.0,), (1.0,), disc_fake)
+        gen_cost = _plus(gen_cost, s_f) * float(lamb)
+        gen_cost = _plus(gen_cost, rec_penalty)
+    if ONLY[0] != 'gen':
+        disc_cost = F.BceSum.apply((0.0, 1.0), (float(lamb) / 2, float(lamb) / 2), disc_fake, disc_real)
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def vegan_wgan_gp(disc_fake, disc_real, rec_penalty, gradient_penalty, gen_params, disc_params, lamb, lr=2e-4, beta1=.5):
+    """tflib/objs/gan_inference.py:227-244."""
+    gen_cost = disc_cost = None
+    if ONLY[0] != 'disc':
+        gen_cost = _plus(F.MeanSum.apply((-float(lamb), float(lamb)), disc_fake, disc_real), rec_penalty)
+    if ONLY[0] != 'gen':
+        disc_cost = _plus(F.MeanSum.apply((float(lamb), -float(lamb)), disc_fake, disc_real), gradient_penalty)
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
 
 

@@ -170,6 +170,14 @@ int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const
 /* loss[0] (+)= weight*mean(x); bwd gx[i] = gloss[0]*weight/n  (wali_gp, gan_inference.py:29-30). */
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
+
+/* reconstruction distances of tflib/utils/distance.py:3-17 (`distance(x, y, 'l1'|'l2')` = reduce_mean(|x-y|^p)), used by the
+ * alice / local_epce / vegan objectives as rec_penalty: out[0] (+)= weight * mean(|x-y|^p), p = 1 | 2; the backward writes
+ * gx and/or gy (either may be NULL). */
+int ggan_dist_fwd(const float* x, const float* y, float* out, size_t n, int p, float weight, int accumulate,
+                  ggan_stream_t stream);
+int ggan_dist_bwd(const float* x, const float* y, const float* gout, float* gx, float* gy, size_t n, int p,
+                  float weight, ggan_stream_t stream);
 /* slopes[b] = sqrt(sum_j g[b,j]^2); pen[0] = lam*mean_b((slopes-1)^2)  (gan_inference_cifar10.py:363-364).
  * bwd: gg[b,j] = gpen[0]*lam*2*(slopes[b]-1)/B * g[b,j]/slopes[b]. */
 int ggan_gp_penalty_fwd(const float* g, float* slopes, float* pen, int B, int D, float lam,

@@ -37,6 +37,24 @@ def weighted_local_epce_costs(disc_fake_list, disc_real_list, ratio_list):
     return gen, disc
 
 
+def distance(x, y, d_type):
+    """tflib/utils/distance.py:3-17"""
+    d = tp.add(x, tp.neg(y))
+    return tp.reduce_mean(tp.square(d)) if d_type == 'l2' else tp.reduce_mean(tp.absolute(d))
+
+
+def alice_costs(disc_fake, disc_real, rec_penalty):
+    """tflib/objs/gan_inference.py:162-184"""
+    g, d = ali_costs(disc_fake, disc_real)
+    return tp.add(g, rec_penalty), d
+
+
+def local_epce_costs(disc_fake_list, disc_real_list, rec_penalty):
+    """tflib/objs/gan_inference.py:121-149"""
+    g, d = local_ep_costs(disc_fake_list, disc_real_list)
+    return tp.add(g, rec_penalty), d
+
+
 def wali_gp_costs(disc_fake, disc_real, gradient_penalty):
     """tflib/objs/gan_inference.py:28-32."""
     gen = tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.reduce_mean(disc_real))

@@ -63,14 +63,29 @@ def forward(cfg, P, feed, mode='ali'):
     def critic(x, z):
         return N.Discriminator(cfg, P, x, z)
 
+    def rec_penalty():
+        """gan_inference_cifar10.py:264-304 / gmgan_inference_cifar10.py:348,399-403 (DISTANCE_X = 'l2')"""
+        r = None
+        if mode != 'alice-x':
+            r = J.distance(real_x, N.Generator(cfg, P, q_z), 'l2')
+        if mode in ('alice', 'alice-x'):
+            rz = J.distance(p_z, N.Extractor(cfg, P, fake_x), 'l2')
+            r = rz if r is None else tp.add(r, rz)
+        return r
+
     if cfg.K:
         d_fake = [N.HyperDiscriminator(cfg, P, p_z, onehot), critic(fake_x, p_z)]
         d_real = [N.HyperDiscriminator(cfg, P, q_z, q_k), critic(real_x, q_z)]
-        gen_cost, disc_cost = J.local_ep_costs(d_fake, d_real)
+        if mode == 'local_epce':
+            gen_cost, disc_cost = J.local_epce_costs(d_fake, d_real, rec_penalty())
+        else:
+            gen_cost, disc_cost = J.local_ep_costs(d_fake, d_real)
     else:
         d_fake, d_real = critic(fake_x, p_z), critic(real_x, q_z)
         if mode == 'ali':
             gen_cost, disc_cost = J.ali_costs(d_fake, d_real)
+        elif mode in ('alice', 'alice-z', 'alice-x'):
+            gen_cost, disc_cost = J.alice_costs(d_fake, d_real, rec_penalty())
         elif mode == 'wali-gp':
             gp = J.gradient_penalty(critic, real_x, fake_x, q_z, p_z, feed['alpha'])
             gen_cost, disc_cost = J.wali_gp_costs(d_fake, d_real, gp)
