@@ -56,6 +56,19 @@ def algorithmic_gflop_per_iteration(cfg):
     return total / 1e9
 
 
+def host_cores():
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota (the GPU boxes expose 256 logical
+    CPUs but grant 16; running the CPU baseline on 256 threads measured 0.6 img/s instead of 670)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def ssgan_gflop_per_iteration(cfg):
     """ssgan_inference_moving_mnist.py (MODE local_ep, mean-field posterior): GEMM-like layers, forward + exactly the
     gradients each step needs (critic frozen in the generator step; no data-gradient into input frames)."""
@@ -230,6 +243,13 @@ def main():
 
     # ---- CPU baseline: the numpy oracle (a port; the reference is Python2+TF1 and cannot run) ------------------
     cpu = None
+    blas_limit = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from threadpoolctl import threadpool_limits
+            blas_limit = threadpool_limits(limits=host_cores())
+        except ImportError:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline and ssgan:
         from oracle import ssgan as OSS
         ob = 2                                         # bounded sample: 2 sequences per minibatch instead of cfg.B
@@ -240,9 +260,31 @@ def main():
         t1 = time.perf_counter()
         otr.iteration(2, feeds)
         cdt = time.perf_counter() - t1
-        cpu = dict(value=round(ob / cdt, 3), unit='sequences/sec', cores=os.cpu_count(), kind='port',
+        cpu = dict(value=round(ob / cdt, 3), unit='sequences/sec', cores=host_cores(), kind='port',
                    sample='1 iteration (gen step + critic step) at %d sequences x 16 frames per minibatch, numpy fp32 '
                    'oracle with multi-threaded BLAS' % ob)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline and args.dataset == 'cifar10' and args.mode == 'ali':
+        # the same step on the host cores with PyTorch-CPU (oneDNN convolutions, every core): the closest stand-in for an
+        # optimised TensorFlow-CPU build of the reference, which cannot run here (oracle/torch_cpu.py)
+        from oracle import nets as ON, step as OS, torch_cpu
+        torch.set_num_threads(host_cores())
+        ocfg = ON.Cfg('cifar10', batch_size=cfg.B)
+        ts = torch_cpu.Step(ocfg, ON.init_params(ocfg, 0), torch.float32)
+        rng = np.random.default_rng(0)
+
+        def cpu_iteration():
+            for which in ('gen', 'disc'):
+                f = OS.make_feed(ocfg, rng, 'ali')
+                ts.step(which, OS.real_x_from_feed(ocfg, f, np.float32), f['p_z_noise'])
+        cpu_iteration()                                # warm-up (thread pool, oneDNN primitive cache)
+        n_cpu, t1 = 0, time.perf_counter()
+        while n_cpu < 3 or (time.perf_counter() - t1 < 10.0 and n_cpu < 2000):
+            cpu_iteration()
+            n_cpu += 1
+        cdt = time.perf_counter() - t1
+        cpu = dict(value=round(cfg.B * n_cpu / cdt, 1), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                   sample='%d iterations (gen step + critic step) of the same workload in %.1f s, PyTorch-CPU fp32 restatement '
+                   '(oneDNN convolutions, TF-SAME padding and TF-Adam emulated)' % (n_cpu, cdt))
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import nets as ON, step as OS
         ocfg = ON.Cfg(args.dataset, batch_size=cfg.B, n_coms=K)
@@ -253,7 +295,7 @@ def main():
         for j in range(args.cpu_iters):
             otr.iteration(2 + j, feeds)
         cdt = time.perf_counter() - t1
-        cpu = dict(value=round(cfg.B * args.cpu_iters / cdt, 2), unit='images/sec', cores=os.cpu_count(),
+        cpu = dict(value=round(cfg.B * args.cpu_iters / cdt, 2), unit='images/sec', cores=host_cores(),
                    kind='port', sample='%d iterations (gen step + %d critic step(s)) of the same workload, numpy fp32 '
                    'oracle with multi-threaded BLAS' % (args.cpu_iters, cfg.critic_iters))
 

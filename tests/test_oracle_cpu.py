@@ -85,62 +85,34 @@ def test_conv_family_vs_torch(H, cin, cout):
 
 
 def test_full_step_vs_torch_autograd():
-    """The whole gen/disc cost graph (cifar ali, small dims) rebuilt with torch-CPU float64 ops + autograd."""
+    """The whole gen/disc cost graph (cifar ali, small dims) rebuilt with torch-CPU float64 ops + autograd
+    (oracle/torch_cpu.py, also the CPU baseline of bench.py), and two Adam steps of it against the numpy Trainer."""
     import torch
-    import torch.nn.functional as F
+    from oracle import torch_cpu
     cfg = N.Cfg('cifar10', batch_size=4, dim=4, dim_latent=8)
     P0 = {k: v.astype(np.float64) for k, v in N.init_params(cfg, 3).items()}
     feed = S.make_feed(cfg, np.random.default_rng(5))
     Pt = {k: tp.T(v) for k, v in P0.items()}
     out = S.forward(cfg, Pt, feed, 'ali')
-    T = {k: torch.tensor(v, requires_grad=True) for k, v in P0.items()}
-
-    def conv(x, name):
-        return F.conv2d(F.pad(x, (1, 2, 1, 2)), T[name + '.Filters'].permute(3, 2, 0, 1), T[name + '.Biases'], stride=2)
-
-    def deconv(x, name):
-        H = x.shape[2]
-        y = F.conv_transpose2d(x, T[name + '.Filters'].permute(3, 2, 0, 1), stride=2)[:, :, 1:1 + 2 * H, 1:1 + 2 * H]
-        return y + T[name + '.Biases'].view(1, -1, 1, 1)
-
-    def bn(x, name, axes):
-        m = x.mean(axes, keepdim=True)
-        v = ((x - m) ** 2).mean(axes, keepdim=True)
-        shp = [1 if i in axes else s for i, s in enumerate(x.shape)]
-        return T[name + '.scale'].view(shp) * (x - m) / torch.sqrt(v + 1e-5) + T[name + '.offset'].view(shp)
-    lrelu = lambda x: torch.maximum(0.2 * x, x)
-    real = torch.tensor(S.real_x_from_feed(cfg, feed, np.float64)).view(-1, 3, 32, 32)
-    e = lrelu(conv(real, 'Extractor.1'))
-    e = lrelu(bn(conv(e, 'Extractor.2'), 'Extractor.BN2', (0, 2, 3)))
-    e = lrelu(bn(conv(e, 'Extractor.3'), 'Extractor.BN3', (0, 2, 3)))
-    q_z = e.reshape(4, -1) @ T['Extractor.Output.W'] + T['Extractor.Output.b']
-    p_z = torch.tensor(feed['p_z_noise'].astype(np.float64))
-    g = torch.relu(bn(p_z @ T['Generator.Input.W'] + T['Generator.Input.b'], 'Generator.BN1', (0,)))
-    g = g.view(-1, 16, 4, 4)
-    g = torch.relu(bn(deconv(g, 'Generator.2'), 'Generator.BN2', (0, 2, 3)))
-    g = torch.relu(bn(deconv(g, 'Generator.3'), 'Generator.BN3', (0, 2, 3)))
-    fake = torch.tanh(deconv(g, 'Generator.5'))
-
-    def D(x, z):
-        o = x
-        for i in (1, 2, 3):
-            o = lrelu(conv(o, 'Discriminator.%d' % i))
-        zo = lrelu(z @ T['Discriminator.z1.W'] + T['Discriminator.z1.b'])
-        o = torch.cat([o.reshape(4, -1), zo], 1)
-        o = lrelu(o @ T['Discriminator.zx1.W'] + T['Discriminator.zx1.b'])
-        return (o @ T['Discriminator.Output.W'] + T['Discriminator.Output.b']).view(-1)
-    df, dr = D(fake, p_z), D(real, q_z)
-    bce = F.binary_cross_entropy_with_logits
-    gen = bce(df, torch.ones_like(df)) + bce(dr, torch.zeros_like(dr))
-    disc = bce(df, torch.zeros_like(df)) + bce(dr, torch.ones_like(dr))
+    ts = torch_cpu.Step(cfg, P0, torch.float64)
+    real = S.real_x_from_feed(cfg, feed, np.float64)
+    gen, disc = ts.costs(real, feed['p_z_noise'])
     assert abs(float(gen) - float(out['gen_cost'].v)) < 1e-12
     assert abs(float(disc) - float(out['disc_cost'].v)) < 1e-12
     for cost_t, cost_o, sub in ((gen, out['gen_cost'], ('Generator', 'Extractor')), (disc, out['disc_cost'], ('Discriminator',))):
         names = [n for n in N.trainable(list(P0)) if any(s in n for s in sub)]
-        tg = torch.autograd.grad(cost_t, [T[n] for n in names], retain_graph=True, allow_unused=True)
+        tg = torch.autograd.grad(cost_t, [ts.T[n] for n in names], retain_graph=True, allow_unused=True)
         og = tp.grad(cost_o, [Pt[n] for n in names])
         for n, a, b in zip(names, tg, og):
             assert np.abs(a.numpy() - b.v).max() < 1e-10, n
+    otr = S.Trainer(cfg, P0, 'ali', np.float64)
+    for which in ('disc', 'gen'):
+        f = S.make_feed(cfg, np.random.default_rng(6 if which == 'disc' else 7))
+        co = otr.disc_step(f) if which == 'disc' else otr.gen_step(f)
+        ct = ts.step(which, S.real_x_from_feed(cfg, f, np.float64), f['p_z_noise'])
+        assert abs(co - ct) < 1e-10
+    for n in ('Discriminator.zx1.W', 'Generator.3.Filters', 'Extractor.BN2.scale'):
+        assert np.abs(ts.T[n].detach().numpy() - otr.P[n]).max() < 1e-9, n
 
 
 # ---- (ii) finite differences ---------------------------------------------------------------------------------
