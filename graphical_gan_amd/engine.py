@@ -21,6 +21,11 @@ from . import functional as F
 from .models import GraphicalGAN
 
 
+# Other host threads keep calling into the HIP runtime while a step is being captured (the RCCL process group's watchdog polls
+# events of finished collectives): thread-local capture mode keeps those calls from invalidating the capture.
+_CAPTURE_MODE = os.environ.get('GGAN_CAPTURE_MODE', 'thread_local')
+
+
 class Trainer(object):
     def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None):
         """model: an object with forward_nets / forward / feed_buffers / sample_noise / set_batch / single_contribution
@@ -109,7 +114,7 @@ class Trainer(object):
         torch.cuda.synchronize(self.device)
         g1 = torch.cuda.CUDAGraph()
         if not self.split_graph:
-            with torch.cuda.graph(g1, stream=s):
+            with torch.cuda.graph(g1, stream=s, capture_error_mode=_CAPTURE_MODE):
                 cost, opt, keep = self._fwd_bwd(which)
                 opt.update()
             return dict(g0=None, g1=g1, g2=None, cost=cost, opt=opt, keep=keep)
@@ -119,12 +124,12 @@ class Trainer(object):
         g0, nets = None, None
         if which == 'gen':
             g0 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g0, stream=s):
+            with torch.cuda.graph(g0, stream=s, capture_error_mode=_CAPTURE_MODE):
                 nets = self._nets()
-        with torch.cuda.graph(g1, stream=s, pool=g0.pool() if g0 is not None else None):
+        with torch.cuda.graph(g1, stream=s, pool=g0.pool() if g0 is not None else None, capture_error_mode=_CAPTURE_MODE):
             cost, opt, keep = self._fwd_bwd(which, nets)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, stream=s):
+        with torch.cuda.graph(g2, stream=s, capture_error_mode=_CAPTURE_MODE):
             opt.update()
         return dict(g0=g0, g1=g1, g2=g2, cost=cost, opt=opt, keep=(keep, nets))
 
