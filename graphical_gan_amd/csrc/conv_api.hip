@@ -53,6 +53,59 @@ static int bwd_data(const ggan_conv_geom* g, const float* gy, GyMask m, const fl
     return conv_dgrad_naive(*g, gy, m, w, bias, gx, act, alpha, s);
 }
 
+// out[row][w'] = in[row][w' - shift] (0 outside [0, W)), optionally times the activation derivative of ref at the same place
+__global__ void pad_width_k(const float* __restrict__ in, const float* __restrict__ ref, float* __restrict__ out, size_t rows,
+                            int W, int Wp, int shift, int act, float alpha) {
+    const size_t total = rows * (size_t)Wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / Wp;
+        const int w = (int)(i - r * Wp) - shift;
+        float v = 0.f;
+        if (w >= 0 && w < W) {
+            v = in[r * W + w];
+            if (ref) v = act_grad(v, ref[r * W + w], act, alpha);
+        }
+        out[i] = v;
+    }
+}
+
+// Filter gradient of a 5x5 / stride-2 conv whose width the MFMA kernel does not take (MNIST: 28, 14, 7 wide; SAME pad_l = 2
+// at 7): the same sum over zero-extended copies.  x gets `pad_l - 1` zero columns in front and zeros behind up to W' = 2*Wo',
+// gy zeros behind up to Wo' (a multiple of 4): every added product has a zero factor, and SAME padding of W' -> Wo' is
+// (1, 2) again, so the widened problem IS the original one.  Two small copy launches instead of the one-thread-per-output
+// fallback (which made the MNIST step 10x slower than the CIFAR one).
+static int wgrad_widened(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
+                         size_t ws_bytes, hipStream_t s) {
+    if (g.k != 5 || g.stride != 2 || (g.pad_l != 1 && g.pad_l != 2)) return 1;
+    const int shift = g.pad_l - 1;
+    int Wop = (g.Wo + 3) & ~3;
+    while (2 * Wop < g.W + shift) Wop += 4;
+    const int Wp = 2 * Wop;
+    if (Wop > 64) return 1;
+    ws = ws_scratch(ws, ws_bytes);
+    const size_t xr = (size_t)g.N * g.Ci * g.H, gr = (size_t)g.N * g.Co * g.Ho;
+    const size_t xb = (xr * Wp * sizeof(float) + 255) & ~(size_t)255, gb = (gr * Wop * sizeof(float) + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < xb + gb + (1u << 20)) return 1;
+    float* xp = (float*)ws;
+    float* gp = (float*)((char*)ws + xb);
+    auto blocks = [](size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+    GGAN_LAUNCH("pad_width_k", 0, 8.0 * xr * Wp, pad_width_k, dim3(blocks(xr * Wp)), dim3(256), 0, s, x, (const float*)nullptr, xp, xr,
+                g.W, Wp, shift, 0, 0.f);
+    GGAN_LAUNCH("pad_width_k", 0, 8.0 * gr * Wop, pad_width_k, dim3(blocks(gr * Wop)), dim3(256), 0, s, gy,
+                m.act != GGAN_ACT_NONE ? m.ref : (const float*)nullptr, gp, gr, g.Wo, Wop, 0, m.act, m.alpha);
+    ggan_conv_geom gp2 = g;
+    gp2.W = Wp; gp2.Wo = Wop; gp2.pad_l = 1;
+    void* rest = (char*)ws + xb + gb;
+    const size_t rest_bytes = ws_bytes - xb - gb;
+    const GyMask none{nullptr, GGAN_ACT_NONE, 0.f};
+    int r = conv_wgrad_mfma(gp2, xp, gp, none, gw, gbias, rest, rest_bytes, s);
+    if (r == 1 && gbias) {     // tile shape without the in-kernel bias sum: channel sums of the widened (already masked) gy instead
+        r = conv_wgrad_mfma(gp2, xp, gp, none, gw, nullptr, rest, rest_bytes, s);
+        if (r == 0) r = ggan_chansum(gp, gbias, g.N, g.Co, g.Ho * Wop, rest, rest_bytes, (ggan_stream_t)s);
+    }
+    return r;
+}
+
 static int bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                       size_t ws_bytes, ggan_stream_t stream) {
     if (check_geom(g)) return -1;
@@ -61,12 +114,17 @@ static int bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, 
     if (!g_force_naive && !getenv("GGAN_NAIVE_WGRAD")) {
         int r = conv_wgrad_mfma(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
+        r = wgrad_widened(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
+        if (r <= 0) return r;
     }
     if (gbias) {   // plain path: separate reduction (needs the masked gradient materialised only when a mask is given)
         if (m.act != GGAN_ACT_NONE) return 1;   // masked bias gradient only exists fused: caller uses act_bwd + the plain entry points
         int r = ggan_chansum(gy, gbias, g->N, g->Co, g->Ho * g->Wo, ws, ws_bytes, stream);
         if (r) return r;
     }
+    if (getenv("GGAN_TRACE_NAIVE"))
+        fprintf(stderr, "[ggan] plain filter-gradient kernel for N=%d Ci=%d H=%d W=%d Co=%d Ho=%d Wo=%d k=%d s=%d pad=(%d,%d)\n", g->N, g->Ci,
+                g->H, g->W, g->Co, g->Ho, g->Wo, g->k, g->stride, g->pad_t, g->pad_l);
     return conv_wgrad_naive(*g, x, gy, m, gw, s);
 }
 
