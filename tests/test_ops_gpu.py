@@ -296,3 +296,154 @@ def test_gemm_colsum_and_splitk_is_deterministic(gpu):
     assert _rel(outs[0], x.astype(np.float64) @ w.astype(np.float64)) < 2e-5
     ws = F.workspace(gpu)
     assert int(ws[:16384].view(torch.int32).abs().sum()) == 0             # arrival counters left at zero
+
+
+# ---- entry points added for launch fusion: each against numpy, through the C ABI --------------------------------------------
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_pack_parts_sums_slabs_and_bumps_counter(gpu):
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((3, 1000 + 12)).astype(np.float32)        # 3 slabs, stride 1012, payload 1000
+    b = rng.standard_normal(77).astype(np.float32)
+    ta, tb = _t(a, gpu), _t(b, gpu)
+    flat = torch.zeros(2048, device=gpu)
+    step = torch.zeros(1, dtype=torch.int32, device=gpu)
+    L = _lib.load()
+    srcs = (C.c_void_p * 2)(ta.data_ptr(), tb.data_ptr())
+    sizes = (C.c_size_t * 2)(1000, 77)
+    offs = (C.c_size_t * 2)(0, 1024)
+    parts = (C.c_int * 2)(3, 1)
+    strides = (C.c_size_t * 2)(1012, 0)
+    for k in range(2):
+        assert L.ggan_pack_parts(srcs, sizes, offs, parts, strides, 2, _ptr(flat), _ptr(step), _stream()) == 0
+    out = flat.cpu().numpy()
+    ref = (a[0, :1000] + a[1, :1000]) + a[2, :1000]                   # slab order
+    assert np.array_equal(out[:1000], ref) and np.array_equal(out[1024:1024 + 77], b) and int(step.item()) == 2
+
+
+def test_bce_multi_equals_per_term_launches(gpu):
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(1)
+    xs = [_t(3 * rng.standard_normal(n), gpu).requires_grad_(True) for n in (64, 128, 7)]
+    labels, weights = (1.0, 0.0, 1.0), (0.5, 0.25, 2.0)
+    loss = F.BceSum.apply(labels, weights, *xs)
+    gs = torch.autograd.grad(loss, xs)
+    ref, refg = 0.0, []
+    for x, z, w in zip(xs, labels, weights):
+        v = x.detach().cpu().numpy().astype(np.float64)
+        ref += w * np.mean(np.maximum(v, 0) - v * z + np.log1p(np.exp(-np.abs(v))))
+        refg.append(w * (1 / (1 + np.exp(-v)) - z) / v.size)
+    assert abs(float(loss.detach()) - ref) <= 1e-6 * abs(ref)
+    for g, r in zip(gs, refg):
+        assert _rel(g.cpu().numpy(), r) < 1e-6
+    # the gradients of the terms sit back to back in one buffer (lets SplitRows.backward skip the concatenation)
+    assert gs[1].data_ptr() == gs[0].data_ptr() + 4 * 64
+
+
+@pytest.mark.parametrize('p', [1, 2])
+def test_distance(gpu, p):
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal((16, 3072)), rng.standard_normal((16, 3072))
+    tx, ty = _t(x, gpu).requires_grad_(True), _t(y, gpu).requires_grad_(True)
+    d = F.Distance.apply(tx, ty, p, 1.0)
+    gx, gy = torch.autograd.grad(d, [tx, ty])
+    diff = x.astype(np.float32).astype(np.float64) - y.astype(np.float32).astype(np.float64)
+    ref = np.mean(np.abs(diff) ** p)
+    rg = (2 * diff if p == 2 else np.sign(diff)) / diff.size
+    assert abs(float(d.detach()) - ref) <= 2e-6 * ref
+    assert _rel(gx.cpu().numpy(), rg) < 1e-6 and _rel(gy.cpu().numpy(), -rg) < 1e-6 and gx.shape == tx.shape
+
+
+@pytest.mark.parametrize('mnk', [(64, 512, 128), (128, 512, 640), (37, 50, 19)])
+def test_linear_backward_with_fused_activation_mask(gpu, mnk):
+    """ggan_linear_bwd_data_act / _weight_act: dx = (g*act'(y)) w^T, dw = x^T (g*act'(y)), db = colsum."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    M, N, K = mnk
+    rng = np.random.default_rng(3)
+    x, w = rng.standard_normal((M, K)), rng.standard_normal((K, N)) / np.sqrt(K)
+    g, y = rng.standard_normal((M, N)), rng.standard_normal((M, N))
+    tx, tw, tg, ty = (_t(a, gpu) for a in (x, w, g, y))
+    dx, dw, db = torch.empty(M, K, device=gpu), torch.empty(K, N, device=gpu), torch.empty(N, device=gpu)
+    ws = F.workspace(tx.device)
+    L = _lib.load()
+    assert L.ggan_linear_bwd_data_act(M, N, K, _ptr(tg), _ptr(ty), 1, 0.2, _ptr(tw), _ptr(dx), _ptr(ws), ws.numel(), _stream()) == 0
+    assert L.ggan_linear_bwd_weight_act(M, N, K, _ptr(tx), _ptr(tg), _ptr(ty), 1, 0.2, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
+                                        _stream()) == 0
+    f64 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    gm = f64(g) * np.where(f64(y) > 0, 1.0, 0.2)
+    assert _rel(dx.cpu().numpy(), gm @ f64(w).T) < 2e-5
+    assert _rel(dw.cpu().numpy(), f64(x).T @ gm) < 2e-5
+    assert _rel(db.cpu().numpy(), gm.sum(0)) < 2e-5
+
+
+def test_bn_backward_with_mask_and_channel_sums(gpu):
+    """ggan_bn_bwd_act: relu derivative applied on load, and sum_{n,h,w} gx per channel as a by-product."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from oracle import tape as tp
+    rng = np.random.default_rng(4)
+    N, Cc, H = 16, 12, 8
+    x = rng.standard_normal((N, Cc, H, H)); sc = 1 + 0.1 * rng.standard_normal(Cc); of = 0.1 * rng.standard_normal(Cc)
+    gy = rng.standard_normal((N, Cc, H, H))
+    X, S_, O = tp.T(x), tp.T(sc), tp.T(of)
+    yo = tp.relu(tp.batchnorm_train(X, S_, O, [0, 2, 3], 1e-5))
+    gxo, gso, goo = tp.grad(tp.reduce_sum(tp.mul(yo, tp.T(gy))), [X, S_, O])
+    tx = _t(x, gpu).requires_grad_(True); ts = _t(sc, gpu).requires_grad_(True); to = _t(of, gpu).requires_grad_(True)
+    y = F.BatchNormTrain.apply(tx, ts, to, 1e-5, 2, 0.0)
+    gx, gs, go = torch.autograd.grad(y, [tx, ts, to], grad_outputs=_t(gy, gpu))
+    assert _rel(gx.cpu().numpy(), gxo.v) < 2e-5 and _rel(gs.cpu().numpy().reshape(-1), gso.v.reshape(-1)) < 2e-5
+    assert _rel(go.cpu().numpy().reshape(-1), goo.v.reshape(-1)) < 2e-5
+    cs = getattr(gx, '_ggan_chansum', None)
+    assert cs is not None
+    assert np.abs(cs.cpu().numpy() - gx.cpu().numpy().astype(np.float64).sum((0, 2, 3))).max() <= 1e-4
+
+
+@pytest.mark.parametrize('case', [(64, 64, 16, 128), (8, 3, 32, 64), (6, 1, 28, 64), (5, 64, 14, 128), (5, 128, 7, 256)])
+def test_filter_gradient_parts_and_widened_paths(gpu, case):
+    """ggan_conv2d_bwd_filter_parts (slabs + bias tails, summed here) and ggan_conv2d_bwd_filter_act (incl. the zero-extended
+    path of the 28/14/7-wide MNIST layers) with the LeakyReLU mask, against the oracle."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from oracle import ops as O
+    N, Ci, H, Co = case
+    rng = np.random.default_rng(5)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2)
+    Ho = geom[5]
+    x = rng.standard_normal((N, Ci, H, H)).astype(np.float32)
+    gy = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    y = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    g2 = gy.astype(np.float64) * np.where(y > 0, 1.0, 0.2)
+    ref_w = O.conv2d_bwd_filter(x.astype(np.float64), g2, 5, 2)
+    ref_b = g2.sum((0, 2, 3))
+    tx, tg, ty = _t(x, gpu), _t(gy, gpu), _t(y, gpu)
+    L = _lib.load()
+    G = F._geom(geom)
+    ws = F.workspace(tx.device)
+    gw, gb = torch.empty(5, 5, Ci, Co, device=gpu), torch.empty(Co, device=gpu)
+    rc = L.ggan_conv2d_bwd_filter_act(C.byref(G), _ptr(tx), _ptr(tg), _ptr(ty), 1, 0.2, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
+    assert rc == 0
+    assert _rel(gw.cpu().numpy(), ref_w) < 3e-5 and _rel(gb.cpu().numpy(), ref_b) < 3e-5
+    elems = 25 * Ci * Co
+    cap = 64 * (elems + Co)
+    part = torch.empty(cap, device=gpu)
+    n, st = C.c_int(0), C.c_size_t(0)
+    rc = L.ggan_conv2d_bwd_filter_parts(C.byref(G), _ptr(tx), _ptr(tg), _ptr(ty), 1, 0.2, 1, _ptr(part), cap, C.byref(n), C.byref(st), _stream())
+    if H in (28, 14, 7):
+        assert rc == 1                  # widths the slab kernel does not take: caller uses the entry point above
+        return
+    assert rc == 0 and n.value >= 1 and st.value == elems + Co
+    slabs = part[:n.value * st.value].cpu().numpy().astype(np.float64).reshape(n.value, st.value).sum(0)
+    assert _rel(slabs[:elems].reshape(5, 5, Ci, Co), ref_w) < 3e-5 and _rel(slabs[elems:], ref_b) < 3e-5
