@@ -118,14 +118,13 @@ class Trainer(object):
                 cost, opt, keep = self._fwd_bwd(which)
                 opt.update()
             return dict(g0=None, g1=g1, g2=None, cost=cost, opt=opt, keep=keep)
-        # data parallel: [forward + backward + pack] -> all-reduce -> [Adam].  A generator step is cut once more, after
-        # the Extractor/Generator passes (g0): they read no critic variable, so they run while the previous critic step's
-        # gradient exchange is still on the wire (step()).
-        g0, nets = None, None
-        if which == 'gen':
-            g0 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g0, stream=s, capture_error_mode=_CAPTURE_MODE):
-                nets = self._nets()
+        # data parallel: [forward + backward + pack] -> all-reduce -> [Adam].  Every step is cut once more, after the
+        # Extractor/Generator passes (g0): they read no critic variable, so they run while the previous critic step's gradient
+        # exchange is still on the wire (step()) -- under the next generator step, or under the next critic step when
+        # CRITIC_ITERS > 1.
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, stream=s, capture_error_mode=_CAPTURE_MODE):
+            nets = self._nets()
         with torch.cuda.graph(g1, stream=s, pool=g0.pool() if g0 is not None else None, capture_error_mode=_CAPTURE_MODE):
             cost, opt, keep = self._fwd_bwd(which, nets)
         g2 = torch.cuda.CUDAGraph()

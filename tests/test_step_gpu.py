@@ -128,9 +128,11 @@ def test_trajectory(gpu, case, graph):
         assert (d > 2e-5).mean() <= 0.02, (n, (d > 2e-5).mean())
 
 
-def test_split_graph_path_matches_single_graph(gpu, monkeypatch):
-    """The data-parallel step runs as [fwd+bwd+pack graph] -> all-reduce -> [Adam graph].  Exercise that exact code path
-    on one GPU (1-rank no-op collective) and require bit-identical weights vs the single-graph path."""
+@pytest.mark.parametrize('mode', ['ali', 'wali-gp'])
+def test_split_graph_path_matches_single_graph(gpu, monkeypatch, mode):
+    """The data-parallel step runs as [nets graph] (pending critic Adam) [critic + backward + pack graph] -> all-reduce ->
+    [Adam graph].  Exercise that exact code path on one GPU (1-rank no-op collective) and require bit-identical weights vs
+    the single-graph path (wali-gp: five critic steps per generator step, the deferred Adam lands under the next critic step)."""
     import torch
     from oracle import step as S
     res = []
@@ -139,9 +141,9 @@ def test_split_graph_path_matches_single_graph(gpu, monkeypatch):
             monkeypatch.setenv('GGAN_FORCE_SPLIT_GRAPH', '1')
         else:
             monkeypatch.delenv('GGAN_FORCE_SPLIT_GRAPH', raising=False)
-        ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, 'ali', 8, 16, True, True, gpu)
+        ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, mode, 8, 16, True, True, gpu)
         assert tr.split_graph == force
-        feeds = iter([S.make_feed(ocfg, np.random.default_rng(300 + i), 'ali') for i in range(12)])
+        feeds = iter([S.make_feed(ocfg, np.random.default_rng(300 + i), mode) for i in range(40)])
         for it in range(5):
             tr.iteration(it, feeds)
         torch.cuda.synchronize()
