@@ -75,6 +75,7 @@ SIGNATURES = {
     'ggan_gp_penalty_bwd': (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     'ggan_adam_step': (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P]),
     'ggan_adam_advance': (_I, [_P, _P]),
+    'ggan_rmsprop_step': (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _F, _F, _P]),
     'ggan_adam_step_counted': (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P]),
     'ggan_pack': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), _I, _P, _P]),
     'ggan_pack_parts': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), _I, _P, _P, _P]),

@@ -302,6 +302,18 @@ __global__ void adam_k(float* __restrict__ theta, const float* __restrict__ g, f
 
 __global__ void adam_advance_k(int32_t* step) { step[0] += 1; }
 
+// tf.train.RMSPropOptimizer (momentum 0, centered=False): ms = decay*ms + (1-decay)*g^2; theta -= lr*g/sqrt(ms+eps);
+// then (optionally) the weight clipping of the original WGAN, tf.clip_by_value(var, lo, hi)
+__global__ void rmsprop_k(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ ms, size_t n, float lr,
+                          float decay, float eps, float gscale, float lo, float hi) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gg = g[i] * gscale;
+        const float m = decay * ms[i] + (1.f - decay) * gg * gg;
+        ms[i] = m;
+        theta[i] = fminf(fmaxf(theta[i] - lr * gg / sqrtf(m + eps), lo), hi);
+    }
+}
+
 struct PackTable {
     const float* src[GGAN_PACK_MAX];
     size_t size[GGAN_PACK_MAX];
@@ -531,6 +543,16 @@ int ggan_adam_step_counted(float* theta, const float* g, float* m, float* v, siz
     if (n == 0) return 0;
     GGAN_CHECK_ARG(aligned16(theta) && aligned16(g) && aligned16(m) && aligned16(v), "buffers must be 16-byte aligned");
     GGAN_LAUNCH("adam_step", 0, 28.0 * n, adam_k<true>, dim3(grid_for(n, 8)), dim3(kBlock), 0, (hipStream_t)stream, theta, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale);
+    return 0;
+}
+
+int ggan_rmsprop_step(float* theta, const float* g, float* ms, size_t n, float lr, float decay, float eps, float grad_scale,
+                      float clip_lo, float clip_hi, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(theta && g && ms, "null pointer");
+    GGAN_CHECK_ARG(clip_lo <= clip_hi, "empty clip interval");
+    if (n == 0) return 0;
+    GGAN_LAUNCH("rmsprop_step", 0, 20.0 * n, rmsprop_k, dim3(grid_for(n, 8)), dim3(kBlock), 0, (hipStream_t)stream, theta, g, ms, n, lr,
+                decay, eps, grad_scale, clip_lo, clip_hi);
     return 0;
 }
 

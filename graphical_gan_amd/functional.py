@@ -834,6 +834,12 @@ def adam_step_(theta, g, m, v, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0,
     check(L.ggan_adam_advance(_p(step), _stream()), 'ggan_adam_advance')
 
 
+def rmsprop_step_(theta, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, clip=None):
+    lo, hi = (float('-inf'), float('inf')) if clip is None else (float(clip[0]), float(clip[1]))
+    check(_L().ggan_rmsprop_step(_p(theta), _p(g), _p(ms), theta.numel(), lr, decay, eps, grad_scale, lo, hi, _stream()),
+          'ggan_rmsprop_step')
+
+
 def pack_(tensors, offsets, flat, bump=None):
     """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros); tensors registered by `defer_wgrad_reduce` are
     summed over their split-K slabs on the way.  bump: int32 device counter incremented once (the Adam step ordinal)."""

@@ -118,6 +118,19 @@ class AdamOptimizer(object):
         return dict(m=self.m.clone(), v=self.v.clone(), step=self.step.clone())
 
 
+class RMSPropOptimizer(AdamOptimizer):
+    """tf.train.RMSPropOptimizer(learning_rate) with TF's defaults (decay .9, momentum 0, epsilon 1e-10, ms starts at 1) over
+    the same flat buffers; `clip`: the wali objective's weight clipping folded into the update kernel."""
+
+    def __init__(self, params, lr=5e-5, decay=0.9, eps=1e-10, clip=None):
+        AdamOptimizer.__init__(self, params, lr=lr)
+        self.decay, self.eps, self.clip = float(decay), float(eps), clip
+        self.m.fill_(1.0)                    # `ms` slot (TF initialises it with ones); self.v is unused
+
+    def update(self):
+        F.rmsprop_step_(self.theta, self.g, self.m, self.lr, self.decay, self.eps, self.bucket.scale, self.clip)
+
+
 class TrainOp(object):
     """What the reference's `*_train_op` is: running it applies one Adam step for `cost`."""
 
@@ -139,7 +152,8 @@ def get_optimizer(role, params, **hp):
     key = (role, tuple(id(p) for p in params if p.requires_grad), tuple(sorted(hp.items())))
     opt = _optimizers.get(key)
     if opt is None:
-        opt = AdamOptimizer(params, **hp)
+        kind = hp.pop('kind', 'adam')
+        opt = RMSPropOptimizer(params, **hp) if kind == 'rmsprop' else AdamOptimizer(params, **hp)
         _optimizers[key] = opt
         if role in _pending_state:                      # a checkpoint restored before this optimizer existed
             load_adam_state(opt, _pending_state.pop(role))

@@ -1,6 +1,6 @@
 """Objectives of tflib/objs/gan_inference.py: ali (:47-79), local_ep (:81-119), weighted_local_epce (:307-358),
 wali_gp (:28-45), and the reconstruction variants local_epce (:121-160), alice (:162-195), vegan (:197-225),
-vegan_wgan_gp (:227-244).  (wali = RMSProp + weight clipping, :4-26, is not built.)  Same signatures and return tuples; `*_train_op` are
+vegan_wgan_gp (:227-244).  wali (:4-26, RMSProp + weight clipping).  Same signatures and return tuples; `*_train_op` are
 callables (TrainOp) that run backward + one TF-flavoured Adam step, the costs are 0-dim device tensors.
 Losses are single fused kernels (ggan_bce_logits_* / ggan_mean_*), not per-term pointwise graphs."""
 import numpy as np
@@ -116,6 +116,18 @@ def weighted_local_epce(disc_fake_list, disc_real_list, ratio_list, gen_params, 
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
     return (gen_cost, disc_cost, gen_debug_list, disc_debug_list,
             TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost))
+
+
+def wali(disc_fake, disc_real, gen_params, disc_params, lr=5e-5):
+    """tflib/objs/gan_inference.py:4-26: Wasserstein costs, two RMSProp optimizers, critic weights clipped to [-.01, .01].
+    Returns the reference's 6-tuple; `clip_disc_weights` / `clip_ops` are no-op callables here because the clipping is part
+    of the critic's update kernel (the reference runs it as a separate session.run right after the critic step)."""
+    gen_cost = F.MeanSum.apply((-1.0, -1.0), disc_fake, disc_real) if ONLY[0] != 'disc' else None
+    disc_cost = F.MeanSum.apply((1.0, -1.0), disc_fake, disc_real) if ONLY[0] != 'gen' else None
+    gen_opt = get_optimizer('gen', gen_params, kind='rmsprop', lr=lr)
+    disc_opt = get_optimizer('disc', disc_params, kind='rmsprop', lr=lr, clip=(-.01, .01))
+    noop = lambda: None
+    return gen_cost, disc_cost, noop, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost), [noop]
 
 
 def wali_gp(disc_fake, disc_real, gradient_penalty, gen_params, disc_params, lr=1e-4):

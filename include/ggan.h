@@ -193,6 +193,12 @@ int ggan_gp_penalty_bwd(const float* g, const float* slopes, const float* gpen, 
 int ggan_adam_step(float* theta, const float* g, float* m, float* v, size_t n, const int32_t* step,
                    float lr, float beta1, float beta2, float eps, float grad_scale, ggan_stream_t stream);
 int ggan_adam_advance(int32_t* step, ggan_stream_t stream);
+
+/* tf.train.RMSPropOptimizer step over a flat buffer (decay 0.9, momentum 0, eps 1e-10 are TF's defaults), followed by the
+ * weight clipping of the `wali` objective (tflib/objs/gan_inference.py:4-26: tf.clip_by_value(var, -.01, .01) on the critic);
+ * pass clip_lo = -INFINITY, clip_hi = INFINITY for no clipping.  ms is initialised to 1.0 by TF. */
+int ggan_rmsprop_step(float* theta, const float* g, float* ms, size_t n, float lr, float decay, float eps,
+                      float grad_scale, float clip_lo, float clip_hi, ggan_stream_t stream);
 /* Adam step whose counter was already advanced: *step holds THIS update's ordinal t (>= 1), e.g. incremented by the
  * ggan_pack_parts launch of the same optimizer step (its `bump` argument) -- no separate ggan_adam_advance launch. */
 int ggan_adam_step_counted(float* theta, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr,

@@ -447,3 +447,30 @@ def test_filter_gradient_parts_and_widened_paths(gpu, case):
     assert rc == 0 and n.value >= 1 and st.value == elems + Co
     slabs = part[:n.value * st.value].cpu().numpy().astype(np.float64).reshape(n.value, st.value).sum(0)
     assert _rel(slabs[:elems].reshape(5, 5, Ci, Co), ref_w) < 3e-5 and _rel(slabs[elems:], ref_b) < 3e-5
+
+
+def test_rmsprop_with_clipping_and_wali_costs(gpu):
+    """ggan_rmsprop_step (TF RMSProp defaults + the wali weight clipping) and the wali costs' signs."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(6)
+    th = (0.02 * rng.standard_normal(5000)).astype(np.float32)
+    ms = np.ones(5000, np.float32)
+    t_th, t_ms = _t(th, gpu), _t(ms, gpu)
+    ref_th, ref_ms = th.astype(np.float64), ms.astype(np.float64)
+    for k in range(3):
+        g = rng.standard_normal(5000).astype(np.float32)
+        F.rmsprop_step_(t_th, _t(g, gpu), t_ms, 5e-5, clip=(-.01, .01))
+        ref_ms = 0.9 * ref_ms + 0.1 * g.astype(np.float64) ** 2
+        ref_th = np.clip(ref_th - 5e-5 * g / np.sqrt(ref_ms + 1e-10), -.01, .01)
+    assert np.abs(t_th.cpu().numpy() - ref_th).max() <= 1e-7 and _rel(t_ms.cpu().numpy(), ref_ms) < 1e-6
+    assert float(t_th.abs().max()) <= 0.01 + 1e-9
+    from graphical_gan_amd import tflib as lib, optim
+    optim.reset_optimizers(); lib.delete_all_params()
+    pg = lib.param('Generator.w', np.ones(4, np.float32)); pd = lib.param('Discriminator.w', np.ones(4, np.float32))
+    df, dr = (pg * pd).sum() * torch.ones(8, device=gpu), (pd * 2).sum() * torch.ones(8, device=gpu)
+    gen_cost, disc_cost, clip, gop, dop, clip_ops = lib.objs.gan_inference.wali(df, dr, [pg], [pd])
+    assert abs(float(gen_cost.detach()) - (-4.0 - 8.0)) < 1e-5 and abs(float(disc_cost.detach()) - (4.0 - 8.0)) < 1e-5
+    dop()
+    assert float(pd.detach().abs().max()) <= 0.01 + 1e-9          # critic weights clipped by the update itself
+    optim.reset_optimizers(); lib.delete_all_params()
