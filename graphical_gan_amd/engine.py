@@ -46,8 +46,8 @@ class Trainer(object):
         # data-parallel runs split the step graph around the gradient all-reduce; the flag lets a single GPU exercise
         # exactly that code path (the collective is then a 1-rank no-op)
         self.split_graph = self.world > 1 or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
-        # weight-gradient kernels on a second stream: needs one gradient contribution per parameter per backward pass
-        # (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
+        # the pack kernel may sum the filter-gradient slabs only if every parameter receives ONE gradient contribution per
+        # backward pass (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
         self.single_contrib = bool(self.model.single_contribution)
         self._opts = None
         self._pending = None         # (work handle, Adam graph) of a critic-step exchange still in flight (see step())
@@ -82,7 +82,7 @@ class Trainer(object):
         opt = op.optimizer
         # (the filter-gradient slabs are summed by the pack kernel: legal under the same one-contribution condition)
         with F.defer_wgrad_reduce(self.single_contrib):
-            grads = opt.compute_gradients(op.cost, side_wgrad=self.single_contrib)
+            grads = opt.compute_gradients(op.cost)
             keep = opt.pack(grads)
         return out[which + '_cost'].detach(), opt, keep
 

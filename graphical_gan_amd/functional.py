@@ -46,96 +46,8 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Backward of a layer = two independent kernels: the data-gradient (on the critical path: the next layer's backward needs
-# it) and the filter/weight-gradient (needed only when the gradients are packed for Adam).  Inside `side_chain` the
-# weight-gradient kernels are issued on a second HIP stream that only ever WAITS for the main stream (one event per
-# layer) and is joined once, when the backward pass is over.  The chip then holds workgroups of both kernels per CU and
-# one kernel's prologue / staging / epilogue latency hides under the other's MFMA phase.  Captured into the step's HIP
-# graph as a parallel branch.  Everything a side-stream kernel reads or writes is held until the join (the caching
-# allocator must not hand the memory to a main-stream kernel earlier).
-# Only valid when every parameter receives exactly ONE gradient contribution per backward pass (autograd would sum
-# several contributions on the main stream without waiting for the side stream) -- the caller guarantees that.
 import os as _os
 FUSED_CONV_BWD = _os.environ.get('GGAN_NO_FUSED_BWD') is None
-# measured on MI355X / ROCm 7.2 (gan_inference_cifar10 ali bs=64, HIP graph): 2.32 ms with the side chain vs 2.01 ms without --
-# parallel graph branches cost more than the overlap wins, so it is opt-in
-SIDE_WGRAD = _os.environ.get('GGAN_SIDE_WGRAD') is not None
-OVERLAP_BWD = False   # per-layer fork AND join: measured no gain (cross-queue graph dependencies cost 6-11 us each)
-_SIDE = {}
-_CHAIN = None
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    s = _SIDE.get(key)
-    if s is None:
-        s = torch.cuda.Stream(device=device)
-        _SIDE[key] = s
-    return s
-
-
-class side_chain(object):
-    """with side_chain(device): <plain backward pass>   (see the comment above)"""
-
-    def __init__(self, device, enabled=True):
-        self.enabled = bool(enabled) and SIDE_WGRAD
-        self.device = device
-
-    def __enter__(self):
-        global _CHAIN
-        if self.enabled:
-            self.main = torch.cuda.current_stream(self.device)
-            self.side = _side_stream(self.device)
-            self.held, self.used = [], False
-            _CHAIN = self
-        return self
-
-    def __exit__(self, *a):
-        global _CHAIN
-        if self.enabled:
-            _CHAIN = None
-            if self.used:
-                self.main.wait_stream(self.side)
-            self.held = []
-
-
-class _fork(object):
-    """with _fork(dev) as side: ... kernels issued on the side stream.  join(): inside a side_chain only registers the
-    tensors the side kernels touch (joined at the end of the chain); with OVERLAP_BWD joins immediately."""
-
-    def __init__(self, device, enabled=True):
-        self.chain = _CHAIN
-        self.enabled = enabled and (OVERLAP_BWD or self.chain is not None) and not torch.is_grad_enabled()
-        self.device = device
-
-    def __enter__(self):
-        if not self.enabled:
-            return None
-        self.main = torch.cuda.current_stream(self.device)
-        if self.chain is not None and self.main != self.chain.main:
-            raise _lib.GganError('side_chain entered on a different stream than the backward pass runs on')
-        self.side = _side_stream(self.device)
-        self.side.wait_stream(self.main)
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
-        return self.side
-
-    def __exit__(self, *a):
-        if self.enabled:
-            self.ctx.__exit__(*a)
-
-    def join(self, *tensors):
-        """call after the main-stream kernel has been issued; `tensors` = everything the side kernels read or wrote"""
-        if not self.enabled:
-            return
-        if self.chain is not None:
-            self.chain.held.extend(t for t in tensors if t is not None)
-            self.chain.used = True
-            return
-        self.main.wait_stream(self.side)
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.main)
 
 
 # Filter gradients as split-K partial slabs: inside `defer_wgrad_reduce` the filter-gradient kernels leave their slabs in a
@@ -262,15 +174,12 @@ class ConvFwd(Function):
             gy = ActBwd.apply(gy, y, ctx.act, ctx.alpha)       # lrelu/relu: sign(y) == sign(pre-activation)
         gx = gw = gb = None
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        fork = _fork(gy.device, ctx.needs_input_grad[0] and need_w)
-        with fork:
-            if ctx.needs_input_grad[1]:
-                gw = ConvWgrad.apply(x, gy, ctx.geom)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ChanSum.apply(gy)
+        if ctx.needs_input_grad[1]:
+            gw = ConvWgrad.apply(x, gy, ctx.geom)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = ChanSum.apply(gy)
         if ctx.needs_input_grad[0]:
             gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
-        fork.join(gw, gb, x, gy)
         return gx, gw, gb, None, None, None, None
 
 
@@ -290,14 +199,10 @@ def _fused_conv_backward(ctx, gy, x, w, y):
         if parts is not None:
             gw, gb = parts
         else:
-            fork = _fork(gy.device, ctx.needs_input_grad[0])
-            with fork:
-                ws_f = workspace(gy.device)
-                gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=gy.device)
-                gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if want_b else None
-                rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(x), _p(gy), yref, act, ctx.alpha, _p(gw), _p(gb), _p(ws_f),
-                                                  ws_f.numel(), _stream())
-            fork.join(gw, gb, x, gy, y)
+            gw = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=gy.device)
+            gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if want_b else None
+            rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(x), _p(gy), yref, act, ctx.alpha, _p(gw), _p(gb), _p(ws), ws.numel(),
+                                              _stream())
             if rc == 1:
                 return None          # geometry not covered by the fused kernels: caller takes the unfused path
             check(rc, 'ggan_conv2d_bwd_filter_act')
@@ -335,18 +240,14 @@ class ConvDgrad(Function):
         if ctx.act != ACT_NONE:
             h = ActBwd.apply(h, out, ctx.act, ctx.alpha)
         d_gy = d_w = d_b = None
-        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        fork = _fork(h.device, ctx.needs_input_grad[0] and need_w)
-        with fork:
-            if ctx.needs_input_grad[1]:
-                parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None
-                d_w = parts[0] if parts is not None else ConvWgrad.apply(h, gy, ctx.geom)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                pre = getattr(h, '_ggan_chansum', None) if not torch.is_grad_enabled() else None
-                d_b = pre if (pre is not None and pre.numel() == h.shape[1]) else ChanSum.apply(h)
+        if ctx.needs_input_grad[1]:
+            parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None
+            d_w = parts[0] if parts is not None else ConvWgrad.apply(h, gy, ctx.geom)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            pre = getattr(h, '_ggan_chansum', None) if not torch.is_grad_enabled() else None
+            d_b = pre if (pre is not None and pre.numel() == h.shape[1]) else ChanSum.apply(h)
         if ctx.needs_input_grad[0]:
             d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
-        fork.join(d_w, d_b, h, gy)
         return d_gy, d_w, d_b, None, None, None
 
 
@@ -447,26 +348,22 @@ class Gemm(Function):
         if ctx.act != ACT_NONE:
             g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
         da = db = dbias = None
-        need_b = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        fork = _fork(g.device, ctx.needs_input_grad[0] and need_b)
-        with fork:
-            if (ctx.needs_input_grad[1] and not tb and ctx.has_bias and ctx.needs_input_grad[2]
-                    and not torch.is_grad_enabled()):
-                db, dbias = gemm_colsum_(a, g, not ta)                             # dW and db in ONE launch
-            else:
-                if ctx.needs_input_grad[1]:
-                    if not tb:
-                        db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0)      # op(A)^T g
-                    else:
-                        db = Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)           # g^T op(A)
-                if ctx.has_bias and ctx.needs_input_grad[2]:
-                    dbias = ColSum.apply(g)
+        if (ctx.needs_input_grad[1] and not tb and ctx.has_bias and ctx.needs_input_grad[2]
+                and not torch.is_grad_enabled()):
+            db, dbias = gemm_colsum_(a, g, not ta)                             # dW and db in ONE launch
+        else:
+            if ctx.needs_input_grad[1]:
+                if not tb:
+                    db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0)      # op(A)^T g
+                else:
+                    db = Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)           # g^T op(A)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                dbias = ColSum.apply(g)
         if ctx.needs_input_grad[0]:
             if not ta:
                 da = Gemm.apply(g, b, None, False, not tb, ACT_NONE, 0.0)      # g op(B)^T
             else:
                 da = Gemm.apply(b, g, None, tb, True, ACT_NONE, 0.0)           # op(B) g^T
-        fork.join(db, dbias, a, g)
         return da, db, dbias, None, None, None, None
 
 

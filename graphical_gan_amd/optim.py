@@ -84,13 +84,10 @@ class AdamOptimizer(object):
         self.world = self.bucket.world
 
     # -- one optimizer step ---------------------------------------------------------------------------
-    def compute_gradients(self, cost, side_wgrad=False):
-        """side_wgrad: run the weight-gradient kernels on a second stream (functional.side_chain); legal only when
-        every parameter is used once in the graph of `cost`."""
+    def compute_gradients(self, cost):
         if self._one is None or self._one.shape != cost.shape:
             self._one = torch.ones_like(cost)            # persistent d(cost)/d(cost) seed (no fill launch per step)
-        with F.side_chain(self.theta.device, side_wgrad):
-            return torch.autograd.grad(cost, self.params, grad_outputs=self._one, allow_unused=True)
+        return torch.autograd.grad(cost, self.params, grad_outputs=self._one, allow_unused=True)
 
     def pack(self, grads):
         gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
