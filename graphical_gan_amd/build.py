@@ -28,7 +28,18 @@ def _digest():
 
 
 def build(force=False, verbose=False):
-    """Compile every .hip translation unit and link libggan.so.  Returns the library path."""
+    """Compile every .hip translation unit and link libggan.so.  Returns the library path.  Safe to call from several
+    processes at once (one rank per GPU does): an exclusive file lock serialises them and the later ones find the stamp."""
+    import fcntl
+    with open(os.path.join(HERE, '.libggan.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
         return LIB
@@ -53,8 +64,10 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode(errors='replace'))
     if failed:
         raise RuntimeError('libggan build failed')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)                       # atomic: a process that already mapped the old file keeps it
     with open(STAMP, 'w') as f:
         f.write(dig)
     return LIB
