@@ -86,6 +86,39 @@ class Trainer(object):
             keep = opt.pack(grads)
         return out[which + '_cost'].detach(), opt, keep
 
+    def _two_bucket_plan(self, opt, nets):
+        """(k, flat offset, cut tensors) when this generator step can exchange the Generator's gradients first, else None"""
+        cut = self.model.cut_tensors(nets) if hasattr(self.model, 'cut_tensors') else None
+        if not cut or any(not t.requires_grad for t in cut) or os.environ.get('GGAN_ONE_BUCKET'):
+            return None
+        sp = opt.split_at(lambda p: 'Extractor' not in getattr(p, 'param_name', ''))
+        return None if sp is None else (sp[0], sp[1], cut)
+
+    def _bwd_phase1(self, nets):
+        """generator step up to the cut: critic pass, backward to the Generator's parameters and to the Extractor's outputs,
+        Generator gradients packed.  Returns everything phase 2 needs."""
+        out = self.model.forward(self.feed, 'gen', nets)
+        op = out['gen_train_op']
+        opt = op.optimizer
+        plan = self._two_bucket_plan(opt, nets)
+        if plan is None:
+            return None
+        k, off, cut = plan
+        if opt._one is None or opt._one.shape != op.cost.shape:
+            opt._one = torch.ones_like(op.cost)
+        with F.defer_wgrad_reduce(self.single_contrib):
+            g = torch.autograd.grad(op.cost, list(opt.params[:k]) + cut, grad_outputs=opt._one, allow_unused=True)
+            keep = opt.pack_subset(g[:k], 0, k, bump=True)
+        return dict(cost=out['gen_cost'].detach(), opt=opt, k=k, off=off, cut=cut, g_cut=g[k:], keep=keep)
+
+    def _bwd_phase2(self, st):
+        """the Extractor's backward from the gradients at the cut; its gradients packed behind the Generator's"""
+        opt, k = st['opt'], st['k']
+        pairs = [(t, g) for t, g in zip(st['cut'], st['g_cut']) if g is not None]
+        with F.defer_wgrad_reduce(self.single_contrib):
+            g = torch.autograd.grad([t for t, _ in pairs], opt.params[k:], grad_outputs=[gg for _, gg in pairs], allow_unused=True)
+            return opt.pack_subset(g, k, len(opt.params), bump=False)
+
     def _eager(self, which):
         self.flush()
         cost, opt, _ = self._fwd_bwd(which)
@@ -117,7 +150,7 @@ class Trainer(object):
             with torch.cuda.graph(g1, stream=s, capture_error_mode=_CAPTURE_MODE):
                 cost, opt, keep = self._fwd_bwd(which)
                 opt.update()
-            return dict(g0=None, g1=g1, g2=None, cost=cost, opt=opt, keep=keep)
+            return dict(g0=None, g1=g1, g1b=None, split=None, g2=None, cost=cost, opt=opt, keep=keep)
         # data parallel: [forward + backward + pack] -> all-reduce -> [Adam].  Every step is cut once more, after the
         # Extractor/Generator passes (g0): they read no critic variable, so they run while the previous critic step's gradient
         # exchange is still on the wire (step()) -- under the next generator step, or under the next critic step when
@@ -125,12 +158,24 @@ class Trainer(object):
         g0 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g0, stream=s, capture_error_mode=_CAPTURE_MODE):
             nets = self._nets()
-        with torch.cuda.graph(g1, stream=s, pool=g0.pool() if g0 is not None else None, capture_error_mode=_CAPTURE_MODE):
-            cost, opt, keep = self._fwd_bwd(which, nets)
+        g1b, st = None, None
+        with torch.cuda.graph(g1, stream=s, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+            if which == 'gen':
+                # two gradient buckets: autograd reaches the Generator's parameters before the Extractor's, so the Generator
+                # bucket goes on the wire while the Extractor's backward pass (g1b) still runs
+                st = self._bwd_phase1(nets)
+            if st is None:
+                cost, opt, keep = self._fwd_bwd(which, nets)
+        if st is not None:
+            g1b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1b, stream=s, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+                keep = (st['keep'], self._bwd_phase2(st), st)
+            cost, opt = st['cost'], st['opt']
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=s, capture_error_mode=_CAPTURE_MODE):
             opt.update()
-        return dict(g0=g0, g1=g1, g2=g2, cost=cost, opt=opt, keep=(keep, nets))
+        return dict(g0=g0, g1=g1, g1b=g1b, split=(st['off'] if st is not None else None), g2=g2, cost=cost, opt=opt,
+                    keep=(keep, nets))
 
     def flush(self):
         """Finish a critic step whose gradient exchange was left in flight: wait for it, apply its Adam update."""
@@ -161,6 +206,15 @@ class Trainer(object):
             rec['g0'].replay()           # overlaps the pending critic-gradient all-reduce
         self.flush()
         rec['g1'].replay()
+        if rec['g1b'] is not None:       # generator step in two buckets
+            w1 = rec['opt'].all_reduce(async_op=True, lo=0, hi=rec['split'])
+            rec['g1b'].replay()          # the Extractor's backward overlaps the Generator bucket's exchange
+            w2 = rec['opt'].all_reduce(async_op=True, lo=rec['split'], hi=None)
+            for w in (w1, w2):
+                if w is not None:
+                    w.wait()
+            rec['g2'].replay()
+            return rec['cost']
         work = rec['opt'].all_reduce(async_op=True)
         if which == 'disc':
             self._pending = (work, rec['g2'])    # finished by the next step (or flush()): nothing before that reads it

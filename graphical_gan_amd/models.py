@@ -64,6 +64,12 @@ class GraphicalGAN(object):
         [fake; real]; the wali-gp penalty re-enters the critic)"""
         return bool(self.cfg.batch_critic) and self.cfg.mode in ('ali', 'local_ep')   # (reconstruction terms reuse G / E)
 
+    def cut_tensors(self, nets):
+        """tensors through which EVERY gradient of the Extractor's parameters flows (None if there is no such cut: the
+        reconstruction modes apply the Extractor a second time) -- lets a data-parallel generator step exchange the
+        Generator's gradients while the Extractor's backward pass is still running (engine.Trainer)."""
+        return [nets['q_z']] if self.cfg.mode in ('ali', 'local_ep', 'wali-gp') else None
+
     def feed_buffers(self, device):
         c, B, feed = self.cfg, self.cfg.B, {}
         if c.dataset == 'mnist':

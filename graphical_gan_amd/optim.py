@@ -40,11 +40,13 @@ class GradBucket(object):
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.scale = 1.0 / self.world
 
-    def all_reduce(self, async_op=False):
+    def all_reduce(self, async_op=False, lo=0, hi=None):
         """async_op: returns the torch.distributed work handle (None when there is nothing to exchange); the caller
-        calls .wait() before the bucket is read -- lets the exchange overlap kernels issued in between."""
+        calls .wait() before the bucket is read -- lets the exchange overlap kernels issued in between.
+        lo/hi: exchange only flat[lo:hi] (a sub-bucket whose gradients are complete before the rest)."""
         if self.world > 1 or (_os.environ.get('GGAN_FORCE_ALLREDUCE') and dist.is_available() and dist.is_initialized()):
-            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            buf = self.flat if (lo == 0 and hi is None) else self.flat[lo:hi]
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             return work if async_op else None
         return None
 
@@ -94,9 +96,23 @@ class AdamOptimizer(object):
         F.pack_(gs, self.slots, self.g, bump=self.step)     # also advances the step counter (read by update())
         return gs  # keep alive until the kernel ran (stream-ordered)
 
-    def all_reduce(self, async_op=False):
-        """Sum the flat gradient bucket over the data-parallel replicas (RCCL over xGMI)."""
-        return self.bucket.all_reduce(async_op)
+    def all_reduce(self, async_op=False, lo=0, hi=None):
+        """Sum the flat gradient bucket (or its slice [lo, hi)) over the data-parallel replicas (RCCL over xGMI)."""
+        return self.bucket.all_reduce(async_op, lo, hi)
+
+    def split_at(self, predicate):
+        """k such that params[:k] all satisfy predicate and params[k:] do not (None if the parameters are not ordered that
+        way), with the flat-buffer offset where params[k] starts -- the boundary of a two-bucket gradient exchange."""
+        flags = [bool(predicate(p)) for p in self.params]
+        k = sum(flags)
+        if k == 0 or k == len(flags) or not all(flags[:k]) or any(flags[k:]):
+            return None
+        return k, self.slots[k][0]
+
+    def pack_subset(self, grads, lo, hi, bump):
+        gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
+        F.pack_(gs, self.slots[lo:hi], self.g, bump=self.step if bump else None)
+        return gs
 
     def update(self):
         F.adam_step_(self.theta, self.g, self.m, self.v, self.step, self.lr, self.beta1, self.beta2, self.eps,

@@ -147,6 +147,9 @@ def test_split_graph_path_matches_single_graph(gpu, monkeypatch, mode):
         for it in range(5):
             tr.iteration(it, feeds)
         torch.cuda.synchronize()
+        if force:      # the generator step ran as [nets][critic + Generator bucket][Extractor bucket][Adam]
+            assert tr._graphs['gen']['g0'] is not None and tr._graphs['gen']['g1b'] is not None
+            assert tr._graphs['disc']['g0'] is not None and tr._graphs['disc']['g1b'] is None
         res.append(tr.get_params())
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k
