@@ -43,7 +43,16 @@ def _worker(rank, world, port, q):
         flat[o:o + n] = torch.as_tensor(g.reshape(-1))
     bucket = GradBucket(flat)
     assert bucket.world == world and bucket.scale == 1.0 / world
-    bucket.all_reduce()
+    # the engine's exchange pattern: two sub-buckets, each asynchronous (the first overlaps the rest of the backward pass),
+    # waited for before the optimizer reads the buffer; must equal one all-reduce of the whole bucket
+    whole = flat.clone()
+    dist.all_reduce(whole)
+    cut = slots[len(slots) // 2][0]
+    w1 = bucket.all_reduce(async_op=True, lo=0, hi=cut)
+    w2 = bucket.all_reduce(async_op=True, lo=cut, hi=None)
+    assert w1 is not None and w2 is not None
+    w1.wait(); w2.wait()
+    assert torch.equal(flat, whole)
     theta = np.concatenate([P0[n].astype(np.float64).reshape(-1) for n in names])
     g = np.concatenate([flat[o:o + n].numpy() for o, n in slots]) * bucket.scale
     th, m, v = O.adam_update(theta, g, np.zeros_like(theta), np.zeros_like(theta), 1, 2e-4, .5, .999)
