@@ -260,3 +260,34 @@ def test_driver_loop_and_counterpart_script(gpu, tmp_path):
                        text=True, timeout=600, env=dict(os.environ, GGAN_DATA_DIR='/nonexistent'))
     assert r.returncode == 0, r.stderr[-2000:]
     assert 'iter 2' in r.stdout and 'disc cost' in r.stdout
+
+
+def test_driver_loop_on_loader_data(gpu, tmp_path, monkeypatch):
+    """real-data plumbing: a (fake) mnist.pkl.gz and CIFAR batch files on disk -> py3 loaders -> pinned ring + copy kernel ->
+    Trainer, for the MNIST, CIFAR and moving-MNIST drivers."""
+    import gzip, os, pickle
+    from graphical_gan_amd import run
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
+    rng = np.random.default_rng(0)
+    mk = lambda n: (rng.random((n, 784), dtype=np.float32), rng.integers(0, 10, size=n))
+    with gzip.open(str(tmp_path / 'mnist.pkl.gz'), 'wb') as f:
+        pickle.dump((mk(64), mk(16), mk(16)), f)
+    monkeypatch.setenv('GGAN_MNIST', str(tmp_path / 'mnist.pkl.gz'))
+    for i in list(range(1, 6)) + ['t']:
+        name = 'test_batch' if i == 't' else 'data_batch_%d' % i
+        with open(str(tmp_path / name), 'wb') as f:
+            pickle.dump({'data': rng.integers(0, 256, size=(16, 3072)).astype(np.uint8), 'labels': list(range(16))}, f)
+    _fresh()
+    tr = run.train(dict(DATASET='mnist', BATCH_SIZE=8, ITERS=5, LOG_EVERY=2), Config('mnist', batch_size=8, dim=8, dim_latent=16))
+    assert tr.feed['real_x'].shape == (8, 784) and float(tr.feed['real_x'].max()) <= 1.0
+    _fresh()
+    tr = run.train(dict(DATASET='cifar10', BATCH_SIZE=8, ITERS=5, LOG_EVERY=2, DATA_DIR=str(tmp_path)),
+                   Config('cifar10', batch_size=8, dim=8, dim_latent=16))
+    assert tr.feed['real_x_int'].dtype.is_floating_point is False and int(tr.feed['real_x_int'].max()) <= 255
+    _fresh()
+    cfg = SSConfig(batch_size=4, length=3, dim=4, dim_op=16, dim_g=8, dim_l=4)
+    tr = run.train(dict(DATASET='moving_mnist', BATCH_SIZE=4, LEN=3, N_C=10, ITERS=4, LOG_EVERY=2), cfg, model=StateSpaceGAN(cfg))
+    x = tr.feed['real_x_unit'].cpu().numpy().reshape(4, 3, 64, 64)
+    assert x.max() <= 1.0 and (x.sum(axis=(2, 3)) > 0).all()             # every frame carries its digit
+    assert np.allclose(tr.feed['real_y'].cpu().numpy().sum(1), 1.0)
