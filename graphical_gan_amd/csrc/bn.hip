@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_k(const float* __restric
 }
 
 // ---- [N, C] layout: block = 64 columns x 4 row-slices -----------------------------------------
-constexpr int kCols = 64, kSlices = 4;
+constexpr int kCols = 32, kSlices = 16;   // 128-byte row segments; 16 row slices keep each thread at N/16 dependent loads
 
 __device__ __forceinline__ float slice_sum(float v, float (*sm)[kCols]) {
     const int col = threadIdx.x, sl = threadIdx.y;
