@@ -256,6 +256,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     }
 }
 
+// N == 1 (the critics' Output layers, 512 -> 1): a matrix-vector product -- one wave per row, no tiles, no split-K, no reduce
+__global__ __launch_bounds__(256) void gemv_rows_k(const float* __restrict__ A, const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ C, int M, int K, int act, float alpha) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* a = A + (size_t)row * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(a[k], w[k], s);
+    s = wave_sum(s);
+    if (lane == 0) C[row] = act_apply(s + (bias ? bias[0] : 0.f), act, alpha);
+}
+
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -270,6 +282,10 @@ size_t ggan_gemm_workspace(int M, int N, int K) {
 static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C,
                        float* colsum, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s,
                        const float* a_ref = nullptr, const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f) {
+    if (N == 1 && !ta && !tb && !colsum && !a_ref && !b_ref) {
+        GGAN_LAUNCH("gemv_rows_k", 2.0 * M * K, 0, gemv_rows_k, dim3(cdiv(M, 4)), dim3(256), 0, s, A, B, bias, C, M, K, act, alpha);
+        return 0;
+    }
     GemmParams P;
     memset(&P, 0, sizeof(P));
     P.a_ref = a_ref; P.b_ref = b_ref; P.ref_act = ref_act; P.ref_alpha = ref_alpha;
