@@ -21,11 +21,11 @@ __device__ __forceinline__ float ld_gy(const float* __restrict__ gy, const GyMas
     return g;
 }
 
-constexpr int kThreads = 512;
+constexpr int kThreads = 1024;
 
-// Register-resident variants: when a channel's N*HW values fit 32 per thread the activation is read from HBM/L2 ONCE
+// Register-resident variants: when a channel's N*HW values fit 16 per thread of a 1024-thread workgroup the activation is read from HBM/L2 ONCE
 // (mean, centred variance and the normalised write all come from registers): 2 passes of traffic instead of 4.
-constexpr int kRegE = 32;
+constexpr int kRegE = 16;
 
 __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ offset, float* __restrict__ y,
