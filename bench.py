@@ -197,22 +197,26 @@ def main():
     # ---- per-kernel timing of the same step with HIP events (eager, on the launch stream) ---------------------
     roofline = None
     kernels = None
-    if rank == 0 and not args.no_kernel_profile:
+    if not args.no_kernel_profile:
+        # EVERY rank runs these eager iterations (they contain the gradient all-reduce: a collective issued by rank 0 alone
+        # would hang the job); only rank 0 records and reports
+        tr.flush()
         tr_graph = tr.graph_enabled
         tr.graph_enabled = False
         L = _lib.load()
         for _ in range(2):
             tr.iteration(it, bi); it += 1
         torch.cuda.synchronize(dev)
-        L.ggan_prof_reset(); L.ggan_prof_enable(1)
+        L.ggan_prof_reset(); L.ggan_prof_enable(1 if rank == 0 else 0)
         n_prof = 5
         for _ in range(n_prof):
             tr.iteration(it, bi); it += 1
         torch.cuda.synchronize(dev)
         L.ggan_prof_enable(0)
-        recs = _lib.prof_report()
+        recs = _lib.prof_report() if rank == 0 else []
         L.ggan_prof_reset()
         tr.graph_enabled = tr_graph
+    if rank == 0 and not args.no_kernel_profile:
         recs.sort(key=lambda r: -r['total_ms'])
         kernels = [dict(name=r['name'], launches_per_iter=r['launches'] / n_prof,
                         ms_per_iter=round(r['total_ms'] / n_prof, 4),
