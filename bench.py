@@ -121,11 +121,17 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' %
                          (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # (GGAN_DIST_BACKEND=gloo + fewer devices than ranks: a control-flow rehearsal of the N>1 path on a single-GPU box)
+    backend = os.environ.get('GGAN_DIST_BACKEND', 'nccl')
+    local_dev = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     ge.build()
