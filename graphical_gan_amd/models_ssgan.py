@@ -10,7 +10,9 @@ What is done differently from a literal transcription (same arithmetic):
   * every frame net runs on all B*LEN frames at once (the reference does too) and the LEN-1 transition critics, which
     share one set of weights, are evaluated in ONE call on the stacked pairs [(LEN-1)*B, 2*dim_l] instead of LEN-1 calls;
     their equal-weight BCE terms collapse into one term (sum_i r*mean_B(.) == r*(LEN-1)*mean over the stack);
-  * generator steps hand the critics their weights without gradient edges (tflib.frozen), as TF's var_list does.
+  * each of the three critics is evaluated once per step on [fake; real] (rows independent: no BatchNorm); generator steps
+    hand the critics their weights without gradient edges (tflib.frozen), as TF's var_list does, and run the frame
+    critic's conv data-gradient on the fake frames only (grad_rows).
 """
 import numpy as np
 import torch
@@ -44,7 +46,10 @@ class SSConfig(object):
 class StateSpaceGAN(object):
     """forward_nets(feed) / forward(feed, which, nets): the interface engine.Trainer drives."""
 
-    single_contribution = False      # the frame critic is applied to the fake and the real sequence separately
+    # every conv filter receives ONE gradient contribution per backward pass (each conv net is applied once: the critics see
+    # [fake; real] as one batch), so the pack kernel may sum the filter-gradient slabs; the shared-weight Linear operators
+    # (applied LEN-1 times) are summed by autograd as usual
+    single_contribution = True
 
     def __init__(self, cfg):
         self.cfg = cfg
@@ -86,10 +91,10 @@ class StateSpaceGAN(object):
             return lib.ops.linear.Linear(name, nin, nout, x, activation=act)
         return F.ActFwd.apply(lib.ops.linear.Linear(name, nin, nout, x), act, 0.2)
 
-    def _conv(self, name, cin, cout, x):
+    def _conv(self, name, cin, cout, x, grad_rows=None):
         if self.cfg.fuse:
-            return lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, activation=LRELU)
-        return F.ActFwd.apply(lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2), LRELU, 0.2)
+            return lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, activation=LRELU, grad_rows=grad_rows)
+        return F.ActFwd.apply(lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, grad_rows=grad_rows), LRELU, 0.2)
 
     def _deconv(self, name, cin, cout, x, act):
         if self.cfg.fuse:
@@ -159,12 +164,12 @@ class StateSpaceGAN(object):
         out = self._deconv('Generator.5', d, 1, out, TANH)
         return out.reshape(c.B, c.LEN, c.output_dim)
 
-    def _conv_stack(self, pre, x, cin):
+    def _conv_stack(self, pre, x, cin, grad_rows=None):
         d = self.cfg.dim
-        out = self._conv(pre + '.1', cin, d, x)
-        out = self._conv(pre + '.2', d, 2 * d, out)
-        out = self._conv(pre + '.3', 2 * d, 4 * d, out)
-        return self._conv(pre + '.4', 4 * d, 8 * d, out)
+        out = self._conv(pre + '.1', cin, d, x, grad_rows)
+        out = self._conv(pre + '.2', d, 2 * d, out, grad_rows)
+        out = self._conv(pre + '.3', 2 * d, 4 * d, out, grad_rows)
+        return self._conv(pre + '.4', 4 * d, 8 * d, out, grad_rows)
 
     def Extractor(self, inputs, labels):
         c = self.cfg
@@ -179,9 +184,15 @@ class StateSpaceGAN(object):
 
     def Discriminator(self, x, z_g, z_l, labels):
         c = self.cfg
-        out = self._conv_stack('Discriminator', x.reshape(c.B * c.LEN, 1, 64, 64), 1).reshape(c.B * c.LEN, c.flat)
-        z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l + c.n_c, 512, self._z_rows(z_g, z_l, labels), LRELU)
-        out = torch.cat([out, z_out, self.expand_labels(labels)], 1)
+        return self._frame_critic(x.reshape(c.B * c.LEN, c.output_dim), self._z_rows(z_g, z_l, labels), self.expand_labels(labels))
+
+    def _frame_critic(self, frames, z_rows, label_rows, grad_rows=None):
+        """the frame critic on any number of (frame, latent row, label row) triples; grad_rows: only the leading frames carry
+        a gradient (generator steps: [fake; real])"""
+        c, n = self.cfg, frames.shape[0]
+        out = self._conv_stack('Discriminator', frames.reshape(n, 1, 64, 64), 1, grad_rows).reshape(n, c.flat)
+        z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l + c.n_c, 512, z_rows, LRELU)
+        out = torch.cat([out, z_out, label_rows], 1)
         out = self._lin('Discriminator.zx1', c.flat + 512 + c.n_c, 512, out, LRELU)
         return self._lin('Discriminator.Output', 512, 1, out).reshape(-1)
 
@@ -197,12 +208,14 @@ class StateSpaceGAN(object):
     def ZGDiscrminator(self, z_g):
         return self._mlp_critic('Discriminator.ZG', z_g)
 
-    def _transitions(self, z_l):
-        """all LEN-1 (z_t, z_t+1) pairs stacked time-major: [(LEN-1)*B, 2*dim_l] -> transition-critic logits"""
+    def _pairs(self, z_l):
+        """all LEN-1 (z_t, z_t+1) pairs stacked time-major: two [(LEN-1)*B, dim_l] tensors"""
         c = self.cfg
-        a = z_l[:, :-1, :].transpose(0, 1).reshape((c.LEN - 1) * c.B, c.dim_l)
-        b = z_l[:, 1:, :].transpose(0, 1).reshape((c.LEN - 1) * c.B, c.dim_l)
-        return self.DynamicDiscrminator(a, b)
+        return (z_l[:, :-1, :].transpose(0, 1).reshape((c.LEN - 1) * c.B, c.dim_l),
+                z_l[:, 1:, :].transpose(0, 1).reshape((c.LEN - 1) * c.B, c.dim_l))
+
+    def _transitions(self, z_l):
+        return self.DynamicDiscrminator(*self._pairs(z_l))
 
     @staticmethod
     def _var_lists():
@@ -230,8 +243,23 @@ class StateSpaceGAN(object):
         J = lib.objs.gan_inference
         J.ONLY[0] = which
         with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
-            disc_fake = [self._transitions(p_z_l), self.ZGDiscrminator(p_z_g), self.Discriminator(fake_x, p_z_g, p_z_l, p_y)]
-            disc_real = [self._transitions(q_z_l), self.ZGDiscrminator(q_z_g), self.Discriminator(real_x, q_z_g, q_z_l, real_y)]
+            if which in ('gen', 'disc'):
+                # every critic once, on [fake; real] (rows are independent: no BatchNorm); in generator steps the conv
+                # data-gradient is needed for the fake frames only
+                nf = c.B * c.LEN
+                (af, bf), (ar, br) = self._pairs(p_z_l), self._pairs(q_z_l)
+                t = self.DynamicDiscrminator(torch.cat([af, ar], 0), torch.cat([bf, br], 0))
+                zg = self.ZGDiscrminator(torch.cat([p_z_g, q_z_g], 0))
+                d = self._frame_critic(torch.cat([fake_x.reshape(nf, -1), real_x.reshape(nf, -1)], 0),
+                                       torch.cat([self._z_rows(p_z_g, p_z_l, p_y), self._z_rows(q_z_g, q_z_l, real_y)], 0),
+                                       torch.cat([self.expand_labels(p_y), self.expand_labels(real_y)], 0),
+                                       grad_rows=nf if which == 'gen' else None)
+                (tf_, tr_), (zf, zr), (df, dr) = (F.SplitRows.apply(t, (c.LEN - 1) * c.B), F.SplitRows.apply(zg, c.B),
+                                                  F.SplitRows.apply(d, nf))
+                disc_fake, disc_real = [tf_, zf, df], [tr_, zr, dr]
+            else:
+                disc_fake = [self._transitions(p_z_l), self.ZGDiscrminator(p_z_g), self.Discriminator(fake_x, p_z_g, p_z_l, p_y)]
+                disc_real = [self._transitions(q_z_l), self.ZGDiscrminator(q_z_g), self.Discriminator(real_x, q_z_g, q_z_l, real_y)]
         r = c.ratio()
         ratios = [float(r[0]) * (c.LEN - 1), float(r[c.LEN - 1]), float(r[c.LEN])]      # the LEN-1 equal transition terms as one
         gen_params, disc_params = self._var_lists()

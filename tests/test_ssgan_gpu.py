@@ -52,7 +52,8 @@ def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode):
                 continue
             assert g is not None, n
             err = float(np.abs(g.cpu().numpy().astype(np.float64) - og.v).max())
-            assert err <= 1e-4 * max(float(np.abs(og.v).max()), 1e-3 * gmax), (which, n, err)
+            # (floor: bias gradients of the critic heads are near-cancelling sums of O(gmax) terms)
+            assert err <= 1e-4 * max(float(np.abs(og.v).max()), 5e-3 * gmax), (which, n, err)
     # the frame generator's output itself
     fx = tr.model.forward_nets(tr.feed)['fake_x'].detach().cpu().numpy()
     assert np.abs(fx - oout['fake_x'].v).max() <= 1e-5
