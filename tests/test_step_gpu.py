@@ -315,3 +315,21 @@ def test_dp_two_ranks_on_one_gpu(gpu, tmp_path, mode):
     a, b = np.load(one), np.load(two)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_trajectory_unfused_epilogues(gpu):
+    """the same 3-iteration trajectory with every pointwise op as its own kernel (Config(fuse=False)): the batched critic with
+    the pruned data-gradient (grad_rows) must not depend on the fused epilogues."""
+    from oracle import step as S
+    ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, 'ali', 8, 16, False, False, gpu)
+    otr = S.Trainer(ocfg, P0, 'ali', np.float64)
+    feeds = [S.make_feed(ocfg, np.random.default_rng(100 + i), 'ali') for i in range(6)]
+    fo, fp = iter(feeds), iter(feeds)
+    for it in range(3):
+        ro, rp = otr.iteration(it, fo), tr.iteration(it, fp)
+        for k in ro:
+            assert abs(float(rp[k]) - ro[k]) <= 2e-3 * max(1.0, abs(ro[k])), (it, k, float(rp[k]), ro[k])
+    P = tr.get_params()
+    for n in ('Discriminator.2.Filters', 'Generator.3.Filters', 'Extractor.Output.W', 'Discriminator.zx1.W'):
+        d = np.abs(P[n].reshape(otr.P[n].shape) - otr.P[n])
+        assert d.max() <= 2.5 * cfg.lr * 6 and (d > 2e-5).mean() <= 0.02, (n, d.max())
