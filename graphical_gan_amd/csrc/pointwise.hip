@@ -340,7 +340,8 @@ __global__ void pack_k(PackTable t, float* __restrict__ flat) {
         float4* d4 = reinterpret_cast<float4*>(d);
         for (size_t i = i0; i < n4; i += stride) {
             float4 a = reinterpret_cast<const float4*>(s)[i];
-            for (int p = 1; p < np; ++p) {
+#pragma unroll 8
+            for (int p = 1; p < np; ++p) {      // (unrolled: the slab loads are independent, only the adds are ordered)
                 const float4 b = reinterpret_cast<const float4*>(s + (size_t)p * ps)[i];
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
