@@ -452,7 +452,8 @@ __global__ void splitk_reduce_k(const float* __restrict__ partial, int SK, size_
                                 size_t n2) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems + n2; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < SK; ++k) s += partial[(size_t)k * stride + i];
+#pragma unroll 8
+        for (int k = 0; k < SK; ++k) s += partial[(size_t)k * stride + i];      // (independent loads, ordered adds)
         if (i < elems) {
             if (bias) s += bias[(i / (size_t)HW) % (size_t)C];
             out[i] = act_apply(s, act, alpha);
@@ -472,6 +473,7 @@ __global__ void splitk_reduce_small_k(const float* __restrict__ partial, int SK,
     const size_t i = (size_t)blockIdx.x * 64 + o;
     float s = 0.f;
     if (i < elems + n2)
+#pragma unroll 4
         for (int k = kg; k < SK; k += 4) s += partial[(size_t)k * stride + i];
     sm[kg][o] = s;
     __syncthreads();
