@@ -272,6 +272,115 @@ __global__ void bn_bwd_rows_k(const float* __restrict__ x, const float* __restri
     }
 }
 
+// ---- cross-replica ("sync") batch norm, SURVEY.md 8(e): the statistics and the normalisation are separate launches with
+//      an all-gather of 2*C floats per replica between them (issued by the host through torch.distributed).  Every
+//      replica merges the gathered rows in rank order, so all of them hold bit-identical statistics.  One workgroup per
+//      channel for both layouts (element i of channel c sits at ((i / HW) * C + c) * HW + i % HW): this is the parity
+//      mode for "1 GPU x B == N GPUs x B/N", not the throughput path. ------------------------------------------------
+constexpr int kSyncThreads = 256;
+
+__device__ __forceinline__ size_t chan_idx(int i, int c, int C, int HW) {
+    const int n = i / HW, p = i - n * HW;
+    return ((size_t)n * C + c) * HW + p;
+}
+
+// local (mean, M2 = sum of squared deviations from the local mean) per channel -> out[0][c], out[1][c]
+__global__ __launch_bounds__(kSyncThreads) void bn_stats_k(const float* __restrict__ x, float* __restrict__ out, int N, int C, int HW) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x, total = N * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) s += x[chan_idx(i, c, C, HW)];
+    const float mean = block_sum(s, sm) / (float)total;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) {
+        const float d = x[chan_idx(i, c, C, HW)] - mean;
+        q += d * d;
+    }
+    const float m2 = block_sum(q, sm);
+    if (threadIdx.x == 0) {
+        out[c] = mean;
+        out[C + c] = m2;
+    }
+}
+
+// stats [W][2][C] (equal element counts on every replica): Chan's pairwise merge collapses to
+//   mean = avg(mean_r),  M2 = sum_r M2_r + n_local * sum_r (mean_r - mean)^2
+__global__ __launch_bounds__(kSyncThreads) void bn_apply_sync_k(const float* __restrict__ x, const float* __restrict__ stats, int W,
+                                                                const float* __restrict__ scale, const float* __restrict__ offset,
+                                                                float* __restrict__ y, float* __restrict__ save_mean,
+                                                                float* __restrict__ save_invstd, int N, int C, int HW, float eps,
+                                                                int act, float alpha) {
+    const int c = blockIdx.x, total = N * HW;
+    float mean = 0.f;
+    for (int r = 0; r < W; ++r) mean += stats[(size_t)r * 2 * C + c];
+    mean /= (float)W;
+    float m2 = 0.f, dev = 0.f;
+    for (int r = 0; r < W; ++r) {
+        const float d = stats[(size_t)r * 2 * C + c] - mean;
+        m2 += stats[(size_t)r * 2 * C + C + c];
+        dev += d * d;
+    }
+    const float var = (m2 + (float)total * dev) / ((float)total * (float)W);
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float g = scale[c], b = offset[c];
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) {
+        const size_t idx = chan_idx(i, c, C, HW);
+        y[idx] = act_apply(g * ((x[idx] - mean) * invstd) + b, act, alpha);
+    }
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+    }
+}
+
+// local (sum g, sum g*xhat) per channel -> out[0][c], out[1][c]
+__global__ __launch_bounds__(kSyncThreads) void bn_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
+                                                               const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                               float* __restrict__ out, int N, int C, int HW) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x, total = N * HW;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) {
+        const size_t idx = chan_idx(i, c, C, HW);
+        const float g = ld_gy(gy, mk, idx);
+        s1 += g;
+        s2 += g * ((x[idx] - mean) * invstd);
+    }
+    const float a = block_sum(s1, sm), b = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        out[c] = a;
+        out[C + c] = b;
+    }
+}
+
+// gx with the means over the GLOBAL batch (W * N * HW elements per channel); the parameter gradients stay this replica's own
+// sums -- the gradient exchange averages them like every other parameter gradient.
+__global__ __launch_bounds__(kSyncThreads) void bn_bwd_apply_sync_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
+                                                                    const float* __restrict__ scale, const float* __restrict__ save_mean,
+                                                                    const float* __restrict__ save_invstd, const float* __restrict__ sums,
+                                                                    int W, int rank, float* __restrict__ gx, float* __restrict__ gscale,
+                                                                    float* __restrict__ goffset, int N, int C, int HW) {
+    const int c = blockIdx.x, total = N * HW;
+    float tg = 0.f, tgx = 0.f;
+    for (int r = 0; r < W; ++r) {
+        tg += sums[(size_t)r * 2 * C + c];
+        tgx += sums[(size_t)r * 2 * C + C + c];
+    }
+    const float inv_cnt = 1.f / ((float)total * (float)W);
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float k = scale[c] * invstd, mg = tg * inv_cnt, mgx = tgx * inv_cnt;
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) {
+        const size_t idx = chan_idx(i, c, C, HW);
+        const float xh = (x[idx] - mean) * invstd;
+        gx[idx] = k * (ld_gy(gy, mk, idx) - mg - xh * mgx);
+    }
+    if (threadIdx.x == 0) {
+        goffset[c] = sums[(size_t)rank * 2 * C + c];
+        gscale[c] = sums[(size_t)rank * 2 * C + C + c];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -316,6 +425,46 @@ int ggan_bn_bwd(const float* x, const float* gy, const float* scale, const float
                 float* gx, float* gscale, float* goffset, int N, int C, int HW, ggan_stream_t stream) {
     return ggan_bn_bwd_act(x, gy, nullptr, GGAN_ACT_NONE, 0.f, scale, save_mean, save_invstd, gx, gscale, goffset, nullptr, N, C,
                            HW, stream);
+}
+
+int ggan_bn_sync_stats(const float* x, float* stats, int N, int C, int HW, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && stats, "null pointer");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
+    GGAN_LAUNCH("bn_sync_stats", 0, 8.0 * N * C * HW, bn_stats_k, dim3(C), dim3(kSyncThreads), 0, (hipStream_t)stream, x, stats, N, C, HW);
+    return 0;
+}
+
+int ggan_bn_sync_apply(const float* x, const float* stats, int world, const float* scale, const float* offset, float* y,
+                       float* save_mean, float* save_invstd, int N, int C, int HW, float eps, int act, float alpha,
+                       ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && stats && scale && offset && y && save_mean && save_invstd, "null pointer");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0 && world > 0, "bad shape");
+    GGAN_LAUNCH("bn_sync_apply", 0, 8.0 * N * C * HW, bn_apply_sync_k, dim3(C), dim3(kSyncThreads), 0, (hipStream_t)stream, x, stats,
+                world, scale, offset, y, save_mean, save_invstd, N, C, HW, eps, act, alpha);
+    return 0;
+}
+
+int ggan_bn_sync_bwd_stats(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* save_mean,
+                           const float* save_invstd, float* sums, int N, int C, int HW, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && gy && save_mean && save_invstd && sums, "null pointer");
+    GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "activation mask needs the forward output");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
+    const GyMask mk{y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha};
+    GGAN_LAUNCH("bn_sync_bwd_stats", 0, 8.0 * N * C * HW, bn_bwd_stats_k, dim3(C), dim3(kSyncThreads), 0, (hipStream_t)stream, x, gy,
+                mk, save_mean, save_invstd, sums, N, C, HW);
+    return 0;
+}
+
+int ggan_bn_sync_bwd_apply(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* scale,
+                           const float* save_mean, const float* save_invstd, const float* sums, int world, int rank, float* gx,
+                           float* gscale, float* goffset, int N, int C, int HW, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && gy && scale && save_mean && save_invstd && sums && gx && gscale && goffset, "null pointer");
+    GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "activation mask needs the forward output");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0 && world > 0 && rank >= 0 && rank < world, "bad shape");
+    const GyMask mk{y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha};
+    GGAN_LAUNCH("bn_sync_bwd_apply", 0, 12.0 * N * C * HW, bn_bwd_apply_sync_k, dim3(C), dim3(kSyncThreads), 0, (hipStream_t)stream, x,
+                gy, mk, scale, save_mean, save_invstd, sums, world, rank, gx, gscale, goffset, N, C, HW);
+    return 0;
 }
 
 }  // extern "C"

@@ -27,8 +27,11 @@ _CAPTURE_MODE = os.environ.get('GGAN_CAPTURE_MODE', 'thread_local')
 
 
 class Trainer(object):
-    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None):
-        """model: an object with forward_nets / forward / feed_buffers / sample_noise / set_batch / single_contribution
+    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None, sync_bn=False):
+        """sync_bn: BatchNorm statistics over the global batch of all replicas (N GPUs x B/N then reproduce
+        1 GPU x B).  The statistics exchange is a host-issued collective inside the forward and the backward, so this mode
+        runs the steps eagerly (no HIP graphs); it is the parity mode, per-replica statistics stay the throughput default.
+        model: an object with forward_nets / forward / feed_buffers / sample_noise / set_batch / single_contribution
         (default: models.GraphicalGAN(cfg); models_ssgan.StateSpaceGAN for the state-space scripts)."""
         self.cfg = cfg
         self.device = torch.device(device) if device is not None else lib.get_device()
@@ -46,6 +49,10 @@ class Trainer(object):
         # data-parallel runs split the step graph around the gradient all-reduce; the flag lets a single GPU exercise
         # exactly that code path (the collective is then a 1-rank no-op)
         self.split_graph = self.world > 1 or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        if self.sync_bn:
+            lib.ops.batchnorm.set_sync_group(True)
+            self.graph_enabled = False
         # the pack kernel may sum the filter-gradient slabs only if every parameter receives ONE gradient contribution per
         # backward pass (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
         self.single_contrib = bool(self.model.single_contribution)

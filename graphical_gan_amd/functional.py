@@ -508,6 +508,67 @@ class BatchNormTrain(Function):
         return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None
 
 
+def _all_gather_rows(t, group):
+    """[world, *t.shape]: every replica's `t`, in rank order"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out, t, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        out = torch.stack(parts)
+    return out
+
+
+class SyncBatchNormTrain(Function):
+    """BatchNormTrain with statistics over the global batch of a process group of equal-sized replicas: local
+    statistics kernel -> all-gather of 2*C floats -> normalisation kernel, the same split in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, eps, act, alpha, group):
+        import torch.distributed as dist
+        x = _c(x)
+        N, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * Cc)
+        y = torch.empty_like(x)
+        mean = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        sc, of = _c(scale).reshape(-1), _c(offset).reshape(-1)
+        st = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        check(_L().ggan_bn_sync_stats(_p(x), _p(st), N, Cc, HW, _stream()), 'ggan_bn_sync_stats')
+        allst = _all_gather_rows(st, group)
+        world = allst.shape[0]
+        check(_L().ggan_bn_sync_apply(_p(x), _p(allst), world, _p(sc), _p(of), _p(y), _p(mean), _p(invstd), N, Cc, HW, eps, act,
+                                      alpha, _stream()), 'ggan_bn_sync_apply')
+        ctx.dims = (N, Cc, HW)
+        ctx.act, ctx.alpha = act, alpha
+        ctx.group, ctx.world, ctx.rank = group, world, dist.get_rank(group)
+        ctx.pshape = tuple(scale.shape)
+        ctx.save_for_backward(x, sc, mean, invstd, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, sc, mean, invstd, y = ctx.saved_tensors
+        N, Cc, HW = ctx.dims
+        gy = _c(gy)
+        yp = _p(y) if ctx.act != ACT_NONE else _p(None)
+        sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        check(_L().ggan_bn_sync_bwd_stats(_p(x), _p(gy), yp, ctx.act, ctx.alpha, _p(mean), _p(invstd), _p(sums), N, Cc, HW,
+                                          _stream()), 'ggan_bn_sync_bwd_stats')
+        allsums = _all_gather_rows(sums, ctx.group)
+        gx = torch.empty_like(x)
+        gs = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        go = torch.empty_like(gs)
+        check(_L().ggan_bn_sync_bwd_apply(_p(x), _p(gy), yp, ctx.act, ctx.alpha, _p(sc), _p(mean), _p(invstd), _p(allsums),
+                                          ctx.world, ctx.rank, _p(gx), _p(gs), _p(go), N, Cc, HW, _stream()),
+              'ggan_bn_sync_bwd_apply')
+        return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None, None
+
+
 class SplitRows(Function):
     """(x[:n], x[n:]) for the critic evaluated once on [fake; real]; the backward is ONE concatenation instead of two
     zero-padded slice gradients and their sum."""

@@ -54,7 +54,7 @@ def train(S, cfg, model=None, out_dir=None):
     device = lib.get_device()
     np.random.seed(S.get('SEED', 0))
     torch.manual_seed(S.get('SEED', 0))
-    tr = Trainer(cfg, device=device, graph=S.get('HIP_GRAPH', True), model=model)
+    tr = Trainer(cfg, device=device, graph=S.get('HIP_GRAPH', True), model=model, sync_bn=S.get('SYNC_BN', False))
     batches, source = _batches(S, tr.model, device)
     print('[run] data: %s' % source)
     out_dir = out_dir or S.get('OUT_DIR')

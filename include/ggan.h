@@ -132,6 +132,21 @@ int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, 
                     const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset,
                     float* gx_chansum, int N, int C, int HW, ggan_stream_t stream);
 
+/* Cross-replica ("sync") BatchNorm, SURVEY.md 8(e): statistics over the GLOBAL batch of `world` equal-sized replicas.  The
+ * reference has no multi-GPU path; this is the mode under which N GPUs x B/N reproduce 1 GPU x B.  The host all-gathers the
+ * 2*C floats each *_stats call produces ([2][C]: forward (mean, M2), backward (sum g, sum g*xhat)) into [world][2][C] and hands
+ * them to the *_apply call, which merges them in rank order (bit-identical on every replica).  gscale / goffset are this
+ * replica's own sums: the gradient exchange averages them with the other parameter gradients.  No second derivative. */
+int ggan_bn_sync_stats(const float* x, float* stats, int N, int C, int HW, ggan_stream_t stream);
+int ggan_bn_sync_apply(const float* x, const float* stats, int world, const float* scale, const float* offset, float* y,
+                       float* save_mean, float* save_invstd, int N, int C, int HW, float eps, int act, float alpha,
+                       ggan_stream_t stream);
+int ggan_bn_sync_bwd_stats(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* save_mean,
+                           const float* save_invstd, float* sums, int N, int C, int HW, ggan_stream_t stream);
+int ggan_bn_sync_bwd_apply(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* scale,
+                           const float* save_mean, const float* save_invstd, const float* sums, int world, int rank, float* gx,
+                           float* gscale, float* goffset, int N, int C, int HW, ggan_stream_t stream);
+
 /* ---- pointwise -------------------------------------------------------------------------------
  * LeakyReLU = tf.maximum(alpha*x, x) (gmgan_inference_cifar10.py:122-123), tf.nn.relu, tf.tanh,
  * tf.nn.sigmoid.  bwd takes the forward INPUT for lrelu/relu and the forward OUTPUT for

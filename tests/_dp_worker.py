@@ -23,12 +23,18 @@ def main():
     from graphical_gan_amd.engine import Trainer, broadcast_params
     from graphical_gan_amd.models import Config
     from oracle import nets as N, step as S
+    sync = mode.endswith(':syncbn')      # global batch 8 either way: one process x 8, or `world` processes x 8/world
+    mode = mode.split(':')[0]
+    B = 8 // world if sync else 8
     ocfg = N.Cfg('cifar10', batch_size=8, n_coms=0, dim=8, dim_latent=16)
-    cfg = Config('cifar10', batch_size=8, mode=mode, dim=8, dim_latent=16)
-    tr = Trainer(cfg, device=dev, graph=True, inject_noise=True)
+    cfg = Config('cifar10', batch_size=B, mode=mode, dim=8, dim_latent=16)
+    tr = Trainer(cfg, device=dev, graph=True, inject_noise=True, sync_bn=sync)
     tr.load_params(N.init_params(ocfg, 0))
-    feeds = iter([S.make_feed(ocfg, np.random.default_rng(900 + i), mode) for i in range(80)])
-    for it in range(6):
+    feeds = [S.make_feed(ocfg, np.random.default_rng(900 + i), mode) for i in range(80)]
+    if sync and world > 1:               # this replica's rows of every fed array
+        feeds = [{k: (v[rank * B:(rank + 1) * B] if np.ndim(v) and np.shape(v)[0] == 8 else v) for k, v in f.items()} for f in feeds]
+    feeds = iter(feeds)
+    for it in range(3 if sync else 6):
         if it == 2:
             broadcast_params(0)
         tr.iteration(it, feeds)

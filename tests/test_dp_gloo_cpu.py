@@ -56,6 +56,17 @@ def _worker(rank, world, port, q):
     theta = np.concatenate([P0[n].astype(np.float64).reshape(-1) for n in names])
     g = np.concatenate([flat[o:o + n].numpy() for o, n in slots]) * bucket.scale
     th, m, v = O.adam_update(theta, g, np.zeros_like(theta), np.zeros_like(theta), 1, 2e-4, .5, .999)
+    # cross-replica BatchNorm statistics: the host side gathers every replica's [2][C] rows in rank order; merged with the
+    # equal-count form of Chan's update (csrc/bn.hip bn_apply_sync_k) they must equal the statistics of the whole batch
+    from graphical_gan_amd.functional import _all_gather_rows
+    full = np.random.default_rng(5).standard_normal((world * 6, 7)) * 3 + 1
+    mine = full[rank * 6:(rank + 1) * 6]
+    st = torch.as_tensor(np.stack([mine.mean(0), ((mine - mine.mean(0)) ** 2).sum(0)]))
+    rows = _all_gather_rows(st, dist.group.WORLD).numpy()
+    assert rows.shape == (world, 2, 7) and np.array_equal(rows[rank], st.numpy())
+    mean = rows[:, 0].mean(0)
+    var = (rows[:, 1].sum(0) + 6 * ((rows[:, 0] - mean) ** 2).sum(0)) / (6 * world)
+    assert np.abs(mean - full.mean(0)).max() < 1e-12 and np.abs(var - full.var(0)).max() < 1e-12
     q.put((rank, th))
     dist.barrier()
     dist.destroy_process_group()

@@ -474,3 +474,57 @@ def test_rmsprop_with_clipping_and_wali_costs(gpu):
     dop()
     assert float(pd.detach().abs().max()) <= 0.01 + 1e-9          # critic weights clipped by the update itself
     optim.reset_optimizers(); lib.delete_all_params()
+
+
+@pytest.mark.parametrize('shape,world,act', [((12, 6, 8, 8), 3, 0), ((8, 5, 4, 4), 2, 2), ((16, 40), 4, 0), ((6, 33), 2, 1)])
+def test_sync_batchnorm_entry_points(gpu, shape, world, act):
+    """ggan_bn_sync_*: the batch cut into `world` equal replicas, statistics rows gathered by hand -> every replica's output and
+    input gradient equal the slices of the full-batch BatchNorm (oracle, float64); scale/offset gradients sum to the full ones."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from graphical_gan_amd.functional import _p, _stream, check
+    from oracle import tape as tp
+    L = _lib.load()
+    rng = np.random.default_rng(77 + world)
+    x = rng.standard_normal(shape) * 1.5 + rng.standard_normal((1, shape[1]) + (1,) * (len(shape) - 2))
+    Cc = shape[1]
+    sc = 1 + 0.2 * rng.standard_normal(Cc); of = 0.3 * rng.standard_normal(Cc)
+    gy = rng.standard_normal(shape)
+    axes = [0, 2, 3] if len(shape) == 4 else [0]
+    X, S_, O = tp.T(x), tp.T(sc), tp.T(of)
+    yo = tp.batchnorm_train(X, S_, O, axes, 1e-5)
+    if act == 2:
+        yo = tp.relu(yo)
+    elif act == 1:
+        yo = tp.leaky_relu(yo, 0.2)
+    gxo, gso, goo = tp.grad(tp.reduce_sum(tp.mul(yo, tp.T(gy))), [X, S_, O])
+    n = shape[0] // world
+    HW = int(np.prod(shape[2:])) if len(shape) == 4 else 1
+    xs = [_t(x[r * n:(r + 1) * n], gpu) for r in range(world)]
+    gys = [_t(gy[r * n:(r + 1) * n], gpu) for r in range(world)]
+    tsc, tof = _t(sc, gpu), _t(of, gpu)
+    stats = torch.empty((world, 2, Cc), device=gpu)
+    for r in range(world):
+        check(L.ggan_bn_sync_stats(_p(xs[r]), _p(stats[r]), n, Cc, HW, _stream()), 'stats')
+    ys, means, invs = [], [], []
+    for r in range(world):
+        y = torch.empty_like(xs[r]); m = torch.empty(Cc, device=gpu); iv = torch.empty(Cc, device=gpu)
+        check(L.ggan_bn_sync_apply(_p(xs[r]), _p(stats), world, _p(tsc), _p(tof), _p(y), _p(m), _p(iv), n, Cc, HW, 1e-5, act, 0.2,
+                                   _stream()), 'apply')
+        ys.append(y); means.append(m); invs.append(iv)
+    assert all(torch.equal(means[0], m) and torch.equal(invs[0], iv) for m, iv in zip(means, invs))   # bit-identical on all replicas
+    yfull = torch.cat(ys).cpu().numpy()
+    assert _rel(yfull, yo.v) < 1e-5
+    sums = torch.empty((world, 2, Cc), device=gpu)
+    for r in range(world):
+        check(L.ggan_bn_sync_bwd_stats(_p(xs[r]), _p(gys[r]), _p(ys[r]) if act else _p(None), act, 0.2, _p(means[r]), _p(invs[r]),
+                                       _p(sums[r]), n, Cc, HW, _stream()), 'bwd_stats')
+    gxs, gss, gos = [], [], []
+    for r in range(world):
+        gx = torch.empty_like(xs[r]); gs = torch.empty(Cc, device=gpu); go = torch.empty(Cc, device=gpu)
+        check(L.ggan_bn_sync_bwd_apply(_p(xs[r]), _p(gys[r]), _p(ys[r]) if act else _p(None), act, 0.2, _p(tsc), _p(means[r]),
+                                       _p(invs[r]), _p(sums), world, r, _p(gx), _p(gs), _p(go), n, Cc, HW, _stream()), 'bwd_apply')
+        gxs.append(gx); gss.append(gs); gos.append(go)
+    assert _rel(torch.cat(gxs).cpu().numpy(), gxo.v) < 2e-5
+    assert _rel(sum(g.cpu().numpy().astype(np.float64) for g in gss), gso.v.reshape(-1)) < 2e-5
+    assert _rel(sum(g.cpu().numpy().astype(np.float64) for g in gos), goo.v.reshape(-1)) < 2e-5
