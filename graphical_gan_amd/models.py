@@ -24,6 +24,8 @@ class Config(object):
         self.dataset, self.B, self.K, self.dim_latent, self.temp, self.fuse = dataset, batch_size, n_coms, dim_latent, temp, fuse
         if dataset == 'cifar10':
             self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, True, 'tanh'
+        elif dataset == 'svhn':          # g(m)gan_inference_svhn.py: the CIFAR nets with BN_FLAG = False (:69-72)
+            self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, False, 'tanh'
         elif dataset == 'mnist':
             self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 1, 28, 64, 3, True, 'sigmoid'
         elif dataset == 'face':

@@ -24,6 +24,9 @@ def _batches(S, model, device):
         if ds == 'cifar10':
             train, _ = lib.cifar10.load(S['BATCH_SIZE'], S.get('DATA_DIR', ''))
             return DevicePrefetcher(train, device, pick=[0], dtypes=[np.int32]), S.get('DATA_DIR')
+        if ds == 'svhn':
+            train, _ = lib.svhn.load(S['BATCH_SIZE'], S.get('DATA_DIR', ''))
+            return DevicePrefetcher(train, device, pick=[0], dtypes=[np.int32]), S.get('DATA_DIR')
         if ds == 'face':
             train, _ = lib.celebA.load(S['BATCH_SIZE'], S.get('DATA_DIR', ''))
             return DevicePrefetcher(train, device, dtypes=[np.int32]), S.get('DATA_DIR')

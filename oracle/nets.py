@@ -25,6 +25,8 @@ class Cfg(object):
         self.mode_k = mode_k
         if dataset == 'cifar10':
             self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, True, 'tanh'
+        elif dataset == 'svhn':          # g(m)gan_inference_svhn.py: the CIFAR nets with BN_FLAG = False (:69-72)
+            self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, False, 'tanh'
         elif dataset == 'mnist':
             self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 1, 28, 64, 3, True, 'sigmoid'
         elif dataset == 'face':

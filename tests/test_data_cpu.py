@@ -66,3 +66,36 @@ def test_moving_mnist_matches_literal_restatement():
     tr, te = M.load_video(6, 5, data=(train, dev, test))
     x, y = next(iter(tr()))
     assert x.shape == (5, 6, 4096) and y.shape == (5,)
+
+
+def test_svhn_loader_layout_labels_and_mat_files(tmp_path):
+    """tflib/svhn.py:33-53: X[32,32,3,N] -> rows in (C,H,W) order, label 10 -> 0, pairs survive the shuffles; also through real
+    .mat files written with scipy."""
+    from graphical_gan_amd.tflib import svhn
+    from scipy.io import savemat
+    rng = np.random.default_rng(2)
+    X = rng.integers(0, 256, size=(32, 32, 3, 24)).astype(np.uint8)
+    y = (np.arange(24) % 10 + 1).reshape(-1, 1).astype(np.uint8)           # 1..10 as in the files
+    X[0, 0, 0, :] = y.reshape(-1)                                          # marker: row[0] (c=0,h=0,w=0) carries the raw label
+    tr, te = svhn.load(8, '/nonexistent', data=((X, y), (X[..., :8], y[:8])))
+    n = 0
+    for x, t in tr():
+        assert x.shape == (8, 3072) and x.dtype == np.uint8
+        assert np.array_equal(x[:, 0] % 10, t)                            # 10 -> 0, everything else unchanged
+        n += 1
+    assert n == 3 and sum(1 for _ in te()) == 1
+    # element order: row[c*1024 + h*32 + w] == X[h, w, c, i]
+    tr2, _ = svhn.load(24, '/nonexistent', data=((X, y), (X[..., :8], y[:8])))
+    np.random.seed(0)
+    xb, tb = next(iter(tr2()))
+    i = int(np.where((X[0, 0, 0, :] == xb[0, 0]) & (X[5, 7, 2, :] == xb[0, 2 * 1024 + 5 * 32 + 7]))[0][0])
+    assert np.array_equal(xb[0].reshape(3, 32, 32), X[..., i].transpose(2, 0, 1))
+    d = tmp_path / 'svhn'
+    d.mkdir()
+    savemat(str(d / 'train_32x32.mat'), {'X': X, 'y': y})
+    savemat(str(d / 'test_32x32.mat'), {'X': X[..., :8], 'y': y[:8]})
+    tr3, te3 = svhn.load(8, str(d))
+    assert sum(1 for _ in tr3()) == 3 and next(iter(te3()))[0].shape == (8, 3072)
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        svhn.load(8, '/nonexistent')

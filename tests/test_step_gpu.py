@@ -46,6 +46,7 @@ CASES = [  # dataset, B, K, mode, dim, dim_latent
     ('cifar10', 8, 5, 'local_epce', 8, 16),    # gmgan + l2(real_x, G(q_z))
     ('mnist', 6, 4, 'local_ep', 8, 16),
     ('face', 4, 6, 'local_ep', 4, 16),
+    ('svhn', 8, 5, 'local_ep', 8, 16),         # the CIFAR nets without BatchNorm (g(m)gan_inference_svhn.py)
     ('cifar10', 64, 0, 'ali', None, 128),      # BASELINE config 2 at full size
 ]
 
@@ -94,7 +95,7 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
             assert np.median(err) <= tol * scale and l2 <= 2e-3, (which, n, err.max(), np.median(err), l2, scale)
 
 
-@pytest.mark.parametrize("case", CASES[:8], ids=lambda c: '-'.join(str(x) for x in c))
+@pytest.mark.parametrize("case", CASES[:9], ids=lambda c: '-'.join(str(x) for x in c))
 @pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hipgraph'])
 def test_trajectory(gpu, case, graph):
     """3 iterations of the loop (iteration 0 = critic only), scripted minibatches + noise: cost sequence and
