@@ -39,13 +39,13 @@ class Config(object):
         self.mode = mode or ('local_ep' if n_coms else 'ali')
         # reconstruction variants (gan_inference_cifar10.py:293-304, gmgan_inference_cifar10.py:399-403):
         #   alice-z: + l2(real_x, G(q_z));  alice-x: + l2(p_z, E(fake_x));  alice: both;  local_epce: gmgan + l2(real_x, G(q_z))
-        assert self.mode in ('ali', 'local_ep', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce')
+        assert self.mode in ('ali', 'local_ep', 'wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce')
         assert not (self.mode.startswith('alice') and n_coms) and not (self.mode == 'local_epce' and not n_coms)
         self.top = self.dim * 2 ** (self.nl - 1)
         self.flat = 16 * self.top
         self.output_dim = self.C * self.S * self.S
-        self.critic_iters = 5 if self.mode == 'wali-gp' else 1          # gan_inference_cifar10.py:53-59
-        self.lr = lr if lr is not None else (1e-4 if self.mode == 'wali-gp' else 2e-4)
+        self.critic_iters = 5 if self.mode in ('wali', 'wali-gp') else 1          # gan_inference_cifar10.py:53-59
+        self.lr = lr if lr is not None else {'wali-gp': 1e-4, 'wali': 5e-5}.get(self.mode, 2e-4)
         self.beta1 = 0.5
         # critic steps evaluate the critic ONCE on [fake; real] (the critics of these scripts have no BatchNorm, so
         # rows are independent and the result is identical); generator steps keep the two branches separate because
@@ -64,13 +64,13 @@ class GraphicalGAN(object):
     def single_contribution(self):
         """every parameter receives exactly one gradient contribution per backward pass (critic evaluated once on
         [fake; real]; the wali-gp penalty re-enters the critic)"""
-        return bool(self.cfg.batch_critic) and self.cfg.mode in ('ali', 'local_ep')   # (reconstruction terms reuse G / E)
+        return bool(self.cfg.batch_critic) and self.cfg.mode in ('ali', 'local_ep', 'wali')   # (reconstruction terms reuse G / E)
 
     def cut_tensors(self, nets):
         """tensors through which EVERY gradient of the Extractor's parameters flows (None if there is no such cut: the
         reconstruction modes apply the Extractor a second time) -- lets a data-parallel generator step exchange the
         Generator's gradients while the Extractor's backward pass is still running (engine.Trainer)."""
-        return [nets['q_z']] if self.cfg.mode in ('ali', 'local_ep', 'wali-gp') else None
+        return [nets['q_z']] if self.cfg.mode in ('ali', 'local_ep', 'wali', 'wali-gp') else None
 
     def feed_buffers(self, device):
         c, B, feed = self.cfg, self.cfg.B, {}
@@ -285,6 +285,9 @@ class GraphicalGAN(object):
             res = J.alice(d_fake, d_real, rec_penalty, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
         elif c.K:
             res = J.local_ep(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        elif c.mode == 'wali':           # RMSProp, critic weights clipped inside the critic's update kernel
+            r = J.wali(d_fake, d_real, gen_params, disc_params)
+            res = (r[0], r[1], r[3], r[4])
         elif c.mode == 'wali-gp':
             if which == 'gen':
                 gp = None                # not part of gen_cost; TF prunes the third critic pass

@@ -55,6 +55,13 @@ def local_epce_costs(disc_fake_list, disc_real_list, rec_penalty):
     return tp.add(g, rec_penalty), d
 
 
+def wali_costs(disc_fake, disc_real):
+    """tflib/objs/gan_inference.py:5-6 (the generator cost really is -mean(fake) - mean(real) there)."""
+    gen = tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.neg(tp.reduce_mean(disc_real)))
+    disc = tp.add(tp.reduce_mean(disc_fake), tp.neg(tp.reduce_mean(disc_real)))
+    return gen, disc
+
+
 def wali_gp_costs(disc_fake, disc_real, gradient_penalty):
     """tflib/objs/gan_inference.py:28-32."""
     gen = tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.reduce_mean(disc_real))
@@ -72,6 +79,28 @@ def gradient_penalty(critic, real_x, fake_x, q_z, p_z, alpha, lam=10.0):
     g = tp.grad(tp.reduce_sum(d_hat), [x_hat])[0]
     slopes = tp.sqrt(tp.reduce_sum(tp.square(g), (1,)))
     return tp.scale(tp.reduce_mean(tp.square(tp.add(slopes, -1.0))), lam)
+
+
+class RMSProp(object):
+    """tf.train.RMSPropOptimizer(learning_rate) with TF's defaults (decay .9, momentum 0, epsilon 1e-10, mean-square slot
+    initialised to ONE) for one var_list (tflib/objs/gan_inference.py:8-13); clip=(lo, hi) applies the weight clipping the
+    scripts run right after every critic step (gan_inference.py:15-24, gan_inference_cifar10.py `session.run(clip_disc_weights)`)."""
+
+    def __init__(self, names, lr=5e-5, decay=0.9, eps=1e-10, clip=None):
+        self.names, self.lr, self.decay, self.eps, self.clip = list(names), lr, decay, eps, clip
+        self.ms = {}
+
+    def apply(self, P, grads):
+        for n in self.names:
+            g = grads.get(n)
+            if g is None:
+                continue
+            g = g.astype(P[n].dtype)
+            ms = self.decay * self.ms.get(n, np.ones_like(P[n])) + (1 - self.decay) * g * g
+            self.ms[n] = ms
+            P[n] = P[n] - self.lr * g / np.sqrt(ms + self.eps)
+            if self.clip is not None:
+                P[n] = np.clip(P[n], self.clip[0], self.clip[1])
 
 
 class Adam(object):

@@ -86,6 +86,8 @@ def forward(cfg, P, feed, mode='ali'):
             gen_cost, disc_cost = J.ali_costs(d_fake, d_real)
         elif mode in ('alice', 'alice-z', 'alice-x'):
             gen_cost, disc_cost = J.alice_costs(d_fake, d_real, rec_penalty())
+        elif mode == 'wali':
+            gen_cost, disc_cost = J.wali_costs(d_fake, d_real)
         elif mode == 'wali-gp':
             gp = J.gradient_penalty(critic, real_x, fake_x, q_z, p_z, feed['alpha'])
             gen_cost, disc_cost = J.wali_gp_costs(d_fake, d_real, gp)
@@ -108,9 +110,13 @@ class Trainer(object):
             hp = dict(lr=1e-4, beta1=0.5, beta2=0.9)
         else:                                       # LR/BETA1 of the scripts, beta2 default
             hp = dict(lr=2e-4, beta1=0.5, beta2=0.999)
-        self.gen_opt = J.Adam(gen_names, **hp)
-        self.disc_opt = J.Adam(disc_names, **hp)
-        self.critic_iters = 5 if mode == 'wali-gp' else 1   # gan_inference_cifar10.py:53-59
+        if mode == 'wali':                          # tflib/objs/gan_inference.py:8-24: RMSProp 5e-5, critic weights clipped
+            self.gen_opt = J.RMSProp(gen_names)
+            self.disc_opt = J.RMSProp(disc_names, clip=(-.01, .01))
+        else:
+            self.gen_opt = J.Adam(gen_names, **hp)
+            self.disc_opt = J.Adam(disc_names, **hp)
+        self.critic_iters = 5 if mode in ('wali', 'wali-gp') else 1   # gan_inference_cifar10.py:53-59
 
     def _run(self, feed, which):
         Pt = {k: tp.T(v) for k, v in self.P.items()}

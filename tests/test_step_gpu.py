@@ -41,6 +41,7 @@ CASES = [  # dataset, B, K, mode, dim, dim_latent
     ('cifar10', 8, 0, 'ali', 8, 16),
     ('cifar10', 8, 5, 'local_ep', 8, 16),
     ('cifar10', 8, 0, 'wali-gp', 8, 16),
+    ('cifar10', 8, 0, 'wali', 8, 16),          # RMSProp + critic weight clipping, CRITIC_ITERS 5
     ('cifar10', 8, 0, 'alice', 8, 16),         # + l2(real_x, G(q_z)) + l2(p_z, E(fake_x))
     ('cifar10', 8, 0, 'alice-x', 8, 16),
     ('cifar10', 8, 5, 'local_epce', 8, 16),    # gmgan + l2(real_x, G(q_z))
@@ -61,7 +62,7 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
     if dim is None and not fuse:
         pytest.skip('full-size case runs fused only (oracle time)')
     ocfg, P0, cfg, tr = _mk(dataset, B, K, mode, dim, dl, fuse, False, gpu)
-    omode = mode if mode in ('wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce') else 'ali'
+    omode = mode if mode in ('wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce') else 'ali'
     feed = S.make_feed(ocfg, np.random.default_rng(11), omode)
     Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
     oout = S.forward(ocfg, Pt, feed, omode)
@@ -95,7 +96,7 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
             assert np.median(err) <= tol * scale and l2 <= 2e-3, (which, n, err.max(), np.median(err), l2, scale)
 
 
-@pytest.mark.parametrize("case", CASES[:9], ids=lambda c: '-'.join(str(x) for x in c))
+@pytest.mark.parametrize("case", CASES[:10], ids=lambda c: '-'.join(str(x) for x in c))
 @pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hipgraph'])
 def test_trajectory(gpu, case, graph):
     """3 iterations of the loop (iteration 0 = critic only), scripted minibatches + noise: cost sequence and
@@ -103,7 +104,7 @@ def test_trajectory(gpu, case, graph):
     from oracle import step as S
     dataset, B, K, mode, dim, dl = case
     ocfg, P0, cfg, tr = _mk(dataset, B, K, mode, dim, dl, True, graph, gpu)
-    omode = mode if mode in ('wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce') else 'ali'
+    omode = mode if mode in ('wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce') else 'ali'
     otr = S.Trainer(ocfg, P0, omode, np.float64)
     n_it = 4 if graph else 3        # graph path: call 1 eager, call 2 captures+replays, ...
     n_feeds = n_it * (1 + otr.critic_iters)
