@@ -23,6 +23,9 @@ int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const
                   float alpha, void* ws, size_t ws_bytes, hipStream_t s);
 int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx,
                     int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s);
+// image side with <= 4 channels (conv_thin.hip): same contract as the MFMA paths
+int conv_dgrad_thin(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx, int act,
+                    float alpha, hipStream_t s);
 // gbias (may be NULL): sum over n,oh,ow of the (masked) gy, produced from the gy tiles the kernel stages anyway
 // parts != NULL: the split-K slabs stay in parts->buf ([n][stride], bias-gradient tail after each slab) for a consumer that
 // sums them (ggan_pack_parts); no reduce kernel is launched and gw/gbias/ws are ignored.

@@ -47,7 +47,9 @@ static int bwd_data(const ggan_conv_geom* g, const float* gy, GyMask m, const fl
     if (!(gy && w && gx)) { set_error("ggan_conv2d_bwd_data: null pointer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     if (!g_force_naive && !getenv("GGAN_NAIVE_DGRAD")) {
-        int r = conv_dgrad_mfma(*g, gy, m, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
+        int r = conv_dgrad_thin(*g, gy, m, w, bias, gx, act, alpha, s);
+        if (r <= 0) return r;
+        r = conv_dgrad_mfma(*g, gy, m, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
     }
     return conv_dgrad_naive(*g, gy, m, w, bias, gx, act, alpha, s);
