@@ -38,6 +38,8 @@ struct WgradParts {
 };
 int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                     size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
+int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
+                    size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
 size_t conv_workspace_bytes(const ggan_conv_geom& g);
 // out[i] = act(sum_s partial[s][i] + bias[(i/HW)%C]) -- deterministic split-K combine (conv + gemm)
 int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,

@@ -114,7 +114,9 @@ static int bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, 
     if (!(x && gy && gw)) { set_error("ggan_conv2d_bwd_filter: null pointer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     if (!g_force_naive && !getenv("GGAN_NAIVE_WGRAD")) {
-        int r = conv_wgrad_mfma(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
+        int r = conv_wgrad_thin(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
+        if (r <= 0) return r;
+        r = conv_wgrad_mfma(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
         r = wgrad_widened(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
@@ -160,7 +162,8 @@ int ggan_conv2d_bwd_filter_parts(const ggan_conv_geom* g, const float* x, const 
     GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "null activation reference");
     if (g_force_naive || getenv("GGAN_NAIVE_WGRAD")) return 1;
     WgradParts po{part, part_cap, with_bias, 0, 0};
-    int r = conv_wgrad_mfma(*g, x, gy, GyMask{y, y_act, y_alpha}, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, &po);
+    int r = conv_wgrad_thin(*g, x, gy, GyMask{y, y_act, y_alpha}, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, &po);
+    if (r == 1) r = conv_wgrad_mfma(*g, x, gy, GyMask{y, y_act, y_alpha}, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, &po);
     if (r == 0) { *n_parts = po.n; *stride = po.stride; }
     return r;
 }

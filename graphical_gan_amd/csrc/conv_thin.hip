@@ -14,6 +14,14 @@
 //     element gathers its terms, adds the bias, applies the activation and is stored once (coalesced rows).  No atomics, no
 //     split-K: deterministic.  Halo rows are recomputed (2x the GEMM, which is 3 % of the old kernel's MFMA time).
 //
+//   filter gradient (im2col form)
+//       gw[tap*Ci + c, co] = sum_{n, p} x[n, c, 2*oh+kh-pt, 2*ow+kw-pl] * gy[n, co, p]      M = 25*Ci (+1), N = Co, K = pixels
+//     The row after the last tap is an all-ones operand row, so the bias gradient sum_p gy[n, co, p] falls out of the same
+//     MFMAs (it lands exactly where the split-K slab convention keeps the bias tail).  One workgroup walks a range of
+//     (image, 4-row band) items: x rows and the gy tile are prefetched into registers under the MFMAs of the previous item,
+//     each wave owns whole 16x16 output tiles (no cross-wave reduction), and the slab leaves through LDS as float4 rows.
+//     At most 64 slabs (what the pack kernel / split-K reduce sums), deterministic.
+//
 // Replaces tf.nn.conv2d_transpose of Generator.5 (tflib/ops/deconv2d.py:101-114) and Conv2DBackpropInput of
 // Discriminator.1 / Extractor.1 (tflib/ops/conv2d.py:106) -- SURVEY.md 8(a) a2/a3.
 #include "common.h"
@@ -39,13 +47,15 @@ struct ThinDgradParams {
     int dbg;
 };
 
-template <int NT>
+template <int NT, bool TWO>
 __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: keeps the MFMA blocks out of exec-mask branches)
     const int l15 = lane & 15, q = lane >> 4;
     const int g0 = blockIdx.x * 2, n = blockIdx.y;
     const int K = P.K, Wo = P.Wo, J = 25 * P.Ci;
+    const float mslope = P.mask_act == GGAN_ACT_LRELU ? P.mask_alpha : 0.f;
     float* Ws = smem;                          // [NT*16][KP]
     float* As = smem + NT * 16 * P.KP;         // [K][PS]; later T [MT*16][TS]
 
@@ -69,12 +79,12 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
                 if ((unsigned)oh < (unsigned)P.Ho) {
                     const size_t off = img + ((size_t)k * P.Ho + oh) * Wo + c4 * 4;
                     v = *reinterpret_cast<const float4*>(P.gy + off);
-                    if (P.ref) {
+                    if (P.ref) {        // lrelu / relu derivative (the launcher admits no other mask): a select
                         const float4 rf = *reinterpret_cast<const float4*>(P.ref + off);
-                        v.x = act_grad(v.x, rf.x, P.mask_act, P.mask_alpha);
-                        v.y = act_grad(v.y, rf.y, P.mask_act, P.mask_alpha);
-                        v.z = act_grad(v.z, rf.z, P.mask_act, P.mask_alpha);
-                        v.w = act_grad(v.w, rf.w, P.mask_act, P.mask_alpha);
+                        v.x = rf.x > 0.f ? v.x : v.x * mslope;
+                        v.y = rf.y > 0.f ? v.y : v.y * mslope;
+                        v.z = rf.z > 0.f ? v.z : v.z * mslope;
+                        v.w = rf.w > 0.f ? v.w : v.w * mslope;
                     }
                 }
                 *reinterpret_cast<float4*>(As + k * P.PS + r * Wo + c4 * 4) = v;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
                 if ((unsigned)oh < (unsigned)P.Ho) {
                     const size_t off = img + ((size_t)k * P.Ho + oh) * Wo + col;
                     v = P.gy[off];
-                    if (P.ref) v = act_grad(v, P.ref[off], P.mask_act, P.mask_alpha);
+                    if (P.ref) v = P.ref[off] > 0.f ? v : v * mslope;
                 }
                 As[k * P.PS + p] = v;
             }
@@ -107,20 +117,21 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool two = wave + 4 < P.MT;
     if (wave < P.MT && !(P.dbg & 1)) {
+        // (TWO: MT == 8, every wave owns two m-tiles; otherwise MT <= 4 and one)
         const float* ap = As + q * P.PS + wave * 16 + l15;
         const float* bp = Ws + l15 * P.KP + q;
-#pragma unroll 4
-        for (int ks = 0; ks < (K >> 2); ++ks) {
+        const int nks = K >> 2;
+        for (int ks = 0; ks < nks; ++ks) {
             const float a0 = ap[ks * 4 * P.PS];
-            const float a1 = two ? ap[ks * 4 * P.PS + 64] : 0.f;
+            float a1 = 0.f;
+            if (TWO) a1 = ap[ks * 4 * P.PS + 64];
             float b[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) b[t] = bp[t * 16 * P.KP + ks * 4];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], acc[0][t], 0, 0, 0);
-            if (two) {
+            if (TWO) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], acc[1][t], 0, 0, 0);
             }
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     __syncthreads();                           // every wave is done reading the gy tile: T may overwrite it
     float* Ts = As;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < (TWO ? 2 : 1); ++i) {
         const int mt = wave + 4 * i;
         if (mt < P.MT) {
 #pragma unroll
@@ -158,6 +169,226 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+struct ThinWgradParams {
+    const float* x;      // [N][Ci][H][W]
+    const float* gy;     // [N][Co][Ho][Wo]
+    const float* ref;    // activation reference of gy (mask), or null
+    float* out;          // slabs [SK][slab_stride] (or gw itself when SK == 1)
+    float* bias_direct;  // SK == 1 without slabs: the bias gradient goes here (may be null)
+    int N, Ci, H, W, Co, Ho, Wo, pad_t, pad_l;
+    int GBR, nb, items, ipw;
+    int SR, XRS, XCS, GS, PB, J;
+    int xunits, gunits;
+    int with_bias, mask_act;
+    float mask_alpha;
+    size_t out_elems, slab_stride;
+    FastDiv d_Wo, d_nb, d_W4, d_SR, d_PB4, d_Ci;
+    unsigned x_bytes, gy_bytes;
+    int gstride;         // floats between the wave groups' staging areas
+};
+
+constexpr int XU_MAX = 3, GU_MAX = 4;
+
+// NTN: 16-wide tiles along Co (2 or 4); the 4 waves are NTN tile columns x (4/NTN) groups of tile rows
+// NG: groups of 4 waves per workgroup, each walking its own items (the step is bound by the latency of the operand loads,
+// and the slab count caps the number of workgroups: more items in flight per workgroup instead); summed through LDS at the end
+template <int NTN, int MPW, int NG>
+__global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MG = 4 / NTN;
+    const int tid = threadIdx.x & (NTHR - 1), lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR);
+    const int l15 = lane & 15, q = lane >> 4;
+    const int nt = wave % NTN, mg = wave / NTN;
+    float* gsm = smem + (size_t)grp * P.gstride;    // this group's staging area
+    float* xs = gsm;                           // [Ci][XCS]: rows SR x (2 halo | W | 2 halo)
+    float* gs = gsm + P.Ci * P.XCS;            // [Co][GS]
+    const int W4 = P.W >> 2, PB4 = P.PB >> 2, HW = P.H * P.W, HoWo = P.Ho * P.Wo;
+
+    // per-lane operand-row descriptors: row j = tap*Ci + c of the im2col matrix -> offset of (c, kh, kw) in the slab
+    // rows past the taps read a constant word kept behind the tiles instead: 1.0 (the bias-gradient row) or 0.0 (padding)
+    const int cbase = P.Ci * P.XCS + P.Co * P.GS;
+    int offA[MPW], pmA[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const int j = (mg + i * MG) * 16 + l15;
+        int off = cbase + 1, pm = 0;
+        if (j < P.J) {
+            const int tap = fdiv(j, P.d_Ci), c = j - tap * P.Ci, kh = tap / 5, kw = tap - kh * 5;
+            off = c * P.XCS + kh * P.XRS + kw + 2 - P.pad_l;
+            pm = -1;
+        } else if (j == P.J && P.with_bias) {
+            off = cbase;
+        }
+        offA[i] = off; pmA[i] = pm;
+    }
+    if (tid == 0) { gsm[cbase] = 1.f; gsm[cbase + 1] = 0.f; }
+    // staging descriptors
+    int xrel[XU_MAX], xrow[XU_MAX], xlds[XU_MAX];
+#pragma unroll
+    for (int j = 0; j < XU_MAX; ++j) {
+        const int u = tid + j * NTHR;
+        int rel = 0, row = -1, l = 0;
+        if (u < P.xunits) {
+            const int t = fdiv(u, P.d_W4), f4 = u - t * W4;
+            const int c = fdiv(t, P.d_SR);
+            row = t - c * P.SR;
+            rel = c * HW + row * P.W + f4 * 4;
+            l = c * P.XCS + row * P.XRS + 2 + f4 * 4;
+        }
+        xrel[j] = rel; xrow[j] = row; xlds[j] = l;
+    }
+    int grel[GU_MAX], gpix[GU_MAX], glds[GU_MAX];
+#pragma unroll
+    for (int j = 0; j < GU_MAX; ++j) {
+        const int u = tid + j * NTHR;
+        int rel = 0, pix = -1, l = 0;
+        if (u < P.gunits) {
+            const int co = fdiv(u, P.d_PB4), p4 = u - co * PB4;
+            pix = p4 * 4;
+            rel = co * HoWo + pix;
+            l = co * P.GS + pix;
+        }
+        grel[j] = rel; gpix[j] = pix; glds[j] = l;
+    }
+    for (int e = tid; e < P.Ci * P.XCS; e += NTHR) xs[e] = 0.f;      // halo columns stay zero
+
+    f32x4 acc[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // branch-free prefetch: raw buffer loads, invalid units aimed past the end of the buffer (hardware returns zeros) --
+    // conditional loads would be serialised behind their exec-mask branches, one memory latency each
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB = 0x7FFFFFF0u;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, (int)P.x_bytes, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)P.gy, (short)0, (int)P.gy_bytes, 0x00020000);
+    const bool masked = P.ref != nullptr;
+    const float mslope = P.mask_act == GGAN_ACT_LRELU ? P.mask_alpha : 0.f;
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)(masked ? P.ref : P.gy), (short)0, (int)P.gy_bytes, 0x00020000);
+    u32x4 xreg[XU_MAX], greg[GU_MAX], rreg[GU_MAX];
+    auto prefetch = [&](int item) {
+        const bool live = item < P.items;
+        const int n = fdiv(item, P.d_nb), b = item - n * P.nb;
+        const int oh0 = b * P.GBR, in_row0 = 2 * oh0 - P.pad_t;
+        const int xbase = n * P.Ci * HW + in_row0 * P.W;
+#pragma unroll
+        for (int j = 0; j < XU_MAX; ++j) {
+            const bool ok = live && xrow[j] >= 0 && (unsigned)(in_row0 + xrow[j]) < (unsigned)P.H;
+            xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(xbase + xrel[j]) * 4u : OOB, 0, 0);
+        }
+        const int gbase = n * P.Co * HoWo + oh0 * P.Wo;
+#pragma unroll
+        for (int j = 0; j < GU_MAX; ++j) {
+            const bool ok = live && gpix[j] >= 0 && oh0 * P.Wo + gpix[j] < HoWo;
+            const unsigned vo = ok ? (unsigned)(gbase + grel[j]) * 4u : OOB;
+            greg[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, vo, 0, 0);
+            if (masked) rreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, vo, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < XU_MAX; ++j) {
+            if (xrow[j] >= 0) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(xs + xlds[j]) = (u32x2){xreg[j].x, xreg[j].y};
+                *reinterpret_cast<u32x2*>(xs + xlds[j] + 2) = (u32x2){xreg[j].z, xreg[j].w};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GU_MAX; ++j) {
+            if (gpix[j] >= 0) {
+                float4 v = make_float4(__uint_as_float(greg[j].x), __uint_as_float(greg[j].y), __uint_as_float(greg[j].z),
+                                       __uint_as_float(greg[j].w));
+                if (masked) {       // lrelu / relu derivative (the launcher admits no other mask): a select
+                    v.x = __uint_as_float(rreg[j].x) > 0.f ? v.x : v.x * mslope;
+                    v.y = __uint_as_float(rreg[j].y) > 0.f ? v.y : v.y * mslope;
+                    v.z = __uint_as_float(rreg[j].z) > 0.f ? v.z : v.z * mslope;
+                    v.w = __uint_as_float(rreg[j].w) > 0.f ? v.w : v.w * mslope;
+                }
+                *reinterpret_cast<float4*>(gs + glds[j]) = v;
+            }
+        }
+    };
+
+    // items i_begin + grp, + NG, ...: every group runs the same number of rounds (the barriers are workgroup-wide); a round
+    // past the end stages zeros (item index >= N * nb -> every unit out of bounds)
+    const int split = blockIdx.x;
+    const int i_begin = split * P.ipw, i_end = min(i_begin + P.ipw, P.items);
+    const int rounds = (i_end - i_begin + NG - 1) / NG;
+    auto item_of = [&](int rd) { const int it = i_begin + rd * NG + grp; return it < i_end ? it : P.items; };
+    if (rounds > 0) prefetch(item_of(0));
+    const float* bp = gs + (nt * 16 + l15) * P.GS + q;
+    for (int rd = 0; rd < rounds; ++rd) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (rd + 1 < rounds) prefetch(item_of(rd + 1));
+        // operand reads of k-step ks+1 are issued before the MFMAs of k-step ks (one wave per SIMD: nothing else hides the
+        // LDS latency)
+        float a[2][MPW], b[2];
+        auto load_step = [&](int ks, float* av, float& bv) {
+            const int p = ks * 4 + q;
+            const int r = fdiv(p, P.d_Wo), ow = p - r * P.Wo;
+            const int pix = 2 * r * P.XRS + 2 * ow;
+            bv = bp[ks * 4];
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) av[i] = xs[offA[i] + (pix & pmA[i])];
+        };
+        load_step(0, a[0], b[0]);
+        for (int ks = 0; ks < PB4; ks += 2) {          // PB4 is even (launcher); the last prefetch re-reads the final step
+            load_step(ks + 1, a[1], b[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][i], b[0], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(min(ks + 2, PB4 - 1), a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][i], b[1], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- the slab leaves through LDS as rows of Co floats: [J (+1 bias row)][Co] is exactly slab + bias tail; the NG groups'
+    //      partial tiles sit side by side and are added in group order on the way out ---------------------------------------
+    __syncthreads();
+    const int rows = P.J + (P.with_bias ? 1 : 0);
+    const int esz = (P.J + 1) * P.Co;
+    float* es = smem + (size_t)grp * esz;
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const int mt = mg + i * MG;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = mt * 16 + 4 * q + r;
+            if (j < rows) es[j * P.Co + nt * 16 + l15] = acc[i][r];
+        }
+    }
+    __syncthreads();
+    float* dst = P.out + (size_t)split * P.slab_stride;
+    float* bdst = P.bias_direct ? P.bias_direct : dst + P.out_elems;
+    const int main4 = (int)(P.out_elems >> 2);
+    for (int u = threadIdx.x; u < main4; u += NTHR * NG) {
+        float4 v = reinterpret_cast<const float4*>(smem)[u];
+#pragma unroll
+        for (int g2 = 1; g2 < NG; ++g2) {
+            const float4 w2 = reinterpret_cast<const float4*>(smem + (size_t)g2 * esz)[u];
+            v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
+        }
+        reinterpret_cast<float4*>(dst)[u] = v;
+    }
+    if (P.with_bias)
+        for (int u = threadIdx.x; u < P.Co; u += NTHR * NG) {
+            float v = smem[P.out_elems + u];
+#pragma unroll
+            for (int g2 = 1; g2 < NG; ++g2) v += smem[(size_t)g2 * esz + P.out_elems + u];
+            bdst[u] = v;
+        }
+}
+
 }  // namespace
 
 namespace ggan {
@@ -165,6 +396,7 @@ namespace ggan {
 int conv_dgrad_thin(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx, int act,
                     float alpha, hipStream_t s) {
     if (g.k != 5 || g.stride != 2 || g.pad_t != 1 || g.pad_l != 1) return 1;
+    if (m.act != GGAN_ACT_NONE && m.act != GGAN_ACT_LRELU && m.act != GGAN_ACT_RELU) return 1;   // other masks: general kernels
     if (g.Ci > 4 || (g.Co & 3) || g.Co > 128 || g.H != 2 * g.Ho || g.W != 2 * g.Wo || (g.Ho & 1) || g.Wo > 32) return 1;
     if ((((uintptr_t)gy) & 15) || (((uintptr_t)w) & 15) || (m.act != GGAN_ACT_NONE && (((uintptr_t)m.ref) & 15))) return 1;
     if (getenv("GGAN_NO_THIN")) return 1;
@@ -186,13 +418,117 @@ int conv_dgrad_thin(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     if (shmem > 64 * 1024) return 1;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     const dim3 grid(g.Ho / 2, g.N);
+    if (P.MT > 4 && P.MT != 8) return 1;       // one m-tile per wave, or exactly two
+#define THIN_DGRAD(NT_) \
+    if (P.MT == 8) { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, true>), grid, dim3(NTHR), shmem, s, P); } \
+    else { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, false>), grid, dim3(NTHR), shmem, s, P); }
     switch (NT) {
-        case 2: GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, thin_dgrad_kernel<2>, grid, dim3(NTHR), shmem, s, P); break;
-        case 4: GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, thin_dgrad_kernel<4>, grid, dim3(NTHR), shmem, s, P); break;
-        case 5: GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, thin_dgrad_kernel<5>, grid, dim3(NTHR), shmem, s, P); break;
-        case 7: GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, thin_dgrad_kernel<7>, grid, dim3(NTHR), shmem, s, P); break;
+        case 2: THIN_DGRAD(2); break;
+        case 4: THIN_DGRAD(4); break;
+        case 5: THIN_DGRAD(5); break;
+        case 7: THIN_DGRAD(7); break;
         default: return 1;
     }
+#undef THIN_DGRAD
+    return 0;
+}
+
+int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
+                    size_t ws_bytes, hipStream_t s, WgradParts* parts) {
+    if (g.k != 5 || g.stride != 2 || g.pad_l < 1 || g.pad_l > 2 || g.Ci > 4 || (g.W & 3)) return 1;
+    if (g.Co != 32 && g.Co != 64) return 1;
+    if (m.act != GGAN_ACT_NONE && m.act != GGAN_ACT_LRELU && m.act != GGAN_ACT_RELU) return 1;   // other masks: general kernels
+    if (((g.Ho * g.Wo) & 3) || getenv("GGAN_NO_THIN")) return 1;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)gy) & 15) || (m.act != GGAN_ACT_NONE && (((uintptr_t)m.ref) & 15))) return 1;
+    const bool with_bias = parts ? parts->with_bias != 0 : gbias != nullptr;
+    const size_t xb = (size_t)g.N * g.Ci * g.H * g.W * 4, gb = (size_t)g.N * g.Co * g.Ho * g.Wo * 4;
+    if (xb >= 0x7FFFFFF0ull || gb >= 0x7FFFFFF0ull) return 1;
+    ThinWgradParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.gy = gy; P.ref = m.act != GGAN_ACT_NONE ? m.ref : nullptr;
+    P.mask_act = m.act; P.mask_alpha = m.alpha;
+    P.x_bytes = (unsigned)xb; P.gy_bytes = (unsigned)gb;
+    P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo; P.pad_t = g.pad_t; P.pad_l = g.pad_l;
+    P.GBR = g.Ho < 4 ? g.Ho : 4;
+    while (P.GBR > 1 && (((P.GBR * g.Wo) & 7) || P.GBR * g.Wo > 128)) --P.GBR;
+    P.PB = P.GBR * g.Wo;
+    if ((P.PB & 7) || P.PB > 128) return 1;      // whole k-steps of 4 pixels, an even number of them
+    P.nb = cdiv(g.Ho, P.GBR);
+    P.items = g.N * P.nb;
+    P.SR = 2 * P.GBR + 3;
+    P.XRS = g.W + 4;
+    P.XCS = P.SR * P.XRS;
+    P.GS = P.PB + 4;
+    P.J = 25 * g.Ci;
+    P.with_bias = with_bias ? 1 : 0;
+    P.xunits = g.Ci * P.SR * (g.W / 4);
+    P.gunits = g.Co * (P.PB / 4);
+    if (P.xunits > XU_MAX * NTHR || P.gunits > GU_MAX * NTHR) return 1;
+    P.out_elems = (size_t)P.J * g.Co;
+    P.slab_stride = P.out_elems + (with_bias ? (size_t)g.Co : 0);
+    size_t cap_slabs;
+    float* slabs;
+    if (parts) {
+        slabs = parts->buf;
+        cap_slabs = parts->cap_floats / P.slab_stride;
+        if (cap_slabs < 1) { set_error("conv_wgrad_thin: partial-slab buffer too small"); return -1; }
+    } else {
+        ws = ws_scratch(ws, ws_bytes);
+        slabs = (float*)ws;
+        cap_slabs = ws ? ws_bytes / (P.slab_stride * sizeof(float)) : 0;
+    }
+    int sk = P.items < 64 ? P.items : 64;
+    if ((size_t)sk > cap_slabs) sk = (int)cap_slabs;
+    if (sk < 1) sk = 1;
+    P.ipw = cdiv(P.items, sk);
+    const int SK = cdiv(P.items, P.ipw);
+    if (SK > 1 || parts) {
+        P.out = slabs;
+        P.bias_direct = nullptr;
+    } else {
+        P.out = gw;
+        P.bias_direct = gbias;
+        P.slab_stride = 0;
+    }
+    P.d_Wo = make_fastdiv(g.Wo); P.d_nb = make_fastdiv(P.nb); P.d_W4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR);
+    P.d_PB4 = make_fastdiv(P.PB / 4); P.d_Ci = make_fastdiv(g.Ci);
+    const int NTM = cdiv(P.J + (with_bias ? 1 : 0), 16);
+    const int NTN = g.Co / 16, MG = 4 / NTN, MPW = cdiv(NTM, MG);
+    constexpr int NG = 4;
+    size_t stage = (size_t)g.Ci * P.XCS + (size_t)g.Co * P.GS + 4;
+    stage = (stage + 3) & ~(size_t)3;
+    P.gstride = (int)stage;
+    const size_t ep = (size_t)(P.J + 1) * g.Co;
+    const size_t shmem = NG * (stage > ep ? stage : ep) * sizeof(float);
+    if (shmem > 160 * 1024) return 1;
+    const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
+    const dim3 grid(SK);
+#define THIN_WGRAD(NTN_, MPW_)                                                                                              \
+    do {                                                                                                                    \
+        static bool attr_set = false;                                                                                       \
+        if (!attr_set) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<NTN_, MPW_, NG>),                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+            attr_set = true;                                                                                                \
+        }                                                                                                                   \
+    } while (0);                                                                                                            \
+    GGAN_LAUNCH("thin_wgrad_kernel", fl, 0, (thin_wgrad_kernel<NTN_, MPW_, NG>), grid, dim3(NTHR * NG), shmem, s, P)
+    if (NTN == 4 && MPW <= 2) { THIN_WGRAD(4, 2); }
+    else if (NTN == 4 && MPW <= 5) { THIN_WGRAD(4, 5); }
+    else if (NTN == 4 && MPW <= 7) { THIN_WGRAD(4, 7); }
+    else if (NTN == 2 && MPW <= 1) { THIN_WGRAD(2, 1); }
+    else if (NTN == 2 && MPW <= 3) { THIN_WGRAD(2, 3); }
+    else if (NTN == 2 && MPW <= 4) { THIN_WGRAD(2, 4); }
+    else return 1;
+#undef THIN_WGRAD
+    if (parts) {
+        parts->n = SK;
+        parts->stride = P.out_elems + (with_bias ? (size_t)g.Co : 0);
+        return 0;
+    }
+    if (SK > 1)
+        return launch_splitk_reduce(slabs, SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s, P.slab_stride, gbias,
+                                    gbias ? (size_t)g.Co : 0);
     return 0;
 }
 
