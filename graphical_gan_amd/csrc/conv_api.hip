@@ -46,6 +46,9 @@ static int bwd_data(const ggan_conv_geom* g, const float* gy, GyMask m, const fl
     if (check_geom(g)) return -1;
     if (!(gy && w && gx)) { set_error("ggan_conv2d_bwd_data: null pointer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    if (getenv("GGAN_TRACE_CONV"))
+        fprintf(stderr, "[ggan] bwd_data N=%d Ci=%d H=%d W=%d Co=%d Ho=%d Wo=%d pad=(%d,%d) mask=%d act=%d\n", g->N, g->Ci, g->H, g->W, g->Co, g->Ho,
+                g->Wo, g->pad_t, g->pad_l, m.act, act);
     if (!g_force_naive && !getenv("GGAN_NAIVE_DGRAD")) {
         int r = conv_dgrad_thin(*g, gy, m, w, bias, gx, act, alpha, s);
         if (r <= 0) return r;

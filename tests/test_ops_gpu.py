@@ -572,3 +572,48 @@ def test_thin_channel_data_gradient(gpu, case):
             os.environ.pop('GGAN_NO_THIN', None)
         assert _rel(res[tag], ref) < 2e-5, tag
     assert _rel(res['thin'], res['general']) < 1e-5
+
+
+@pytest.mark.parametrize('case', [(37, 3, 32, 64), (130, 3, 32, 64), (9, 1, 28, 64), (7, 3, 64, 32), (3, 2, 16, 32)])
+def test_thin_channel_filter_gradient_slabs(gpu, case):
+    """conv_thin.hip filter gradient: ragged item ranges (N * bands not a multiple of the wave groups / slab count), the bias
+    gradient produced by the all-ones operand row, LeakyReLU mask on gy; slabs summed here must equal the oracle."""
+    import torch
+    import ctypes as C
+    from graphical_gan_amd import functional as F, _lib
+    from oracle import ops as O
+    N, Ci, H, Co = case
+    rng = np.random.default_rng(17 + N)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2)
+    Ho = geom[5]
+    x = rng.standard_normal((N, Ci, H, H)).astype(np.float32)
+    gy = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    y = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    g2 = gy.astype(np.float64) * np.where(y > 0, 1.0, 0.2)
+    ref_w = O.conv2d_bwd_filter(x.astype(np.float64), g2, 5, 2)
+    ref_b = g2.sum((0, 2, 3))
+    tx, tg, ty = _t(x, gpu), _t(gy, gpu), _t(y, gpu)
+    L = _lib.load()
+    G = F._geom(geom)
+    elems = 25 * Ci * Co
+    for with_bias in (1, 0):
+        stride = elems + (Co if with_bias else 0)
+        cap = 64 * stride
+        part = torch.full((cap,), float('nan'), device=gpu)
+        n, st = C.c_int(0), C.c_size_t(0)
+        rc = L.ggan_conv2d_bwd_filter_parts(C.byref(G), _ptr(tx), _ptr(tg), _ptr(ty), 1, 0.2, with_bias, _ptr(part), cap, C.byref(n),
+                                            C.byref(st), _stream())
+        assert rc == 0 and 1 <= n.value <= 64 and st.value == stride
+        slabs = part[:n.value * st.value].cpu().numpy().astype(np.float64).reshape(n.value, st.value)
+        assert np.isfinite(slabs).all()
+        tot = slabs.sum(0)
+        assert _rel(tot[:elems].reshape(5, 5, Ci, Co), ref_w) < 3e-5
+        if with_bias:
+            assert _rel(tot[elems:], ref_b) < 3e-5
+    # non-deferred entry point (slabs in the workspace + reduce launch), no mask
+    ws = F.workspace(tx.device)
+    gw, gb = torch.empty(5, 5, Ci, Co, device=gpu), torch.empty(Co, device=gpu)
+    rc = L.ggan_conv2d_bwd_filter(C.byref(G), _ptr(tx), _ptr(tg), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
+    assert rc == 0
+    assert _rel(gw.cpu().numpy(), O.conv2d_bwd_filter(x.astype(np.float64), gy.astype(np.float64), 5, 2)) < 3e-5
+    assert _rel(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3))) < 3e-5
