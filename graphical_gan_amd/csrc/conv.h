@@ -38,6 +38,8 @@ struct WgradParts {
 };
 int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                     size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
+int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
+                  hipStream_t s);
 int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                     size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
 size_t conv_workspace_bytes(const ggan_conv_geom& g);

@@ -35,7 +35,9 @@ int ggan_conv2d_fwd(const ggan_conv_geom* g, const float* x, const float* w, con
     GGAN_CHECK_ARG(x && w && y, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (!g_force_naive && !getenv("GGAN_NAIVE_FWD")) {
-        int r = conv_fwd_mfma(*g, x, w, bias, y, act, alpha, ws, ws ? ws_bytes : 0, s);
+        int r = conv_fwd_thin(*g, x, w, bias, y, act, alpha, s);
+        if (r <= 0) return r;
+        r = conv_fwd_mfma(*g, x, w, bias, y, act, alpha, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
     }
     return conv_fwd_naive(*g, x, w, bias, y, act, alpha, s);

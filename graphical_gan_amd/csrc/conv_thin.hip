@@ -22,6 +22,12 @@
 //     each wave owns whole 16x16 output tiles (no cross-wave reduction), and the slab leaves through LDS as float4 rows.
 //     At most 64 slabs (what the pack kernel / split-K reduce sums), deterministic.
 //
+//   forward / Deconv2D data gradient (im2col form)
+//       y[n, co, p] = act(bias[co] + sum_j x[n, c(j), 2*oh+kh(j)-pt, 2*ow+kw(j)-pl] * W[j, co])      K = 25*Ci (75 -> 80)
+//     instead of 8 padded channels x 25 taps = 200.  One workgroup = one image x band of output rows; the x rows sit in LDS
+//     once and the A fragments are gathered from them (pixel offset + tap offset), the filter is staged as it lies in memory
+//     ([j][Co]), every lane ends up with 4 consecutive pixels of one output channel: 16-byte stores straight into NCHW.
+//
 // Replaces tf.nn.conv2d_transpose of Generator.5 (tflib/ops/deconv2d.py:101-114) and Conv2DBackpropInput of
 // Discriminator.1 / Extractor.1 (tflib/ops/conv2d.py:106) -- SURVEY.md 8(a) a2/a3.
 #include "common.h"
@@ -389,6 +395,143 @@ __global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradPa
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+struct ThinFwdParams {
+    const float* x;      // [N][Ci][H][W]
+    const float* w;      // [25*Ci][Co]
+    const float* bias;   // [Co] or null
+    float* y;            // [N][Co][Ho][Wo]
+    int N, Ci, H, W, Co, Ho, Wo, pad_t, pad_l;
+    int GBR, nb, SR, XRS, XCS, WS, PB, MT, J, KS;
+    int xunits, act;
+    float alpha;
+    FastDiv d_Wo, d_W4, d_SR, d_Ci, d_5;
+    unsigned x_bytes;
+};
+
+template <int NTN, int MPW>
+__global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x, n = blockIdx.y;
+    float* xs = smem;                                    // [Ci][XCS]: rows SR x (2 halo | W | 2 halo), then {1.0, 0.0}
+    const int cbase = P.Ci * P.XCS;
+    float* wsm = smem + ((cbase + 2 + 3) & ~3);          // [KS*4][WS]
+    const int W4 = P.W >> 2, HW = P.H * P.W, HoWo = P.Ho * P.Wo;
+    const int oh0 = b * P.GBR, in_row0 = 2 * oh0 - P.pad_t;
+
+    // ---- stage: zero the slab (halo columns), x rows (hardware-zero-filled out of range), the filter -----------------
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    constexpr unsigned OOB = 0x7FFFFFF0u;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, (int)P.x_bytes, 0x00020000);
+    u32x4 xreg[XU_MAX];
+    int xlds[XU_MAX];
+    const int xbase = n * P.Ci * HW + in_row0 * P.W;
+#pragma unroll
+    for (int j = 0; j < XU_MAX; ++j) {
+        const int u = tid + j * NTHR;
+        unsigned vo = OOB;
+        int l = -1;
+        if (u < P.xunits) {
+            const int t = fdiv(u, P.d_W4), f4 = u - t * W4;
+            const int c = fdiv(t, P.d_SR), row = t - c * P.SR;
+            l = c * P.XCS + row * P.XRS + 2 + f4 * 4;
+            if ((unsigned)(in_row0 + row) < (unsigned)P.H) vo = (unsigned)(xbase + c * HW + row * P.W + f4 * 4) * 4u;
+        }
+        xlds[j] = l;
+        xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+    }
+    for (int e = tid; e < cbase; e += NTHR) xs[e] = 0.f;
+    if (tid == 0) { xs[cbase] = 1.f; xs[cbase + 1] = 0.f; }
+    {
+        const int c4 = P.Co >> 2, rows = P.KS * 4;
+        for (int u = tid; u < rows * c4; u += NTHR) {
+            const int j = u / c4, f = u - j * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < P.J) v = *reinterpret_cast<const float4*>(P.w + (size_t)j * P.Co + f * 4);
+            *reinterpret_cast<float4*>(wsm + j * P.WS + f * 4) = v;
+        }
+    }
+    __syncthreads();                                     // zeros before the rows land on top of them
+#pragma unroll
+    for (int j = 0; j < XU_MAX; ++j) {
+        if (xlds[j] >= 0) {
+            *reinterpret_cast<u32x2*>(xs + xlds[j]) = (u32x2){xreg[j].x, xreg[j].y};
+            *reinterpret_cast<u32x2*>(xs + xlds[j] + 2) = (u32x2){xreg[j].z, xreg[j].w};
+        }
+    }
+    __syncthreads();
+
+    // ---- wave w: m-tiles w, w+4 (16 pixels each) x all NTN channel tiles ------------------------------------------------
+    int pix[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const int mt = wave + 4 * i;
+        int p = mt * 16 + l15;
+        if (mt >= P.MT) p = 0;                            // (results of a tile past the band are never stored)
+        const int r = fdiv(p, P.d_Wo), ow = p - r * P.Wo;
+        pix[i] = 2 * r * P.XRS + 2 * ow;
+    }
+    f32x4 acc[MPW][NTN];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* bp = wsm + q * P.WS + l15;
+    float av[2][MPW], bv[2][NTN];
+    auto load_step = [&](int ks, float* a, float* bb) {
+        const int j = ks * 4 + q;
+        const int tap = fdiv(j, P.d_Ci), c = j - tap * P.Ci, kh = fdiv(tap, P.d_5), kw = tap - kh * 5;
+        const bool real = j < P.J;
+        const int joff = real ? c * P.XCS + kh * P.XRS + kw + 2 - P.pad_l : cbase + 1;
+        const int pm = real ? -1 : 0;
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) a[i] = xs[joff + (pix[i] & pm)];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) bb[t] = bp[ks * 4 * P.WS + t * 16];
+    };
+    load_step(0, av[0], bv[0]);
+    for (int ks = 0; ks < P.KS; ks += 2) {               // KS is even (K padded to a multiple of 8 with zero rows)
+        load_step(ks + 1, av[1], bv[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i], bv[0][t], acc[i][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(min(ks + 2, P.KS - 1), av[0], bv[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i], bv[1][t], acc[i][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- lane (q, l15) holds pixels 4q..4q+3 of channel l15 of each tile: bias, activation, one 16-byte store ----------
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const int mt = wave + 4 * i;
+        const int pp = oh0 * P.Wo + mt * 16 + 4 * q;     // pixel index within the channel plane (a multiple of 4)
+        if (mt < P.MT && mt * 16 + 4 * q < P.PB && pp < HoWo) {
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) {
+                const int co = t * 16 + l15;
+                const float bs = P.bias ? P.bias[co] : 0.f;
+                float4 v;
+                v.x = act_apply(acc[i][t][0] + bs, P.act, P.alpha);
+                v.y = act_apply(acc[i][t][1] + bs, P.act, P.alpha);
+                v.z = act_apply(acc[i][t][2] + bs, P.act, P.alpha);
+                v.w = act_apply(acc[i][t][3] + bs, P.act, P.alpha);
+                *reinterpret_cast<float4*>(P.y + ((size_t)n * P.Co + co) * HoWo + pp) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace ggan {
@@ -529,6 +672,53 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     if (SK > 1)
         return launch_splitk_reduce(slabs, SK, P.out_elems, gw, nullptr, 1, 1, GGAN_ACT_NONE, 0.f, s, P.slab_stride, gbias,
                                     gbias ? (size_t)g.Co : 0);
+    return 0;
+}
+
+int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
+                  hipStream_t s) {
+    if (g.k != 5 || g.stride != 2 || g.pad_l < 1 || g.pad_l > 2 || g.Ci > 4 || (g.W & 3)) return 1;
+    if ((g.Co != 32 && g.Co != 64) || ((g.Ho * g.Wo) & 3) || getenv("GGAN_NO_THIN")) return 1;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)w) & 15) || (((uintptr_t)y) & 15)) return 1;
+    const size_t xb = (size_t)g.N * g.Ci * g.H * g.W * 4;
+    if (xb >= 0x7FFFFFF0ull) return 1;
+    ThinFwdParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.w = w; P.bias = bias; P.y = y; P.act = act; P.alpha = alpha; P.x_bytes = (unsigned)xb;
+    P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo; P.pad_t = g.pad_t; P.pad_l = g.pad_l;
+    // band of output rows: whole 16-pixel tiles, at most 8 of them; the smallest band that still gives every wave a tile
+    // (more workgroups to spread over the chip), one that divides the image if possible
+    P.GBR = 0;
+    for (int pass = 0; pass < 2 && !P.GBR; ++pass)
+        for (int r = 1; r <= g.Ho && r * g.Wo <= 128; ++r)
+            if (((r * g.Wo) & 15) == 0 && r * g.Wo >= 64 && (pass == 1 || g.Ho % r == 0)) { P.GBR = r; break; }
+    if (!P.GBR)
+        for (int r = 1; r <= g.Ho && r * g.Wo <= 128; ++r)
+            if (((r * g.Wo) & 15) == 0) P.GBR = r;
+    if (!P.GBR) return 1;
+    P.PB = P.GBR * g.Wo;
+    P.MT = P.PB / 16;
+    P.nb = cdiv(g.Ho, P.GBR);
+    P.SR = 2 * P.GBR + 3;
+    P.XRS = g.W + 4;
+    P.XCS = P.SR * P.XRS;
+    P.J = 25 * g.Ci;
+    P.KS = 2 * cdiv(P.J, 8);
+    P.WS = g.Co + 16;                                        // == 16 (mod 32): the four k-rows of a B fragment on disjoint bank halves
+    P.xunits = g.Ci * P.SR * (g.W / 4);
+    if (P.xunits > XU_MAX * NTHR) return 1;
+    P.d_Wo = make_fastdiv(g.Wo); P.d_W4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR); P.d_Ci = make_fastdiv(g.Ci);
+    P.d_5 = make_fastdiv(5);
+    const size_t shmem = ((((size_t)g.Ci * P.XCS + 2 + 3) & ~(size_t)3) + (size_t)P.KS * 4 * P.WS) * sizeof(float);
+    if (shmem > 64 * 1024) return 1;
+    const int NTN = g.Co / 16, MPW = cdiv(P.MT, 4);
+    const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
+    const dim3 grid(P.nb, g.N);
+    if (NTN == 4 && MPW == 1) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 1>), grid, dim3(NTHR), shmem, s, P); }
+    else if (NTN == 4 && MPW == 2) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 2>), grid, dim3(NTHR), shmem, s, P); }
+    else if (NTN == 2 && MPW == 1) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<2, 1>), grid, dim3(NTHR), shmem, s, P); }
+    else if (NTN == 2 && MPW == 2) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<2, 2>), grid, dim3(NTHR), shmem, s, P); }
+    else return 1;
     return 0;
 }
 
