@@ -221,11 +221,11 @@ class ConvDgrad(Function):
     """gx[N,Ci,H,W] = conv^T(gy[N,Co,Ho,Wo], w) + bias[Ci]  (Conv2DBackpropInput; also the Deconv2D forward)."""
 
     @staticmethod
-    def forward(ctx, gy, w, bias, geom, act, alpha):
+    def forward(ctx, gy, w, bias, geom, act, alpha, slot=None):
         gy, w = _c(gy), _c(w)
         N, Ci, H, W, Co, Ho, Wo = geom[:7]
         assert tuple(gy.shape) == (N, Co, Ho, Wo) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (gy.shape, w.shape, geom)
-        gx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gy.device)
+        gx = _new_out(slot, (N, Ci, H, W), gy.device)
         ws = workspace(gy.device)
         g = _geom(geom)
         check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
@@ -248,7 +248,7 @@ class ConvDgrad(Function):
             d_b = pre if (pre is not None and pre.numel() == h.shape[1]) else ChanSum.apply(h)
         if ctx.needs_input_grad[0]:
             d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
-        return d_gy, d_w, d_b, None, None, None
+        return (d_gy, d_w, d_b) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
 class ConvWgrad(Function):
@@ -323,12 +323,12 @@ class Gemm(Function):
     """C[M,N] = op(A) op(B) + bias[N]; ta/tb read the stored operand transposed."""
 
     @staticmethod
-    def forward(ctx, a, b, bias, ta, tb, act, alpha):
+    def forward(ctx, a, b, bias, ta, tb, act, alpha, slot=None):
         a, b = _c(a), _c(b)
         M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
         K2, N = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
         assert K == K2, (a.shape, b.shape, ta, tb)
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        out = _new_out(slot, (M, N), a.device)
         ws = workspace(a.device)
         check(_L().ggan_gemm(int(ta), int(tb), M, N, K, _p(a), _p(b), _p(_c(bias)) if bias is not None else _p(None),
                              _p(out), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm')
@@ -364,7 +364,7 @@ class Gemm(Function):
                 da = Gemm.apply(g, b, None, False, not tb, ACT_NONE, 0.0)      # g op(B)^T
             else:
                 da = Gemm.apply(b, g, None, tb, True, ACT_NONE, 0.0)           # op(B) g^T
-        return da, db, dbias, None, None, None, None
+        return (da, db, dbias) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
 def _fused_linear_backward(ctx, g, x, w, y):
@@ -386,7 +386,7 @@ def _fused_linear_backward(ctx, g, x, w, y):
         dx = torch.empty((M, K), dtype=torch.float32, device=g.device)
         check(L.ggan_linear_bwd_data_act(M, N, K, _p(g), _p(y), ctx.act, ctx.alpha, _p(w), _p(dx), _p(ws), ws.numel(), _stream()),
               'ggan_linear_bwd_data_act')
-    return dx, dw, db, None, None, None, None
+    return (dx, dw, db) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
 def gemm_colsum_(a, g, ta):
@@ -569,6 +569,53 @@ class SyncBatchNormTrain(Function):
         return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None, None
 
 
+class RowSlot(object):
+    """Rows [lo, hi) of a preallocated [rows, cols] buffer: where a producer is asked to leave its result so that a later
+    row concatenation costs nothing (JoinRows).  Deliberately not a tensor: autograd sees the view a producer returns as a
+    freshly created output."""
+
+    def __init__(self, buf, lo, hi):
+        assert buf.is_contiguous() and buf.dim() == 2 and 0 <= lo < hi <= buf.shape[0]
+        self.buf, self.lo, self.hi = buf, lo, hi
+
+    def take(self, shape):
+        v = self.buf[self.lo:self.hi]
+        n = 1
+        for d in shape:
+            n *= int(d)
+        assert v.numel() == n and v.dtype == torch.float32, (tuple(v.shape), tuple(shape))
+        return v.view(tuple(shape))
+
+
+def _new_out(slot, shape, device):
+    return slot.take(shape) if slot is not None else torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
+def _adjacent(a, b):
+    return (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and tuple(a.shape[1:]) == tuple(b.shape[1:])
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel())
+
+
+class JoinRows(Function):
+    """cat([a, b], 0) for the critic evaluated once on [fake; real].  When the two operands already sit back to back in one
+    buffer (their producers were handed RowSlots) the result is an alias of that memory: no copy kernel; the backward hands
+    out the two row ranges of the incoming gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.n = a.shape[0]
+        if _adjacent(a, b):
+            out = torch.empty(0, dtype=a.dtype, device=a.device)
+            out.set_(a.untyped_storage(), a.storage_offset(), (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride())
+            return out
+        return torch.cat([a, b], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.n], g[ctx.n:]
+
+
 class SplitRows(Function):
     """(x[:n], x[n:]) for the critic evaluated once on [fake; real]; the backward is ONE concatenation instead of two
     zero-padded slice gradients and their sum."""
@@ -599,28 +646,28 @@ class CastScaleI32(Function):
     """real_x = mul*(float(x)/div - .5) + noise  (no gradient: the input is data)."""
 
     @staticmethod
-    def forward(ctx, x_int, noise, div, mul):
+    def forward(ctx, x_int, noise, div, mul, slot=None):
         _dev(x_int)
         assert x_int.dtype == torch.int32
         x_int = x_int.contiguous()
-        y = torch.empty(x_int.shape, dtype=torch.float32, device=x_int.device)
+        y = _new_out(slot, x_int.shape, x_int.device)
         check(_L().ggan_cast_scale_i32(_p(x_int), _p(_c(noise)) if noise is not None else _p(None), _p(y), x_int.numel(),
                                        div, mul, _stream()), 'ggan_cast_scale_i32')
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return None, None, None, None
+        return (None,) * len(ctx.needs_input_grad)
 
 
 class Axpby(Function):
     """out = a*x + b*y + c"""
 
     @staticmethod
-    def forward(ctx, x, y, a, b, c):
+    def forward(ctx, x, y, a, b, c, slot=None):
         x = _c(x)
         y = _c(y) if y is not None else None
-        out = torch.empty_like(x)
+        out = _new_out(slot, x.shape, x.device)
         check(_L().ggan_axpby(_p(x), _p(y), _p(out), x.numel(), a, b, c, _stream()), 'ggan_axpby')
         ctx.a, ctx.b, ctx.has_y = a, b, y is not None
         return out
@@ -629,7 +676,7 @@ class Axpby(Function):
     def backward(ctx, g):
         gx = Axpby.apply(g, None, ctx.a, 0.0, 0.0) if ctx.needs_input_grad[0] else None
         gy = Axpby.apply(g, None, ctx.b, 0.0, 0.0) if (ctx.has_y and ctx.needs_input_grad[1]) else None
-        return gx, gy, None, None, None
+        return (gx, gy) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
 class RowLerp(Function):

@@ -80,7 +80,9 @@ class GraphicalGAN(object):
             feed['real_x_int'] = torch.zeros(B, c.output_dim, dtype=torch.int32, device=device)
         if c.dataset == 'face':
             feed['dequant_u'] = torch.zeros(B, c.output_dim, device=device)
-        feed['p_z_noise'] = torch.zeros(B, c.dim_latent, device=device)
+        # latent pair [p_z ; q_z] of the batched critic: the noise IS the first half (K == 0), the Extractor writes the second
+        feed['z_pair'] = torch.zeros(2 * B, c.dim_latent, device=device)
+        feed['p_z_noise'] = feed['z_pair'][:B] if not c.K else torch.zeros(B, c.dim_latent, device=device)
         if c.K:
             feed['k_onehot'] = torch.zeros(B, c.K, device=device)
             feed['gumbel_u'] = torch.zeros(B, c.K, device=device)
@@ -133,13 +135,15 @@ class GraphicalGAN(object):
         return F.ActFwd.apply(lib.ops.batchnorm.Batchnorm(name, axes, x), act, 0.2)
 
     # ---- nets ---------------------------------------------------------------------------------------
-    def Generator(self, noise):
+    def Generator(self, noise, out_slot=None):
+        """out_slot: optional functional.RowSlot for the generated images (only honoured with fused epilogues)"""
         c = self.cfg
         if c.bn:
             out = lib.ops.linear.Linear('Generator.Input', c.dim_latent, c.flat, noise)
             out = self._bn('Generator.BN1', [0], out, RELU)
         else:
             out = self._lin('Generator.Input', c.dim_latent, c.flat, noise, RELU)
+        slot = out_slot
         out = out.reshape(-1, c.top, 4, 4)
         names = ['2', '3', '4', '5'] if c.nl == 4 else ['2', '3', '5']
         ch = c.top
@@ -149,7 +153,7 @@ class GraphicalGAN(object):
             final_act = TANH if c.out_act == 'tanh' else SIGMOID
             if last:
                 if c.fuse:
-                    out = lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out, activation=final_act)
+                    out = lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out, activation=final_act, out=slot)
                 else:
                     out = F.ActFwd.apply(lib.ops.deconv2d.Deconv2D('Generator.' + nm, ch, cout, 5, out), final_act, 0.0)
             elif c.bn:
@@ -164,7 +168,7 @@ class GraphicalGAN(object):
             ch = cout
         return out.reshape(-1, c.output_dim)
 
-    def Extractor(self, inputs):
+    def Extractor(self, inputs, out_slot=None):
         c = self.cfg
         out = inputs.reshape(-1, c.C, c.S, c.S)
         ch = c.C
@@ -178,7 +182,7 @@ class GraphicalGAN(object):
                 out = self._conv(name, ch, cout, out, LRELU)
             ch = cout
         out = out.reshape(-1, c.flat)
-        return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out)
+        return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out, out=out_slot)
 
     def Discriminator(self, x, z, grad_rows=None):
         """grad_rows: only the first grad_rows images of x carry a gradient (generator steps: [fake; real])"""
@@ -209,9 +213,9 @@ class GraphicalGAN(object):
         c = self.cfg
         return lib.param('Generator.Hyper.Mu', np.random.normal(size=(c.K, c.dim_latent)).astype('float32'))
 
-    def HyperGenerator(self, hyper_k, hyper_noise):
+    def HyperGenerator(self, hyper_k, hyper_noise, out_slot=None):
         """gmgan_inference_cifar10.py:150-153: onehot(k) @ Mu + eps."""
-        return F.Axpby.apply(F.Gemm.apply(hyper_k, self._mu(), None, False, False, F.ACT_NONE, 0.0), hyper_noise, 1.0, 1.0, 0.0)
+        return F.Axpby.apply(F.Gemm.apply(hyper_k, self._mu(), None, False, False, F.ACT_NONE, 0.0), hyper_noise, 1.0, 1.0, 0.0, out_slot)
 
     def HyperExtractor(self, latent_z, gumbel_u):
         """gmgan_inference_cifar10.py:156-173 (MODE_K='CONCRETE').  [B,K] latent glue: <0.1% of the step's work,
@@ -231,27 +235,34 @@ class GraphicalGAN(object):
                 lib.params_with_name('Discriminator'))
 
     # ---- loss wiring ------------------------------------------------------------------------------------
-    def real_x(self, feed):
+    def real_x(self, feed, out_slot=None):
         c = self.cfg
         if c.dataset == 'mnist':
             return feed['real_x']
         if c.dataset == 'face':
-            return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'])
-        return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2.)
+            return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'], out=out_slot)
+        return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2., out=out_slot)
 
     def forward_nets(self, feed):
         """Extractor and Generator passes: everything of a session.run that does not read a critic variable."""
-        c = self.cfg
-        real_x = self.real_x(feed)
-        q_z = self.Extractor(real_x)
+        c, B = self.cfg, self.cfg.B
+        # the batched critic reads [fake_x ; real_x] and [p_z ; q_z]: the producers write straight into the two halves of one
+        # buffer each, so those concatenations are aliases instead of copy kernels (functional.RowSlot / JoinRows)
+        xs = zs = [None, None]
+        if c.batch_critic and 'z_pair' in feed:
+            xp = torch.empty((2 * B, c.output_dim), dtype=torch.float32, device=feed['z_pair'].device)
+            xs = [F.RowSlot(xp, 0, B), F.RowSlot(xp, B, 2 * B)]
+            zs = [F.RowSlot(feed['z_pair'], 0, B), F.RowSlot(feed['z_pair'], B, 2 * B)]
+        real_x = self.real_x(feed, xs[1])
+        q_z = self.Extractor(real_x, zs[1])
         out = dict(real_x=real_x, q_z=q_z)
         if c.K:
             _, q_k = self.HyperExtractor(q_z, feed['gumbel_u'])
-            out['p_z'] = self.HyperGenerator(feed['k_onehot'], feed['p_z_noise'])
+            out['p_z'] = self.HyperGenerator(feed['k_onehot'], feed['p_z_noise'], zs[0])
             out['q_k'] = q_k
         else:
             out['p_z'] = feed['p_z_noise']
-        out['fake_x'] = self.Generator(out['p_z'])
+        out['fake_x'] = self.Generator(out['p_z'], xs[0])
         return out
 
     def forward(self, feed, which=None, nets=None):
@@ -318,7 +329,7 @@ class GraphicalGAN(object):
             fake_x, p_z, q_z = fake_x.detach(), p_z.detach(), q_z.detach()
             q_k = q_k.detach() if c.K else None
         B = fake_x.shape[0]
-        x_cat, z_cat = torch.cat([fake_x, real_x], 0), torch.cat([p_z, q_z], 0)
+        x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
         d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B)
         if c.K:
             h = self.HyperDiscriminator(z_cat, torch.cat([onehot, q_k], 0))

@@ -28,6 +28,6 @@ def dropout(x, rate=0.0, training=False):
     return x
 
 
-def cast_scale(x_int, div=255., mul=2., noise=None):
-    """2*((float(x)/255.)-.5) (+ dequantisation noise for the 64x64 scripts)."""
-    return F.CastScaleI32.apply(x_int, noise, float(div), float(mul))
+def cast_scale(x_int, div=255., mul=2., noise=None, out=None):
+    """2*((float(x)/255.)-.5) (+ dequantisation noise for the 64x64 scripts).  out: optional functional.RowSlot."""
+    return F.CastScaleI32.apply(x_int, noise, float(div), float(mul), out)

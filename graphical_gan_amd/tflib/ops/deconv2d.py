@@ -32,8 +32,9 @@ def _uniform(stdev, size):
 
 
 def Deconv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, weightnorm=None, biases=True, gain=1.,
-             mask_type=None, stride=2, padding='SAME', activation=None, alpha=0.2):
-    """inputs: (batch, input_dim, h, w) -> (batch, output_dim, stride*h, stride*w)."""
+             mask_type=None, stride=2, padding='SAME', activation=None, alpha=0.2, out=None):
+    """inputs: (batch, input_dim, h, w) -> (batch, output_dim, stride*h, stride*w).  `activation`/`alpha`: optional fused
+    epilogue; `out`: optional functional.RowSlot the result is written into (extensions)."""
     if mask_type is not None:
         raise Exception('Unsupported configuration')
     fan_in = input_dim * filter_size ** 2 / (stride ** 2)
@@ -61,4 +62,4 @@ def Deconv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, wei
     geom = F.conv_geom(N, output_dim, H, W, input_dim, filter_size, stride, padding)
     assert geom[5] == h and geom[6] == w, (geom, h, w)
     act = F.ACT_NONE if activation is None else activation
-    return F.ConvDgrad.apply(inputs, filters, b, geom, act, float(alpha))
+    return F.ConvDgrad.apply(inputs, filters, b, geom, act, float(alpha), out)

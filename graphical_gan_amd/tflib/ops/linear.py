@@ -59,8 +59,9 @@ def _initial(initialization, input_dim, output_dim):
 
 
 def Linear(name, input_dim, output_dim, inputs, biases=True, initialization=None, weightnorm=None, gain=1.,
-           activation=None, alpha=0.2):
-    """Same signature as the reference; `activation`/`alpha` are an optional fused epilogue (extension)."""
+           activation=None, alpha=0.2, out=None):
+    """Same signature as the reference; `activation`/`alpha` are an optional fused epilogue and `out` an optional
+    functional.RowSlot the result is written into (extensions)."""
     weight_values = _initial(initialization, input_dim, output_dim)
     weight_values *= gain
     weight = _param(name + '.W', weight_values)
@@ -74,7 +75,7 @@ def Linear(name, input_dim, output_dim, inputs, biases=True, initialization=None
     b = _param(name + '.b', np.zeros((output_dim,), dtype='float32')) if biases else None
     x = inputs if inputs.dim() == 2 else inputs.reshape(-1, input_dim)
     act = F.ACT_NONE if activation is None else activation
-    result = F.Gemm.apply(x, weight, b, False, False, act, float(alpha))
+    result = F.Gemm.apply(x, weight, b, False, False, act, float(alpha), out)
     if inputs.dim() != 2:
         result = result.reshape(tuple(inputs.shape[:-1]) + (output_dim,))
     return result

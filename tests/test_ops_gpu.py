@@ -617,3 +617,35 @@ def test_thin_channel_filter_gradient_slabs(gpu, case):
     assert rc == 0
     assert _rel(gw.cpu().numpy(), O.conv2d_bwd_filter(x.astype(np.float64), gy.astype(np.float64), 5, 2)) < 3e-5
     assert _rel(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3))) < 3e-5
+
+
+def test_row_slots_make_the_critic_concatenation_free(gpu):
+    """functional.RowSlot / JoinRows: producers handed the two halves of one buffer leave their results back to back, the join is
+    an alias of that memory (no copy) and its backward routes the two row ranges of the gradient; non-adjacent operands fall back
+    to a real concatenation with the same values."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(8)
+    B, K, N = 6, 10, 7
+    a = _t(rng.standard_normal((B, K)), gpu).requires_grad_(True)
+    w = _t(rng.standard_normal((K, N)), gpu).requires_grad_(True)
+    xi = torch.as_tensor(rng.integers(0, 256, size=(B, N)).astype(np.int32), device=gpu)
+    buf = torch.full((2 * B, N), float('nan'), device=gpu)
+    top = F.Gemm.apply(a, w, None, False, False, F.ACT_NONE, 0.0, F.RowSlot(buf, 0, B))
+    bot = F.CastScaleI32.apply(xi, None, 255.0, 2.0, F.RowSlot(buf, B, 2 * B))
+    assert top.data_ptr() == buf.data_ptr() and bot.data_ptr() == buf[B:].data_ptr()
+    j = F.JoinRows.apply(top, bot)
+    assert j.data_ptr() == buf.data_ptr() and tuple(j.shape) == (2 * B, N)                  # alias, not a copy
+    ref = torch.cat([a.detach() @ w.detach(), 2 * (xi.float() / 255. - .5)], 0)
+    assert torch.allclose(j.detach(), ref, rtol=1e-5, atol=1e-5) and torch.equal(buf, j.detach())
+    g = _t(rng.standard_normal((2 * B, N)), gpu)
+    ga, gw = torch.autograd.grad(j, [a, w], grad_outputs=g)
+    assert torch.allclose(ga, g[:B] @ w.detach().t(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gw, a.detach().t() @ g[:B], rtol=1e-4, atol=1e-5)
+    # operands that are not back to back: plain concatenation
+    c = _t(rng.standard_normal((3, N)), gpu).requires_grad_(True)
+    d = _t(rng.standard_normal((4, N)), gpu).requires_grad_(True)
+    j2 = F.JoinRows.apply(c, d)
+    assert j2.data_ptr() not in (c.data_ptr(), d.data_ptr()) and torch.equal(j2.detach(), torch.cat([c, d], 0).detach())
+    gc, gd = torch.autograd.grad(j2.sum(), [c, d])
+    assert torch.equal(gc, torch.ones_like(c)) and torch.equal(gd, torch.ones_like(d))
