@@ -151,7 +151,8 @@ def main():
         model = StateSpaceGAN(cfg)
         tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank, model=model)
     else:
-        K = 30 if args.mode == 'local_ep' else 0
+        # N_COMS of the gmgan scripts: 30 (cifar10 :78, mnist), 50 (svhn :72), 100 (face :68)
+        K = ({'svhn': 50, 'face': 100}.get(args.dataset, 30)) if args.mode in ('local_ep', 'local_epce') else 0
         cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse)
         tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
     torch.manual_seed(1234 + rank)

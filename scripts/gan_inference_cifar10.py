@@ -15,7 +15,7 @@ BATCH_SIZE = 64
 CRITIC_ITERS = 5 if MODE in ("wali", "wali-gp") else 1
 LR = {"wali-gp": 1e-4, "wali": 5e-5}.get(MODE, 2e-4)  # the wali objectives ignore the scripts' LR (gan_inference.py:4,28)
 BETA1 = .5
-ITERS = 100000  # number of iterations to train
+ITERS = 200000  # number of iterations to train
 DATA_DIR = os.environ.get('GGAN_DATA_DIR', '')
 OUT_DIR = os.environ.get('GGAN_OUT_DIR', '')
 SAVE_EVERY = 10000

@@ -11,7 +11,7 @@ DATASET = 'face'
 MODE = 'ali'  # ali, alice, alice-z, alice-x, wali, wali-gp
 
 DIM_LATENT = 128  # latent dimension
-BATCH_SIZE = 64
+BATCH_SIZE = 128
 CRITIC_ITERS = 5 if MODE in ("wali", "wali-gp") else 1
 LR = {"wali-gp": 1e-4, "wali": 5e-5}.get(MODE, 2e-4)  # the wali objectives ignore the scripts' LR (gan_inference.py:4,28)
 BETA1 = .5

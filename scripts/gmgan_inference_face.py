@@ -9,9 +9,9 @@ from graphical_gan_amd.models import Config
 
 DATASET = 'face'
 MODE = 'local_ep'  # local_ep, local_epce
-N_COMS = 30  # mixture components of the latent prior
+N_COMS = 100  # mixture components of the latent prior
 DIM_LATENT = 128  # latent dimension
-BATCH_SIZE = 64
+BATCH_SIZE = 128
 CRITIC_ITERS = 1
 LR = 2e-4
 BETA1 = .5

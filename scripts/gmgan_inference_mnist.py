@@ -11,11 +11,11 @@ DATASET = 'mnist'
 MODE = 'local_ep'  # local_ep, local_epce
 N_COMS = 30  # mixture components of the latent prior
 DIM_LATENT = 128  # latent dimension
-BATCH_SIZE = 64
+BATCH_SIZE = 50
 CRITIC_ITERS = 1
 LR = 2e-4
 BETA1 = .5
-ITERS = 100000  # number of iterations to train
+ITERS = 200000  # number of iterations to train
 DATA_DIR = os.environ.get('GGAN_DATA_DIR', '')
 OUT_DIR = os.environ.get('GGAN_OUT_DIR', '')
 SAVE_EVERY = 10000
