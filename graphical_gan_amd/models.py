@@ -1,7 +1,7 @@
 """Net definitions + loss wiring of the reference's driver scripts, written against the tflib mirror.
 
 One parametrised definition covers the six image scripts (the reference repeats it per file):
-  gan_inference_cifar10.py:133-255,261-366      Generator / Extractor / Discriminator, MODE ali | wali-gp
+  gan_inference_cifar10.py:133-255,261-366      Generator / Extractor / Discriminator, MODE ali | alice* | wali | wali-gp | vegan | vegan-wgan-gp
   gmgan_inference_cifar10.py:114-301,341-398    + HyperGenerator / HyperExtractor / HyperDiscriminator, MODE local_ep
   gmgan_inference_mnist.py:166-300              28x28x1, crop [:,:,:7,:7], sigmoid output, float input
   gmgan_inference_face.py:82-274                64x64x3, four conv stages, DIM 32, no BatchNorm, dequantisation
@@ -39,12 +39,20 @@ class Config(object):
         self.mode = mode or ('local_ep' if n_coms else 'ali')
         # reconstruction variants (gan_inference_cifar10.py:293-304, gmgan_inference_cifar10.py:399-403):
         #   alice-z: + l2(real_x, G(q_z));  alice-x: + l2(p_z, E(fake_x));  alice: both;  local_epce: gmgan + l2(real_x, G(q_z))
-        assert self.mode in ('ali', 'local_ep', 'wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce')
+        #   vegan / vegan-wgan-gp (gan_inference_cifar10.py:192-222,305-322): the critic is an MLP on codes, + l2(real_x, G(q_z))
+        assert self.mode in ('ali', 'local_ep', 'wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce', 'vegan',
+                             'vegan-wgan-gp')
+        self.latent_critic = self.mode in ('vegan', 'vegan-wgan-gp')
+        self.lamb = 1.0                                                  # LAMBDA (gan_inference_cifar10.py:62)
+        assert not (self.latent_critic and n_coms)
+        if self.mode == 'vegan-wgan-gp' and self.bn:
+            raise NotImplementedError('vegan-wgan-gp differentiates the latent critic twice; the BatchNorm kernels have no second '
+                                      'derivative (use a BN_FLAG = False configuration: svhn, face, or bn=False)')
         assert not (self.mode.startswith('alice') and n_coms) and not (self.mode == 'local_epce' and not n_coms)
         self.top = self.dim * 2 ** (self.nl - 1)
         self.flat = 16 * self.top
         self.output_dim = self.C * self.S * self.S
-        self.critic_iters = 5 if self.mode in ('wali', 'wali-gp') else 1          # gan_inference_cifar10.py:53-59
+        self.critic_iters = 5 if self.mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else 1   # gan_inference_cifar10.py:53-59
         self.lr = lr if lr is not None else {'wali-gp': 1e-4, 'wali': 5e-5}.get(self.mode, 2e-4)
         self.beta1 = 0.5
         # critic steps evaluate the critic ONCE on [fake; real] (the critics of these scripts have no BatchNorm, so
@@ -70,7 +78,7 @@ class GraphicalGAN(object):
         """tensors through which EVERY gradient of the Extractor's parameters flows (None if there is no such cut: the
         reconstruction modes apply the Extractor a second time) -- lets a data-parallel generator step exchange the
         Generator's gradients while the Extractor's backward pass is still running (engine.Trainer)."""
-        return [nets['q_z']] if self.cfg.mode in ('ali', 'local_ep', 'wali', 'wali-gp') else None
+        return [nets['q_z']] if self.cfg.mode in ('ali', 'local_ep', 'wali', 'wali-gp') else None   # (vegan: G(q_z) re-enters)
 
     def feed_buffers(self, device):
         c, B, feed = self.cfg, self.cfg.B, {}
@@ -86,8 +94,12 @@ class GraphicalGAN(object):
         if c.K:
             feed['k_onehot'] = torch.zeros(B, c.K, device=device)
             feed['gumbel_u'] = torch.zeros(B, c.K, device=device)
-        if c.mode == 'wali-gp':
+        if c.mode in ('wali-gp', 'vegan-wgan-gp'):
             feed['alpha'] = torch.zeros(B, 1, device=device)
+        if c.latent_critic:          # the Gaussian noise layers of the latent critic: one set of draws per critic call
+            for tag in ('f', 'r') + (('h',) if c.mode == 'vegan-wgan-gp' else ()):
+                for i, w in enumerate((c.dim_latent, 1024, 512, 256)):
+                    feed['dn_%s%d' % (tag, i)] = torch.zeros(B, w, device=device)
         return feed
 
     def sample_noise(self, f):
@@ -98,8 +110,11 @@ class GraphicalGAN(object):
             idx = torch.randint(0, c.K, (c.B, 1), device=f['p_z_noise'].device)
             f['k_onehot'].zero_().scatter_(1, idx, 1.0)
             f['gumbel_u'].uniform_()
-        if c.mode == 'wali-gp':
+        if 'alpha' in f:
             f['alpha'].uniform_()
+        for k in f:
+            if k.startswith('dn_'):
+                f[k].normal_()
         if c.dataset == 'face':
             f['dequant_u'].uniform_(0., 1. / 128)
 
@@ -200,6 +215,51 @@ class GraphicalGAN(object):
         out = lib.ops.linear.Linear('Discriminator.Output', 512, 1, out)
         return out.reshape(-1)
 
+    def LatentDiscriminator(self, z, noise):
+        """gan_inference_cifar10.py:192-222: the vegan critic on codes; Gaussian noise (std .3 on the input, .5 after the first
+        three hidden layers) comes in as N(0,1) draws and is scaled here."""
+        c = self.cfg
+        out = F.Axpby.apply(z, noise[0], 1.0, 0.3, 0.0)
+        for i, (nm, nin, nout) in enumerate([('Input', c.dim_latent, 1024), ('2', 1024, 512), ('3', 512, 256), ('4', 256, 256)]):
+            if c.bn:
+                out = lib.ops.linear.Linear('Discriminator.' + nm, nin, nout, out)
+                out = self._bn('Discriminator.BN%d' % (i + 1), [0], out, LRELU)
+            else:
+                out = self._lin('Discriminator.' + nm, nin, nout, out, LRELU)
+            if i < 3:
+                out = F.Axpby.apply(out, noise[i + 1], 1.0, 0.5, 0.0)
+        return lib.ops.linear.Linear('Discriminator.Output', 256, 1, out).reshape(-1)
+
+    def _forward_latent(self, feed, which, out):
+        """MODE vegan / vegan-wgan-gp (gan_inference_cifar10.py:272-275,305-322)"""
+        c = self.cfg
+        real_x, q_z, p_z = out['real_x'], out['q_z'], out['p_z']
+        J = lib.objs.gan_inference
+        J.ONLY[0] = which
+        noise = lambda tag: [feed['dn_%s%d' % (tag, i)] for i in range(4)]
+        det = (lambda t: t.detach()) if which == 'disc' else (lambda t: t)
+        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
+            d_real = self.LatentDiscriminator(p_z, noise('r'))
+            d_fake = self.LatentDiscriminator(det(q_z), noise('f'))
+            gp = None
+            if c.mode == 'vegan-wgan-gp' and which != 'gen':
+                z_hat = F.RowLerp.apply(p_z, det(q_z), feed['alpha'])      # p_z + alpha*(q_z - p_z)
+                if not z_hat.requires_grad:
+                    z_hat.requires_grad_(True)
+                d_hat = self.LatentDiscriminator(z_hat, noise('h'))
+                (g,) = torch.autograd.grad(d_hat, [z_hat], grad_outputs=torch.ones_like(d_hat), create_graph=True)
+                gp = F.GradPenalty.apply(g, 10.0)
+        rec = 1. * lib.utils.distance.distance(real_x, self.Generator(q_z), 'l2') if which != 'disc' else None
+        gen_params, disc_params = self._var_lists()
+        if c.mode == 'vegan':
+            res = J.vegan(d_fake, d_real, rec, gen_params, disc_params, c.lamb, lr=c.lr, beta1=c.beta1)
+        else:
+            res = J.vegan_wgan_gp(d_fake, d_real, rec, gp, gen_params, disc_params, c.lamb, lr=c.lr, beta1=c.beta1)
+        J.ONLY[0] = None
+        out.update(disc_fake=d_fake, disc_real=d_real, rec_penalty=rec, gradient_penalty=gp, gen_cost=res[0], disc_cost=res[1],
+                   gen_train_op=res[2], disc_train_op=res[3])
+        return out
+
     def HyperDiscriminator(self, z, k):
         c = self.cfg
         out = torch.cat([z, k], 1)
@@ -270,6 +330,8 @@ class GraphicalGAN(object):
         is not part of gen_cost); None builds everything.  nets: a forward_nets() result to continue from."""
         c = self.cfg
         out = dict(nets) if nets is not None else self.forward_nets(feed)
+        if c.latent_critic:
+            return self._forward_latent(feed, which, out)
         real_x, q_z, p_z, fake_x = out['real_x'], out['q_z'], out['p_z'], out['fake_x']
         if c.K:
             onehot, q_k = feed['k_onehot'], out['q_k']

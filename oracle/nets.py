@@ -16,13 +16,14 @@ from . import tape as tp
 
 class Cfg(object):
     def __init__(self, dataset='cifar10', batch_size=64, n_coms=0, dim=None, dim_latent=128,
-                 bn=None, mode_k='CONCRETE', temp=0.1):
+                 bn=None, mode_k='CONCRETE', temp=0.1, latent_critic=False):
         self.dataset = dataset
         self.B = batch_size
         self.K = n_coms                      # 0 => plain gan_inference_* (no GMM prior)
         self.dim_latent = dim_latent
         self.temp = temp
         self.mode_k = mode_k
+        self.latent_critic = latent_critic     # MODE vegan / vegan-wgan-gp: the critic sees codes only (gan_inference_cifar10.py:192-222)
         if dataset == 'cifar10':
             self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, True, 'tanh'
         elif dataset == 'svhn':          # g(m)gan_inference_svhn.py: the CIFAR nets with BN_FLAG = False (:69-72)
@@ -108,6 +109,13 @@ def init_params(cfg, seed=0):
         if cfg.bn and i < len(names_dec) - 1:
             bn('Generator.BN%s' % nm, dch[i + 1])
     # Discriminator(s)
+    if getattr(cfg, 'latent_critic', False):
+        for i, (nm, nin, nout) in enumerate([('Input', cfg.dim_latent, 1024), ('2', 1024, 512), ('3', 512, 256), ('4', 256, 256)]):
+            lin('Discriminator.' + nm, nin, nout)
+            if cfg.bn:
+                bn('Discriminator.BN%d' % (i + 1), nout, fused=False)
+        lin('Discriminator.Output', 256, 1)
+        return P
     for i in range(nl):
         P['Discriminator.%d.Filters' % (i + 1)] = conv_init(rng, chans[i], chans[i + 1])
         P['Discriminator.%d.Biases' % (i + 1)] = np.zeros(chans[i + 1], 'float32')
@@ -193,6 +201,21 @@ def Discriminator(cfg, P, x, z):
     zo = tp.leaky_relu(Linear(P, 'Discriminator.z1', z))
     out = tp.concat([out, zo], 1)
     out = tp.leaky_relu(Linear(P, 'Discriminator.zx1', out))
+    return tp.reshape(Linear(P, 'Discriminator.Output', out), (-1,))
+
+
+def LatentDiscriminator(cfg, P, z, noise):
+    """gan_inference_cifar10.py:192-222 (MODE vegan / vegan-wgan-gp): an MLP on codes with Gaussian noise layers (std .3 on the
+    input, .5 after the first three hidden layers).  noise: the four N(0,1) draws of this call, scaled here."""
+    dt = z.v.dtype
+    out = tp.add(z, tp.T(np.asarray(noise[0], dtype=dt) * dt.type(.3)))
+    for i, nm in enumerate(['Input', '2', '3', '4']):
+        out = Linear(P, 'Discriminator.' + nm, out)
+        if cfg.bn:
+            out = Batchnorm(P, 'Discriminator.BN%d' % (i + 1), [0], out)
+        out = tp.leaky_relu(out)
+        if i < 3:
+            out = tp.add(out, tp.T(np.asarray(noise[i + 1], dtype=dt) * dt.type(.5)))
     return tp.reshape(Linear(P, 'Discriminator.Output', out), (-1,))
 
 

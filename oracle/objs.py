@@ -55,6 +55,29 @@ def local_epce_costs(disc_fake_list, disc_real_list, rec_penalty):
     return tp.add(g, rec_penalty), d
 
 
+def vegan_costs(disc_fake, disc_real, rec_penalty, lamb):
+    """tflib/objs/gan_inference.py:194-212."""
+    gen = tp.add(tp.scale(_bce_mean(disc_fake, 1.0), lamb), rec_penalty)
+    disc = tp.scale(tp.add(_bce_mean(disc_fake, 0.0), _bce_mean(disc_real, 1.0)), lamb / 2)
+    return gen, disc
+
+
+def vegan_wgan_gp_costs(disc_fake, disc_real, rec_penalty, gradient_penalty, lamb):
+    """tflib/objs/gan_inference.py:225-233."""
+    gen = tp.add(tp.scale(tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.reduce_mean(disc_real)), lamb), rec_penalty)
+    disc = tp.add(tp.scale(tp.add(tp.reduce_mean(disc_fake), tp.neg(tp.reduce_mean(disc_real))), lamb), gradient_penalty)
+    return gen, disc
+
+
+def latent_gradient_penalty(critic, q_z, p_z, alpha, lam=10.0):
+    """gan_inference_cifar10.py:309-317: interpolates = p_z + alpha*(q_z - p_z); lam*mean((||dD/dz_hat|| - 1)^2)."""
+    a = tp.T(np.asarray(alpha, dtype=q_z.v.dtype).reshape(-1, 1))
+    z_hat = tp.add(p_z, tp.mul(a, tp.add(q_z, tp.neg(p_z))))
+    g = tp.grad(tp.reduce_sum(critic(z_hat)), [z_hat])[0]
+    slopes = tp.sqrt(tp.reduce_sum(tp.square(g), (1,)))
+    return tp.scale(tp.reduce_mean(tp.square(tp.add(slopes, -1.0))), lam)
+
+
 def wali_costs(disc_fake, disc_real):
     """tflib/objs/gan_inference.py:5-6 (the generator cost really is -mean(fake) - mean(real) there)."""
     gen = tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.neg(tp.reduce_mean(disc_real)))

@@ -27,8 +27,12 @@ def make_feed(cfg, rng, mode='ali'):
     if cfg.K:
         f['k_idx'] = rng.integers(0, cfg.K, size=(cfg.B,)).astype(np.int64)
         f['gumbel_u'] = rng.random((cfg.B, cfg.K), dtype=np.float32)
-    if mode == 'wali-gp':
+    if mode in ('wali-gp', 'vegan-wgan-gp'):
         f['alpha'] = rng.random((cfg.B, 1), dtype=np.float32)
+    if mode in ('vegan', 'vegan-wgan-gp'):          # the latent critic's Gaussian noise layers, one set per critic call
+        for tag in ('f', 'r') + (('h',) if mode == 'vegan-wgan-gp' else ()):
+            for i, w in enumerate((cfg.dim_latent, 1024, 512, 256)):
+                f['dn_%s%d' % (tag, i)] = rng.standard_normal((cfg.B, w), dtype=np.float32)
     return f
 
 
@@ -62,6 +66,20 @@ def forward(cfg, P, feed, mode='ali'):
 
     def critic(x, z):
         return N.Discriminator(cfg, P, x, z)
+
+    if mode in ('vegan', 'vegan-wgan-gp'):          # gan_inference_cifar10.py:272-275,305-322: the critic discriminates codes
+        noise = lambda tag: [feed['dn_%s%d' % (tag, i)] for i in range(4)]
+        d_real = N.LatentDiscriminator(cfg, P, p_z, noise('r'))
+        d_fake = N.LatentDiscriminator(cfg, P, q_z, noise('f'))
+        rec = J.distance(real_x, N.Generator(cfg, P, q_z), 'l2')
+        if mode == 'vegan':
+            gen_cost, disc_cost = J.vegan_costs(d_fake, d_real, rec, 1.0)
+        else:
+            gp = J.latent_gradient_penalty(lambda zz: N.LatentDiscriminator(cfg, P, zz, noise('h')), q_z, p_z, feed['alpha'])
+            gen_cost, disc_cost = J.vegan_wgan_gp_costs(d_fake, d_real, rec, gp, 1.0)
+            out['gradient_penalty'] = gp
+        out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=gen_cost, disc_cost=disc_cost, rec_penalty=rec)
+        return out
 
     def rec_penalty():
         """gan_inference_cifar10.py:264-304 / gmgan_inference_cifar10.py:348,399-403 (DISTANCE_X = 'l2')"""
@@ -116,7 +134,7 @@ class Trainer(object):
         else:
             self.gen_opt = J.Adam(gen_names, **hp)
             self.disc_opt = J.Adam(disc_names, **hp)
-        self.critic_iters = 5 if mode in ('wali', 'wali-gp') else 1   # gan_inference_cifar10.py:53-59
+        self.critic_iters = 5 if mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else 1   # gan_inference_cifar10.py:53-59
 
     def _run(self, feed, which):
         Pt = {k: tp.T(v) for k, v in self.P.items()}

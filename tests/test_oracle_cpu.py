@@ -117,9 +117,10 @@ def test_full_step_vs_torch_autograd():
 
 # ---- (ii) finite differences ---------------------------------------------------------------------------------
 @pytest.mark.parametrize('mode,K,dataset', [('ali', 0, 'cifar10'), ('wali-gp', 0, 'cifar10'), ('ali', 5, 'cifar10'),
-                                            ('ali', 3, 'mnist'), ('ali', 3, 'face')])
+                                            ('ali', 3, 'mnist'), ('ali', 3, 'face'), ('wali', 0, 'cifar10'),
+                                            ('vegan', 0, 'cifar10'), ('vegan-wgan-gp', 0, 'svhn')])
 def test_costs_finite_differences(mode, K, dataset):
-    cfg = N.Cfg(dataset, batch_size=3, n_coms=K, dim=4, dim_latent=6, temp=1.0)
+    cfg = N.Cfg(dataset, batch_size=3, n_coms=K, dim=4, dim_latent=6, temp=1.0, latent_critic=mode.startswith('vegan'))
     rng = np.random.default_rng(2)
     P = {k: v.astype(np.float64) + (0.1 * rng.standard_normal(v.shape) if v.ndim <= 2 else 0) for k, v in N.init_params(cfg, 0).items()}
     feed = S.make_feed(cfg, np.random.default_rng(1), mode)

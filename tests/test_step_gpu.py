@@ -22,7 +22,7 @@ def _mk(dataset, B, K, mode, dim, dl, fuse, graph, gpu):
     from graphical_gan_amd.models import Config
     from graphical_gan_amd.engine import Trainer
     from oracle import nets as N
-    ocfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl)
+    ocfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl, latent_critic=mode.startswith('vegan'))
     P0 = N.init_params(ocfg, seed=0)
     rng = np.random.default_rng(7)
     for k in P0:   # make biases / BN params non-trivial so their gradients paths are exercised
@@ -48,6 +48,8 @@ CASES = [  # dataset, B, K, mode, dim, dim_latent
     ('mnist', 6, 4, 'local_ep', 8, 16),
     ('face', 4, 6, 'local_ep', 4, 16),
     ('svhn', 8, 5, 'local_ep', 8, 16),         # the CIFAR nets without BatchNorm (g(m)gan_inference_svhn.py)
+    ('cifar10', 8, 0, 'vegan', 8, 16),         # latent MLP critic with BatchNorm + Gaussian noise layers, + l2(real_x, G(q_z))
+    ('svhn', 8, 0, 'vegan-wgan-gp', 8, 16),    # latent critic differentiated twice (no BatchNorm)
     ('cifar10', 64, 0, 'ali', None, 128),      # BASELINE config 2 at full size
 ]
 
@@ -62,7 +64,7 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
     if dim is None and not fuse:
         pytest.skip('full-size case runs fused only (oracle time)')
     ocfg, P0, cfg, tr = _mk(dataset, B, K, mode, dim, dl, fuse, False, gpu)
-    omode = mode if mode in ('wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce') else 'ali'
+    omode = mode if mode in ('wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce', 'vegan', 'vegan-wgan-gp') else 'ali'
     feed = S.make_feed(ocfg, np.random.default_rng(11), omode)
     Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
     oout = S.forward(ocfg, Pt, feed, omode)
@@ -76,7 +78,7 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
         names = [p.param_name for p in opt.params]
         grads = torch.autograd.grad(out[which + '_cost'], opt.params, allow_unused=True, retain_graph=True)
         ogs = tp.grad(oout[which + '_cost'], [Pt[n] for n in names])
-        tol = 1e-3 if mode == 'wali-gp' and which == 'disc' else 1e-4
+        tol = 1e-3 if mode in ('wali-gp', 'vegan-wgan-gp') and which == 'disc' else 1e-4
         gmax = max(np.abs(og.v).max() for og in ogs if og is not None)   # scale for mathematically-zero grads
         for n, g, og in zip(names, grads, ogs):
             if og is None:
@@ -96,7 +98,7 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
             assert np.median(err) <= tol * scale and l2 <= 2e-3, (which, n, err.max(), np.median(err), l2, scale)
 
 
-@pytest.mark.parametrize("case", CASES[:10], ids=lambda c: '-'.join(str(x) for x in c))
+@pytest.mark.parametrize("case", CASES[:12], ids=lambda c: '-'.join(str(x) for x in c))
 @pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hipgraph'])
 def test_trajectory(gpu, case, graph):
     """3 iterations of the loop (iteration 0 = critic only), scripted minibatches + noise: cost sequence and
@@ -104,7 +106,7 @@ def test_trajectory(gpu, case, graph):
     from oracle import step as S
     dataset, B, K, mode, dim, dl = case
     ocfg, P0, cfg, tr = _mk(dataset, B, K, mode, dim, dl, True, graph, gpu)
-    omode = mode if mode in ('wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce') else 'ali'
+    omode = mode if mode in ('wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce', 'vegan', 'vegan-wgan-gp') else 'ali'
     otr = S.Trainer(ocfg, P0, omode, np.float64)
     n_it = 4 if graph else 3        # graph path: call 1 eager, call 2 captures+replays, ...
     n_feeds = n_it * (1 + otr.critic_iters)
@@ -123,8 +125,10 @@ def test_trajectory(gpu, case, graph):
         if cfg.bn and (n.endswith('.Biases') or n == 'Generator.Input.b') and not n.startswith('Discriminator') \
                 and n not in ('Extractor.1.Biases', 'Generator.5.Biases'):
             continue   # bias feeding BatchNorm: true gradient is 0, Adam random-walks on rounding noise (fp64 too)
-        if mode == 'wali-gp' and n == 'Discriminator.Output.b':
+        if mode in ('wali-gp', 'vegan-wgan-gp') and n == 'Discriminator.Output.b':
             continue   # Wasserstein critic cost: the output bias cancels exactly, same random walk
+        if cfg.bn and cfg.latent_critic and n in ('Discriminator.Input.b', 'Discriminator.2.b', 'Discriminator.3.b', 'Discriminator.4.b'):
+            continue   # latent critic: every hidden Linear feeds a BatchNorm
         d = np.abs(P[n].reshape(ref.shape) - ref)
         assert d.max() <= 2.5 * lr * steps, (n, d.max())
         assert (d > 2e-5).mean() <= 0.02, (n, (d > 2e-5).mean())
