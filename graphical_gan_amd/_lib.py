@@ -57,6 +57,7 @@ SIGNATURES = {
     'ggan_bn_fwd_train': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),
     'ggan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ggan_bn_bwd_act': (_I, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'ggan_bn_bwd_bwd': (_I, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ggan_bn_sync_stats': (_I, [_P, _P, _I, _I, _I, _P]),
     'ggan_bn_sync_apply': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),
     'ggan_bn_sync_bwd_stats': (_I, [_P, _P, _P, _I, _F, _P, _P, _P, _I, _I, _I, _P]),

@@ -381,6 +381,52 @@ __global__ __launch_bounds__(kSyncThreads) void bn_bwd_apply_sync_k(const float*
     }
 }
 
+// ---- second derivative of training-mode BatchNorm (the gradient penalty of MODE vegan-wgan-gp differentiates the latent critic,
+//      BatchNorm included, twice).  With xh = (x - mean) * invstd, P(v) = v - mean(v) - xh * mean(v * xh), a = P(gy):
+//        first backward        gx  = scale * invstd * a
+//        given h = dL/d(gx):   ggy     = scale * invstd * P(h)                                    (P is self-adjoint)
+//                              gx2     = -scale * invstd^2 * ( mean(h*a) * xh + mean(gy*xh) * P(h) + mean(h*xh) * a )
+//                              gscale2 = invstd * sum(h * a)
+//      (the whole dependence on x, through mean and invstd too).  One workgroup per channel, three passes over the channel. ----
+__global__ __launch_bounds__(kSyncThreads) void bn_bwd_bwd_k(const float* __restrict__ x, const float* __restrict__ gy, GyMask mk,
+                                                             const float* __restrict__ h, const float* __restrict__ scale,
+                                                             const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                             float* __restrict__ ggy, float* __restrict__ gx2, float* __restrict__ gscale2,
+                                                             int N, int C, int HW) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x, total = N * HW;
+    const float mean = save_mean[c], invstd = save_invstd[c], g = scale[c];
+    const float inv_cnt = 1.f / (float)total;
+    float s_g = 0.f, s_gx = 0.f, s_h = 0.f, s_hx = 0.f;
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) {
+        const size_t idx = chan_idx(i, c, C, HW);
+        const float xh = (x[idx] - mean) * invstd, gv = ld_gy(gy, mk, idx), hv = h[idx];
+        s_g += gv; s_gx += gv * xh; s_h += hv; s_hx += hv * xh;
+    }
+    const float m_g = block_sum(s_g, sm) * inv_cnt, m_gx = block_sum(s_gx, sm) * inv_cnt;
+    const float m_h = block_sum(s_h, sm) * inv_cnt, m_hx = block_sum(s_hx, sm) * inv_cnt;
+    float s_ha = 0.f;
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) {
+        const size_t idx = chan_idx(i, c, C, HW);
+        const float xh = (x[idx] - mean) * invstd;
+        const float a = ld_gy(gy, mk, idx) - m_g - xh * m_gx;
+        s_ha += h[idx] * a;
+    }
+    const float sum_ha = block_sum(s_ha, sm), m_ha = sum_ha * inv_cnt;
+    const float k1 = g * invstd, k2 = -g * invstd * invstd;
+    for (int i = threadIdx.x; i < total; i += kSyncThreads) {
+        const size_t idx = chan_idx(i, c, C, HW);
+        const float xh = (x[idx] - mean) * invstd;
+        const float a = ld_gy(gy, mk, idx) - m_g - xh * m_gx;
+        const float ph = h[idx] - m_h - xh * m_hx;
+        float o = k1 * ph;
+        if (mk.act) o = act_grad(o, mk.ref[idx], mk.act, mk.alpha);      // d(gy * act'(y)) / d(gy); act' is piecewise constant
+        ggy[idx] = o;
+        gx2[idx] = k2 * (m_ha * xh + m_gx * ph + m_hx * a);
+    }
+    if (threadIdx.x == 0) gscale2[c] = invstd * sum_ha;
+}
+
 }  // namespace
 
 extern "C" {
@@ -464,6 +510,20 @@ int ggan_bn_sync_bwd_apply(const float* x, const float* gy, const float* y, int 
     const GyMask mk{y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha};
     GGAN_LAUNCH("bn_sync_bwd_apply", 0, 12.0 * N * C * HW, bn_bwd_apply_sync_k, dim3(C), dim3(kSyncThreads), 0, (hipStream_t)stream, x,
                 gy, mk, scale, save_mean, save_invstd, sums, world, rank, gx, gscale, goffset, N, C, HW);
+    return 0;
+}
+
+int ggan_bn_bwd_bwd(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* h, const float* scale,
+                    const float* save_mean, const float* save_invstd, float* ggy, float* gx2, float* gscale2, int N, int C, int HW,
+                    ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && gy && h && scale && save_mean && save_invstd && ggy && gx2 && gscale2, "null pointer");
+    GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "activation mask needs the forward output");
+    GGAN_CHECK_ARG(y_act == GGAN_ACT_NONE || y_act == GGAN_ACT_LRELU || y_act == GGAN_ACT_RELU,
+                   "second derivative only through piecewise-linear fused activations");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bad shape");
+    const GyMask mk{y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha};
+    GGAN_LAUNCH("bn_bwd_bwd", 0, 32.0 * N * C * HW, bn_bwd_bwd_k, dim3(C), dim3(kSyncThreads), 0, (hipStream_t)stream, x, gy, mk, h, scale,
+                save_mean, save_invstd, ggy, gx2, gscale2, N, C, HW);
     return 0;
 }
 

@@ -487,14 +487,16 @@ class BatchNormTrain(Function):
         ctx.dims = (N, Cc, HW)
         ctx.act, ctx.alpha = act, alpha
         ctx.pshape = tuple(scale.shape)
-        ctx.save_for_backward(x, sc, mean, invstd, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, sc, mean, invstd, y if act != ACT_NONE else None, scale)
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
-        x, sc, mean, invstd, y = ctx.saved_tensors
+        x, sc, mean, invstd, y, scale = ctx.saved_tensors
         N, Cc, HW = ctx.dims
+        if torch.is_grad_enabled():        # a double backward is being recorded (gradient penalty through this layer)
+            gx, gs, go = BatchNormBwd.apply(x, gy, y, scale.reshape(-1), mean, invstd, ctx.act, ctx.alpha, ctx.dims)
+            return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None
         gy = _c(gy)
         gx = torch.empty_like(x)
         gs = torch.empty((Cc,), dtype=torch.float32, device=x.device)
@@ -506,6 +508,42 @@ class BatchNormTrain(Function):
         if csum is not None:
             gx._ggan_chansum = csum      # picked up by the producing layer's backward if gx reaches it unchanged
         return gx, gs.view(ctx.pshape), go.view(ctx.pshape), None, None, None
+
+
+class BatchNormBwd(Function):
+    """The first backward of BatchNormTrain as a differentiable op: only on the tape while a double backward is recorded (MODE
+    vegan-wgan-gp: gradient penalty on a critic with BatchNorm).  Its own backward (ggan_bn_bwd_bwd) covers gradients arriving
+    at gx; the scale / offset gradients are not differentiated again (no objective of the reference needs that)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, y, sc, mean, invstd, act, alpha, dims):
+        N, Cc, HW = dims
+        gy = _c(gy)
+        gx = torch.empty_like(x)
+        gs = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        go = torch.empty_like(gs)
+        check(_L().ggan_bn_bwd_act(_p(x), _p(gy), _p(y) if act != ACT_NONE else _p(None), act, alpha, _p(sc), _p(mean), _p(invstd),
+                                   _p(gx), _p(gs), _p(go), _p(None), N, Cc, HW, _stream()), 'ggan_bn_bwd_act')
+        ctx.dims, ctx.act, ctx.alpha = dims, act, alpha
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, gy, y, sc, mean, invstd)
+        return gx, gs, go
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h, hs, ho):
+        if hs is not None or ho is not None:
+            raise NotImplementedError('second derivative of the BatchNorm scale/offset gradients')
+        if h is None:
+            return (None,) * 9
+        x, gy, y, sc, mean, invstd = ctx.saved_tensors
+        N, Cc, HW = ctx.dims
+        h = _c(h)
+        ggy, gx2 = torch.empty_like(x), torch.empty_like(x)
+        gsc = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        check(_L().ggan_bn_bwd_bwd(_p(x), _p(gy), _p(y) if ctx.act != ACT_NONE else _p(None), ctx.act, ctx.alpha, _p(h), _p(sc),
+                                   _p(mean), _p(invstd), _p(ggy), _p(gx2), _p(gsc), N, Cc, HW, _stream()), 'ggan_bn_bwd_bwd')
+        return gx2, ggy, None, gsc.view(sc.shape), None, None, None, None, None
 
 
 def _all_gather_rows(t, group):

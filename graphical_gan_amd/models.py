@@ -45,10 +45,6 @@ class Config(object):
         self.latent_critic = self.mode in ('vegan', 'vegan-wgan-gp')
         self.lamb = 1.0                                                  # LAMBDA (gan_inference_cifar10.py:62)
         assert not (self.latent_critic and n_coms)
-        if self.mode == 'vegan-wgan-gp' and self.bn:
-            raise NotImplementedError('vegan-wgan-gp differentiates the latent critic twice; the BatchNorm kernels have no second '
-                                      'derivative (use a BN_FLAG = False configuration: svhn, face, or bn=False)')
-        assert not (self.mode.startswith('alice') and n_coms) and not (self.mode == 'local_epce' and not n_coms)
         self.top = self.dim * 2 ** (self.nl - 1)
         self.flat = 16 * self.top
         self.output_dim = self.C * self.S * self.S

@@ -132,6 +132,14 @@ int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, 
                     const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset,
                     float* gx_chansum, int N, int C, int HW, ggan_stream_t stream);
 
+/* Second derivative of ggan_bn_bwd_act w.r.t. its inputs, for objectives that differentiate a network containing BatchNorm twice
+ * (MODE vegan-wgan-gp: the gradient penalty on the latent critic, gan_inference_cifar10.py:305-317 with BN_FLAG = True).  h =
+ * dL/d(gx).  Outputs: ggy = dL/d(gy), gx2 = dL/d(x) (all of it: through the batch statistics too), gscale2 = dL/d(scale).  The
+ * fused activation must be piecewise linear (lrelu / relu / none). */
+int ggan_bn_bwd_bwd(const float* x, const float* gy, const float* y, int y_act, float y_alpha, const float* h, const float* scale,
+                    const float* save_mean, const float* save_invstd, float* ggy, float* gx2, float* gscale2, int N, int C, int HW,
+                    ggan_stream_t stream);
+
 /* Cross-replica ("sync") BatchNorm, SURVEY.md 8(e): statistics over the GLOBAL batch of `world` equal-sized replicas.  The
  * reference has no multi-GPU path; this is the mode under which N GPUs x B/N reproduce 1 GPU x B.  The host all-gathers the
  * 2*C floats each *_stats call produces ([2][C]: forward (mean, M2), backward (sum g, sum g*xhat)) into [world][2][C] and hands

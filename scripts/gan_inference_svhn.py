@@ -8,7 +8,7 @@ from graphical_gan_amd import run
 from graphical_gan_amd.models import Config
 
 DATASET = 'svhn'  # the CIFAR nets with BN_FLAG = False
-MODE = 'ali'  # ali, alice, alice-z, alice-x, wali, wali-gp, vegan, vegan-wgan-gp (BN_FLAG False only)
+MODE = 'ali'  # ali, alice, alice-z, alice-x, wali, wali-gp, vegan, vegan-wgan-gp
 
 DIM_LATENT = 128  # latent dimension
 BATCH_SIZE = 64

@@ -649,3 +649,40 @@ def test_row_slots_make_the_critic_concatenation_free(gpu):
     assert j2.data_ptr() not in (c.data_ptr(), d.data_ptr()) and torch.equal(j2.detach(), torch.cat([c, d], 0).detach())
     gc, gd = torch.autograd.grad(j2.sum(), [c, d])
     assert torch.equal(gc, torch.ones_like(c)) and torch.equal(gd, torch.ones_like(d))
+
+
+@pytest.mark.parametrize('shape,act', [((8, 24), 0), ((7, 40), 1), ((4, 6, 4, 4), 2)])
+def test_batchnorm_second_derivative(gpu, shape, act):
+    """ggan_bn_bwd_bwd through autograd: L = sum(w * d(sum(g0 * BN(x)))/dx) differentiated w.r.t. x, g0 and scale, against the
+    oracle tape (which is closed under differentiation), float64."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import tape as tp
+    rng = np.random.default_rng(41 + len(shape))
+    Cc = shape[1]
+    x = rng.standard_normal(shape) * 1.3 + 0.2
+    sc = 1 + 0.3 * rng.standard_normal(Cc); of = 0.2 * rng.standard_normal(Cc)
+    g0 = rng.standard_normal(shape); w = rng.standard_normal(shape)
+    axes = [0, 2, 3] if len(shape) == 4 else [0]
+    X, S_, O, G0 = tp.T(x), tp.T(sc), tp.T(of), tp.T(g0)
+    yo = tp.batchnorm_train(X, S_, O, axes, 1e-5)
+    if act == 1:
+        yo = tp.leaky_relu(yo, 0.2)
+    elif act == 2:
+        yo = tp.relu(yo)
+    gxo = tp.grad(tp.reduce_sum(tp.mul(yo, G0)), [X])[0]
+    Lo = tp.reduce_sum(tp.mul(gxo, tp.T(w)))
+    rx, rg, rs = tp.grad(Lo, [X, G0, S_])
+    pshape = (Cc,) if len(shape) == 4 else (1, Cc)
+    tx = _t(x, gpu).requires_grad_(True)
+    ts = _t(sc.reshape(pshape), gpu).requires_grad_(True)
+    to = _t(of.reshape(pshape), gpu).requires_grad_(True)
+    tg = _t(g0, gpu).requires_grad_(True)
+    y = F.BatchNormTrain.apply(tx, ts, to, 1e-5, act, 0.2)
+    (gx,) = torch.autograd.grad(y, [tx], grad_outputs=tg, create_graph=True)
+    assert _rel(gx.detach().cpu().numpy(), gxo.v) < 2e-5
+    L = (gx * _t(w, gpu)).sum()
+    dx, dg, ds = torch.autograd.grad(L, [tx, tg, ts])
+    assert _rel(dx.cpu().numpy(), rx.v) < 5e-5, _rel(dx.cpu().numpy(), rx.v)
+    assert _rel(dg.cpu().numpy(), rg.v) < 5e-5
+    assert _rel(ds.cpu().numpy().reshape(-1), rs.v.reshape(-1)) < 5e-5

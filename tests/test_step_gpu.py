@@ -50,6 +50,7 @@ CASES = [  # dataset, B, K, mode, dim, dim_latent
     ('svhn', 8, 5, 'local_ep', 8, 16),         # the CIFAR nets without BatchNorm (g(m)gan_inference_svhn.py)
     ('cifar10', 8, 0, 'vegan', 8, 16),         # latent MLP critic with BatchNorm + Gaussian noise layers, + l2(real_x, G(q_z))
     ('svhn', 8, 0, 'vegan-wgan-gp', 8, 16),    # latent critic differentiated twice (no BatchNorm)
+    ('cifar10', 8, 0, 'vegan-wgan-gp', 8, 16), # ... with BatchNorm: second derivative of the BatchNorm backward
     ('cifar10', 64, 0, 'ali', None, 128),      # BASELINE config 2 at full size
 ]
 
@@ -98,7 +99,7 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
             assert np.median(err) <= tol * scale and l2 <= 2e-3, (which, n, err.max(), np.median(err), l2, scale)
 
 
-@pytest.mark.parametrize("case", CASES[:12], ids=lambda c: '-'.join(str(x) for x in c))
+@pytest.mark.parametrize("case", CASES[:13], ids=lambda c: '-'.join(str(x) for x in c))
 @pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hipgraph'])
 def test_trajectory(gpu, case, graph):
     """3 iterations of the loop (iteration 0 = critic only), scripted minibatches + noise: cost sequence and
