@@ -38,6 +38,15 @@ struct GemmParams {
     const float* b_ref;
     int ref_act;
     float ref_alpha;
+    // "concatenated" operands without the concatenation (the critic's Linear on [conv features | latent features]):
+    //   A2 != null: op(A) is [A | A2] side by side along its second stored dimension -- columns (k, or m when TA) >= a_split
+    //               come from A2 (leading dimension lda2); a_split is a multiple of the tile step, so a tile has ONE source
+    //   C2 != null: output columns >= c_split go to C2 (leading dimension N - c_split), the others to C with leading dimension
+    //               c_split (direct stores only: SK == 1)
+    const float* A2;
+    int a_split, lda2;
+    float* C2;
+    int c_split;
 };
 
 // Load a [64 rows(r) x 16 k] tile of a matrix into LDS as T[k][r].
@@ -179,7 +188,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     float csum = 0.f;
     float4 ra[2], rb[2], rma[2], rmb[2];
     auto load_step = [&](int k0) {
-        load_step_tile<AK>(P.A, P.lda, P.M, m0, k0, ke, P.vecA, ra);
+        if (P.A2 == nullptr) {
+            load_step_tile<AK>(P.A, P.lda, P.M, m0, k0, ke, P.vecA, ra);
+        } else if (AK) {        // element (m, k) at A[m*lda + k]: the sources split the k range
+            const bool second = k0 >= P.a_split;
+            load_step_tile<AK>(second ? P.A2 - P.a_split : P.A, second ? P.lda2 : P.lda, P.M, m0, k0, second ? ke : min(ke, P.a_split),
+                               P.vecA, ra);
+        } else {                // element (m, k) at A[k*lda + m]: the sources split the m range
+            const bool second = m0 >= P.a_split;
+            load_step_tile<AK>(second ? P.A2 - P.a_split : P.A, second ? P.lda2 : P.lda, second ? P.M : P.a_split, m0, k0, ke,
+                               P.vecA, ra);
+        }
         if (MASK == 1) load_step_tile<AK>(P.a_ref, P.lda, P.M, m0, k0, ke, P.vecA, rma);
         load_step_tile<BKc>(P.B, P.ldb, P.N, n0, k0, ke, P.vecB, rb);
         if (MASK == 2) load_step_tile<BKc>(P.b_ref, P.ldb, P.N, n0, k0, ke, P.vecB, rmb);
@@ -231,7 +250,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     __syncthreads();
     const bool direct = P.SK == 1;
     float* Cp = direct ? P.C : P.C + (size_t)split * P.out_elems;
-    const bool vec_out = (P.N & 3) == 0 && ((uintptr_t)Cp & 15) == 0;
+    int ldc = P.N, ncol0 = 0, nend = P.N;       // output columns [ncol0, nend) live in Cp with leading dimension ldc
+    if (P.C2 != nullptr) {
+        if (n0 >= P.c_split) { Cp = P.C2; ldc = P.N - P.c_split; ncol0 = P.c_split; }
+        else { ldc = P.c_split; nend = P.c_split; }
+    }
+    const bool vec_out = (ldc & 3) == 0 && ((uintptr_t)Cp & 15) == 0;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int idx = tid + pass * 256, ml = idx >> 4, c4 = (idx & 15) * 4;
@@ -246,12 +270,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
                 vv[q] = act_apply(vv[q] + bv, P.act, P.alpha);
             }
         }
-        float* dst = Cp + (size_t)m * P.N + n;
-        if (vec_out && n + 3 < P.N) {
+        float* dst = Cp + (size_t)m * ldc + (n - ncol0);
+        if (vec_out && n + 3 < nend) {
             *reinterpret_cast<float4*>(dst) = v;
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (n + q < P.N) dst[q] = vv[q];
+            for (int q = 0; q < 4; ++q) if (n + q < nend) dst[q] = vv[q];
         }
     }
 }
@@ -281,7 +305,8 @@ size_t ggan_gemm_workspace(int M, int N, int K) {
 
 static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C,
                        float* colsum, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s,
-                       const float* a_ref = nullptr, const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f) {
+                       const float* a_ref = nullptr, const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f,
+                       const float* A2 = nullptr, int a_split = 0, float* C2 = nullptr, int c_split = 0) {
     if (N == 1 && !ta && !tb && !colsum && !a_ref && !b_ref) {
         GGAN_LAUNCH("gemv_rows_k", 2.0 * M * K, 0, gemv_rows_k, dim3(cdiv(M, 4)), dim3(256), 0, s, A, B, bias, C, M, K, act, alpha);
         return 0;
@@ -293,8 +318,18 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     P.M = M; P.N = N; P.K = K;
     P.lda = ta ? M : K;
     P.ldb = tb ? K : N;
+    if (A2) {
+        const int whole = ta ? M : K;
+        if (a_split <= 0 || a_split >= whole || (a_split % 64) || a_ref) { set_error("gemm: bad operand split"); return -1; }
+        P.A2 = A2; P.a_split = a_split;
+        P.lda = a_split; P.lda2 = whole - a_split;
+    }
+    if (C2) {
+        if (c_split <= 0 || c_split >= N || (c_split % BN) || colsum || bias || act != GGAN_ACT_NONE) { set_error("gemm: bad output split"); return -1; }
+        P.C2 = C2; P.c_split = c_split;
+    }
     // float4 legality: base aligned, leading dimension multiple of 4 (row starts stay aligned)
-    P.vecA = al16(A) && (P.lda % 4 == 0) && (!a_ref || al16(a_ref));
+    P.vecA = al16(A) && (P.lda % 4 == 0) && (!a_ref || al16(a_ref)) && (!A2 || (al16(A2) && P.lda2 % 4 == 0));
     P.vecB = al16(B) && (P.ldb % 4 == 0) && (!b_ref || al16(b_ref));
     P.act = act; P.alpha = alpha;
     P.out_elems = (size_t)M * N;
@@ -302,7 +337,7 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     ws = ws_scratch(ws, ws_bytes);
     const int gx = cdiv(N, BN), gy = cdiv(M, BM);
     int sk = 1;
-    if (!colsum && ws) {       // (a fused column sum needs the whole K range in one workgroup)
+    if (!colsum && ws && !C2) {       // (a fused column sum needs the whole K range in one workgroup; so does a split output)
         const char* e = getenv("GGAN_GEMM_SK");
         if (e) sk = atoi(e);
         else {
@@ -340,6 +375,16 @@ int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* 
     GGAN_CHECK_ARG(A && B && C, "null pointer");
     GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
     return gemm_launch(ta, tb, M, N, K, A, B, bias, C, nullptr, act, alpha, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ggan_gemm_split(int ta, int tb, int M, int N, int K, const float* A, const float* A2, int a_split, const float* B,
+                    const float* bias, float* C, float* C2, int c_split, float* colsum_b, int act, float alpha, void* ws,
+                    size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(A && B && C, "null pointer");
+    GGAN_CHECK_ARG(M > 0 && N > 0 && K > 0, "bad shape");
+    GGAN_CHECK_ARG(!colsum_b || !tb, "column sums need B stored [K,N]");
+    return gemm_launch(ta, tb, M, N, K, A, B, bias, C, colsum_b, act, alpha, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, 0,
+                       0.f, A2, a_split, C2, c_split);
 }
 
 int ggan_gemm_colsum(int ta, int M, int N, int K, const float* A, const float* B, float* C, float* colsum_b, void* ws,

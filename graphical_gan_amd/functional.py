@@ -389,6 +389,66 @@ def _fused_linear_backward(ctx, g, x, w, y):
     return (dx, dw, db) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
+class Gemm2(Function):
+    """[a1 | a2] @ w + bias without materialising the concatenation (tf.concat + Linear of the joint critic,
+    gan_inference_cifar10.py:246-248): the GEMM reads its A operand from two buffers, its weight gradient likewise, and its
+    data gradient leaves in two buffers (ggan_gemm_split).  Falls back to concatenate + Gemm while a double backward is
+    recorded (wali-gp) or when the split is not tile-aligned."""
+
+    @staticmethod
+    def usable(a1, a2):
+        return a1.shape[1] % 64 == 0 and a2.shape[1] % 4 == 0 and a1.shape[0] == a2.shape[0]
+
+    @staticmethod
+    def forward(ctx, a1, a2, w, bias, act, alpha):
+        a1, a2, w = _c(a1), _c(a2), _c(w)
+        M, K1, K2 = a1.shape[0], a1.shape[1], a2.shape[1]
+        K, N = w.shape
+        assert K == K1 + K2, (a1.shape, a2.shape, w.shape)
+        out = torch.empty((M, N), dtype=torch.float32, device=a1.device)
+        ws = workspace(a1.device)
+        check(_L().ggan_gemm_split(0, 0, M, N, K, _p(a1), _p(a2), K1, _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(out),
+                                   _p(None), 0, _p(None), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
+        ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
+        ctx.save_for_backward(a1, a2, w, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a1, a2, w, out = ctx.saved_tensors
+        K1 = a1.shape[1]
+        if torch.is_grad_enabled():          # differentiable composition (second derivatives: wali-gp)
+            if ctx.act != ACT_NONE:
+                g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
+            a = torch.cat([a1, a2], 1)
+            da = Gemm.apply(g, w, None, False, True, ACT_NONE, 0.0) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+            dw = Gemm.apply(a, g, None, True, False, ACT_NONE, 0.0) if ctx.needs_input_grad[2] else None
+            db = ColSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+            return (da[:, :K1] if da is not None else None, da[:, K1:] if da is not None else None, dw, db, None, None)
+        g = _c(g)
+        if ctx.act != ACT_NONE:
+            g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
+        M, N = g.shape
+        K = w.shape[0]
+        L, ws = _L(), workspace(g.device)
+        da1 = da2 = dw = db = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw = torch.empty((K, N), dtype=torch.float32, device=g.device)
+            db = torch.empty((N,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            # dW[K,N] = [a1 | a2]^T g (A stored [M, K]: transposed read, the sources split the OUTPUT rows) + column sums of g
+            check(L.ggan_gemm_split(1, 0, K, N, M, _p(a1), _p(a2), K1, _p(g), _p(None), _p(dw), _p(None), 0, _p(db), ACT_NONE, 0.0,
+                                    _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
+            if not ctx.needs_input_grad[2]:
+                dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            da1 = torch.empty_like(a1)
+            da2 = torch.empty_like(a2)
+            # [da1 | da2] = g w^T, columns < K1 to da1, the rest to da2
+            check(L.ggan_gemm_split(0, 1, M, K, N, _p(g), _p(None), 0, _p(w), _p(None), _p(da1), _p(da2), K1, _p(None), ACT_NONE, 0.0,
+                                    _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
+        return da1, da2, dw, db if (ctx.has_bias and ctx.needs_input_grad[3]) else None, None, None
+
+
 def gemm_colsum_(a, g, ta):
     """C = op(A) @ g and colsum[n] = sum_k g[k, n] in one kernel (no autograd: used inside plain backward passes)."""
     a, g = _c(a), _c(g)

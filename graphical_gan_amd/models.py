@@ -206,8 +206,7 @@ class GraphicalGAN(object):
             ch = cout
         out = out.reshape(-1, c.flat)
         z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
-        out = torch.cat([out, z_out], 1)
-        out = self._lin('Discriminator.zx1', c.flat + 512, 512, out, LRELU)
+        out = self._lin('Discriminator.zx1', c.flat + 512, 512, (out, z_out), LRELU)     # Linear on concat([out, z_out], 1)
         out = lib.ops.linear.Linear('Discriminator.Output', 512, 1, out)
         return out.reshape(-1)
 

@@ -73,8 +73,16 @@ def Linear(name, input_dim, output_dim, inputs, biases=True, initialization=None
         norms = (weight * weight).sum(dim=0).sqrt()
         weight = weight * (target_norms / norms)
     b = _param(name + '.b', np.zeros((output_dim,), dtype='float32')) if biases else None
-    x = inputs if inputs.dim() == 2 else inputs.reshape(-1, input_dim)
     act = F.ACT_NONE if activation is None else activation
+    if isinstance(inputs, (tuple, list)):
+        # extension: a pair (x1, x2) stands for tf.concat([x1, x2], 1) -- the GEMM reads both operands in place
+        x1, x2 = inputs
+        assert x1.dim() == 2 and x2.dim() == 2 and x1.shape[1] + x2.shape[1] == input_dim, (name, x1.shape, x2.shape, input_dim)
+        if out is None and F.Gemm2.usable(x1, x2):
+            return F.Gemm2.apply(x1, x2, weight, b, act, float(alpha))
+        import torch
+        inputs = torch.cat([x1, x2], 1)
+    x = inputs if inputs.dim() == 2 else inputs.reshape(-1, input_dim)
     result = F.Gemm.apply(x, weight, b, False, False, act, float(alpha), out)
     if inputs.dim() != 2:
         result = result.reshape(tuple(inputs.shape[:-1]) + (output_dim,))

@@ -98,6 +98,18 @@ int ggan_linear_bwd_data_act(int M, int N, int K, const float* g, const float* y
 int ggan_linear_bwd_weight_act(int M, int N, int K, const float* x, const float* g, const float* y, int y_act,
                                float y_alpha, float* dw, float* db, void* ws, size_t ws_bytes, ggan_stream_t stream);
 
+/* ggan_gemm with "concatenated" operands that are never concatenated (the critic's Linear on [conv features | z features],
+ * gan_inference_cifar10.py:246-248 tf.concat + Linear, and its two gradients):
+ *   A2 != NULL: op(A) = [A | A2] side by side along the SECOND stored dimension of A (k when ta == 0, m when ta == 1); the
+ *               first a_split columns come from A (leading dimension a_split), the rest from A2 (leading dimension whole -
+ *               a_split); a_split must be a multiple of 64.
+ *   C2 != NULL: output columns [0, c_split) go to C (leading dimension c_split), [c_split, N) to C2 (leading dimension N -
+ *               c_split); c_split a multiple of 64; no bias / activation / column sums with a split output.
+ *   colsum_b (may be NULL; tb == 0 only): column sums of B, as ggan_gemm_colsum. */
+int ggan_gemm_split(int ta, int tb, int M, int N, int K, const float* A, const float* A2, int a_split, const float* B,
+                    const float* bias, float* C, float* C2, int c_split, float* colsum_b, int act, float alpha, void* ws,
+                    size_t ws_bytes, ggan_stream_t stream);
+
 /* ---- dense -------------------------------------------------------------------------------
  * C[M,N] = op(A) * op(B) (+ bias[N]) (+act), row-major, ta/tb = 1 reads the operand transposed
  * (A stored [K,M] / B stored [N,K]).  tf.matmul + bias_add of tflib/ops/linear.py:133-146 is

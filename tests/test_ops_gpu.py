@@ -686,3 +686,34 @@ def test_batchnorm_second_derivative(gpu, shape, act):
     assert _rel(dx.cpu().numpy(), rx.v) < 5e-5, _rel(dx.cpu().numpy(), rx.v)
     assert _rel(dg.cpu().numpy(), rg.v) < 5e-5
     assert _rel(ds.cpu().numpy().reshape(-1), rs.v.reshape(-1)) < 5e-5
+
+
+@pytest.mark.parametrize('M,K1,K2,N', [(128, 4096, 512, 512), (8, 128, 16, 40), (37, 64, 36, 70)])
+def test_linear_on_a_pair_of_inputs_equals_linear_on_their_concatenation(gpu, M, K1, K2, N):
+    """functional.Gemm2 / ggan_gemm_split: [a1 | a2] @ w + b (+ LeakyReLU) with the operands left where they are -- forward, both
+    data gradients (split output), weight and bias gradient (two-source transposed operand) -- against float64 numpy."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(M + K2)
+    a1, a2 = rng.standard_normal((M, K1)), rng.standard_normal((M, K2))
+    w = rng.standard_normal((K1 + K2, N)) / np.sqrt(K1 + K2); b = rng.standard_normal(N)
+    g = rng.standard_normal((M, N))
+    a = np.concatenate([a1, a2], 1)
+    pre = a @ w + b
+    ref = np.where(pre > 0, pre, 0.2 * pre)
+    gm = g * np.where(pre > 0, 1.0, 0.2)
+    t1, t2 = _t(a1, gpu).requires_grad_(True), _t(a2, gpu).requires_grad_(True)
+    tw, tb = _t(w, gpu).requires_grad_(True), _t(b, gpu).requires_grad_(True)
+    assert F.Gemm2.usable(t1, t2)
+    y = F.Gemm2.apply(t1, t2, tw, tb, F.ACT_LRELU, 0.2)
+    assert _rel(y.detach().cpu().numpy(), ref) < 2e-5
+    d1, d2, dw, db = torch.autograd.grad(y, [t1, t2, tw, tb], grad_outputs=_t(g, gpu))
+    da = gm @ w.T
+    assert _rel(d1.cpu().numpy(), da[:, :K1]) < 3e-5 and _rel(d2.cpu().numpy(), da[:, K1:]) < 3e-5
+    assert _rel(dw.cpu().numpy(), a.T @ gm) < 3e-5 and _rel(db.cpu().numpy(), gm.sum(0)) < 3e-5
+    # while a double backward is recorded the differentiable composition takes over: same first derivatives
+    y2 = F.Gemm2.apply(t1, t2, tw, tb, F.ACT_LRELU, 0.2)
+    e1, e2 = torch.autograd.grad(y2, [t1, t2], grad_outputs=_t(g, gpu), create_graph=True)
+    assert _rel(e1.detach().cpu().numpy(), da[:, :K1]) < 3e-5 and _rel(e2.detach().cpu().numpy(), da[:, K1:]) < 3e-5
+    (hw,) = torch.autograd.grad((e1 * e1).sum() + (e2 * e2).sum(), [tw])
+    assert np.isfinite(hw.cpu().numpy()).all() and float(hw.abs().max()) > 0
