@@ -20,6 +20,10 @@ TRAJ = {   # name -> (dataset, B, K, mode, dim, dim_latent, iterations)
     'traj_cifar_wali_gp': ('cifar10', 6, 0, 'wali-gp', 8, 16, 2),
     'traj_mnist_gmgan': ('mnist', 6, 4, 'ali', 8, 16, 2),
     'traj_face_gmgan': ('face', 4, 6, 'ali', 4, 16, 2),
+    'traj_svhn_gmgan': ('svhn', 6, 5, 'ali', 8, 16, 2),             # no BatchNorm
+    'traj_cifar_wali': ('cifar10', 6, 0, 'wali', 8, 16, 2),         # RMSProp + weight clipping, 5 critic steps
+    'traj_cifar_alice': ('cifar10', 6, 0, 'alice', 8, 16, 2),       # both reconstruction terms
+    'traj_cifar_vegan': ('cifar10', 4, 0, 'vegan', 8, 16, 2),       # latent critic with BatchNorm + noise layers
 }
 
 
@@ -67,7 +71,7 @@ def make_ops():
 
 def make_traj(name):
     dataset, B, K, mode, dim, dl, iters = TRAJ[name]
-    cfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl)
+    cfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl, latent_critic=mode.startswith('vegan'))
     P0 = perturbed_params(cfg)
     tr = S.Trainer(cfg, P0, mode, np.float64)
     n_feeds = iters * (1 + tr.critic_iters)
@@ -90,7 +94,9 @@ def make_traj(name):
 
 
 if __name__ == '__main__':
-    make_ops()
-    for n in TRAJ:
+    only = sys.argv[1:]                       # optional: just these trajectories (existing files stay byte-identical)
+    if not only:
+        make_ops()
+    for n in (only or TRAJ):
         make_traj(n)
     print('wrote', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))

@@ -365,3 +365,34 @@ def test_trajectory_unfused_epilogues(gpu):
     for n in ('Discriminator.2.Filters', 'Generator.3.Filters', 'Extractor.Output.W', 'Discriminator.zx1.W'):
         d = np.abs(P[n].reshape(otr.P[n].shape) - otr.P[n])
         assert d.max() <= 2.5 * cfg.lr * 6 and (d > 2e-5).mean() <= 0.02, (n, d.max())
+
+
+def test_bench_contract_line_single_and_two_ranks(gpu):
+    """bench.py end to end: the one-line JSON contract at N=1 (with roofline and cpu_baseline objects), and the N=2 launch the
+    driver uses (python -m torch.distributed.run ... bench.py --gpus 2) rehearsed with two gloo ranks sharing the one GPU."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '2'], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 2 and d['dtype'] == 'f32' and d['value'] > 0
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-3
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
+    port = 29700 + (os.getpid() % 200)
+    env2 = dict(env, GGAN_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2'],
+                       capture_output=True, text=True, timeout=900, env=env2, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                  # rank 0 only
+    d2 = json.loads(lines[0])
+    assert d2['n_gpus'] == 2 and d2['scaling'] == 'weak' and d2['config']['global_batch'] == 128 and d2['value'] > 0
