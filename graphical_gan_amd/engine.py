@@ -53,6 +53,8 @@ class Trainer(object):
         if self.sync_bn:
             lib.ops.batchnorm.set_sync_group(True)
             self.graph_enabled = False
+            if hasattr(self.model, 'fork_nets'):
+                self.model.fork_nets = False      # keep the statistics exchanges of the two passes in one stream order
         # the pack kernel may sum the filter-gradient slabs only if every parameter receives ONE gradient contribution per
         # backward pass (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
         self.single_contrib = bool(self.model.single_contribution)
@@ -138,6 +140,18 @@ class Trainer(object):
         return list(_optimizers.values())
 
     def _capture(self, which):
+        # two-stream nets pass inside the step graph (models.GraphicalGAN.forward_nets): single-graph steps only -- with the
+        # graph cut for the gradient exchange it measured slower (40.1 k vs 41.7 k img/s on the forced-split path)
+        forkable = hasattr(self.model, 'fork_now') and not self.split_graph and not self.sync_bn
+        if forkable:
+            self.model.fork_now = True
+        try:
+            return self._capture_impl(which)
+        finally:
+            if forkable:
+                self.model.fork_now = False
+
+    def _capture_impl(self, which):
         # warm-up eagerly on a side stream (allocator + lazy init), restoring optimizer state afterwards
         if getattr(self, '_cap_stream', None) is None:
             self._cap_stream = torch.cuda.Stream(device=self.device)    # warm-up AND capture run on this stream, so the
@@ -196,6 +210,8 @@ class Trainer(object):
     def step(self, which):
         """One gen or disc session.run on the current contents of the static buffers -> 0-dim cost tensor."""
         self._calls[which] += 1
+        if self._calls['gen'] >= 2 and self._calls['disc'] >= 2:
+            lib.end_build_phase()        # both step kinds have been built once: from here on the layer calls draw no initial values
         if not self.graph_enabled:
             return self._eager(which)
         rec = self._graphs.get(which)

@@ -79,6 +79,25 @@ def named_params():
 
 def delete_all_params():
     _params.clear()
+    _build_phase[0] = True
+
+
+# The reference draws every initial value at GRAPH-BUILD time, on every layer call (even when the parameter exists:
+# conv2d.py:75-88) -- that is how its scripts consume numpy RNG state.  An eager framework calls the layer functions again on
+# every step, where TensorFlow only replays the built graph and draws nothing.  A Trainer marks that boundary: once a generator
+# and a critic step have been built, layer calls that find their parameters skip the draw (a 4608x512 uniform draw per
+# Linear call otherwise: 45 of the 48 ms of an eager iteration).  Until then, and for any direct use of the ops, every call
+# draws, as in the reference.
+_build_phase = [True]
+
+
+def end_build_phase():
+    _build_phase[0] = False
+
+
+def initial_values_needed(*names):
+    """False only after end_build_phase() for parameters that all exist already"""
+    return _build_phase[0] or any(n not in _params for n in names)
 
 
 def alias_params(replace_dict):

@@ -5,6 +5,7 @@ import numpy as np
 
 from ... import functional as F
 from .. import param as _param
+from .. import initial_values_needed as _draw
 
 _default_weightnorm = False
 
@@ -41,13 +42,16 @@ def Deconv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, wei
     fan_out = output_dim * filter_size ** 2
     filters_stdev = np.sqrt(4. / (fan_in + fan_out)) if he_init else np.sqrt(2. / (fan_in + fan_out))
     shape = (filter_size, filter_size, output_dim, input_dim)
-    filter_values = _uniform(_weights_stdev if _weights_stdev is not None else filters_stdev, shape)
-    filter_values *= gain
+    if _draw(name + '.Filters'):
+        filter_values = _uniform(_weights_stdev if _weights_stdev is not None else filters_stdev, shape)
+        filter_values *= gain
+    else:
+        filter_values = None          # session.run time: the graph exists, nothing is drawn (tflib.end_build_phase)
     filters = _param(name + '.Filters', filter_values)
     if weightnorm is None:
         weightnorm = _default_weightnorm
     if weightnorm:
-        norm_values = np.sqrt(np.sum(np.square(filter_values), axis=(0, 1, 3)))
+        norm_values = np.sqrt(np.sum(np.square(filter_values), axis=(0, 1, 3))) if filter_values is not None else None
         target_norms = _param(name + '.g', norm_values)
         norms = (filters * filters).sum(dim=(0, 1, 3)).sqrt()
         filters = filters * (target_norms / norms).unsqueeze(1)

@@ -3,6 +3,7 @@ import numpy as np
 
 from ... import functional as F
 from .. import param as _param
+from .. import initial_values_needed as _draw
 
 _default_weightnorm = False
 
@@ -62,13 +63,16 @@ def Linear(name, input_dim, output_dim, inputs, biases=True, initialization=None
            activation=None, alpha=0.2, out=None):
     """Same signature as the reference; `activation`/`alpha` are an optional fused epilogue and `out` an optional
     functional.RowSlot the result is written into (extensions)."""
-    weight_values = _initial(initialization, input_dim, output_dim)
-    weight_values *= gain
+    if _draw(name + '.W'):
+        weight_values = _initial(initialization, input_dim, output_dim)
+        weight_values *= gain
+    else:
+        weight_values = None          # session.run time: the graph exists, nothing is drawn (tflib.end_build_phase)
     weight = _param(name + '.W', weight_values)
     if weightnorm is None:
         weightnorm = _default_weightnorm
     if weightnorm:
-        norm_values = np.sqrt(np.sum(np.square(weight_values), axis=0))
+        norm_values = np.sqrt(np.sum(np.square(weight_values), axis=0)) if weight_values is not None else None
         target_norms = _param(name + '.g', norm_values)
         norms = (weight * weight).sum(dim=0).sqrt()
         weight = weight * (target_norms / norms)

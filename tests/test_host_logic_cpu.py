@@ -75,6 +75,18 @@ def test_initialisers_consume_rng_like_the_reference(lib):
     with pytest.raises(_lib.GganError):
         lib.ops.conv2d.Conv2D('Extractor.1', 3, 4, 5, x, stride=2)
     assert np.array_equal(np.random.get_state()[1][:4], expect)
+    # once a Trainer has declared the graphs built (session.run time in the reference), calls that find their parameters draw
+    # nothing; new parameters still do, and delete_all_params() starts a new build phase
+    lib.end_build_phase()
+    before = np.random.get_state()[1][:4].copy()
+    with pytest.raises(_lib.GganError):
+        lib.ops.conv2d.Conv2D('Extractor.1', 3, 4, 5, x, stride=2)
+    assert np.array_equal(np.random.get_state()[1][:4], before)
+    with pytest.raises(_lib.GganError):
+        lib.ops.conv2d.Conv2D('Extractor.9', 3, 4, 5, x, stride=2)
+    assert not np.array_equal(np.random.get_state()[1][:4], before)
+    lib.delete_all_params()
+    assert lib.initial_values_needed('anything')
     assert lib.ops.deconv2d.Deconv2D.__defaults__ is not None
     with pytest.raises(Exception, match='Unsupported configuration'):
         lib.ops.deconv2d.Deconv2D('G.2', 4, 2, 5, x, mask_type=('a', 1))
