@@ -407,6 +407,7 @@ struct ThinFwdParams {
     float alpha;
     FastDiv d_Wo, d_W4, d_SR, d_Ci, d_5;
     unsigned x_bytes;
+    int dbg;
 };
 
 template <int NTN, int MPW>
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     }
     for (int e = tid; e < cbase; e += NTHR) xs[e] = 0.f;
     if (tid == 0) { xs[cbase] = 1.f; xs[cbase + 1] = 0.f; }
-    {
+    if (!(P.dbg & 2)) {
         const int c4 = P.Co >> 2, rows = P.KS * 4;
         for (int u = tid; u < rows * c4; u += NTHR) {
             const int j = u / c4, f = u - j * c4;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
         for (int t = 0; t < NTN; ++t) bb[t] = bp[ks * 4 * P.WS + t * 16];
     };
     load_step(0, av[0], bv[0]);
-    for (int ks = 0; ks < P.KS; ks += 2) {               // KS is even (K padded to a multiple of 8 with zero rows)
+    for (int ks = 0; ks < ((P.dbg & 1) ? 0 : P.KS); ks += 2) {               // KS is even (K padded to a multiple of 8 with zero rows)
         load_step(ks + 1, av[1], bv[1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     for (int i = 0; i < MPW; ++i) {
         const int mt = wave + 4 * i;
         const int pp = oh0 * P.Wo + mt * 16 + 4 * q;     // pixel index within the channel plane (a multiple of 4)
-        if (mt < P.MT && mt * 16 + 4 * q < P.PB && pp < HoWo) {
+        if (mt < P.MT && mt * 16 + 4 * q < P.PB && pp < HoWo && !(P.dbg & 4)) {
 #pragma unroll
             for (int t = 0; t < NTN; ++t) {
                 const int co = t * 16 + l15;
@@ -685,6 +686,7 @@ int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const
     ThinFwdParams P;
     memset(&P, 0, sizeof(P));
     P.x = x; P.w = w; P.bias = bias; P.y = y; P.act = act; P.alpha = alpha; P.x_bytes = (unsigned)xb;
+    { const char* d = getenv("GGAN_THIN_DBG"); P.dbg = d ? atoi(d) : 0; }
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo; P.pad_t = g.pad_t; P.pad_l = g.pad_l;
     // band of output rows: whole 16-pixel tiles, at most 8 of them; the smallest band that still gives every wave a tile
     // (more workgroups to spread over the chip), one that divides the image if possible
