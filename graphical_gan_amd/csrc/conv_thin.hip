@@ -194,28 +194,31 @@ struct ThinWgradParams {
     int gstride;         // floats between the wave groups' staging areas
 };
 
-constexpr int XU_MAX = 3, GU_MAX = 4;
+constexpr int XU_MAX = 3, GU_MAX = 2;
 
 // NTN: 16-wide tiles along Co (2 or 4); the 4 waves are NTN tile columns x (4/NTN) groups of tile rows
-// NG: groups of 4 waves per workgroup, each walking its own items (the step is bound by the latency of the operand loads,
-// and the slab count caps the number of workgroups: more items in flight per workgroup instead); summed through LDS at the end
-template <int NTN, int MPW, int NG>
+// Grid = (image ranges, 16-wide tiles of Co): the slab count (<= 64, what the consumer sums) caps the image ranges, so the output
+// COLUMNS are spread over workgroups as well -- every workgroup of a column tile writes its own columns of the same slab.
+// NG: groups of 4 waves per workgroup, each walking its own items of the image range (the step is bound by the latency of the
+// operand loads: more items in flight); within a group the waves own the 16-row tiles of the 25*Ci (+1) operand rows.  The
+// groups' partial tiles are added in group order through LDS at the end.
+template <int MPW, int NG>
 __global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int MG = 4 / NTN;
+    constexpr int MG = 4;
     const int tid = threadIdx.x & (NTHR - 1), lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR);
     const int l15 = lane & 15, q = lane >> 4;
-    const int nt = wave % NTN, mg = wave / NTN;
+    const int nt = blockIdx.y, mg = wave;
     float* gsm = smem + (size_t)grp * P.gstride;    // this group's staging area
     float* xs = gsm;                           // [Ci][XCS]: rows SR x (2 halo | W | 2 halo)
-    float* gs = gsm + P.Ci * P.XCS;            // [Co][GS]
+    float* gs = gsm + P.Ci * P.XCS;            // [16][GS]: this workgroup's 16 output channels
     const int W4 = P.W >> 2, PB4 = P.PB >> 2, HW = P.H * P.W, HoWo = P.Ho * P.Wo;
 
     // per-lane operand-row descriptors: row j = tap*Ci + c of the im2col matrix -> offset of (c, kh, kw) in the slab
     // rows past the taps read a constant word kept behind the tiles instead: 1.0 (the bias-gradient row) or 0.0 (padding)
-    const int cbase = P.Ci * P.XCS + P.Co * P.GS;
+    const int cbase = P.Ci * P.XCS + 16 * P.GS;
     int offA[MPW], pmA[MPW];
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradPa
         if (u < P.gunits) {
             const int co = fdiv(u, P.d_PB4), p4 = u - co * PB4;
             pix = p4 * 4;
-            rel = co * HoWo + pix;
+            rel = (nt * 16 + co) * HoWo + pix;
             l = co * P.GS + pix;
         }
         grel[j] = rel; gpix[j] = pix; glds[j] = l;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradPa
     const int rounds = (i_end - i_begin + NG - 1) / NG;
     auto item_of = [&](int rd) { const int it = i_begin + rd * NG + grp; return it < i_end ? it : P.items; };
     if (rounds > 0) prefetch(item_of(0));
-    const float* bp = gs + (nt * 16 + l15) * P.GS + q;
+    const float* bp = gs + l15 * P.GS + q;
     for (int rd = 0; rd < rounds; ++rd) {
         __syncthreads();
         commit();
@@ -358,11 +361,11 @@ __global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradPa
         }
     }
 
-    // ---- the slab leaves through LDS as rows of Co floats: [J (+1 bias row)][Co] is exactly slab + bias tail; the NG groups'
-    //      partial tiles sit side by side and are added in group order on the way out ---------------------------------------
+    // ---- [J (+1 bias row)][16] per group through LDS; added in group order and written into this tile's columns of the slab
+    //      (row J is the bias gradient: it goes to the bias tail behind the slab) ---------------------------------------------
     __syncthreads();
     const int rows = P.J + (P.with_bias ? 1 : 0);
-    const int esz = (P.J + 1) * P.Co;
+    const int esz = (P.J + 1) * 16;
     float* es = smem + (size_t)grp * esz;
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
@@ -370,29 +373,23 @@ __global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradPa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = mt * 16 + 4 * q + r;
-            if (j < rows) es[j * P.Co + nt * 16 + l15] = acc[i][r];
+            if (j < rows) es[j * 16 + l15] = acc[i][r];
         }
     }
     __syncthreads();
     float* dst = P.out + (size_t)split * P.slab_stride;
     float* bdst = P.bias_direct ? P.bias_direct : dst + P.out_elems;
-    const int main4 = (int)(P.out_elems >> 2);
-    for (int u = threadIdx.x; u < main4; u += NTHR * NG) {
-        float4 v = reinterpret_cast<const float4*>(smem)[u];
+    for (int u = threadIdx.x; u < rows * 4; u += NTHR * NG) {
+        const int j = u >> 2, c4 = (u & 3) * 4;
+        float4 v = *reinterpret_cast<const float4*>(smem + j * 16 + c4);
 #pragma unroll
         for (int g2 = 1; g2 < NG; ++g2) {
-            const float4 w2 = reinterpret_cast<const float4*>(smem + (size_t)g2 * esz)[u];
+            const float4 w2 = *reinterpret_cast<const float4*>(smem + (size_t)g2 * esz + j * 16 + c4);
             v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
         }
-        reinterpret_cast<float4*>(dst)[u] = v;
+        float* d = (j < P.J ? dst + (size_t)j * P.Co : bdst) + nt * 16 + c4;
+        *reinterpret_cast<float4*>(d) = v;
     }
-    if (P.with_bias)
-        for (int u = threadIdx.x; u < P.Co; u += NTHR * NG) {
-            float v = smem[P.out_elems + u];
-#pragma unroll
-            for (int g2 = 1; g2 < NG; ++g2) v += smem[(size_t)g2 * esz + P.out_elems + u];
-            bdst[u] = v;
-        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -580,7 +577,7 @@ int conv_dgrad_thin(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
 int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                     size_t ws_bytes, hipStream_t s, WgradParts* parts) {
     if (g.k != 5 || g.stride != 2 || g.pad_l < 1 || g.pad_l > 2 || g.Ci > 4 || (g.W & 3)) return 1;
-    if (g.Co != 32 && g.Co != 64) return 1;
+    if ((g.Co & 15) || g.Co > 256) return 1;
     if (m.act != GGAN_ACT_NONE && m.act != GGAN_ACT_LRELU && m.act != GGAN_ACT_RELU) return 1;   // other masks: general kernels
     if (((g.Ho * g.Wo) & 3) || getenv("GGAN_NO_THIN")) return 1;
     if ((((uintptr_t)x) & 15) || (((uintptr_t)gy) & 15) || (m.act != GGAN_ACT_NONE && (((uintptr_t)m.ref) & 15))) return 1;
@@ -606,7 +603,7 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     P.J = 25 * g.Ci;
     P.with_bias = with_bias ? 1 : 0;
     P.xunits = g.Ci * P.SR * (g.W / 4);
-    P.gunits = g.Co * (P.PB / 4);
+    P.gunits = 16 * (P.PB / 4);
     if (P.xunits > XU_MAX * NTHR || P.gunits > GU_MAX * NTHR) return 1;
     P.out_elems = (size_t)P.J * g.Co;
     P.slab_stride = P.out_elems + (with_bias ? (size_t)g.Co : 0);
@@ -637,33 +634,29 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     P.d_Wo = make_fastdiv(g.Wo); P.d_nb = make_fastdiv(P.nb); P.d_W4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR);
     P.d_PB4 = make_fastdiv(P.PB / 4); P.d_Ci = make_fastdiv(g.Ci);
     const int NTM = cdiv(P.J + (with_bias ? 1 : 0), 16);
-    const int NTN = g.Co / 16, MG = 4 / NTN, MPW = cdiv(NTM, MG);
+    const int MPW = cdiv(NTM, 4);
+    if (MPW > 2) return 1;
     constexpr int NG = 4;
-    size_t stage = (size_t)g.Ci * P.XCS + (size_t)g.Co * P.GS + 4;
+    size_t stage = (size_t)g.Ci * P.XCS + (size_t)16 * P.GS + 4;
     stage = (stage + 3) & ~(size_t)3;
     P.gstride = (int)stage;
-    const size_t ep = (size_t)(P.J + 1) * g.Co;
+    const size_t ep = (size_t)(P.J + 1) * 16;
     const size_t shmem = NG * (stage > ep ? stage : ep) * sizeof(float);
     if (shmem > 160 * 1024) return 1;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
-    const dim3 grid(SK);
-#define THIN_WGRAD(NTN_, MPW_)                                                                                              \
+    const dim3 grid(SK, g.Co / 16);
+#define THIN_WGRAD(MPW_)                                                                                                    \
     do {                                                                                                                    \
         static bool attr_set = false;                                                                                       \
         if (!attr_set) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<NTN_, MPW_, NG>),                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<MPW_, NG>),                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
             attr_set = true;                                                                                                \
         }                                                                                                                   \
     } while (0);                                                                                                            \
-    GGAN_LAUNCH("thin_wgrad_kernel", fl, 0, (thin_wgrad_kernel<NTN_, MPW_, NG>), grid, dim3(NTHR * NG), shmem, s, P)
-    if (NTN == 4 && MPW <= 2) { THIN_WGRAD(4, 2); }
-    else if (NTN == 4 && MPW <= 5) { THIN_WGRAD(4, 5); }
-    else if (NTN == 4 && MPW <= 7) { THIN_WGRAD(4, 7); }
-    else if (NTN == 2 && MPW <= 1) { THIN_WGRAD(2, 1); }
-    else if (NTN == 2 && MPW <= 3) { THIN_WGRAD(2, 3); }
-    else if (NTN == 2 && MPW <= 4) { THIN_WGRAD(2, 4); }
-    else return 1;
+    GGAN_LAUNCH("thin_wgrad_kernel", fl, 0, (thin_wgrad_kernel<MPW_, NG>), grid, dim3(NTHR * NG), shmem, s, P)
+    if (MPW == 1) { THIN_WGRAD(1); }
+    else { THIN_WGRAD(2); }
 #undef THIN_WGRAD
     if (parts) {
         parts->n = SK;
