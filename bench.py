@@ -100,6 +100,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--dataset', default='cifar10')
     ap.add_argument('--mode', default='ali', help="ali | wali-gp | local_ep (gmgan, N_COMS=30)")
+    ap.add_argument('--n-coms', type=int, default=None, help='mixture components of the gmgan prior (default: the script value, 30 / 50 / 100)')
     ap.add_argument('--batch-size', type=int, default=None, help='per-GPU minibatch (default 64; 32 sequences for moving_mnist)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-fuse', action='store_true')
@@ -153,6 +154,8 @@ def main():
     else:
         # N_COMS of the gmgan scripts: 30 (cifar10 :78, mnist), 50 (svhn :72), 100 (face :68)
         K = ({'svhn': 50, 'face': 100}.get(args.dataset, 30)) if args.mode in ('local_ep', 'local_epce') else 0
+        if K and args.n_coms:
+            K = args.n_coms
         cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse)
         tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
     torch.manual_seed(1234 + rank)
