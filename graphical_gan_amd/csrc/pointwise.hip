@@ -366,6 +366,112 @@ __global__ void pack_k(PackTable t, float* __restrict__ flat) {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+
+// ---- mixture-of-Gaussians latent glue of the gmgan scripts (gmgan_inference_cifar10.py:156-173, MODE_K = 'CONCRETE'):
+//        logits[b, j] = -.5 * sum_d (z[b, d] - mu[j, d])^2 + log_pi
+//        k[b, :]      = softmax((logits[b, :] - log(-log(u[b, :] + 1e-20) + 1e-20)) / temp)          (Gumbel-softmax relaxation)
+//      a dozen [B, K] / [B, K, D] pointwise launches in the TF graph, one here: a workgroup per batch row, a wave per
+//      component for the distance (lanes over d, shuffle reduce), the softmax over the K values in LDS. ----
+constexpr int kGmmMaxK = 256;
+
+__global__ __launch_bounds__(256) void gmm_latent_fwd_k(const float* __restrict__ z, const float* __restrict__ mu,
+                                                        const float* __restrict__ u, float* __restrict__ logits, float* __restrict__ k,
+                                                        int K, int D, float log_pi, float inv_temp) {
+    __shared__ float sv[kGmmMaxK];
+    __shared__ float red[32];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* zb = z + (size_t)b * D;
+    for (int j = wave; j < K; j += 4) {
+        const float* mj = mu + (size_t)j * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float t = zb[d] - mj[d];
+            s = fmaf(t, t, s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float lg = -0.5f * s + log_pi;
+            if (logits) logits[(size_t)b * K + j] = lg;
+            const float g = -logf(-logf(u[(size_t)b * K + j] + 1e-20f) + 1e-20f);
+            sv[j] = (lg + g) * inv_temp;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < K; j += 256) m = fmaxf(m, sv[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float e = 0.f;
+    for (int j = threadIdx.x; j < K; j += 256) {
+        const float t = expf(sv[j] - m);
+        sv[j] = t;
+        e += t;
+    }
+    const float tot = block_sum(e, red + 8);
+    const float inv = 1.f / tot;
+    for (int j = threadIdx.x; j < K; j += 256) k[(size_t)b * K + j] = sv[j] * inv;
+}
+
+// Backward in ONE launch: blocks [0, B) own a batch row (-> dz), blocks [B, B + K) own a component (-> dmu, a sum over the batch
+// in row order: deterministic).  dlog[b, j] = gl[b, j] + k[b, j] * (gk[b, j] - sum_i gk[b, i] * k[b, i]) / temp.
+__global__ __launch_bounds__(256) void gmm_latent_bwd_k(const float* __restrict__ z, const float* __restrict__ mu,
+                                                        const float* __restrict__ kk, const float* __restrict__ gl,
+                                                        const float* __restrict__ gk, float* __restrict__ dz, float* __restrict__ dmu,
+                                                        int B, int K, int D, float inv_temp) {
+    __shared__ float sv[kGmmMaxK];
+    __shared__ float red[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < B) {
+        const int b = blockIdx.x;
+        float dot = 0.f;
+        if (gk)
+            for (int j = threadIdx.x; j < K; j += 256) dot += gk[(size_t)b * K + j] * kk[(size_t)b * K + j];
+        dot = block_sum(dot, red);
+        for (int j = threadIdx.x; j < K; j += 256) {
+            float v = gl ? gl[(size_t)b * K + j] : 0.f;
+            if (gk) v += kk[(size_t)b * K + j] * (gk[(size_t)b * K + j] - dot) * inv_temp;
+            sv[j] = v;
+        }
+        __syncthreads();
+        if (dz) {
+            // dz[b, d] = -sum_j dlog[j] * (z[b, d] - mu[j, d])
+            for (int d = threadIdx.x; d < D; d += 256) {
+                const float zv = z[(size_t)b * D + d];
+                float acc = 0.f;
+                for (int j = 0; j < K; ++j) acc = fmaf(sv[j], zv - mu[(size_t)j * D + d], acc);
+                dz[(size_t)b * D + d] = -acc;
+            }
+        }
+        return;
+    }
+    if (!dmu) return;
+    const int j = blockIdx.x - B;
+    // dlog[b, j] for every b (one wave per row: the softmax-backward dot product is a K-long reduction), then
+    // dmu[j, d] = sum_b dlog[b, j] * (z[b, d] - mu[j, d])
+    float* col = sv;                       // B <= kGmmMaxK values
+    for (int b = wave; b < B; b += 4) {
+        float dot = 0.f;
+        if (gk)
+            for (int i = lane; i < K; i += 64) dot += gk[(size_t)b * K + i] * kk[(size_t)b * K + i];
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            float v = gl ? gl[(size_t)b * K + j] : 0.f;
+            if (gk) v += kk[(size_t)b * K + j] * (gk[(size_t)b * K + j] - dot) * inv_temp;
+            col[b] = v;
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float mv = mu[(size_t)j * D + d];
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(col[b], z[(size_t)b * D + d] - mv, acc);
+        dmu[(size_t)j * D + d] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -588,6 +694,24 @@ int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t*
 
 int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count, float* flat, ggan_stream_t stream) {
     return ggan_pack_parts(srcs, sizes, offsets, nullptr, nullptr, count, flat, nullptr, stream);
+}
+
+int ggan_gmm_latent_fwd(const float* z, const float* mu, const float* gumbel_u, float* logits, float* k, int B, int K, int D,
+                        float log_pi, float temp, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(z && mu && gumbel_u && k, "null pointer");
+    GGAN_CHECK_ARG(B > 0 && K > 0 && K <= kGmmMaxK && D > 0 && temp > 0.f, "bad shape");
+    GGAN_LAUNCH("gmm_latent_fwd", 3.0 * B * K * D, 0, gmm_latent_fwd_k, dim3(B), dim3(256), 0, (hipStream_t)stream, z, mu, gumbel_u, logits, k,
+                K, D, log_pi, 1.f / temp);
+    return 0;
+}
+
+int ggan_gmm_latent_bwd(const float* z, const float* mu, const float* k, const float* g_logits, const float* g_k, float* dz,
+                        float* dmu, int B, int K, int D, float temp, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(z && mu && k && (g_logits || g_k) && (dz || dmu), "null pointer");
+    GGAN_CHECK_ARG(B > 0 && B <= kGmmMaxK && K > 0 && K <= kGmmMaxK && D > 0 && temp > 0.f, "bad shape");
+    GGAN_LAUNCH("gmm_latent_bwd", 4.0 * B * K * D, 0, gmm_latent_bwd_k, dim3(B + (dmu ? K : 0)), dim3(256), 0, (hipStream_t)stream, z, mu, k,
+                g_logits, g_k, dz, dmu, B, K, D, 1.f / temp);
+    return 0;
 }
 
 }  // extern "C"

@@ -397,7 +397,7 @@ class Gemm2(Function):
 
     @staticmethod
     def usable(a1, a2):
-        return a1.shape[1] % 64 == 0 and a2.shape[1] % 4 == 0 and a1.shape[0] == a2.shape[0]
+        return a1.shape[1] % 64 == 0 and a2.shape[1] >= 1 and a1.shape[0] == a2.shape[0]
 
     @staticmethod
     def forward(ctx, a1, a2, w, bias, act, alpha):
@@ -775,6 +775,43 @@ class Axpby(Function):
         gx = Axpby.apply(g, None, ctx.a, 0.0, 0.0) if ctx.needs_input_grad[0] else None
         gy = Axpby.apply(g, None, ctx.b, 0.0, 0.0) if (ctx.has_y and ctx.needs_input_grad[1]) else None
         return (gx, gy) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class GmmLatent(Function):
+    """HyperExtractor of the gmgan scripts in one launch per direction (ggan_gmm_latent_*): component logits of z under the
+    mixture prior and the Gumbel-softmax relaxation of the component assignment.  Returns (logits, k)."""
+
+    @staticmethod
+    def forward(ctx, z, mu, gumbel_u, log_pi, temp, slot=None):
+        z, mu, gumbel_u = _c(z), _c(mu), _c(gumbel_u)
+        B, D = z.shape
+        K = mu.shape[0]
+        assert tuple(mu.shape) == (K, D) and tuple(gumbel_u.shape) == (B, K)
+        logits = torch.empty((B, K), dtype=torch.float32, device=z.device)
+        k = _new_out(slot, (B, K), z.device)
+        check(_L().ggan_gmm_latent_fwd(_p(z), _p(mu), _p(gumbel_u), _p(logits), _p(k), B, K, D, float(log_pi), float(temp),
+                                       _stream()), 'ggan_gmm_latent_fwd')
+        ctx.temp = float(temp)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z, mu, k)
+        return logits, k
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_logits, g_k):
+        z, mu, k = ctx.saved_tensors
+        n_in = len(ctx.needs_input_grad)
+        if (g_logits is None and g_k is None) or not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return (None,) * n_in
+        B, D = z.shape
+        K = mu.shape[0]
+        dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        dmu = torch.empty_like(mu) if ctx.needs_input_grad[1] else None
+        gl = _c(g_logits) if g_logits is not None else None
+        gk = _c(g_k) if g_k is not None else None
+        check(_L().ggan_gmm_latent_bwd(_p(z), _p(mu), _p(k), _p(gl), _p(gk), _p(dz), _p(dmu), B, K, D, ctx.temp, _stream()),
+              'ggan_gmm_latent_bwd')
+        return (dz, dmu) + (None,) * (n_in - 2)
 
 
 class RowLerp(Function):

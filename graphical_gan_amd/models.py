@@ -96,7 +96,9 @@ class GraphicalGAN(object):
         feed['z_pair'] = torch.zeros(2 * B, c.dim_latent, device=device)
         feed['p_z_noise'] = feed['z_pair'][:B] if not c.K else torch.zeros(B, c.dim_latent, device=device)
         if c.K:
-            feed['k_onehot'] = torch.zeros(B, c.K, device=device)
+            # assignment pair [one-hot prior draw ; q_k] of the batched critic (same idea as z_pair)
+            feed['k_pair'] = torch.zeros(2 * B, c.K, device=device)
+            feed['k_onehot'] = feed['k_pair'][:B]
             feed['gumbel_u'] = torch.zeros(B, c.K, device=device)
         if c.mode in ('wali-gp', 'vegan-wgan-gp'):
             feed['alpha'] = torch.zeros(B, 1, device=device)
@@ -265,8 +267,7 @@ class GraphicalGAN(object):
 
     def HyperDiscriminator(self, z, k):
         c = self.cfg
-        out = torch.cat([z, k], 1)
-        out = self._lin('Discriminator.HyperInput', c.dim_latent + c.K, 512, out, LRELU)
+        out = self._lin('Discriminator.HyperInput', c.dim_latent + c.K, 512, (z, k), LRELU)     # Linear on concat([z, k], 1)
         out = self._lin('Discriminator.Hyper2', 512, 512, out, LRELU)
         out = self._lin('Discriminator.Hyper3', 512, 512, out, LRELU)
         out = lib.ops.linear.Linear('Discriminator.HyperOutput', 512, 1, out)
@@ -280,16 +281,11 @@ class GraphicalGAN(object):
         """gmgan_inference_cifar10.py:150-153: onehot(k) @ Mu + eps."""
         return F.Axpby.apply(F.Gemm.apply(hyper_k, self._mu(), None, False, False, F.ACT_NONE, 0.0), hyper_noise, 1.0, 1.0, 0.0, out_slot)
 
-    def HyperExtractor(self, latent_z, gumbel_u):
-        """gmgan_inference_cifar10.py:156-173 (MODE_K='CONCRETE').  [B,K] latent glue: <0.1% of the step's work,
-        composed from torch pointwise ops on tiny tensors."""
+    def HyperExtractor(self, latent_z, gumbel_u, out_slot=None):
+        """gmgan_inference_cifar10.py:156-173 (MODE_K='CONCRETE'): component logits and the Gumbel-softmax assignment, one
+        launch per direction (ggan_gmm_latent_*; the TF graph spends a dozen [B,K] / [B,K,D] pointwise ops on it)."""
         c = self.cfg
-        mu = self._mu()
-        diff = latent_z.unsqueeze(1) - mu.unsqueeze(0)
-        logits = -.5 * (diff * diff).sum(-1) + math.log(1. / c.K)
-        g = -torch.log(-torch.log(gumbel_u + 1e-20) + 1e-20)
-        k = torch.softmax((logits + g) / c.temp, dim=-1)
-        return logits, k
+        return F.GmmLatent.apply(latent_z, self._mu(), gumbel_u, float(np.log(np.float32(1.0) / np.float32(c.K))), c.temp, out_slot)
 
     @staticmethod
     def _var_lists():
@@ -334,7 +330,8 @@ class GraphicalGAN(object):
         q_z = self.Extractor(real_x, zs[1])
         out = dict(real_x=real_x, q_z=q_z, p_z=p_z)
         if c.K:
-            _, q_k = self.HyperExtractor(q_z, feed['gumbel_u'])
+            ks = F.RowSlot(feed['k_pair'], B, 2 * B) if (c.batch_critic and 'k_pair' in feed) else None
+            _, q_k = self.HyperExtractor(q_z, feed['gumbel_u'], ks)
             out['q_k'] = q_k
         if fork:
             cur.wait_stream(self._side)
@@ -412,7 +409,7 @@ class GraphicalGAN(object):
         x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
         d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B)
         if c.K:
-            h = self.HyperDiscriminator(z_cat, torch.cat([onehot, q_k], 0))
+            h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
             (hf, hr), (df, dr) = F.SplitRows.apply(h, B), F.SplitRows.apply(d, B)
             return [hf, df], [hr, dr]
         return F.SplitRows.apply(d, B)

@@ -206,6 +206,16 @@ int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
 
+/* Mixture-of-Gaussians latent glue of the gmgan scripts (HyperExtractor, gmgan_inference_cifar10.py:156-173 with MODE_K =
+ * 'CONCRETE'): logits[b,j] = -.5*||z_b - mu_j||^2 + log_pi and k[b,:] = softmax((logits[b,:] + gumbel(u[b,:])) / temp), gumbel(u) =
+ * -log(-log(u + 1e-20) + 1e-20) (:117-120).  One launch instead of the dozen [B,K] / [B,K,D] pointwise ops of the TF graph.
+ * logits may be NULL (not fetched).  Backward: g_logits / g_k are dL/dlogits, dL/dk (either may be NULL); dz / dmu may be NULL.
+ * K, B <= 256. */
+int ggan_gmm_latent_fwd(const float* z, const float* mu, const float* gumbel_u, float* logits, float* k, int B, int K, int D,
+                        float log_pi, float temp, ggan_stream_t stream);
+int ggan_gmm_latent_bwd(const float* z, const float* mu, const float* k, const float* g_logits, const float* g_k, float* dz,
+                        float* dmu, int B, int K, int D, float temp, ggan_stream_t stream);
+
 /* reconstruction distances of tflib/utils/distance.py:3-17 (`distance(x, y, 'l1'|'l2')` = reduce_mean(|x-y|^p)), used by the
  * alice / local_epce / vegan objectives as rec_penalty: out[0] (+)= weight * mean(|x-y|^p), p = 1 | 2; the backward writes
  * gx and/or gy (either may be NULL). */

@@ -717,3 +717,33 @@ def test_linear_on_a_pair_of_inputs_equals_linear_on_their_concatenation(gpu, M,
     assert _rel(e1.detach().cpu().numpy(), da[:, :K1]) < 3e-5 and _rel(e2.detach().cpu().numpy(), da[:, K1:]) < 3e-5
     (hw,) = torch.autograd.grad((e1 * e1).sum() + (e2 * e2).sum(), [tw])
     assert np.isfinite(hw.cpu().numpy()).all() and float(hw.abs().max()) > 0
+
+
+@pytest.mark.parametrize('B,K,D', [(64, 30, 128), (5, 7, 16), (128, 100, 128)])
+def test_gmm_latent_fused_op(gpu, B, K, D):
+    """ggan_gmm_latent_fwd/bwd (HyperExtractor, MODE_K = 'CONCRETE') against the oracle tape: logits, Gumbel-softmax assignment,
+    gradients w.r.t. z and the component means through BOTH outputs."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import tape as tp, nets as N
+    rng = np.random.default_rng(B + K)
+    z = rng.standard_normal((B, D)) * 0.7
+    mu = rng.standard_normal((K, D))
+    u = rng.random((B, K))
+    gl, gk = rng.standard_normal((B, K)) * 0.1, rng.standard_normal((B, K))
+    cfg = type('C', (), dict(K=K, temp=0.5))()
+    Z, MU = tp.T(z), tp.T(mu)
+    lo, ko = N.HyperExtractor(cfg, {'Generator.Hyper.Mu': MU}, Z, u)
+    L = tp.add(tp.reduce_sum(tp.mul(lo, tp.T(gl))), tp.reduce_sum(tp.mul(ko, tp.T(gk))))
+    rz, rmu = tp.grad(L, [Z, MU])
+    tz, tmu = _t(z, gpu).requires_grad_(True), _t(mu, gpu).requires_grad_(True)
+    lg, kk = F.GmmLatent.apply(tz, tmu, _t(u, gpu), float(np.log(np.float32(1.0) / np.float32(K))), 0.5)
+    assert _rel(lg.detach().cpu().numpy(), lo.v) < 2e-5 and np.abs(kk.detach().cpu().numpy() - ko.v).max() < 2e-5
+    assert np.abs(kk.detach().cpu().numpy().sum(1) - 1).max() < 1e-5
+    dz, dmu = torch.autograd.grad([lg, kk], [tz, tmu], grad_outputs=[_t(gl, gpu), _t(gk, gpu)])
+    assert _rel(dz.cpu().numpy(), rz.v) < 1e-4 and _rel(dmu.cpu().numpy(), rmu.v) < 1e-4
+    # only k fetched (what the scripts do): the logits gradient is absent
+    lg2, k2 = F.GmmLatent.apply(tz, tmu, _t(u, gpu), float(np.log(np.float32(1.0) / np.float32(K))), 0.5)
+    (dz2,) = torch.autograd.grad(k2, [tz], grad_outputs=_t(gk, gpu))
+    rz2 = tp.grad(tp.reduce_sum(tp.mul(ko, tp.T(gk))), [Z])[0]
+    assert _rel(dz2.cpu().numpy(), rz2.v) < 1e-4

@@ -9,7 +9,8 @@ from graphical_gan_amd.engine import Trainer, synthetic_ring
 from graphical_gan_amd.models import Config
 
 dev = torch.device('cuda:0')
-cfg = Config('cifar10', batch_size=64, mode=sys.argv[1] if len(sys.argv) > 1 else 'ali')
+mode = sys.argv[1] if len(sys.argv) > 1 else 'ali'
+cfg = Config('cifar10', batch_size=64, mode=mode, n_coms=30 if mode.startswith('local_ep') else 0)
 np.random.seed(0)
 tr = Trainer(cfg, device=dev, graph=False)
 ring = synthetic_ring(cfg, dev, n=4)
