@@ -472,6 +472,85 @@ __global__ __launch_bounds__(256) void gmm_latent_bwd_k(const float* __restrict_
     }
 }
 
+
+// ---- all the noise of one session.run in ONE launch (the TF graph draws p_z ~ N(0,1), k ~ Cat(1/K) as a one-hot, Gumbel U, the GP
+//      alpha and the dequantisation noise with separate random ops: gmgan_inference_cifar10.py:115-120,344-346).  Counter-based
+//      generator (Philox4x32-10, key = seed, counter = (element group, tensor, draw number)); the draw number lives in device
+//      memory and is advanced by the last workgroup to arrive, so a captured graph produces fresh noise on every replay. ----
+struct NoiseTable {
+    float* dst[GGAN_NOISE_MAX];
+    unsigned n[GGAN_NOISE_MAX];
+    int kind[GGAN_NOISE_MAX];      // 0 normal(a, b) = a + b*N(0,1); 1 uniform [a, b); 2 one-hot rows of width K (n = rows * K)
+    float a[GGAN_NOISE_MAX], b[GGAN_NOISE_MAX];
+    int K[GGAN_NOISE_MAX];
+    int count;
+};
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
+
+__global__ __launch_bounds__(256) void noise_fill_k(const NoiseTable t, unsigned long long* __restrict__ state) {
+    const int ti = blockIdx.y;
+    const unsigned long long seed = state[0], draw = state[1];
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    float* dst = t.dst[ti];
+    const unsigned n = t.n[ti];
+    const int kind = t.kind[ti];
+    for (unsigned g = blockIdx.x * 256 + threadIdx.x; g * 4 < n; g += gridDim.x * 256) {
+        unsigned r[4];
+        float v[4];
+        if (kind == 2) {
+            // element e of a one-hot row: the row's component index comes from a draw keyed by the ROW
+            const int K = t.K[ti];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned e = g * 4 + q, row = e / (unsigned)K, col = e - row * (unsigned)K;
+                philox4x32_10(row, (unsigned)ti | 0x80000000u, (unsigned)draw, (unsigned)(draw >> 32), k0, k1, r);
+                const unsigned idx = min((unsigned)(u01(r[0]) * (float)K), (unsigned)K - 1u);
+                v[q] = col == idx ? 1.f : 0.f;
+            }
+        } else {
+            philox4x32_10(g, (unsigned)ti, (unsigned)draw, (unsigned)(draw >> 32), k0, k1, r);
+            if (kind == 0) {            // Box-Muller, two pairs
+                const float r0 = sqrtf(-2.f * logf(u01(r[0]))), r1 = sqrtf(-2.f * logf(u01(r[2])));
+                float s0, c0, s1, c1;
+                sincosf(6.28318530718f * u01(r[1]), &s0, &c0);
+                sincosf(6.28318530718f * u01(r[3]), &s1, &c1);
+                v[0] = t.a[ti] + t.b[ti] * r0 * c0; v[1] = t.a[ti] + t.b[ti] * r0 * s0;
+                v[2] = t.a[ti] + t.b[ti] * r1 * c1; v[3] = t.a[ti] + t.b[ti] * r1 * s1;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = t.a[ti] + (t.b[ti] - t.a[ti]) * u01(r[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (g * 4 + q < n) dst[g * 4 + q] = v[q];
+    }
+    // every workgroup has read `draw` before it arrives here; the last one advances it
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+        const unsigned long long prev = atomicAdd(&state[2], 1ull);
+        if (prev == total - 1) {
+            state[1] = draw + 1;
+            state[2] = 0;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -711,6 +790,27 @@ int ggan_gmm_latent_bwd(const float* z, const float* mu, const float* k, const f
     GGAN_CHECK_ARG(B > 0 && B <= kGmmMaxK && K > 0 && K <= kGmmMaxK && D > 0 && temp > 0.f, "bad shape");
     GGAN_LAUNCH("gmm_latent_bwd", 4.0 * B * K * D, 0, gmm_latent_bwd_k, dim3(B + (dmu ? K : 0)), dim3(256), 0, (hipStream_t)stream, z, mu, k,
                 g_logits, g_k, dz, dmu, B, K, D, 1.f / temp);
+    return 0;
+}
+
+int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
+                    int count, uint64_t* state, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(dsts && sizes && kinds && a && b && widths && state, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_NOISE_MAX, "count out of range");
+    NoiseTable t;
+    size_t mx = 0, tot = 0;
+    for (int i = 0; i < count; ++i) {
+        GGAN_CHECK_ARG(dsts[i] && sizes[i] > 0 && sizes[i] < 0x7FFFFFFFull && kinds[i] >= 0 && kinds[i] <= 2, "bad noise spec");
+        GGAN_CHECK_ARG(kinds[i] != 2 || (widths[i] > 0 && sizes[i] % (size_t)widths[i] == 0), "one-hot rows need a width dividing the size");
+        t.dst[i] = dsts[i]; t.n[i] = (unsigned)sizes[i]; t.kind[i] = kinds[i]; t.a[i] = a[i]; t.b[i] = b[i]; t.K[i] = widths[i];
+        if (sizes[i] > mx) mx = sizes[i];
+        tot += sizes[i];
+    }
+    t.count = count;
+    int gx = (int)cdivz(mx, (size_t)1024);
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    GGAN_LAUNCH("noise_fill", 0, 4.0 * tot, noise_fill_k, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, t, (unsigned long long*)state);
     return 0;
 }
 

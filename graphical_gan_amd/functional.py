@@ -980,6 +980,32 @@ def rmsprop_step_(theta, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, clip=N
           'ggan_rmsprop_step')
 
 
+NOISE_NORMAL, NOISE_UNIFORM, NOISE_ONEHOT = 0, 1, 2
+
+
+def noise_state(device, seed=None):
+    """{seed, draw number, arrival counter} of ggan_noise_fill as an int64[3] device tensor (seed: torch.initial_seed())"""
+    seed = torch.initial_seed() if seed is None else seed
+    return torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+
+
+def noise_fill_(state, specs):
+    """One launch for all the noise of a step.  specs: list of (tensor, kind, a, b) -- NOISE_NORMAL: a + b*N(0,1); NOISE_UNIFORM:
+    [a, b); NOISE_ONEHOT: rows of the 2-D tensor become one-hot with a uniformly drawn index.  In place; graph-capturable (the
+    draw number advances on the device)."""
+    assert state.dtype == torch.int64 and state.numel() == 3 and state.is_cuda
+    n = len(specs)
+    for t, _, _, _ in specs:
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.device == state.device
+    dsts = (C.c_void_p * n)(*[t.data_ptr() for t, _, _, _ in specs])
+    sizes = (C.c_size_t * n)(*[t.numel() for t, _, _, _ in specs])
+    kinds = (C.c_int * n)(*[int(k) for _, k, _, _ in specs])
+    a = (C.c_float * n)(*[float(x) for _, _, x, _ in specs])
+    b = (C.c_float * n)(*[float(x) for _, _, _, x in specs])
+    widths = (C.c_int * n)(*[int(t.shape[-1]) if k == NOISE_ONEHOT else 0 for t, k, _, _ in specs])
+    check(_L().ggan_noise_fill(dsts, sizes, kinds, a, b, widths, n, _p(state), _stream()), 'ggan_noise_fill')
+
+
 def pack_(tensors, offsets, flat, bump=None):
     """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros); tensors registered by `defer_wgrad_reduce` are
     summed over their split-K slabs on the way.  bump: int32 device counter incremented once (the Adam step ordinal)."""

@@ -109,20 +109,21 @@ class GraphicalGAN(object):
         return feed
 
     def sample_noise(self, f):
-        """Fresh noise for one session.run, drawn on device (graph-capturable)."""
+        """Fresh noise for one session.run, drawn on device in ONE launch (graph-capturable: the generator's draw number lives in
+        device memory, functional.noise_fill_): p_z ~ N(0,1), k ~ Cat(1/K) as one-hot rows, Gumbel U, GP alpha, dequantisation
+        noise, the latent critic's noise layers (gmgan_inference_cifar10.py:115-120,344-346)."""
         c = self.cfg
-        f['p_z_noise'].normal_()
+        if 'rng_state' not in f:
+            f['rng_state'] = F.noise_state(f['p_z_noise'].device)
+        specs = [(f['p_z_noise'], F.NOISE_NORMAL, 0., 1.)]
         if c.K:
-            idx = torch.randint(0, c.K, (c.B, 1), device=f['p_z_noise'].device)
-            f['k_onehot'].zero_().scatter_(1, idx, 1.0)
-            f['gumbel_u'].uniform_()
+            specs += [(f['k_onehot'], F.NOISE_ONEHOT, 0., 0.), (f['gumbel_u'], F.NOISE_UNIFORM, 0., 1.)]
         if 'alpha' in f:
-            f['alpha'].uniform_()
-        for k in f:
-            if k.startswith('dn_'):
-                f[k].normal_()
+            specs.append((f['alpha'], F.NOISE_UNIFORM, 0., 1.))
+        specs += [(f[k], F.NOISE_NORMAL, 0., 1.) for k in sorted(f) if k.startswith('dn_')]
         if c.dataset == 'face':
-            f['dequant_u'].uniform_(0., 1. / 128)
+            specs.append((f['dequant_u'], F.NOISE_UNIFORM, 0., 1. / 128))
+        F.noise_fill_(f['rng_state'], specs)
 
     def set_batch(self, feed, batch):
         feed['real_x' if self.cfg.dataset == 'mnist' else 'real_x_int'].copy_(batch, non_blocking=True)

@@ -206,6 +206,16 @@ int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
 
+/* All the noise of one session.run in one launch: up to GGAN_NOISE_MAX device tensors, each filled with kind 0 = a + b*N(0,1),
+ * 1 = uniform [a, b), 2 = one-hot rows of width `widths[i]` with a uniformly drawn index (the prior's k ~ Cat(1/K)).  Replaces
+ * tf.random_normal / tf.random_uniform / Categorical.sample + one_hot of the scripts (gmgan_inference_cifar10.py:115-120,344-346;
+ * gan_inference_cifar10.py:353-357).  state = {seed, draw number, arrival counter} (3 x uint64 in DEVICE memory, arrival counter
+ * zero): Philox4x32-10 keyed by the seed; the draw number is advanced on the device, so a captured HIP graph yields new noise on
+ * every replay.  Same seed + draw number => same values on every box. */
+#define GGAN_NOISE_MAX 16
+int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
+                    int count, uint64_t* state, ggan_stream_t stream);
+
 /* Mixture-of-Gaussians latent glue of the gmgan scripts (HyperExtractor, gmgan_inference_cifar10.py:156-173 with MODE_K =
  * 'CONCRETE'): logits[b,j] = -.5*||z_b - mu_j||^2 + log_pi and k[b,:] = softmax((logits[b,:] + gumbel(u[b,:])) / temp), gumbel(u) =
  * -log(-log(u + 1e-20) + 1e-20) (:117-120).  One launch instead of the dozen [B,K] / [B,K,D] pointwise ops of the TF graph.

@@ -747,3 +747,45 @@ def test_gmm_latent_fused_op(gpu, B, K, D):
     (dz2,) = torch.autograd.grad(k2, [tz], grad_outputs=_t(gk, gpu))
     rz2 = tp.grad(tp.reduce_sum(tp.mul(ko, tp.T(gk))), [Z])[0]
     assert _rel(dz2.cpu().numpy(), rz2.v) < 1e-4
+
+
+def test_noise_fill_one_launch_generator(gpu):
+    """ggan_noise_fill: moments of the normal / uniform draws, one-hot rows with a uniformly distributed index, determinism per
+    (seed, draw number), fresh values on every call AND on every replay of a captured graph."""
+    import torch
+    from graphical_gan_amd import functional as F
+    st = F.noise_state(gpu, seed=77)
+    nrm = torch.empty(64, 4096, device=gpu); uni = torch.empty(300, 7, device=gpu); oh = torch.empty(20000, 30, device=gpu)
+    specs = [(nrm, F.NOISE_NORMAL, 1.0, 2.0), (uni, F.NOISE_UNIFORM, -1.0, 3.0), (oh, F.NOISE_ONEHOT, 0., 0.)]
+    F.noise_fill_(st, specs)
+    a = nrm.cpu().numpy().astype(np.float64)
+    assert abs(a.mean() - 1.0) < 0.02 and abs(a.std() - 2.0) < 0.02
+    assert abs(((a - 1) / 2) ** 3).mean() < 2.0 and abs((((a - 1) / 2) ** 4).mean() - 3.0) < 0.1          # kurtosis of a normal
+    u = uni.cpu().numpy()
+    assert u.min() >= -1.0 and u.max() < 3.0 and abs(u.mean() - 1.0) < 0.15
+    o = oh.cpu().numpy()
+    assert set(np.unique(o)) == {0.0, 1.0} and np.all(o.sum(1) == 1.0)
+    freq = o.sum(0) / o.shape[0]
+    assert np.abs(freq - 1 / 30).max() < 0.008                                      # ~3.8 sigma of a binomial(20000, 1/30)
+    assert st.cpu().tolist() == [77, 1, 0]
+    first = nrm.clone()
+    F.noise_fill_(st, specs)
+    assert not torch.equal(first, nrm) and st.cpu().tolist() == [77, 2, 0]
+    corr = np.corrcoef(first.cpu().numpy().ravel(), nrm.cpu().numpy().ravel())[0, 1]
+    assert abs(corr) < 0.01
+    st2 = F.noise_state(gpu, seed=77)
+    n2 = torch.empty_like(nrm)
+    F.noise_fill_(st2, [(n2, F.NOISE_NORMAL, 1.0, 2.0)])
+    assert torch.equal(n2, first)                                                    # same seed, draw 0, tensor slot 0
+    # graph replay: the draw number lives on the device
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        F.noise_fill_(st, specs)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            F.noise_fill_(st, specs)
+        g.replay(); torch.cuda.synchronize()
+        r1 = nrm.clone()
+        g.replay(); torch.cuda.synchronize()
+        assert not torch.equal(r1, nrm)
