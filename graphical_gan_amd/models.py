@@ -87,7 +87,9 @@ class GraphicalGAN(object):
     def feed_buffers(self, device):
         c, B, feed = self.cfg, self.cfg.B, {}
         if c.dataset == 'mnist':
-            feed['real_x'] = torch.zeros(B, c.output_dim, device=device)
+            # float images are fed as they are: the feed buffer IS the second half of the critic's [fake_x ; real_x] pair
+            feed['x_pair'] = torch.zeros(2 * B, c.output_dim, device=device)
+            feed['real_x'] = feed['x_pair'][B:]
         else:
             feed['real_x_int'] = torch.zeros(B, c.output_dim, dtype=torch.int32, device=device)
         if c.dataset == 'face':
@@ -310,7 +312,8 @@ class GraphicalGAN(object):
         # buffer each, so those concatenations are aliases instead of copy kernels (functional.RowSlot / JoinRows)
         xs = zs = [None, None]
         if c.batch_critic and 'z_pair' in feed:
-            xp = torch.empty((2 * B, c.output_dim), dtype=torch.float32, device=feed['z_pair'].device)
+            xp = feed['x_pair'] if 'x_pair' in feed else torch.empty((2 * B, c.output_dim), dtype=torch.float32,
+                                                                     device=feed['z_pair'].device)
             xs = [F.RowSlot(xp, 0, B), F.RowSlot(xp, B, 2 * B)]
             zs = [F.RowSlot(feed['z_pair'], 0, B), F.RowSlot(feed['z_pair'], B, 2 * B)]
         # the Generator pass does not depend on the Extractor pass: it is issued on a second HIP stream (forked here, joined
