@@ -136,8 +136,8 @@ def main():
 
     import __graft_entry__ as ge
     ge.build()
-    from graphical_gan_amd import _lib, tflib as lib
-    from graphical_gan_amd.engine import Trainer, synthetic_ring, broadcast_params
+    from graphical_gan_amd import _lib
+    from graphical_gan_amd.engine import Trainer, broadcast_params
     from graphical_gan_amd.models import Config
 
     ssgan = args.dataset == 'moving_mnist'

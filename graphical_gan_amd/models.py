@@ -8,7 +8,6 @@ One parametrised definition covers the six image scripts (the reference repeats 
 Layer names are the reference's, so the registry keys match.
 `fuse=True` folds bias+activation into the producing conv/linear/BN kernel (identical math, fewer HBM passes).
 """
-import math
 import os
 
 import numpy as np
