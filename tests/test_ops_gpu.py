@@ -789,3 +789,35 @@ def test_noise_fill_one_launch_generator(gpu):
         r1 = nrm.clone()
         g.replay(); torch.cuda.synchronize()
         assert not torch.equal(r1, nrm)
+
+
+@pytest.mark.parametrize('case', [(512, 1, 64, 32), (128, 3, 64, 32), (128, 3, 32, 64), (100, 1, 28, 64)])
+def test_thin_kernels_agree_with_general_kernels_at_full_size(gpu, case):
+    """BASELINE-size launches of the three conv_thin.hip kernels (state-space GAN: 512 frames of 64x64x1; face; CIFAR critic batch;
+    MNIST) against the general MFMA kernels they replace (GGAN_NO_THIN=1) -- two independent implementations of the same sums."""
+    import os
+    import torch
+    from graphical_gan_amd import functional as F
+    N, Ci, H, Co = case
+    rng = np.random.default_rng(N + H)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2)
+    Ho = geom[5]
+    x = _t(rng.standard_normal((N, Ci, H, H)), gpu)
+    w = _t(rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci), gpu)
+    b = _t(rng.standard_normal(Co), gpu)
+    gy = _t(rng.standard_normal((N, Co, Ho, Ho)), gpu)
+    bi = _t(rng.standard_normal(Ci), gpu)
+    res = {}
+    for tag in ('thin', 'general'):
+        if tag == 'general':
+            os.environ['GGAN_NO_THIN'] = '1'
+        try:
+            res[tag] = (F.ConvFwd.apply(x, w, b, geom, F.ACT_LRELU, 0.2), F.ConvDgrad.apply(gy, w, bi, geom, F.ACT_TANH, 0.0),
+                        F.ConvWgrad.apply(x, gy, geom))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop('GGAN_NO_THIN', None)
+    for name, a, c in zip(('fwd', 'dgrad', 'wgrad'), res['thin'], res['general']):
+        a, c = a.cpu().numpy().astype(np.float64), c.cpu().numpy().astype(np.float64)
+        assert np.isfinite(a).all()
+        assert np.abs(a - c).max() <= 3e-5 * np.abs(c).max(), (name, np.abs(a - c).max(), np.abs(c).max())
