@@ -74,9 +74,9 @@ def ssgan_gflop_per_iteration(cfg):
     gradients each step needs (critic frozen in the generator step; no data-gradient into input frames)."""
     B, L, d = cfg.B, cfg.LEN, cfg.dim
     F = B * L
-    chans, sizes = [1, d, 2 * d, 4 * d, 8 * d], [32, 16, 8, 4]
+    chans, sizes = [getattr(cfg, 'C', 1), d, 2 * d, 4 * d, 8 * d], [32, 16, 8, 4]
     conv = [2.0 * chans[i + 1] * sizes[i] ** 2 * chans[i] * 25 for i in range(4)]             # per image
-    convG1 = 2.0 * d * 32 ** 2 * L * 25                                                        # G_Extractor layer 1 (LEN channels)
+    convG1 = 2.0 * d * 32 ** 2 * L * getattr(cfg, 'C', 1) * 25                                 # G_Extractor layer 1 (C*LEN channels)
     lin = lambda n, i, o: 2.0 * n * i * o
     zin = cfg.dim_g + cfg.dim_l + cfg.n_c
     fE = F * sum(conv) + lin(F, cfg.flat + cfg.n_c, cfg.dim_l)
@@ -140,15 +140,19 @@ def main():
     from graphical_gan_amd.engine import Trainer, broadcast_params
     from graphical_gan_amd.models import Config
 
-    ssgan = args.dataset == 'moving_mnist'
+    ssgan = args.dataset in ('moving_mnist', 'chairs')
     if args.batch_size is None:
-        args.batch_size = 32 if ssgan else 64
+        args.batch_size = (32 if args.dataset == 'moving_mnist' else 16) if ssgan else 64
     np.random.seed(0)                                  # reference initialisers draw from numpy's global RNG
     if ssgan:                                          # BASELINE configs[4]: ssgan_inference_moving_mnist.py, T=16
         from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
         K = 0
         args.mode = 'local_ep'
-        cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse)
+        if args.dataset == 'chairs':                   # ssgan_inference_chairs.py: 31 RGB views, no labels, res_w operator
+            cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse, length=31, n_c=0, channels=3, op_dyn_mode='res_w',
+                           dataset='chairs')
+        else:
+            cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse)
         model = StateSpaceGAN(cfg)
         tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank, model=model)
     else:
@@ -267,7 +271,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and ssgan:
         from oracle import ssgan as OSS
         ob = 2                                         # bounded sample: 2 sequences per minibatch instead of cfg.B
-        ocfg = OSS.Cfg(batch_size=ob)
+        ocfg = OSS.Cfg(batch_size=ob, length=cfg.LEN, n_c=cfg.n_c, channels=cfg.C, op_dyn_mode=cfg.op_dyn_mode)
         otr = OSS.Trainer(ocfg, OSS.init_params(ocfg, 0), np.float32)
         feeds = iter([OSS.make_feed(ocfg, np.random.default_rng(i)) for i in range(8)])
         otr.iteration(1, feeds)
@@ -315,13 +319,14 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': ('sequences/sec (G+D step) moving_mnist T=%d 64x64 bs=%d' % (cfg.LEN, cfg.B)) if ssgan else
+            'metric': ('sequences/sec (G+D step) %s T=%d 64x64 bs=%d' % (args.dataset, cfg.LEN, cfg.B)) if ssgan else
                       'images/sec (G+D%s step) %s %dx%d bs=%d' % ('+GP' if args.mode == 'wali-gp' else '', args.dataset, cfg.S, cfg.S, cfg.B),
             'value': round(images_per_s, 1), 'unit': 'sequences/sec' if ssgan else 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('ssgan_inference_moving_mnist.py MODE=local_ep POS_MODE=%s LEN=%d BATCH_SIZE=%d sequences '
-                                    '(per GPU) of 64x64x1 frames%s' % (cfg.pos_mode, cfg.LEN, cfg.B, ', eager' if args.no_graph else ''))
+            'config': {'workload': ('ssgan_inference_%s.py MODE=local_ep POS_MODE=%s LEN=%d BATCH_SIZE=%d sequences '
+                                    '(per GPU) of 64x64x%d frames%s' % (args.dataset, cfg.pos_mode, cfg.LEN, cfg.B, cfg.C,
+                                                                        ', eager' if args.no_graph else ''))
                        if ssgan else '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
                 'gmgan' if K else 'gan', args.dataset, args.mode, ' N_COMS=%d' % K if K else '', cfg.B, cfg.S, cfg.S, cfg.C,
                 cfg.critic_iters, '' if not args.no_graph else ', eager'),

@@ -23,13 +23,17 @@ from .tflib.ops.act import LRELU, RELU, TANH
 
 
 class SSConfig(object):
-    dataset, K, mode = 'moving_mnist', 0, 'local_ep'
+    K, mode = 0, 'local_ep'
 
     def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
-                 pos_mode='naive_mean_field', op_dyn_mode='res', lr=1e-4, fuse=True):
+                 pos_mode='naive_mean_field', op_dyn_mode='res', lr=1e-4, fuse=True, channels=1, dataset='moving_mnist'):
+        """defaults: ssgan_inference_moving_mnist.py:26-53.  channels=3, n_c=0, length=31, op_dyn_mode='res_w',
+        dataset='chairs': ssgan_inference_chairs.py:28-54 (RGB frames, no class labels)."""
+        self.dataset = dataset
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
-        self.S, self.C, self.output_dim = 64, 1, 64 * 64
+        self.S, self.C, self.output_dim = 64, channels, channels * 64 * 64
+        self.x_div = 256.0 if dataset == 'chairs' else 1.0     # chairs frames are 0..255: real_x = 2*((x/256.)-.5) (chairs :508)
         self.flat = 4 * 4 * 8 * dim
         assert pos_mode in ('naive_mean_field', 'inverse', 'forward_inverse', 'gsp'), pos_mode
         assert op_dyn_mode in ('res', 'res_w'), op_dyn_mode
@@ -66,20 +70,23 @@ class StateSpaceGAN(object):
         feed['p_z_l_0'].normal_()
         feed['epsilon'].normal_()
         feed['p_z_g'].normal_()
-        idx = torch.randint(0, c.n_c, (c.B, 1), device=feed['p_y'].device)
-        feed['p_y'].zero_().scatter_(1, idx, 1.0)
+        if c.n_c:
+            idx = torch.randint(0, c.n_c, (c.B, 1), device=feed['p_y'].device)
+            feed['p_y'].zero_().scatter_(1, idx, 1.0)
 
     def set_batch(self, feed, batch):
-        x, y = batch
+        x, y = batch if isinstance(batch, (tuple, list)) else (batch, None)
         feed['real_x_unit'].copy_(x.reshape(feed['real_x_unit'].shape), non_blocking=True)
-        feed['real_y'].copy_(y, non_blocking=True)
+        if y is not None and self.cfg.n_c:
+            feed['real_y'].copy_(y, non_blocking=True)
 
     def synthetic_ring(self, device, n=4, seed=1234):
         c, rng, ring = self.cfg, np.random.default_rng(seed), []
         for _ in range(n):
-            x = torch.as_tensor(rng.random((c.B, c.LEN, c.output_dim), dtype=np.float32))
+            x = torch.as_tensor(rng.random((c.B, c.LEN, c.output_dim), dtype=np.float32) * np.float32(256.0 if c.x_div > 1 else 1.0))
             y = np.zeros((c.B, c.n_c), np.float32)
-            y[np.arange(c.B), rng.integers(0, c.n_c, size=c.B)] = 1
+            if c.n_c:
+                y[np.arange(c.B), rng.integers(0, c.n_c, size=c.B)] = 1
             ring.append((x.to(device), torch.as_tensor(y).to(device)))
         return ring
 
@@ -161,7 +168,7 @@ class StateSpaceGAN(object):
         out = self._deconv('Generator.2', 8 * d, 4 * d, out, RELU)
         out = self._deconv('Generator.3', 4 * d, 2 * d, out, RELU)
         out = self._deconv('Generator.4', 2 * d, d, out, RELU)
-        out = self._deconv('Generator.5', d, 1, out, TANH)
+        out = self._deconv('Generator.5', d, c.C, out, TANH)
         return out.reshape(c.B, c.LEN, c.output_dim)
 
     def _conv_stack(self, pre, x, cin, grad_rows=None):
@@ -173,13 +180,13 @@ class StateSpaceGAN(object):
 
     def Extractor(self, inputs, labels):
         c = self.cfg
-        out = self._conv_stack('Extractor', inputs.reshape(c.B * c.LEN, 1, 64, 64), 1).reshape(c.B * c.LEN, c.flat)
+        out = self._conv_stack('Extractor', inputs.reshape(c.B * c.LEN, c.C, 64, 64), c.C).reshape(c.B * c.LEN, c.flat)
         out = torch.cat([out, self.expand_labels(labels)], 1)
         return self._lin('Extractor.Output', c.flat + c.n_c, c.dim_l, out).reshape(c.B, c.LEN, c.dim_l)
 
     def G_Extractor(self, inputs, labels):
         c = self.cfg
-        out = self._conv_stack('Extractor.G', inputs.reshape(c.B, c.LEN, 64, 64), c.LEN).reshape(c.B, c.flat)
+        out = self._conv_stack('Extractor.G', inputs.reshape(c.B, c.C * c.LEN, 64, 64), c.C * c.LEN).reshape(c.B, c.flat)
         return self._lin('Extractor.G.Output', c.flat + c.n_c, c.dim_g, torch.cat([out, labels], 1))
 
     def Discriminator(self, x, z_g, z_l, labels):
@@ -190,7 +197,7 @@ class StateSpaceGAN(object):
         """the frame critic on any number of (frame, latent row, label row) triples; grad_rows: only the leading frames carry
         a gradient (generator steps: [fake; real])"""
         c, n = self.cfg, frames.shape[0]
-        out = self._conv_stack('Discriminator', frames.reshape(n, 1, 64, 64), 1, grad_rows).reshape(n, c.flat)
+        out = self._conv_stack('Discriminator', frames.reshape(n, c.C, 64, 64), c.C, grad_rows).reshape(n, c.flat)
         z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l + c.n_c, 512, z_rows, LRELU)
         out = torch.cat([out, z_out, label_rows], 1)
         out = self._lin('Discriminator.zx1', c.flat + 512 + c.n_c, 512, out, LRELU)
@@ -226,7 +233,7 @@ class StateSpaceGAN(object):
     def forward_nets(self, feed):
         """everything that reads no critic variable (:515-527)"""
         real_y, p_y = feed['real_y'], feed['p_y']
-        real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0, 0.0, -1.0)      # 2*(x-.5)
+        real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0 / self.cfg.x_div, 0.0, -1.0)      # 2*(x/div-.5)
         q_z_l = self.DynamicExtractor(self.Extractor(real_x, real_y))
         q_z_g = self.G_Extractor(real_x, real_y)
         p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])

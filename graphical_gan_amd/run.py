@@ -39,6 +39,9 @@ def _batches(S, model, device):
                     oh[np.arange(len(y)), y] = 1
                     yield x, oh
             return DevicePrefetcher(with_onehot, device), 'mnist.pkl.gz'
+        if ds == 'chairs':
+            train, _ = lib.chairs.load(S['LEN'], S['BATCH_SIZE'], 64, S.get('DATA_DIR', ''))
+            return DevicePrefetcher(train, device), S.get('DATA_DIR')
     except FileNotFoundError as e:
         print('[run] %s -> synthetic minibatches' % e)
     ring = model.synthetic_ring(device, n=8)

@@ -136,4 +136,4 @@ def print_model_settings_dict(settings):
 
 
 from . import ops, objs, plot, utils  # noqa: E402,F401
-from . import mnist, cifar10, svhn, celebA, simple_moving_mnist, save_images  # noqa: E402,F401
+from . import mnist, cifar10, svhn, celebA, simple_moving_mnist, chairs, save_images  # noqa: E402,F401

@@ -19,10 +19,13 @@ from . import tape as tp
 
 class Cfg(object):
     def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
-                 pos_mode='naive_mean_field', op_dyn_mode='res'):
+                 pos_mode='naive_mean_field', op_dyn_mode='res', channels=1):
+        """channels=3, n_c=0, length=31, op_dyn_mode='res_w': ssgan_inference_chairs.py (RGB frames, no labels)"""
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
-        self.S, self.output_dim = 64, 64 * 64
+        self.C = channels
+        self.x_div = 256.0 if channels == 3 else 1.0      # chairs: real_x = 2*((x/256.)-.5) (:508); moving-MNIST: 2*(x-.5) (:514)
+        self.S, self.output_dim = 64, channels * 64 * 64
         self.flat = 4 * 4 * 8 * dim
         self.pos_mode, self.op_dyn_mode = pos_mode, op_dyn_mode
         self.lr, self.beta1, self.beta2 = 1e-4, 0.5, 0.999          # :49-53 (weighted_local_epce pins beta2 = .999)
@@ -53,7 +56,7 @@ def init_params(cfg, seed=0):
         P[name + '.Biases'] = np.zeros(cout, np.float32)
 
     d = cfg.dim
-    for pre, cin in (('Extractor', 1), ('Extractor.G', cfg.LEN)):
+    for pre, cin in (('Extractor', cfg.C), ('Extractor.G', cfg.C * cfg.LEN)):
         conv(pre + '.1', cin, d); conv(pre + '.2', d, 2 * d); conv(pre + '.3', 2 * d, 4 * d); conv(pre + '.4', 4 * d, 8 * d)
     lin('Extractor.Output', cfg.flat + cfg.n_c, cfg.dim_l)
     lin('Extractor.G.Output', cfg.flat + cfg.n_c, cfg.dim_g)
@@ -62,11 +65,11 @@ def init_params(cfg, seed=0):
         lin(nm + '.Output', cfg.dim_op, cfg.dim_l); lin(nm + '.ZW', cfg.dim_l, cfg.dim_l)
     lin('Generator.Input', cfg.dim_g + cfg.dim_l + cfg.n_c, cfg.flat)
     deconv('Generator.2', 8 * d, 4 * d); deconv('Generator.3', 4 * d, 2 * d); deconv('Generator.4', 2 * d, d)
-    deconv('Generator.5', d, 1)
+    deconv('Generator.5', d, cfg.C)
     nm = 'Generator.Dynamic'
     lin(nm + '.Input', cfg.dim_l + cfg.dim_t, cfg.dim_op); lin(nm + '.1', cfg.dim_op, cfg.dim_op)
     lin(nm + '.Output', cfg.dim_op, cfg.dim_l); lin(nm + '.ZW', cfg.dim_l, cfg.dim_l)
-    conv('Discriminator.1', 1, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
+    conv('Discriminator.1', cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
     conv('Discriminator.4', 4 * d, 8 * d)
     lin('Discriminator.z1', cfg.dim_g + cfg.dim_l + cfg.n_c, 512)
     lin('Discriminator.zx1', cfg.flat + 512 + cfg.n_c, 512)
@@ -181,19 +184,19 @@ def _conv_stack(cfg, P, pre, x):
 
 
 def Extractor(cfg, P, x, labels):                            # :206-234
-    out = _conv_stack(cfg, P, 'Extractor', tp.reshape(x, (cfg.B * cfg.LEN, 1, 64, 64)))
+    out = _conv_stack(cfg, P, 'Extractor', tp.reshape(x, (cfg.B * cfg.LEN, cfg.C, 64, 64)))
     out = tp.concat([tp.reshape(out, (cfg.B * cfg.LEN, cfg.flat)), expand_labels(cfg, labels)], axis=1)
     return tp.reshape(N.Linear(P, 'Extractor.Output', out), (cfg.B, cfg.LEN, cfg.dim_l))
 
 
 def G_Extractor(cfg, P, x, labels):                          # :236-262
-    out = _conv_stack(cfg, P, 'Extractor.G', tp.reshape(x, (cfg.B, cfg.LEN, 64, 64)))
+    out = _conv_stack(cfg, P, 'Extractor.G', tp.reshape(x, (cfg.B, cfg.C * cfg.LEN, 64, 64)))
     out = tp.concat([tp.reshape(out, (cfg.B, cfg.flat)), labels], axis=1)
     return N.Linear(P, 'Extractor.G.Output', out)
 
 
 def Discriminator(cfg, P, x, z_g, z_l, labels):              # :265-315
-    out = _conv_stack(cfg, P, 'Discriminator', tp.reshape(x, (cfg.B * cfg.LEN, 1, 64, 64)))
+    out = _conv_stack(cfg, P, 'Discriminator', tp.reshape(x, (cfg.B * cfg.LEN, cfg.C, 64, 64)))
     out = tp.reshape(out, (cfg.B * cfg.LEN, cfg.flat))
     z_out = _lrelu(N.Linear(P, 'Discriminator.z1', _z_rows(cfg, z_g, z_l, labels)))
     out = tp.concat([out, z_out, expand_labels(cfg, labels)], axis=1)
@@ -218,15 +221,17 @@ def ZGDiscriminator(cfg, P, z_g):                            # :335-349
 
 # ---- one session.run ---------------------------------------------------------------------------------------------------
 def make_feed(cfg, rng):
-    f = {'real_x_unit': rng.random((cfg.B, cfg.LEN, cfg.output_dim), dtype=np.float32)}
+    f = {'real_x_unit': rng.random((cfg.B, cfg.LEN, cfg.output_dim), dtype=np.float32) * np.float32(256.0 if cfg.x_div > 1 else 1.0)}
     y = np.zeros((cfg.B, cfg.n_c), np.float32)
-    y[np.arange(cfg.B), rng.integers(0, cfg.n_c, size=cfg.B)] = 1
+    if cfg.n_c:
+        y[np.arange(cfg.B), rng.integers(0, cfg.n_c, size=cfg.B)] = 1
     f['real_y'] = y
     f['p_z_l_0'] = rng.standard_normal((cfg.B, cfg.dim_l), dtype=np.float32)
     f['epsilon'] = rng.standard_normal((cfg.B, cfg.dim_t), dtype=np.float32)
     f['p_z_g'] = rng.standard_normal((cfg.B, cfg.dim_g), dtype=np.float32)
     py = np.zeros((cfg.B, cfg.n_c), np.float32)
-    py[np.arange(cfg.B), rng.integers(0, cfg.n_c, size=cfg.B)] = 1
+    if cfg.n_c:
+        py[np.arange(cfg.B), rng.integers(0, cfg.n_c, size=cfg.B)] = 1
     f['p_y'] = py
     return f
 
@@ -235,7 +240,7 @@ def forward(cfg, P, feed):
     """:510-547 -- P: name -> tape.T.  Returns dict incl. gen_cost / disc_cost (weighted_local_epce, MODE 'local_ep')."""
     dt = next(iter(P.values())).v.dtype.type
     T = lambda k: tp.T(np.asarray(feed[k], dtype=dt))
-    real_x = tp.T(dt(2) * (np.asarray(feed['real_x_unit'], dtype=dt) - dt(.5)))
+    real_x = tp.T(dt(2) * (np.asarray(feed['real_x_unit'], dtype=dt) / dt(cfg.x_div) - dt(.5)))
     real_y, p_y = T('real_y'), T('p_y')
     q_z_l = DynamicExtractor(cfg, P, Extractor(cfg, P, real_x, real_y))
     q_z_g = G_Extractor(cfg, P, real_x, real_y)

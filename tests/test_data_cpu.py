@@ -99,3 +99,34 @@ def test_svhn_loader_layout_labels_and_mat_files(tmp_path):
     import pytest
     with pytest.raises(FileNotFoundError):
         svhn.load(8, '/nonexistent')
+
+
+def test_chairs_loader_layout_and_clips(tmp_path):
+    """tflib/chairs.py:36-44: [objects, 31, H, W, 3] -> [B, seq, 3*H*W] in (C,H,W) order, dev split first, whole sequences / leading
+    views / random 4-view clips; also through a real .npy file."""
+    from graphical_gan_amd.tflib import chairs
+    rng = np.random.default_rng(4)
+    size, n = 8, 12
+    data = rng.integers(0, 256, size=(n, 31, size, size, 3)).astype(np.uint8)
+    data[:, :, 0, 0, 0] = np.arange(n)[:, None]               # object id in pixel (0,0) of channel 0
+    data[:, :, 0, 1, 0] = np.arange(31)[None, :]              # view index in pixel (0,1) of channel 0
+    np.random.seed(1)
+    tr, dev = chairs.load(31, 4, size, '/nonexistent', num_dev=4, data=data)
+    xb = next(iter(tr()))
+    assert xb.shape == (4, 31, 3 * size * size) and xb.dtype == np.float32
+    assert np.array_equal(xb[:, :, 1], np.tile(np.arange(31, dtype=np.float32), (4, 1)))      # views in order, (C,H,W) layout
+    obj = int(xb[0, 0, 0])
+    assert np.array_equal(xb[0, 5].reshape(3, size, size), data[obj, 5].transpose(2, 0, 1).astype(np.float32))
+    assert sum(1 for _ in tr()) == (n - 4) // 4 and sum(1 for _ in dev()) == 1
+    tr16, _ = chairs.load(16, 4, size, '/nonexistent', num_dev=4, data=data)
+    x16 = next(iter(tr16()))
+    assert x16.shape == (4, 16, 3 * size * size) and np.array_equal(x16[0, :, 1], np.arange(16, dtype=np.float32))
+    tr4, _ = chairs.load(4, 4, size, '/nonexistent', num_dev=4, data=data)
+    x4 = next(iter(tr4()))
+    assert x4.shape == (4, 4, 3 * size * size) and np.all(np.diff(x4[:, :, 1], axis=1) == 1)   # consecutive views of one object
+    np.save(str(tmp_path / ('chairs_%d.npy' % size)), data)
+    tr2, _ = chairs.load(31, 2, size, str(tmp_path), num_dev=2)
+    assert next(iter(tr2())).shape == (2, 31, 3 * size * size)
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        chairs.load(31, 2, size, '/nonexistent')
