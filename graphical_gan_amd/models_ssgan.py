@@ -23,13 +23,16 @@ from .tflib.ops.act import LRELU, RELU, TANH
 
 
 class SSConfig(object):
-    K, mode = 0, 'local_ep'
+    K = 0
 
     def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
-                 pos_mode='naive_mean_field', op_dyn_mode='res', lr=1e-4, fuse=True, channels=1, dataset='moving_mnist'):
+                 pos_mode='naive_mean_field', op_dyn_mode='res', lr=1e-4, fuse=True, channels=1, dataset='moving_mnist',
+                 mode='local_ep', lamb=0.1):
         """defaults: ssgan_inference_moving_mnist.py:26-53.  channels=3, n_c=0, length=31, op_dyn_mode='res_w',
         dataset='chairs': ssgan_inference_chairs.py:28-54 (RGB frames, no class labels)."""
         self.dataset = dataset
+        assert mode in ('local_ep', 'local_epce-z'), mode      # (MODE ali / alice-z: one joint critic, not built)
+        self.mode, self.lamb = mode, lamb                      # local_epce-z: + LAMBDA * l2(real_x, G(q_z_g, q_z_l, real_y)) (:549-552)
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
         self.S, self.C, self.output_dim = 64, channels, channels * 64 * 64
@@ -53,7 +56,10 @@ class StateSpaceGAN(object):
     # every conv filter receives ONE gradient contribution per backward pass (each conv net is applied once: the critics see
     # [fake; real] as one batch), so the pack kernel may sum the filter-gradient slabs; the shared-weight Linear operators
     # (applied LEN-1 times) are summed by autograd as usual
-    single_contribution = True
+    @property
+    def single_contribution(self):
+        return self.cfg.mode == 'local_ep'          # local_epce-z applies the frame generator twice
+
 
     def __init__(self, cfg):
         self.cfg = cfg
@@ -270,7 +276,12 @@ class StateSpaceGAN(object):
         r = c.ratio()
         ratios = [float(r[0]) * (c.LEN - 1), float(r[c.LEN - 1]), float(r[c.LEN])]      # the LEN-1 equal transition terms as one
         gen_params, disc_params = self._var_lists()
-        res = J.weighted_local_epce(disc_fake, disc_real, ratios, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        rec_penalty = None
+        if c.mode == 'local_epce-z' and which != 'disc':
+            rec_x = self.Generator(q_z_g, q_z_l, real_y)
+            rec_penalty = c.lamb * lib.utils.distance.distance(real_x, rec_x, 'l2')
+        res = J.weighted_local_epce(disc_fake, disc_real, ratios, gen_params, disc_params, lr=c.lr, beta1=c.beta1,
+                                    rec_penalty=rec_penalty)
         J.ONLY[0] = None
         out.update(disc_fake=disc_fake, disc_real=disc_real, gen_cost=res[0], disc_cost=res[1], gen_train_op=res[4],
                    disc_train_op=res[5])

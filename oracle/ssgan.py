@@ -19,11 +19,12 @@ from . import tape as tp
 
 class Cfg(object):
     def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
-                 pos_mode='naive_mean_field', op_dyn_mode='res', channels=1):
+                 pos_mode='naive_mean_field', op_dyn_mode='res', channels=1, mode='local_ep', lamb=0.1):
         """channels=3, n_c=0, length=31, op_dyn_mode='res_w': ssgan_inference_chairs.py (RGB frames, no labels)"""
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
         self.C = channels
+        self.mode, self.lamb = mode, lamb              # 'local_ep' | 'local_epce-z' (+ LAMBDA * l2(real_x, G(q_z_g, q_z_l)), :549-552)
         self.x_div = 256.0 if channels == 3 else 1.0      # chairs: real_x = 2*((x/256.)-.5) (:508); moving-MNIST: 2*(x-.5) (:514)
         self.S, self.output_dim = 64, channels * 64 * 64
         self.flat = 4 * 4 * 8 * dim
@@ -256,6 +257,9 @@ def forward(cfg, P, feed):
     disc_fake.append(Discriminator(cfg, P, fake_x, p_z_g, p_z_l, p_y))
     disc_real.append(Discriminator(cfg, P, real_x, q_z_g, q_z_l, real_y))
     gen_cost, disc_cost = J.weighted_local_epce_costs(disc_fake, disc_real, list(cfg.ratio()))
+    if getattr(cfg, 'mode', 'local_ep') == 'local_epce-z':
+        rec_x = Generator(cfg, P, q_z_g, q_z_l, real_y)
+        gen_cost = tp.add(gen_cost, tp.scale(J.distance(real_x, rec_x, 'l2'), cfg.lamb))
     return dict(real_x=real_x, q_z_l=q_z_l, q_z_g=q_z_g, p_z_l=p_z_l, fake_x=fake_x, disc_fake=disc_fake,
                 disc_real=disc_real, gen_cost=gen_cost, disc_cost=disc_cost)
 

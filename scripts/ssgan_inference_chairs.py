@@ -8,7 +8,7 @@ from graphical_gan_amd import run
 from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
 
 DATASET = 'chairs'  # rotating chairs: 31 RGB views of 64x64 per object, no class labels
-MODE = 'local_ep'  # (ali / alice-z and the 3-D critic are not built)
+MODE = 'local_ep'  # local_ep, local_epce-z (ali / alice-z and the 3-D critic are not built)
 POS_MODE = 'naive_mean_field'  # gsp, naive_mean_field, inverse, forward_inverse
 OP_DYN_MODE = 'res_w'  # res, res_w
 DIM_LATENT_G = 128  # global latent variable
@@ -18,6 +18,7 @@ DIM_OP = 256  # model size of the dynamic operator
 LEN = 31  # data length
 N_C = 0  # (no labels)
 CHANNELS = 3
+LAMBDA = 0.1  # reconstruction weight (local_epce-z)
 LR = 1e-4
 BATCH_SIZE = 50
 CRITIC_ITERS = 1
@@ -31,5 +32,5 @@ if len(sys.argv) > 1:
     ITERS = int(sys.argv[1])
 SETTINGS = {k: v for k, v in dict(globals()).items() if k.isupper() and k != 'SETTINGS'}
 cfg = SSConfig(batch_size=BATCH_SIZE, length=LEN, dim=DIM, dim_op=DIM_OP, dim_g=DIM_LATENT_G, dim_l=DIM_LATENT_L, n_c=N_C,
-               pos_mode=POS_MODE, op_dyn_mode=OP_DYN_MODE, lr=LR, channels=CHANNELS, dataset=DATASET)
+               pos_mode=POS_MODE, op_dyn_mode=OP_DYN_MODE, lr=LR, mode=MODE, lamb=LAMBDA, channels=CHANNELS, dataset=DATASET)
 run.train(SETTINGS, cfg, model=StateSpaceGAN(cfg))

@@ -8,13 +8,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10):
+def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10, mode='local_ep'):
     from graphical_gan_amd import tflib as lib, optim
     from graphical_gan_amd.engine import Trainer
     from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
     from oracle import ssgan as O
     kw = dict(batch_size=B, length=L, dim=dim, dim_op=16, dim_g=8, dim_l=4, pos_mode=pos_mode, op_dyn_mode=op_dyn_mode, channels=channels,
-              n_c=n_c)
+              n_c=n_c, mode=mode)
     ocfg = O.Cfg(**kw)
     P0 = O.init_params(ocfg, seed=0)
     rng = np.random.default_rng(5)
@@ -29,12 +29,14 @@ def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10):
     return ocfg, P0, cfg, tr
 
 
-@pytest.mark.parametrize('pos_mode,op_dyn_mode,channels,n_c', [('naive_mean_field', 'res', 1, 10), ('gsp', 'res_w', 1, 10), ('inverse', 'res', 1, 10),
-                                                               ('naive_mean_field', 'res_w', 3, 0)])   # last: ssgan_inference_chairs.py
-def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, n_c):
+@pytest.mark.parametrize('pos_mode,op_dyn_mode,channels,n_c,mode', [
+    ('naive_mean_field', 'res', 1, 10, 'local_ep'), ('gsp', 'res_w', 1, 10, 'local_ep'), ('inverse', 'res', 1, 10, 'local_ep'),
+    ('naive_mean_field', 'res_w', 3, 0, 'local_ep'),            # ssgan_inference_chairs.py
+    ('naive_mean_field', 'res', 1, 10, 'local_epce-z')])        # + LAMBDA * l2(real_x, rec_x)
+def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, n_c, mode):
     import torch
     from oracle import ssgan as O, tape as tp
-    ocfg, P0, cfg, tr = _mk(gpu, pos_mode, op_dyn_mode, False, channels=channels, n_c=n_c)
+    ocfg, P0, cfg, tr = _mk(gpu, pos_mode, op_dyn_mode, False, channels=channels, n_c=n_c, mode=mode)
     feed = O.make_feed(ocfg, np.random.default_rng(3))
     Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
     oout = O.forward(ocfg, Pt, feed)
@@ -61,11 +63,12 @@ def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, 
     assert np.abs(fx - oout['fake_x'].v).max() <= 1e-5
 
 
-@pytest.mark.parametrize('graph,chairs', [(False, False), (True, False), (True, True)], ids=['eager', 'hipgraph', 'hipgraph-chairs'])
-def test_ssgan_trajectory(gpu, graph, chairs):
+@pytest.mark.parametrize('graph,chairs,mode', [(False, False, 'local_ep'), (True, False, 'local_ep'), (True, True, 'local_ep'),
+                                               (True, False, 'local_epce-z')], ids=['eager', 'hipgraph', 'hipgraph-chairs', 'hipgraph-epce-z'])
+def test_ssgan_trajectory(gpu, graph, chairs, mode):
     """4 iterations (critic step, then gen + critic) with TF-Adam on both sides: costs and every weight."""
     from oracle import ssgan as O
-    ocfg, P0, cfg, tr = _mk(gpu, 'naive_mean_field', 'res_w' if chairs else 'res', graph, **(dict(channels=3, n_c=0) if chairs else {}))
+    ocfg, P0, cfg, tr = _mk(gpu, 'naive_mean_field', 'res_w' if chairs else 'res', graph, mode=mode, **(dict(channels=3, n_c=0) if chairs else {}))
     rng = np.random.default_rng(9)
     feeds = [O.make_feed(ocfg, rng) for _ in range(8)]
     otr = O.Trainer(ocfg, P0, np.float64)
