@@ -8,7 +8,7 @@ cd $R
 OUT=$R/gpurun_out/${TAG}_other_workloads.json
 : > $OUT.lines
 for a in "--mode local_ep" "--mode wali-gp" "--mode wali" "--dataset svhn --mode local_ep" "--dataset mnist" "--dataset mnist --mode local_ep" \
-         "--dataset face" "--dataset face --mode local_ep" "--dataset moving_mnist" "--host-feed" \
+         "--dataset face" "--dataset face --mode local_ep" "--dataset moving_mnist" "--dataset chairs" "--host-feed" \
          "--dataset mnist --mode local_ep --batch-size 50" "--dataset face --mode local_ep --batch-size 128"; do
     python bench.py $a --steps 200 --warmup 20 --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep '^{' | tail -1 >> $OUT.lines
 done
