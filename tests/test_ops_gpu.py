@@ -821,3 +821,34 @@ def test_thin_kernels_agree_with_general_kernels_at_full_size(gpu, case):
         a, c = a.cpu().numpy().astype(np.float64), c.cpu().numpy().astype(np.float64)
         assert np.isfinite(a).all()
         assert np.abs(a - c).max() <= 3e-5 * np.abs(c).max(), (name, np.abs(a - c).max(), np.abs(c).max())
+
+
+@pytest.mark.parametrize('case', [(512, 1, 64, 32), (512, 32, 32, 64), (512, 64, 16, 128), (512, 128, 8, 256), (128, 3, 64, 32),
+                                  (128, 64, 16, 128), (128, 128, 8, 256)])
+def test_conv_family_bilinear_identities_at_full_size(gpu, case):
+    """Size-independent parity property at BASELINE sizes (state-space GAN: 512 frames per launch; face / CIFAR critic batches),
+    where the numpy oracle is too slow: the three kernels of a layer are the three partial maps of ONE trilinear form,
+        <Conv(x; w), gy>  ==  <x, ConvDgrad(gy; w)>  ==  <w, ConvWgrad(x, gy)>,
+    evaluated in float64 on the host from fp32 kernel outputs.  Any misplaced tap, halo or stride in one kernel breaks an
+    equality (each kernel has its own indexing: forward / parity-class data gradient / split-K filter gradient / thin forms)."""
+    import torch
+    from graphical_gan_amd import functional as F
+    N, Ci, H, Co = case
+    rng = np.random.default_rng(N + Ci + H)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2)
+    Ho = geom[5]
+    x = _t(rng.standard_normal((N, Ci, H, H)), gpu)
+    w = _t(rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci), gpu)
+    gy = _t(rng.standard_normal((N, Co, Ho, Ho)), gpu)
+    y = F.ConvFwd.apply(x, w, None, geom, F.ACT_NONE, 0.0)
+    gx = F.ConvDgrad.apply(gy, w, None, geom, F.ACT_NONE, 0.0)
+    gw = F.ConvWgrad.apply(x, gy, geom)
+    d = lambda a, b: float((a.double() * b.double()).sum())
+    t1, t2, t3 = d(y, gy), d(x, gx), d(w, gw)
+    scale = float(y.double().norm() * gy.double().norm())
+    assert abs(t1 - t2) <= 2e-6 * scale and abs(t1 - t3) <= 2e-6 * scale, (t1, t2, t3, scale)
+    # linearity in the input: Conv(a*x1 + x2) == a*Conv(x1) + Conv(x2)
+    x2 = _t(rng.standard_normal((N, Ci, H, H)), gpu)
+    lhs = F.ConvFwd.apply(1.5 * x + x2, w, None, geom, F.ACT_NONE, 0.0)
+    rhs = 1.5 * y + F.ConvFwd.apply(x2, w, None, geom, F.ACT_NONE, 0.0)
+    assert float((lhs - rhs).abs().max()) <= 2e-5 * float(rhs.abs().max())
