@@ -396,3 +396,29 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert len(lines) == 1                                  # rank 0 only
     d2 = json.loads(lines[0])
     assert d2['n_gpus'] == 2 and d2['scaling'] == 'weak' and d2['config']['global_batch'] == 128 and d2['value'] > 0
+
+
+@pytest.mark.parametrize('mode,K', [('ali', 0), ('local_ep', 30)])
+def test_full_size_training_is_bitwise_reproducible(gpu, mode, K):
+    """BASELINE-size step (batch 64, HIP-graph replay, two-stream nets pass for ali, on-device noise): two runs from the same
+    seeds end in bit-identical weights -- no atomics, no order-dependent reductions anywhere on the path, and the parallel graph
+    branches only reorder independent kernels."""
+    import torch
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    finals = []
+    for run in range(2):
+        _fresh()
+        np.random.seed(0)
+        cfg = Config('cifar10', batch_size=64, n_coms=K, mode=mode)
+        tr = Trainer(cfg, device=gpu, graph=True, seed=4321)
+        ring = tr.model.synthetic_ring(gpu, n=4, seed=99)
+        batches = iter(ring * 8)
+        for it in range(6):
+            res = tr.iteration(it, batches)
+        tr.flush()
+        torch.cuda.synchronize()
+        assert all(np.isfinite(float(v)) for v in res.values())
+        finals.append({k: v.copy() for k, v in tr.get_params().items()})
+    for k in finals[0]:
+        assert np.array_equal(finals[0][k], finals[1][k]), k
