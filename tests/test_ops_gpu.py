@@ -852,3 +852,36 @@ def test_conv_family_bilinear_identities_at_full_size(gpu, case):
     lhs = F.ConvFwd.apply(1.5 * x + x2, w, None, geom, F.ACT_NONE, 0.0)
     rhs = 1.5 * y + F.ConvFwd.apply(x2, w, None, geom, F.ACT_NONE, 0.0)
     assert float((lhs - rhs).abs().max()) <= 2e-5 * float(rhs.abs().max())
+
+
+def test_optimizer_path_properties_at_full_size(gpu):
+    """BASELINE-size optimizer path (7.19 M parameters in one flat bucket) through size-independent properties: the pack kernel
+    conserves the checksum of its inputs (incl. split-K slabs summed on the way), Adam's first step has the closed form
+    -lr*g/(|g| + eps/sqrt(1-beta2)) for EVERY element, and a zero gradient leaves a parameter untouched."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(12)
+    shapes = [(5, 5, 3, 64), (64,), (5, 5, 64, 128), (5, 5, 128, 256), (4608, 512), (512,), (128, 4096), (4096,), (5, 5, 256, 128)]
+    tensors = [_t(rng.standard_normal(s), gpu) for s in shapes]
+    sizes = [t.numel() for t in tensors]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append((o, n)); o += (n + 3) // 4 * 4
+    flat = torch.full((o,), float('nan'), device=gpu)
+    flat.zero_()
+    F.pack_(tensors, offs, flat)
+    want = sum(float(t.double().sum()) for t in tensors)
+    assert abs(float(flat.double().sum()) - want) <= 1e-9 * sum(float(t.double().abs().sum()) for t in tensors)
+    for t, (o0, n) in zip(tensors, offs):
+        assert torch.equal(flat[o0:o0 + n], t.reshape(-1))
+    n = 7190000
+    g = _t(rng.standard_normal(n), gpu)
+    g[::7] = 0.0
+    th0 = _t(rng.standard_normal(n), gpu)
+    theta, m, v = th0.clone(), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    step = torch.zeros(1, dtype=torch.int32, device=gpu)
+    lr, b1, b2, eps = 2e-4, 0.5, 0.999, 1e-8
+    F.adam_step_(theta, g, m, v, step, lr, b1, b2, eps)
+    closed = -lr * g.double() / (g.double().abs() + eps / np.sqrt(1 - b2))
+    assert float(((theta.double() - th0.double()) - closed).abs().max()) < 5e-7
+    assert torch.equal(theta[::7], th0[::7])
