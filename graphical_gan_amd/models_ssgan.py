@@ -31,8 +31,10 @@ class SSConfig(object):
         """defaults: ssgan_inference_moving_mnist.py:26-53.  channels=3, n_c=0, length=31, op_dyn_mode='res_w',
         dataset='chairs': ssgan_inference_chairs.py:28-54 (RGB frames, no class labels)."""
         self.dataset = dataset
-        assert mode in ('local_ep', 'local_epce-z'), mode      # (MODE ali / alice-z: one joint critic, not built)
-        self.mode, self.lamb = mode, lamb                      # local_epce-z: + LAMBDA * l2(real_x, G(q_z_g, q_z_l, real_y)) (:549-552)
+        assert mode in ('local_ep', 'local_epce-z', 'ali', 'alice-z'), mode
+        self.mode, self.lamb = mode, lamb                      # *-z: + LAMBDA * l2(real_x, G(q_z_g, q_z_l, real_y)) (:549-558)
+        # MODE ali / alice-z: ONE critic on the whole sequence (ALI_MODE = 'concat_x', :407-449; 'concat_z' / '3dcnn' are not built)
+        self.seq_critic = mode in ('ali', 'alice-z')
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
         self.S, self.C, self.output_dim = 64, channels, channels * 64 * 64
@@ -58,7 +60,7 @@ class StateSpaceGAN(object):
     # (applied LEN-1 times) are summed by autograd as usual
     @property
     def single_contribution(self):
-        return self.cfg.mode == 'local_ep'          # local_epce-z applies the frame generator twice
+        return self.cfg.mode in ('local_ep', 'ali')          # the *-z modes apply the frame generator twice
 
 
     def __init__(self, cfg):
@@ -209,6 +211,43 @@ class StateSpaceGAN(object):
         out = self._lin('Discriminator.zx1', c.flat + 512 + c.n_c, 512, out, LRELU)
         return self._lin('Discriminator.Output', 512, 1, out).reshape(-1)
 
+    def SequenceDiscriminator(self, x, z_g, z_l, labels, grad_rows=None):
+        """ALI_MODE = 'concat_x' (:407-449): the frames of a sequence as input channels, one logit per sequence; works on any
+        number of (sequence, z_g, z_l, labels) rows (the critic step hands it [fake; real])"""
+        c, n = self.cfg, x.shape[0]
+        out = self._conv_stack('Discriminator', x.reshape(n, c.C * c.LEN, 64, 64), c.C * c.LEN, grad_rows).reshape(n, c.flat)
+        z = torch.cat([z_g, z_l.reshape(n, c.LEN * c.dim_l), labels], 1)
+        z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l * c.LEN + c.n_c, 512, z, LRELU)
+        out = self._lin('Discriminator.zx1', c.flat + 512, 512, (out, z_out), LRELU)
+        return self._lin('Discriminator.Output', 512, 1, out).reshape(-1)
+
+    def _forward_seq(self, feed, which, out):
+        """MODE ali / alice-z (:536-538, :553-558)"""
+        c = self.cfg
+        real_y, p_y = feed['real_y'], feed['p_y']
+        real_x, fake_x, q_z_l, q_z_g, p_z_l, p_z_g = (out[k] for k in ('real_x', 'fake_x', 'q_z_l', 'q_z_g', 'p_z_l', 'p_z_g'))
+        if which == 'disc':
+            fake_x, q_z_l, q_z_g, p_z_l = fake_x.detach(), q_z_l.detach(), q_z_g.detach(), p_z_l.detach()
+        J = lib.objs.gan_inference
+        J.ONLY[0] = which
+        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
+            if which in ('gen', 'disc'):
+                d = self.SequenceDiscriminator(torch.cat([fake_x, real_x], 0), torch.cat([p_z_g, q_z_g], 0), torch.cat([p_z_l, q_z_l], 0),
+                                               torch.cat([p_y, real_y], 0), grad_rows=c.B if which == 'gen' else None)
+                d_fake, d_real = F.SplitRows.apply(d, c.B)
+            else:
+                d_fake = self.SequenceDiscriminator(fake_x, p_z_g, p_z_l, p_y)
+                d_real = self.SequenceDiscriminator(real_x, q_z_g, q_z_l, real_y)
+        gen_params, disc_params = self._var_lists()
+        if c.mode == 'alice-z':
+            rec = c.lamb * lib.utils.distance.distance(real_x, self.Generator(q_z_g, q_z_l, real_y), 'l2') if which != 'disc' else None
+            res = J.alice(d_fake, d_real, rec, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        else:
+            res = J.ali(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
+        J.ONLY[0] = None
+        out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=res[0], disc_cost=res[1], gen_train_op=res[2], disc_train_op=res[3])
+        return out
+
     def _mlp_critic(self, pre, x):
         out = self._lin(pre + '.Input', x.shape[1], 512, x, LRELU)
         out = self._lin(pre + '.2', 512, 512, out, LRELU)
@@ -249,6 +288,8 @@ class StateSpaceGAN(object):
     def forward(self, feed, which=None, nets=None):
         c = self.cfg
         out = dict(nets) if nets is not None else self.forward_nets(feed)
+        if c.seq_critic:
+            return self._forward_seq(feed, which, out)
         real_y, p_y = feed['real_y'], feed['p_y']
         real_x, fake_x, q_z_l, q_z_g, p_z_l, p_z_g = (out[k] for k in ('real_x', 'fake_x', 'q_z_l', 'q_z_g', 'p_z_l', 'p_z_g'))
         if which == 'disc':      # the critic step needs no gradient w.r.t. the generator/extractor outputs

@@ -25,6 +25,8 @@ class Cfg(object):
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
         self.C = channels
         self.mode, self.lamb = mode, lamb              # 'local_ep' | 'local_epce-z' (+ LAMBDA * l2(real_x, G(q_z_g, q_z_l)), :549-552)
+        # 'ali' | 'alice-z': ONE critic on the whole sequence, ALI_MODE = 'concat_x' (:407-449, :536-538, :553-558)
+        self.seq_critic = mode in ('ali', 'alice-z')
         self.x_div = 256.0 if channels == 3 else 1.0      # chairs: real_x = 2*((x/256.)-.5) (:508); moving-MNIST: 2*(x-.5) (:514)
         self.S, self.output_dim = 64, channels * 64 * 64
         self.flat = 4 * 4 * 8 * dim
@@ -70,10 +72,14 @@ def init_params(cfg, seed=0):
     nm = 'Generator.Dynamic'
     lin(nm + '.Input', cfg.dim_l + cfg.dim_t, cfg.dim_op); lin(nm + '.1', cfg.dim_op, cfg.dim_op)
     lin(nm + '.Output', cfg.dim_op, cfg.dim_l); lin(nm + '.ZW', cfg.dim_l, cfg.dim_l)
-    conv('Discriminator.1', cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
+    conv('Discriminator.1', cfg.C * cfg.LEN if getattr(cfg, 'seq_critic', False) else cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
     conv('Discriminator.4', 4 * d, 8 * d)
-    lin('Discriminator.z1', cfg.dim_g + cfg.dim_l + cfg.n_c, 512)
-    lin('Discriminator.zx1', cfg.flat + 512 + cfg.n_c, 512)
+    if getattr(cfg, 'seq_critic', False):
+        lin('Discriminator.z1', cfg.dim_g + cfg.dim_l * cfg.LEN + cfg.n_c, 512)
+        lin('Discriminator.zx1', cfg.flat + 512, 512)
+    else:
+        lin('Discriminator.z1', cfg.dim_g + cfg.dim_l + cfg.n_c, 512)
+        lin('Discriminator.zx1', cfg.flat + 512 + cfg.n_c, 512)
     lin('Discriminator.Output', 512, 1)
     for nm, nin in (('Discriminator.Dynamic', 2 * cfg.dim_l), ('Discriminator.ZG', cfg.dim_g)):
         lin(nm + '.Input', nin, 512); lin(nm + '.2', 512, 512); lin(nm + '.3', 512, 512); lin(nm + '.Output', 512, 1)
@@ -85,6 +91,8 @@ def used_names(cfg):
     skip = []
     if cfg.op_dyn_mode != 'res_w':
         skip.append('.ZW')
+    if getattr(cfg, 'seq_critic', False):
+        skip += ['Discriminator.Dynamic', 'Discriminator.ZG']
     if cfg.pos_mode in ('naive_mean_field',):
         skip.append('Extractor.Dynamic')
     elif cfg.pos_mode == 'inverse':
@@ -205,6 +213,15 @@ def Discriminator(cfg, P, x, z_g, z_l, labels):              # :265-315
     return tp.reshape(N.Linear(P, 'Discriminator.Output', out), (cfg.B * cfg.LEN,))
 
 
+def SequenceDiscriminator(cfg, P, x, z_g, z_l, labels):      # :407-449 (ALI_MODE = 'concat_x'): frames as channels, one logit per sequence
+    out = _conv_stack(cfg, P, 'Discriminator', tp.reshape(x, (cfg.B, cfg.C * cfg.LEN, 64, 64)))
+    out = tp.reshape(out, (cfg.B, cfg.flat))
+    z = tp.concat([z_g, tp.reshape(z_l, (cfg.B, cfg.LEN * cfg.dim_l)), labels], axis=1)
+    z_out = _lrelu(N.Linear(P, 'Discriminator.z1', z))
+    out = _lrelu(N.Linear(P, 'Discriminator.zx1', tp.concat([out, z_out], axis=1)))
+    return tp.reshape(N.Linear(P, 'Discriminator.Output', out), (cfg.B,))
+
+
 def _mlp_critic(P, pre, x):
     out = _lrelu(N.Linear(P, pre + '.Input', x))
     out = _lrelu(N.Linear(P, pre + '.2', out))
@@ -248,6 +265,16 @@ def forward(cfg, P, feed):
     p_z_l = DynamicGenerator(cfg, P, T('p_z_l_0'), T('epsilon'))
     p_z_g = T('p_z_g')
     fake_x = Generator(cfg, P, p_z_g, p_z_l, p_y)
+    if getattr(cfg, 'seq_critic', False):
+        d_fake = SequenceDiscriminator(cfg, P, fake_x, p_z_g, p_z_l, p_y)
+        d_real = SequenceDiscriminator(cfg, P, real_x, q_z_g, q_z_l, real_y)
+        if cfg.mode == 'alice-z':
+            rec = tp.scale(J.distance(real_x, Generator(cfg, P, q_z_g, q_z_l, real_y), 'l2'), cfg.lamb)
+            gen_cost, disc_cost = J.alice_costs(d_fake, d_real, rec)
+        else:
+            gen_cost, disc_cost = J.ali_costs(d_fake, d_real)
+        return dict(real_x=real_x, q_z_l=q_z_l, q_z_g=q_z_g, p_z_l=p_z_l, fake_x=fake_x, disc_fake=d_fake, disc_real=d_real,
+                    gen_cost=gen_cost, disc_cost=disc_cost)
     disc_fake, disc_real = [], []
     for i in range(cfg.LEN - 1):
         disc_fake.append(DynamicDiscriminator(cfg, P, _step(cfg, p_z_l, i), _step(cfg, p_z_l, i + 1)))

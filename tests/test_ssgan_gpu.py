@@ -32,7 +32,8 @@ def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10, 
 @pytest.mark.parametrize('pos_mode,op_dyn_mode,channels,n_c,mode', [
     ('naive_mean_field', 'res', 1, 10, 'local_ep'), ('gsp', 'res_w', 1, 10, 'local_ep'), ('inverse', 'res', 1, 10, 'local_ep'),
     ('naive_mean_field', 'res_w', 3, 0, 'local_ep'),            # ssgan_inference_chairs.py
-    ('naive_mean_field', 'res', 1, 10, 'local_epce-z')])        # + LAMBDA * l2(real_x, rec_x)
+    ('naive_mean_field', 'res', 1, 10, 'local_epce-z'),         # + LAMBDA * l2(real_x, rec_x)
+    ('naive_mean_field', 'res', 1, 10, 'ali'), ('gsp', 'res', 1, 10, 'alice-z')])      # one critic on the whole sequence (concat_x)
 def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, n_c, mode):
     import torch
     from oracle import ssgan as O, tape as tp
@@ -64,7 +65,8 @@ def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, 
 
 
 @pytest.mark.parametrize('graph,chairs,mode', [(False, False, 'local_ep'), (True, False, 'local_ep'), (True, True, 'local_ep'),
-                                               (True, False, 'local_epce-z')], ids=['eager', 'hipgraph', 'hipgraph-chairs', 'hipgraph-epce-z'])
+                                               (True, False, 'local_epce-z'), (True, False, 'alice-z')],
+                         ids=['eager', 'hipgraph', 'hipgraph-chairs', 'hipgraph-epce-z', 'hipgraph-alice-z'])
 def test_ssgan_trajectory(gpu, graph, chairs, mode):
     """4 iterations (critic step, then gen + critic) with TF-Adam on both sides: costs and every weight."""
     from oracle import ssgan as O
