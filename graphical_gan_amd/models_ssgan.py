@@ -27,7 +27,7 @@ class SSConfig(object):
 
     def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
                  pos_mode='naive_mean_field', op_dyn_mode='res', lr=1e-4, fuse=True, channels=1, dataset='moving_mnist',
-                 mode='local_ep', lamb=0.1):
+                 mode='local_ep', lamb=0.1, ali_mode='concat_x'):
         """defaults: ssgan_inference_moving_mnist.py:26-53.  channels=3, n_c=0, length=31, op_dyn_mode='res_w',
         dataset='chairs': ssgan_inference_chairs.py:28-54 (RGB frames, no class labels)."""
         self.dataset = dataset
@@ -35,6 +35,8 @@ class SSConfig(object):
         self.mode, self.lamb = mode, lamb                      # *-z: + LAMBDA * l2(real_x, G(q_z_g, q_z_l, real_y)) (:549-558)
         # MODE ali / alice-z: ONE critic on the whole sequence (ALI_MODE = 'concat_x', :407-449; 'concat_z' / '3dcnn' are not built)
         self.seq_critic = mode in ('ali', 'alice-z')
+        assert ali_mode in ('concat_x', 'concat_z'), ali_mode
+        self.ali_mode = ali_mode
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
         self.S, self.C, self.output_dim = 64, channels, channels * 64 * 64
@@ -215,6 +217,14 @@ class StateSpaceGAN(object):
         """ALI_MODE = 'concat_x' (:407-449): the frames of a sequence as input channels, one logit per sequence; works on any
         number of (sequence, z_g, z_l, labels) rows (the critic step hands it [fake; real])"""
         c, n = self.cfg, x.shape[0]
+        if c.ali_mode == 'concat_z':     # :451-497: per-frame conv stack + a 4x4 VALID conv to DIM_LATENT_G features per frame
+            fr = None if grad_rows is None else grad_rows * c.LEN
+            out = self._conv_stack('Discriminator', x.reshape(n * c.LEN, c.C, 64, 64), c.C, fr)
+            out = lib.ops.conv2d.Conv2D('Discriminator.5', 8 * c.dim, c.dim_g, 4, out, stride=1, padding='VALID').reshape(n, c.LEN * c.dim_g)
+            z = torch.cat([z_g, z_l.reshape(n, c.LEN * c.dim_l), labels], 1)
+            z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l * c.LEN + c.n_c, 512, z, LRELU)
+            out = self._lin('Discriminator.zx1', c.LEN * c.dim_g + 512 + c.n_c, 512, torch.cat([out, z_out, labels], 1), LRELU)
+            return self._lin('Discriminator.Output', 512, 1, out).reshape(-1)
         out = self._conv_stack('Discriminator', x.reshape(n, c.C * c.LEN, 64, 64), c.C * c.LEN, grad_rows).reshape(n, c.flat)
         z = torch.cat([z_g, z_l.reshape(n, c.LEN * c.dim_l), labels], 1)
         z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l * c.LEN + c.n_c, 512, z, LRELU)

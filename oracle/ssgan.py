@@ -19,7 +19,7 @@ from . import tape as tp
 
 class Cfg(object):
     def __init__(self, batch_size=50, length=16, dim=32, dim_op=256, dim_g=128, dim_l=8, n_c=10,
-                 pos_mode='naive_mean_field', op_dyn_mode='res', channels=1, mode='local_ep', lamb=0.1):
+                 pos_mode='naive_mean_field', op_dyn_mode='res', channels=1, mode='local_ep', lamb=0.1, ali_mode='concat_x'):
         """channels=3, n_c=0, length=31, op_dyn_mode='res_w': ssgan_inference_chairs.py (RGB frames, no labels)"""
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
@@ -27,6 +27,7 @@ class Cfg(object):
         self.mode, self.lamb = mode, lamb              # 'local_ep' | 'local_epce-z' (+ LAMBDA * l2(real_x, G(q_z_g, q_z_l)), :549-552)
         # 'ali' | 'alice-z': ONE critic on the whole sequence, ALI_MODE = 'concat_x' (:407-449, :536-538, :553-558)
         self.seq_critic = mode in ('ali', 'alice-z')
+        self.ali_mode = ali_mode                       # 'concat_x' (:407-449) | 'concat_z' (:451-497)
         self.x_div = 256.0 if channels == 3 else 1.0      # chairs: real_x = 2*((x/256.)-.5) (:508); moving-MNIST: 2*(x-.5) (:514)
         self.S, self.output_dim = 64, channels * 64 * 64
         self.flat = 4 * 4 * 8 * dim
@@ -72,9 +73,16 @@ def init_params(cfg, seed=0):
     nm = 'Generator.Dynamic'
     lin(nm + '.Input', cfg.dim_l + cfg.dim_t, cfg.dim_op); lin(nm + '.1', cfg.dim_op, cfg.dim_op)
     lin(nm + '.Output', cfg.dim_op, cfg.dim_l); lin(nm + '.ZW', cfg.dim_l, cfg.dim_l)
-    conv('Discriminator.1', cfg.C * cfg.LEN if getattr(cfg, 'seq_critic', False) else cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
+    seq_x = getattr(cfg, 'seq_critic', False) and cfg.ali_mode == 'concat_x'
+    seq_z = getattr(cfg, 'seq_critic', False) and cfg.ali_mode == 'concat_z'
+    conv('Discriminator.1', cfg.C * cfg.LEN if seq_x else cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
     conv('Discriminator.4', 4 * d, 8 * d)
-    if getattr(cfg, 'seq_critic', False):
+    if seq_z:
+        P['Discriminator.5.Filters'] = N.conv_init(rng, 8 * d, cfg.dim_g, 4, 1)
+        P['Discriminator.5.Biases'] = np.zeros(cfg.dim_g, np.float32)
+        lin('Discriminator.z1', cfg.dim_g + cfg.dim_l * cfg.LEN + cfg.n_c, 512)
+        lin('Discriminator.zx1', cfg.LEN * cfg.dim_g + 512 + cfg.n_c, 512)
+    elif seq_x:
         lin('Discriminator.z1', cfg.dim_g + cfg.dim_l * cfg.LEN + cfg.n_c, 512)
         lin('Discriminator.zx1', cfg.flat + 512, 512)
     else:
@@ -213,7 +221,16 @@ def Discriminator(cfg, P, x, z_g, z_l, labels):              # :265-315
     return tp.reshape(N.Linear(P, 'Discriminator.Output', out), (cfg.B * cfg.LEN,))
 
 
-def SequenceDiscriminator(cfg, P, x, z_g, z_l, labels):      # :407-449 (ALI_MODE = 'concat_x'): frames as channels, one logit per sequence
+def SequenceDiscriminator(cfg, P, x, z_g, z_l, labels):
+    if cfg.ali_mode == 'concat_z':      # :451-497: per-frame conv stack, a 4x4 VALID conv to DIM_LATENT_G features per frame, concatenated
+        out = _conv_stack(cfg, P, 'Discriminator', tp.reshape(x, (cfg.B * cfg.LEN, cfg.C, 64, 64)))
+        out = tp.add(tp.conv2d(out, P['Discriminator.5.Filters'], 1, 'VALID'), tp.reshape(P['Discriminator.5.Biases'], (1, -1, 1, 1)))
+        out = tp.reshape(out, (cfg.B, cfg.LEN * cfg.dim_g))
+        z = tp.concat([z_g, tp.reshape(z_l, (cfg.B, cfg.LEN * cfg.dim_l)), labels], axis=1)
+        z_out = _lrelu(N.Linear(P, 'Discriminator.z1', z))
+        out = _lrelu(N.Linear(P, 'Discriminator.zx1', tp.concat([out, z_out, labels], axis=1)))
+        return tp.reshape(N.Linear(P, 'Discriminator.Output', out), (cfg.B,))
+    # :407-449 (ALI_MODE = 'concat_x'): frames as channels, one logit per sequence
     out = _conv_stack(cfg, P, 'Discriminator', tp.reshape(x, (cfg.B, cfg.C * cfg.LEN, 64, 64)))
     out = tp.reshape(out, (cfg.B, cfg.flat))
     z = tp.concat([z_g, tp.reshape(z_l, (cfg.B, cfg.LEN * cfg.dim_l)), labels], axis=1)

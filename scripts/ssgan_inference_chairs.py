@@ -8,7 +8,8 @@ from graphical_gan_amd import run
 from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
 
 DATASET = 'chairs'  # rotating chairs: 31 RGB views of 64x64 per object, no class labels
-MODE = 'local_ep'  # local_ep, local_epce-z, ali, alice-z (ALI_MODE 'concat_x'; 'concat_z' and '3dcnn' are not built)
+MODE = 'local_ep'  # local_ep, local_epce-z, ali, alice-z
+ALI_MODE = 'concat_x'  # concat_x, concat_z (the 3-D conv critic '3dcnn' is not built)
 POS_MODE = 'naive_mean_field'  # gsp, naive_mean_field, inverse, forward_inverse
 OP_DYN_MODE = 'res_w'  # res, res_w
 DIM_LATENT_G = 128  # global latent variable
@@ -32,5 +33,5 @@ if len(sys.argv) > 1:
     ITERS = int(sys.argv[1])
 SETTINGS = {k: v for k, v in dict(globals()).items() if k.isupper() and k != 'SETTINGS'}
 cfg = SSConfig(batch_size=BATCH_SIZE, length=LEN, dim=DIM, dim_op=DIM_OP, dim_g=DIM_LATENT_G, dim_l=DIM_LATENT_L, n_c=N_C,
-               pos_mode=POS_MODE, op_dyn_mode=OP_DYN_MODE, lr=LR, mode=MODE, lamb=LAMBDA, channels=CHANNELS, dataset=DATASET)
+               pos_mode=POS_MODE, op_dyn_mode=OP_DYN_MODE, lr=LR, mode=MODE, lamb=LAMBDA, ali_mode=ALI_MODE, channels=CHANNELS, dataset=DATASET)
 run.train(SETTINGS, cfg, model=StateSpaceGAN(cfg))

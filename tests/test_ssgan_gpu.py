@@ -8,13 +8,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10, mode='local_ep'):
+def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10, mode='local_ep', ali_mode='concat_x'):
     from graphical_gan_amd import tflib as lib, optim
     from graphical_gan_amd.engine import Trainer
     from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
     from oracle import ssgan as O
     kw = dict(batch_size=B, length=L, dim=dim, dim_op=16, dim_g=8, dim_l=4, pos_mode=pos_mode, op_dyn_mode=op_dyn_mode, channels=channels,
-              n_c=n_c, mode=mode)
+              n_c=n_c, mode=mode, ali_mode=ali_mode)
     ocfg = O.Cfg(**kw)
     P0 = O.init_params(ocfg, seed=0)
     rng = np.random.default_rng(5)
@@ -33,11 +33,13 @@ def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10, 
     ('naive_mean_field', 'res', 1, 10, 'local_ep'), ('gsp', 'res_w', 1, 10, 'local_ep'), ('inverse', 'res', 1, 10, 'local_ep'),
     ('naive_mean_field', 'res_w', 3, 0, 'local_ep'),            # ssgan_inference_chairs.py
     ('naive_mean_field', 'res', 1, 10, 'local_epce-z'),         # + LAMBDA * l2(real_x, rec_x)
-    ('naive_mean_field', 'res', 1, 10, 'ali'), ('gsp', 'res', 1, 10, 'alice-z')])      # one critic on the whole sequence (concat_x)
+    ('naive_mean_field', 'res', 1, 10, 'ali'), ('gsp', 'res', 1, 10, 'alice-z'),       # one critic on the whole sequence (concat_x)
+    ('naive_mean_field', 'res', 1, 10, 'ali:concat_z')])
 def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, n_c, mode):
     import torch
     from oracle import ssgan as O, tape as tp
-    ocfg, P0, cfg, tr = _mk(gpu, pos_mode, op_dyn_mode, False, channels=channels, n_c=n_c, mode=mode)
+    mode, _, ali_mode = mode.partition(':')
+    ocfg, P0, cfg, tr = _mk(gpu, pos_mode, op_dyn_mode, False, channels=channels, n_c=n_c, mode=mode, ali_mode=ali_mode or 'concat_x')
     feed = O.make_feed(ocfg, np.random.default_rng(3))
     Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
     oout = O.forward(ocfg, Pt, feed)
