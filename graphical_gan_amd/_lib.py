@@ -49,6 +49,8 @@ SIGNATURES = {
     'ggan_deconv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_gemm_workspace': (_Z, [_I, _I, _I]),
     'ggan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_mix_rbf_mmd2_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    'ggan_mix_rbf_mmd2_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'ggan_noise_fill': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'ggan_gmm_latent_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     'ggan_gmm_latent_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),

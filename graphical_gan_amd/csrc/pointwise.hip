@@ -551,6 +551,89 @@ __global__ __launch_bounds__(256) void noise_fill_k(const NoiseTable t, unsigned
     }
 }
 
+
+// ---- biased MMD^2 with a mixture of RBF kernels between two sets of codes (MODE vegan-mmd: tflib/objs/mmd.py:20-71,
+//      mix_rbf_mmd2(q_z, p_z), sigmas 2..80): k(a, b) = sum_s wt_s exp(-gamma_s ||a-b||^2), gamma_s = 1/(2 sigma_s^2),
+//      mmd2 = mean k(X,X) + mean k(Y,Y) - 2 mean k(X,Y).  The TF graph builds three Gram matrices and 18 exp maps; here the
+//      pairwise distances are formed on the fly.  One workgroup per row of Z = [X; Y] computes that row's weighted kernel sum
+//      (forward: into a per-row partial, summed in row order by the last stage) or its gradient row (backward). ----
+constexpr int kMmdMaxSigmas = 8;
+struct MmdParams {
+    const float* X;
+    const float* Y;
+    int m, n, d, ns;
+    float gamma[kMmdMaxSigmas], wt[kMmdMaxSigmas];
+};
+
+__device__ __forceinline__ const float* mmd_row(const MmdParams& P, int r) { return r < P.m ? P.X + (size_t)r * P.d : P.Y + (size_t)(r - P.m) * P.d; }
+
+// coefficient of k(z_r, z_j) in mmd2 seen from row r: 1/m^2 (both in X), 1/n^2 (both in Y), -1/(mn) (mixed: each unordered mixed
+// pair is visited from both sides, which makes the -2/(mn) of the definition)
+__device__ __forceinline__ float mmd_coef(const MmdParams& P, int r, int j) {
+    const bool rx = r < P.m, jx = j < P.m;
+    if (rx && jx) return 1.f / ((float)P.m * (float)P.m);
+    if (!rx && !jx) return 1.f / ((float)P.n * (float)P.n);
+    return -1.f / ((float)P.m * (float)P.n);
+}
+
+__global__ __launch_bounds__(256) void mmd2_rows_k(const MmdParams P, float* __restrict__ partial) {
+    __shared__ float sm[32];
+    const int r = blockIdx.x, tot = P.m + P.n;
+    const float* zr = mmd_row(P, r);
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < tot; j += 256) {
+        const float* zj = mmd_row(P, j);
+        float dist = 0.f;
+        for (int k = 0; k < P.d; ++k) {
+            const float t = zr[k] - zj[k];
+            dist = fmaf(t, t, dist);
+        }
+        float kv = 0.f;
+        for (int s2 = 0; s2 < P.ns; ++s2) kv += P.wt[s2] * expf(-P.gamma[s2] * dist);
+        acc += mmd_coef(P, r, j) * kv;
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[r] = t;
+}
+
+__global__ __launch_bounds__(256) void mmd2_final_k(const float* __restrict__ partial, int tot, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s2 = 0.f;
+        for (int r = 0; r < tot; ++r) s2 += partial[r];          // row order: deterministic
+        out[0] = s2;
+    }
+}
+
+// gradient row r: sum_j 2 * coef(r, j) * (-2 G_rj) (z_r - z_j) with G_rj = sum_s wt_s gamma_s exp(-gamma_s D_rj)
+// (the factor 2: the pair (r, j) enters the double sum as (r, j) and as (j, r))
+__global__ __launch_bounds__(256) void mmd2_bwd_k(const MmdParams P, const float* __restrict__ gout, float* __restrict__ dX,
+                                                  float* __restrict__ dY) {
+    __shared__ float cf[512];
+    const int r = blockIdx.x, tot = P.m + P.n;
+    const float* zr = mmd_row(P, r);
+    const float go = gout[0];
+    for (int j = threadIdx.x; j < tot; j += 256) {
+        const float* zj = mmd_row(P, j);
+        float dist = 0.f;
+        for (int k = 0; k < P.d; ++k) {
+            const float t = zr[k] - zj[k];
+            dist = fmaf(t, t, dist);
+        }
+        float gv = 0.f;
+        for (int s2 = 0; s2 < P.ns; ++s2) gv += P.wt[s2] * P.gamma[s2] * expf(-P.gamma[s2] * dist);
+        cf[j] = -4.f * mmd_coef(P, r, j) * gv * go;
+    }
+    __syncthreads();
+    float* dst = r < P.m ? (dX ? dX + (size_t)r * P.d : nullptr) : (dY ? dY + (size_t)(r - P.m) * P.d : nullptr);
+    if (!dst) return;
+    for (int k = threadIdx.x; k < P.d; k += 256) {
+        const float zv = zr[k];
+        float acc = 0.f;
+        for (int j = 0; j < tot; ++j) acc = fmaf(cf[j], zv - mmd_row(P, j)[k], acc);
+        dst[k] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -811,6 +894,33 @@ int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, c
     if (gx < 1) gx = 1;
     if (gx > 256) gx = 256;
     GGAN_LAUNCH("noise_fill", 0, 4.0 * tot, noise_fill_k, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, t, (unsigned long long*)state);
+    return 0;
+}
+
+static int mmd_params(MmdParams& P, const float* X, const float* Y, int m, int n, int d, const float* sigmas, const float* wts, int ns) {
+    if (!(X && Y && sigmas) || m <= 0 || n <= 0 || d <= 0 || ns <= 0 || ns > kMmdMaxSigmas || m + n > 512) return -1;
+    P.X = X; P.Y = Y; P.m = m; P.n = n; P.d = d; P.ns = ns;
+    for (int i = 0; i < ns; ++i) {
+        P.gamma[i] = 1.f / (2.f * sigmas[i] * sigmas[i]);
+        P.wt[i] = wts ? wts[i] : 1.f;
+    }
+    return 0;
+}
+
+int ggan_mix_rbf_mmd2_fwd(const float* X, const float* Y, int m, int n, int d, const float* sigmas, const float* wts, int ns,
+                          float* out, float* row_scratch, ggan_stream_t stream) {
+    MmdParams P;
+    GGAN_CHECK_ARG(mmd_params(P, X, Y, m, n, d, sigmas, wts, ns) == 0 && out && row_scratch, "bad argument");
+    GGAN_LAUNCH("mmd2_rows", 3.0 * (m + n) * (m + n) * d, 0, mmd2_rows_k, dim3(m + n), dim3(256), 0, (hipStream_t)stream, P, row_scratch);
+    GGAN_LAUNCH("mmd2_final", 0, 0, mmd2_final_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)row_scratch, m + n, out);
+    return 0;
+}
+
+int ggan_mix_rbf_mmd2_bwd(const float* X, const float* Y, int m, int n, int d, const float* sigmas, const float* wts, int ns,
+                          const float* gout, float* dX, float* dY, ggan_stream_t stream) {
+    MmdParams P;
+    GGAN_CHECK_ARG(mmd_params(P, X, Y, m, n, d, sigmas, wts, ns) == 0 && gout && (dX || dY), "bad argument");
+    GGAN_LAUNCH("mmd2_bwd", 5.0 * (m + n) * (m + n) * d, 0, mmd2_bwd_k, dim3(m + n), dim3(256), 0, (hipStream_t)stream, P, gout, dX, dY);
     return 0;
 }
 

@@ -814,6 +814,40 @@ class GmmLatent(Function):
         return (dz, dmu) + (None,) * (n_in - 2)
 
 
+class MixRbfMmd2(Function):
+    """biased MMD^2 between two sets of codes under a mixture of RBF kernels (tflib/objs/mmd.py:65-67) -> 0-dim tensor"""
+
+    @staticmethod
+    def forward(ctx, x, y, sigmas, wts):
+        x, y = _c(x), _c(y)
+        m, d = x.shape
+        n = y.shape[0]
+        assert y.shape[1] == d
+        ns = len(sigmas)
+        sg = (C.c_float * ns)(*[float(v) for v in sigmas])
+        wt = (C.c_float * ns)(*[float(v) for v in wts]) if wts is not None else None
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((m + n,), dtype=torch.float32, device=x.device)
+        check(_L().ggan_mix_rbf_mmd2_fwd(_p(x), _p(y), m, n, d, sg, wt, ns, _p(out), _p(scratch), _stream()), 'ggan_mix_rbf_mmd2_fwd')
+        ctx.sg, ctx.wt, ctx.ns = sg, wt, ns
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        m, d = x.shape
+        n = y.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if dx is None and dy is None:
+            return None, None, None, None
+        check(_L().ggan_mix_rbf_mmd2_bwd(_p(x), _p(y), m, n, d, ctx.sg, ctx.wt, ctx.ns, _p(_c(g)), _p(dx), _p(dy), _stream()),
+              'ggan_mix_rbf_mmd2_bwd')
+        return dx, dy, None, None
+
+
 class RowLerp(Function):
     """out[r,:] = x[r,:] + alpha[r]*(y[r,:]-x[r,:])  (the wali-gp interpolates)."""
 

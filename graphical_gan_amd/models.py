@@ -40,15 +40,18 @@ class Config(object):
         # reconstruction variants (gan_inference_cifar10.py:293-304, gmgan_inference_cifar10.py:399-403):
         #   alice-z: + l2(real_x, G(q_z));  alice-x: + l2(p_z, E(fake_x));  alice: both;  local_epce: gmgan + l2(real_x, G(q_z))
         #   vegan / vegan-wgan-gp (gan_inference_cifar10.py:192-222,305-322): the critic is an MLP on codes, + l2(real_x, G(q_z))
+        #   vegan-mmd (:327-329, tflib/objs/mmd.py): no critic at all -- lamb * MMD^2(q_z, p_z) + l2(real_x, G(q_z)), generator steps only
         assert self.mode in ('ali', 'local_ep', 'wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce', 'vegan',
-                             'vegan-wgan-gp')
+                             'vegan-wgan-gp', 'vegan-mmd')
         self.latent_critic = self.mode in ('vegan', 'vegan-wgan-gp')
         self.lamb = 1.0                                                  # LAMBDA (gan_inference_cifar10.py:62)
-        assert not (self.latent_critic and n_coms)
+        assert not ((self.latent_critic or self.mode == 'vegan-mmd') and n_coms)
         self.top = self.dim * 2 ** (self.nl - 1)
         self.flat = 16 * self.top
         self.output_dim = self.C * self.S * self.S
         self.critic_iters = 5 if self.mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else 1   # gan_inference_cifar10.py:53-59
+        if self.mode == 'vegan-mmd':
+            self.critic_iters = 0          # 'No discriminators' (:52-53)
         self.lr = lr if lr is not None else {'wali-gp': 1e-4, 'wali': 5e-5}.get(self.mode, 2e-4)
         self.beta1 = 0.5
         # critic steps evaluate the critic ONCE on [fake; real] (the critics of these scripts have no BatchNorm, so
@@ -350,6 +353,12 @@ class GraphicalGAN(object):
         out = dict(nets) if nets is not None else self.forward_nets(feed)
         if c.latent_critic:
             return self._forward_latent(feed, which, out)
+        if c.mode == 'vegan-mmd':
+            rec = 1. * lib.utils.distance.distance(out['real_x'], self.Generator(out['q_z']), 'l2')
+            gen_params, _ = self._var_lists()
+            gen_cost, gen_op = lib.objs.mmd.vegan_mmd(out['q_z'], out['p_z'], rec, gen_params, c.B, c.lamb, lr=c.lr, beta1=c.beta1)
+            out.update(rec_penalty=rec, gen_cost=gen_cost, gen_train_op=gen_op, disc_cost=None, disc_train_op=None)
+            return out
         real_x, q_z, p_z, fake_x = out['real_x'], out['q_z'], out['p_z'], out['fake_x']
         if c.K:
             onehot, q_k = feed['k_onehot'], out['q_k']

@@ -1,1 +1,1 @@
-from . import gan_inference  # noqa: F401
+from . import gan_inference, mmd  # noqa: F401

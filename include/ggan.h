@@ -206,6 +206,15 @@ int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
 
+/* Biased MMD^2 with a mixture of RBF kernels between two sets of codes X[m,d], Y[n,d] (MODE vegan-mmd:
+ * tflib/objs/mmd.py:20-71 mix_rbf_mmd2(q_z, p_z, sigmas, wts, biased=True)): k(a,b) = sum_s wt_s exp(-||a-b||^2 / (2 sigma_s^2)),
+ * out = mean k(X,X) + mean k(Y,Y) - 2 mean k(X,Y).  sigmas / wts are HOST arrays (wts may be NULL = all 1), ns <= 8, m + n <= 512.
+ * row_scratch: m + n floats of device scratch.  Backward: gout = dL/d(out) (device scalar), dX / dY may be NULL. */
+int ggan_mix_rbf_mmd2_fwd(const float* X, const float* Y, int m, int n, int d, const float* sigmas, const float* wts, int ns,
+                          float* out, float* row_scratch, ggan_stream_t stream);
+int ggan_mix_rbf_mmd2_bwd(const float* X, const float* Y, int m, int n, int d, const float* sigmas, const float* wts, int ns,
+                          const float* gout, float* dX, float* dY, ggan_stream_t stream);
+
 /* All the noise of one session.run in one launch: up to GGAN_NOISE_MAX device tensors, each filled with kind 0 = a + b*N(0,1),
  * 1 = uniform [a, b), 2 = one-hot rows of width `widths[i]` with a uniformly drawn index (the prior's k ~ Cat(1/K)).  Replaces
  * tf.random_normal / tf.random_uniform / Categorical.sample + one_hot of the scripts (gmgan_inference_cifar10.py:115-120,344-346;

@@ -78,6 +78,25 @@ def latent_gradient_penalty(critic, q_z, p_z, alpha, lam=10.0):
     return tp.scale(tp.reduce_mean(tp.square(tp.add(slopes, -1.0))), lam)
 
 
+def mix_rbf_mmd2(X, Y, sigmas=(2., 5., 10., 20., 40., 80.)):
+    """tflib/objs/mmd.py:20-67 (biased=True, wts = 1): Gram matrices from the matmul form -2*X.Y^T + |x|^2 + |y|^2."""
+    def sq(a):
+        return tp.reduce_sum(tp.square(a), (1,), keepdims=True)
+    def gram(a, b):
+        return tp.add(tp.add(tp.scale(tp.matmul(a, tp.transpose(b, (1, 0))), -2.0), sq(a)), tp.transpose(sq(b), (1, 0)))
+    dxx, dxy, dyy = gram(X, X), gram(X, Y), gram(Y, Y)
+    kxx = kxy = kyy = None
+    for sg in sigmas:
+        gm = 1.0 / (2.0 * sg * sg)
+        exx, exy, eyy = (tp.exp(tp.scale(d, -gm)) for d in (dxx, dxy, dyy))
+        kxx = exx if kxx is None else tp.add(kxx, exx)
+        kxy = exy if kxy is None else tp.add(kxy, exy)
+        kyy = eyy if kyy is None else tp.add(kyy, eyy)
+    m, n = X.v.shape[0], Y.v.shape[0]
+    return tp.add(tp.add(tp.scale(tp.reduce_sum(kxx), 1.0 / (m * m)), tp.scale(tp.reduce_sum(kyy), 1.0 / (n * n))),
+                  tp.scale(tp.reduce_sum(kxy), -2.0 / (m * n)))
+
+
 def wali_costs(disc_fake, disc_real):
     """tflib/objs/gan_inference.py:5-6 (the generator cost really is -mean(fake) - mean(real) there)."""
     gen = tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.neg(tp.reduce_mean(disc_real)))

@@ -67,6 +67,11 @@ def forward(cfg, P, feed, mode='ali'):
     def critic(x, z):
         return N.Discriminator(cfg, P, x, z)
 
+    if mode == 'vegan-mmd':                         # gan_inference_cifar10.py:327-329: no critic
+        rec = J.distance(real_x, N.Generator(cfg, P, q_z), 'l2')
+        gen_cost = tp.add(tp.scale(J.mix_rbf_mmd2(q_z, p_z), 1.0), rec)
+        out.update(gen_cost=gen_cost, disc_cost=None, rec_penalty=rec)
+        return out
     if mode in ('vegan', 'vegan-wgan-gp'):          # gan_inference_cifar10.py:272-275,305-322: the critic discriminates codes
         noise = lambda tag: [feed['dn_%s%d' % (tag, i)] for i in range(4)]
         d_real = N.LatentDiscriminator(cfg, P, p_z, noise('r'))
@@ -134,7 +139,7 @@ class Trainer(object):
         else:
             self.gen_opt = J.Adam(gen_names, **hp)
             self.disc_opt = J.Adam(disc_names, **hp)
-        self.critic_iters = 5 if mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else 1   # gan_inference_cifar10.py:53-59
+        self.critic_iters = 5 if mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else (0 if mode == 'vegan-mmd' else 1)   # :52-59
 
     def _run(self, feed, which):
         Pt = {k: tp.T(v) for k, v in self.P.items()}

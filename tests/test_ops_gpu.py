@@ -885,3 +885,23 @@ def test_optimizer_path_properties_at_full_size(gpu):
     closed = -lr * g.double() / (g.double().abs() + eps / np.sqrt(1 - b2))
     assert float(((theta.double() - th0.double()) - closed).abs().max()) < 5e-7
     assert torch.equal(theta[::7], th0[::7])
+
+
+@pytest.mark.parametrize('m,n,d', [(64, 64, 128), (5, 9, 16)])
+def test_mix_rbf_mmd2_fused_op(gpu, m, n, d):
+    """ggan_mix_rbf_mmd2_fwd/bwd (MODE vegan-mmd) against the oracle's Gram-matrix restatement of tflib/objs/mmd.py: value and both
+    gradients; MMD^2(X, X) == 0."""
+    import torch
+    from graphical_gan_amd import tflib as lib
+    from oracle import objs as J, tape as tp
+    rng = np.random.default_rng(m + d)
+    x, y = rng.standard_normal((m, d)) * 1.5, rng.standard_normal((n, d)) + 0.3
+    X, Y = tp.T(x), tp.T(y)
+    ref = J.mix_rbf_mmd2(X, Y)
+    rx, ry = tp.grad(ref, [X, Y])
+    tx, ty = _t(x, gpu).requires_grad_(True), _t(y, gpu).requires_grad_(True)
+    v = lib.objs.mmd.mix_rbf_mmd2(tx, ty)
+    assert abs(float(v.detach()) - float(ref.v)) <= 2e-5 * max(1.0, abs(float(ref.v)))
+    dx, dy = torch.autograd.grad(v * 3.0, [tx, ty])
+    assert _rel(dx.cpu().numpy(), 3.0 * rx.v) < 1e-4 and _rel(dy.cpu().numpy(), 3.0 * ry.v) < 1e-4
+    assert abs(float(lib.objs.mmd.mix_rbf_mmd2(tx.detach(), tx.detach()))) < 1e-5

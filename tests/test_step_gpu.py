@@ -422,3 +422,42 @@ def test_full_size_training_is_bitwise_reproducible(gpu, mode, K):
         finals.append({k: v.copy() for k, v in tr.get_params().items()})
     for k in finals[0]:
         assert np.array_equal(finals[0][k], finals[1][k]), k
+
+
+def test_vegan_mmd_mode_generator_only_steps(gpu):
+    """MODE vegan-mmd (gan_inference_cifar10.py:327-329, CRITIC_ITERS = 0): no critic -- cost, every Generator / Extractor gradient
+    and a 4-iteration trajectory (generator steps only, from iteration 1) against the oracle."""
+    import torch
+    from oracle import step as S, tape as tp
+    ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, 'vegan-mmd', 8, 16, True, True, gpu)
+    assert cfg.critic_iters == 0
+    feed = S.make_feed(ocfg, np.random.default_rng(11), 'vegan-mmd')
+    Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
+    oout = S.forward(ocfg, Pt, feed, 'vegan-mmd')
+    tr.set_feed(feed)
+    out = tr.model.forward(tr.feed, 'gen')
+    assert out['disc_cost'] is None
+    oc, c = float(oout['gen_cost'].v), float(out['gen_cost'].detach())
+    assert abs(c - oc) <= 1e-5 * max(1.0, abs(oc)), (c, oc)
+    opt = out['gen_train_op'].optimizer
+    names = [p.param_name for p in opt.params]
+    grads = torch.autograd.grad(out['gen_cost'], opt.params, allow_unused=True)
+    ogs = tp.grad(oout['gen_cost'], [Pt[n] for n in names])
+    gmax = max(np.abs(og.v).max() for og in ogs if og is not None)
+    for n, g, og in zip(names, grads, ogs):
+        if og is None:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        err = np.abs(g.cpu().numpy().reshape(og.v.shape) - og.v).max()
+        assert err <= 1e-4 * max(np.abs(og.v).max(), 1e-2 * gmax), (n, err)
+    # (a fresh Trainer: the autograd graph built above on the default stream must not be alive while the step graph is captured)
+    del out, grads, opt
+    ocfg, P0, cfg, tr = _mk('cifar10', 8, 0, 'vegan-mmd', 8, 16, True, True, gpu)
+    otr = S.Trainer(ocfg, P0, 'vegan-mmd', np.float64)
+    feeds = [S.make_feed(ocfg, np.random.default_rng(200 + i), 'vegan-mmd') for i in range(6)]
+    fo, fp = iter(feeds), iter(feeds)
+    for it in range(4):
+        ro, rp = otr.iteration(it, fo), tr.iteration(it, fp)
+        assert set(ro) == set(rp) == ({'gen_cost'} if it > 0 else set())
+        for k in ro:
+            assert abs(float(rp[k]) - ro[k]) <= 2e-3 * max(1.0, abs(ro[k])), (it, k, float(rp[k]), ro[k])
