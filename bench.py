@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--dataset', default='cifar10')
     ap.add_argument('--mode', default='ali', help="ali | wali-gp | local_ep (gmgan, N_COMS=30)")
+    ap.add_argument('--ssgan-mode', default='local_ep', help="moving_mnist / chairs: local_ep | local_epce-z | ali | alice-z, optionally "
+                    "':concat_x' | ':concat_z' | ':3dcnn' (the sequence critic of ali / alice-z)")
     ap.add_argument('--n-coms', type=int, default=None, help='mixture components of the gmgan prior (default: the script value, 30 / 50 / 100)')
     ap.add_argument('--batch-size', type=int, default=None, help='per-GPU minibatch (default 64; 32 sequences for moving_mnist)')
     ap.add_argument('--no-graph', action='store_true')
@@ -147,12 +149,13 @@ def main():
     if ssgan:                                          # BASELINE configs[4]: ssgan_inference_moving_mnist.py, T=16
         from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
         K = 0
-        args.mode = 'local_ep'
+        args.mode, _, ali_mode = args.ssgan_mode.partition(':')
+        skw = dict(mode=args.mode, ali_mode=ali_mode or 'concat_x')
         if args.dataset == 'chairs':                   # ssgan_inference_chairs.py: 31 RGB views, no labels, res_w operator
             cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse, length=31, n_c=0, channels=3, op_dyn_mode='res_w',
-                           dataset='chairs')
+                           dataset='chairs', **skw)
         else:
-            cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse)
+            cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse, **skw)
         model = StateSpaceGAN(cfg)
         tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank, model=model)
     else:

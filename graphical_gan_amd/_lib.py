@@ -49,6 +49,9 @@ SIGNATURES = {
     'ggan_deconv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_gemm_workspace': (_Z, [_I, _I, _I]),
     'ggan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_conv3d_out_shape': (_I, [_P, _P]),
+    'ggan_im2col3d': (_I, [_P, _P, _P, _P]),
+    'ggan_col2im3d': (_I, [_P, _P, _P, _P]),
     'ggan_mix_rbf_mmd2_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'ggan_mix_rbf_mmd2_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'ggan_noise_fill': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
@@ -59,6 +62,7 @@ SIGNATURES = {
     'ggan_linear_bwd_data_act': (_I, [_I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_linear_bwd_weight_act': (_I, [_I, _I, _I, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_colsum': (_I, [_P, _P, _I, _I, _P]),
+    'ggan_colsum_tall': (_I, [_P, _P, _I, _I, _P, _Z, _P]),
     'ggan_chansum': (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     'ggan_bn_fwd_train': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),
     'ggan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

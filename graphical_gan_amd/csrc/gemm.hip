@@ -344,10 +344,13 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
             // a workgroup's k-step is latency-bound (~0.6 us measured), so spread K over the idle CUs down to one
             // BK-step per split; measured optimum on the hot path's shapes (tools/bench_gemm.py)
             const int base = gx * gy;
-            sk = 256 / base;
+            // (long reductions -- the Conv3D patch-matrix filter gradients, K = 10^4..10^6 rows: four workgroups per CU and up to
+            // 256 slabs, so each workgroup's serial chain stays ~10^3 rows)
+            const bool tall = K >= 16384;
+            sk = (tall ? 1024 : 256) / base;
             const int max_sk = K / BK;
             if (sk > max_sk) sk = max_sk;
-            if (sk > 64) sk = 64;
+            if (sk > (tall ? 256 : 64)) sk = tall ? 256 : 64;
         }
         if (sk < 1) sk = 1;
         while (sk > 1 && (size_t)sk * P.out_elems * sizeof(float) > ws_bytes) sk /= 2;

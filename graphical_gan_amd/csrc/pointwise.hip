@@ -91,6 +91,21 @@ __global__ void colsum_k(const float* __restrict__ x, float* __restrict__ out, i
     out[c] = s;
 }
 
+// tall matrices (the patch-matrix layers of Conv3D: 10^5..10^6 rows): block (column tile of 64, slab p) sums a contiguous range of rows
+// with 4 row lanes, the lanes are added through LDS in a fixed order, part[c*P + p]; chansum_final_k adds the slabs in order.
+__global__ void __launch_bounds__(256) colsum_part_k(const float* __restrict__ x, float* __restrict__ part, int rows, int cols,
+                                                     int rows_per_slab, int P) {
+    __shared__ float sm[4][64];
+    const int lc = threadIdx.x & 63, lr = threadIdx.x >> 6, c = blockIdx.x * 64 + lc, p = blockIdx.y;
+    const int r0 = p * rows_per_slab, r1 = min(rows, r0 + rows_per_slab);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + lr; r < r1; r += 4) s += x[(size_t)r * cols + c];
+    sm[lr][lc] = s;
+    __syncthreads();
+    if (lr == 0 && c < cols) part[(size_t)c * P + p] = (sm[0][lc] + sm[1][lc]) + (sm[2][lc] + sm[3][lc]);
+}
+
 // per-channel sum over (n, hw) of NCHW: block (c, p) sums images p, p+P, ... of channel c (each image-channel plane is HW
 // contiguous floats: float4 loads when HW % 4 == 0) into part[c*P + p]; launched with P = 1 (one block per channel).
 __global__ void chansum_part_k(const float* __restrict__ x, float* __restrict__ part, int N, int C, int HW, int P) {
@@ -687,6 +702,21 @@ int ggan_row_lerp(const float* x, const float* y, const float* alpha, float* out
 int ggan_colsum(const float* x, float* out, int rows, int cols, ggan_stream_t stream) {
     GGAN_CHECK_ARG(x && out && rows > 0 && cols > 0, "bad argument");
     GGAN_LAUNCH("colsum", 0, 4.0 * rows * cols, colsum_k, dim3(cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, x, out, rows, cols);
+    return 0;
+}
+
+int ggan_colsum_tall(const float* x, float* out, int rows, int cols, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && out && rows > 0 && cols > 0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = cdiv(cols, 64);
+    int P = cdiv(1024, tiles);                       // ~1024 workgroups, at least 64 rows per slab
+    if (P > rows / 64) P = rows / 64;
+    ws = ws_scratch(ws, ws_bytes);
+    if (P < 2 || !ws || (size_t)cols * P * sizeof(float) > ws_bytes) return ggan_colsum(x, out, rows, cols, stream);
+    const int rows_per_slab = cdiv(rows, P);
+    float* part = (float*)ws;
+    GGAN_LAUNCH("colsum_tall", 0, 4.0 * rows * cols, colsum_part_k, dim3(tiles, P), dim3(256), 0, s, x, part, rows, cols, rows_per_slab, P);
+    GGAN_LAUNCH("chansum_final", 0, 4.0 * cols * P, chansum_final_k, dim3(cdiv(cols, 64)), dim3(64), 0, s, (const float*)part, out, cols, P);
     return 0;
 }
 

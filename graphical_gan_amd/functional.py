@@ -299,6 +299,12 @@ class ChanSum(Function):
         return g.view(1, -1, *([1] * (len(shp) - 2))).expand(shp).contiguous()
 
 
+# Linear backward on a tall operand (the Conv3D patch matrices, 10^4..10^6 rows): the single-launch fused paths below keep the whole
+# row range in one workgroup per output tile, right for minibatch-sized operands and serial for these -- tall operands take the split-K
+# GEMM and the slab column sum instead.
+TALL_ROWS = 8192
+
+
 class ColSum(Function):
     """out[c] = sum_r x[r,c]  (BiasAddGrad of Linear)."""
 
@@ -307,7 +313,11 @@ class ColSum(Function):
         x = _c(x)
         rows, cols = x.shape
         out = torch.empty((cols,), dtype=torch.float32, device=x.device)
-        check(_L().ggan_colsum(_p(x), _p(out), rows, cols, _stream()), 'ggan_colsum')
+        if rows >= TALL_ROWS:
+            ws = workspace(x.device)
+            check(_L().ggan_colsum_tall(_p(x), _p(out), rows, cols, _p(ws), ws.numel(), _stream()), 'ggan_colsum_tall')
+        else:
+            check(_L().ggan_colsum(_p(x), _p(out), rows, cols, _stream()), 'ggan_colsum')
         ctx.rows = rows
         return out
 
@@ -341,7 +351,7 @@ class Gemm(Function):
         a, b, out = ctx.saved_tensors
         ta, tb = ctx.ta, ctx.tb
         if (ctx.act != ACT_NONE and not ta and not tb and not torch.is_grad_enabled() and FUSED_CONV_BWD
-                and a.shape[1] <= 1024):
+                and a.shape[1] <= 1024 and a.shape[0] < TALL_ROWS):
             # (measured, tools/bench_gemm.py: for the long-K layers the masked operand loads cost more than the separate
             # act_bwd pass they replace, 27-48 us vs 26-39 us; for K <= 1024 the fused pair wins)
             return _fused_linear_backward(ctx, g, a, b, out)
@@ -349,7 +359,7 @@ class Gemm(Function):
             g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
         da = db = dbias = None
         if (ctx.needs_input_grad[1] and not tb and ctx.has_bias and ctx.needs_input_grad[2]
-                and not torch.is_grad_enabled()):
+                and not torch.is_grad_enabled() and g.shape[0] < TALL_ROWS):
             db, dbias = gemm_colsum_(a, g, not ta)                             # dW and db in ONE launch
         else:
             if ctx.needs_input_grad[1]:
@@ -846,6 +856,57 @@ class MixRbfMmd2(Function):
         check(_L().ggan_mix_rbf_mmd2_bwd(_p(x), _p(y), m, n, d, ctx.sg, ctx.wt, ctx.ns, _p(_c(g)), _p(dx), _p(dy), _stream()),
               'ggan_mix_rbf_mmd2_bwd')
         return dx, dy, None, None
+
+
+def _dims3(x_shape, fl, fs, Co, stride_len, stride):
+    N, L, H, W, Ci = x_shape
+    dims = (C.c_int * 10)(N, L, H, W, Ci, Co, fl, fs, int(stride_len), int(stride))
+    out3 = (C.c_int * 3)()
+    check(_L().ggan_conv3d_out_shape(dims, out3), 'ggan_conv3d_out_shape')
+    return dims, tuple(out3)
+
+
+class Im2Col3d(Function):
+    """col[N*Lo*Ho*Wo, fl*fs*fs*Ci] of an NDHWC volume (SAME padding, strides (stride_len, stride, stride)); adjoint: Col2Im3d."""
+
+    @staticmethod
+    def forward(ctx, x, fl, fs, stride_len, stride):
+        x = _c(x)
+        dims, (Lo, Ho, Wo) = _dims3(x.shape, fl, fs, 1, stride_len, stride)
+        col = torch.empty((x.shape[0] * Lo * Ho * Wo, fl * fs * fs * x.shape[4]), dtype=torch.float32, device=x.device)
+        check(_L().ggan_im2col3d(dims, _p(x), _p(col), _stream()), 'ggan_im2col3d')
+        ctx.args = (tuple(x.shape), fl, fs, stride_len, stride)
+        return col
+
+    @staticmethod
+    def backward(ctx, g):
+        return Col2Im3d.apply(g, *ctx.args), None, None, None, None
+
+
+class Col2Im3d(Function):
+    @staticmethod
+    def forward(ctx, col, x_shape, fl, fs, stride_len, stride):
+        col = _c(col)
+        dims, _ = _dims3(x_shape, fl, fs, 1, stride_len, stride)
+        gx = torch.empty(x_shape, dtype=torch.float32, device=col.device)
+        check(_L().ggan_col2im3d(dims, _p(col), _p(gx), _stream()), 'ggan_col2im3d')
+        ctx.args = (fl, fs, stride_len, stride)
+        return gx
+
+    @staticmethod
+    def backward(ctx, g):
+        return Im2Col3d.apply(g, *ctx.args), None, None, None, None, None
+
+
+def conv3d(x, w, bias, stride_len, stride, act=ACT_NONE, alpha=0.2):
+    """act(conv3d(x[N,L,H,W,Ci], w[fl,fs,fs,Ci,Co], strides (sl,s,s), SAME) + bias)  (tflib/ops/conv3d.py:33-48): the patch matrix
+    times the filter read in place as a [K, Co] matrix, on the MFMA GEMM; every derivative is again im2col / col2im / Gemm."""
+    fl, fs, fs2, Ci, Co = w.shape
+    assert x.dim() == 5 and fs == fs2 and x.shape[4] == Ci, (tuple(x.shape), tuple(w.shape))
+    _, (Lo, Ho, Wo) = _dims3(x.shape, fl, fs, Co, stride_len, stride)
+    col = Im2Col3d.apply(x, fl, fs, stride_len, stride)
+    y = Gemm.apply(col, w.reshape(fl * fs * fs * Ci, Co), bias.reshape(-1) if bias is not None else None, False, False, act, alpha)
+    return y.view(x.shape[0], Lo, Ho, Wo, Co)
 
 
 class RowLerp(Function):

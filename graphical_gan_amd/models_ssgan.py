@@ -33,9 +33,11 @@ class SSConfig(object):
         self.dataset = dataset
         assert mode in ('local_ep', 'local_epce-z', 'ali', 'alice-z'), mode
         self.mode, self.lamb = mode, lamb                      # *-z: + LAMBDA * l2(real_x, G(q_z_g, q_z_l, real_y)) (:549-558)
-        # MODE ali / alice-z: ONE critic on the whole sequence (ALI_MODE = 'concat_x', :407-449; 'concat_z' / '3dcnn' are not built)
+        # MODE ali / alice-z: ONE critic on the whole sequence (ALI_MODE = 'concat_x' :407-449 | 'concat_z' :451-497 | '3dcnn' :352-405)
         self.seq_critic = mode in ('ali', 'alice-z')
-        assert ali_mode in ('concat_x', 'concat_z'), ali_mode
+        assert ali_mode in ('concat_x', 'concat_z', '3dcnn'), ali_mode
+        if self.seq_critic and ali_mode == '3dcnn':   # the script hard-codes one input channel and the LEN 4 / 16 stride plans
+            assert length in (4, 16) and channels == 1, (length, channels)
         self.ali_mode = ali_mode
         self.B, self.LEN, self.dim, self.dim_op = batch_size, length, dim, dim_op
         self.dim_g, self.dim_l, self.dim_t, self.n_c = dim_g, dim_l, dim_l, n_c
@@ -217,6 +219,16 @@ class StateSpaceGAN(object):
         """ALI_MODE = 'concat_x' (:407-449): the frames of a sequence as input channels, one logit per sequence; works on any
         number of (sequence, z_g, z_l, labels) rows (the critic step hands it [fake; real])"""
         c, n = self.cfg, x.shape[0]
+        if c.ali_mode == '3dcnn':        # :352-405: the sequence as an NLHWC volume (one channel: the transpose is a reshape)
+            out, cin, s24 = x.reshape(n, c.LEN, 64, 64, 1), 1, (2 if c.LEN == 16 else 1)
+            for i, (cout, sl) in enumerate(((c.dim, 2), (2 * c.dim, s24), (4 * c.dim, 2), (8 * c.dim, s24))):
+                out = lib.ops.conv3d.Conv3D('Discriminator.%d' % (i + 1), 4, cin, cout, 4, out, stride=2, stride_len=sl,
+                                            activation=LRELU if c.fuse else None)
+                out, cin = (out if c.fuse else lib.ops.act.LeakyReLU(out)), cout
+            z = torch.cat([z_g, z_l.reshape(n, c.LEN * c.dim_l), labels], 1)
+            z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l * c.LEN + c.n_c, 512, z, LRELU)
+            out = self._lin('Discriminator.zx1', c.flat + 512, 512, (out.reshape(n, c.flat), z_out), LRELU)
+            return self._lin('Discriminator.Output', 512, 1, out).reshape(-1)
         if c.ali_mode == 'concat_z':     # :451-497: per-frame conv stack + a 4x4 VALID conv to DIM_LATENT_G features per frame
             fr = None if grad_rows is None else grad_rows * c.LEN
             out = self._conv_stack('Discriminator', x.reshape(n * c.LEN, c.C, 64, 64), c.C, fr)

@@ -1,1 +1,1 @@
-from . import linear, conv2d, deconv2d, batchnorm, act  # noqa: F401
+from . import linear, conv2d, deconv2d, conv3d, batchnorm, act  # noqa: F401

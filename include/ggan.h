@@ -123,6 +123,8 @@ int ggan_gemm_colsum(int ta, int M, int N, int K, const float* A, const float* B
                      void* ws, size_t ws_bytes, ggan_stream_t stream);
 /* out[c] = sum_r x[r,c] over a [rows,cols] matrix (BiasAddGrad of Linear). */
 int ggan_colsum(const float* x, float* out, int rows, int cols, ggan_stream_t stream);
+/* the same sum for tall matrices (Conv3D bias gradients: 10^5..10^6 rows): row slabs + a fixed-order second stage; ws = scratch */
+int ggan_colsum_tall(const float* x, float* out, int rows, int cols, void* ws, size_t ws_bytes, ggan_stream_t stream);
 /* out[c] = sum_{n,hw} x[n,c,hw] (BiasAddGrad NCHW).  ws: optional scratch (>= 4 KiB * C) enabling a chip-wide
  * two-stage reduction; with ws == NULL one workgroup per channel is used. */
 int ggan_chansum(const float* x, float* out, int N, int C, int HW, void* ws, size_t ws_bytes, ggan_stream_t stream);
@@ -205,6 +207,17 @@ int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const
 /* loss[0] (+)= weight*mean(x); bwd gx[i] = gloss[0]*weight/n  (wali_gp, gan_inference.py:29-30). */
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
+
+/* Conv3D of the '3dcnn' sequence critic (tflib/ops/conv3d.py:6-51: tf.nn.conv3d, data NDHWC [N,L,H,W,C], filter [fl,fs,fs,in,out],
+ * strides (stride_len, stride, stride), SAME padding; ssgan_inference_moving_mnist.py:352-405).  The filter is already the [K, Co]
+ * operand of a GEMM (K = fl*fs*fs*in, ordered (dl,dh,dw,ci)), so the layer is ggan_im2col3d followed by ggan_gemm (bias / activation in
+ * its epilogue); the filter gradient is ggan_gemm(col^T, gy) and the data gradient ggan_col2im3d(ggan_gemm(gy, W^T)).
+ * dims10 = {N, L, H, W, Ci, Co, fl, fs, stride_len, stride} (host array).
+ *   col [N*Lo*Ho*Wo, K]: col[(n,ol,oh,ow)][(dl,dh,dw,ci)] = x[n, ol*sl+dl-pl, oh*s+dh-ph, ow*s+dw-pw, ci], 0 in the padding
+ *   ggan_col2im3d is its adjoint (a gather: deterministic). */
+int ggan_conv3d_out_shape(const int* dims10, int* lo_ho_wo);
+int ggan_im2col3d(const int* dims10, const float* x, float* col, ggan_stream_t stream);
+int ggan_col2im3d(const int* dims10, const float* col, float* gx, ggan_stream_t stream);
 
 /* Biased MMD^2 with a mixture of RBF kernels between two sets of codes X[m,d], Y[n,d] (MODE vegan-mmd:
  * tflib/objs/mmd.py:20-71 mix_rbf_mmd2(q_z, p_z, sigmas, wts, biased=True)): k(a,b) = sum_s wt_s exp(-||a-b||^2 / (2 sigma_s^2)),

@@ -140,3 +140,61 @@ def adam_update(theta, g, m, v, t, lr, beta1, beta2, eps=1e-8):
     lr_t = lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
     theta = theta - lr_t * m / (np.sqrt(v) + eps)
     return theta, m, v
+
+
+def conv3d_geometry(n, k, stride):
+    """SAME: (out, pad_before)"""
+    o = -(-n // stride)
+    t = max((o - 1) * stride + k - n, 0)
+    return o, t // 2
+
+
+def conv3d(x, w, stride_len, stride):
+    """tf.nn.conv3d, NDHWC, SAME (tflib/ops/conv3d.py:33-39).  x [N,L,H,W,Ci], w [fl,fs,fs,Ci,Co]."""
+    N, L, H, W, Ci = x.shape
+    fl, fs, _, _, Co = w.shape
+    (Lo, pl), (Ho, ph), (Wo, pw) = conv3d_geometry(L, fl, stride_len), conv3d_geometry(H, fs, stride), conv3d_geometry(W, fs, stride)
+    xp = np.zeros((N, (Lo - 1) * stride_len + fl, (Ho - 1) * stride + fs, (Wo - 1) * stride + fs, Ci), dtype=x.dtype)
+    xp[:, pl:pl + L, ph:ph + H, pw:pw + W] = x[:, :xp.shape[1] - pl, :xp.shape[2] - ph, :xp.shape[3] - pw]
+    y = np.zeros((N, Lo, Ho, Wo, Co), dtype=x.dtype)
+    for dl in range(fl):
+        for dh in range(fs):
+            for dw in range(fs):
+                patch = xp[:, dl:dl + (Lo - 1) * stride_len + 1:stride_len, dh:dh + (Ho - 1) * stride + 1:stride,
+                           dw:dw + (Wo - 1) * stride + 1:stride]
+                y += patch @ w[dl, dh, dw]
+    return y
+
+
+def conv3d_bwd_data(gy, w, in_shape, stride_len, stride):
+    N, L, H, W, Ci = in_shape
+    fl, fs, _, _, Co = w.shape
+    _, Lo, Ho, Wo, _ = gy.shape
+    pl, ph, pw = conv3d_geometry(L, fl, stride_len)[1], conv3d_geometry(H, fs, stride)[1], conv3d_geometry(W, fs, stride)[1]
+    gxp = np.zeros((N, (Lo - 1) * stride_len + fl, (Ho - 1) * stride + fs, (Wo - 1) * stride + fs, Ci), dtype=gy.dtype)
+    for dl in range(fl):
+        for dh in range(fs):
+            for dw in range(fs):
+                gxp[:, dl:dl + (Lo - 1) * stride_len + 1:stride_len, dh:dh + (Ho - 1) * stride + 1:stride,
+                    dw:dw + (Wo - 1) * stride + 1:stride] += gy @ w[dl, dh, dw].T
+    gx = np.zeros(in_shape, dtype=gy.dtype)
+    src = gxp[:, pl:pl + L, ph:ph + H, pw:pw + W]
+    gx[:, :src.shape[1], :src.shape[2], :src.shape[3]] = src
+    return gx
+
+
+def conv3d_bwd_filter(x, gy, fl, fs, stride_len, stride):
+    N, L, H, W, Ci = x.shape
+    _, Lo, Ho, Wo, Co = gy.shape
+    pl, ph, pw = conv3d_geometry(L, fl, stride_len)[1], conv3d_geometry(H, fs, stride)[1], conv3d_geometry(W, fs, stride)[1]
+    xp = np.zeros((N, (Lo - 1) * stride_len + fl, (Ho - 1) * stride + fs, (Wo - 1) * stride + fs, Ci), dtype=x.dtype)
+    xp[:, pl:pl + L, ph:ph + H, pw:pw + W] = x[:, :xp.shape[1] - pl, :xp.shape[2] - ph, :xp.shape[3] - pw]
+    gw = np.zeros((fl, fs, fs, Ci, Co), dtype=x.dtype)
+    for dl in range(fl):
+        for dh in range(fs):
+            for dw in range(fs):
+                patch = xp[:, dl:dl + (Lo - 1) * stride_len + 1:stride_len, dh:dh + (Ho - 1) * stride + 1:stride,
+                           dw:dw + (Wo - 1) * stride + 1:stride]
+                gw[dl, dh, dw] = np.tensordot(patch, gy, axes=([0, 1, 2, 3], [0, 1, 2, 3]))
+    return gw
+

@@ -27,7 +27,8 @@ class Cfg(object):
         self.mode, self.lamb = mode, lamb              # 'local_ep' | 'local_epce-z' (+ LAMBDA * l2(real_x, G(q_z_g, q_z_l)), :549-552)
         # 'ali' | 'alice-z': ONE critic on the whole sequence, ALI_MODE = 'concat_x' (:407-449, :536-538, :553-558)
         self.seq_critic = mode in ('ali', 'alice-z')
-        self.ali_mode = ali_mode                       # 'concat_x' (:407-449) | 'concat_z' (:451-497)
+        self.ali_mode = ali_mode                       # 'concat_x' (:407-449) | 'concat_z' (:451-497) | '3dcnn' (:352-405)
+        assert ali_mode != '3dcnn' or (not self.seq_critic) or (length in (4, 16) and channels == 1), 'the 3dcnn critic is LEN 4/16, 1 channel'
         self.x_div = 256.0 if channels == 3 else 1.0      # chairs: real_x = 2*((x/256.)-.5) (:508); moving-MNIST: 2*(x-.5) (:514)
         self.S, self.output_dim = 64, channels * 64 * 64
         self.flat = 4 * 4 * 8 * dim
@@ -75,6 +76,16 @@ def init_params(cfg, seed=0):
     lin(nm + '.Output', cfg.dim_op, cfg.dim_l); lin(nm + '.ZW', cfg.dim_l, cfg.dim_l)
     seq_x = getattr(cfg, 'seq_critic', False) and cfg.ali_mode == 'concat_x'
     seq_z = getattr(cfg, 'seq_critic', False) and cfg.ali_mode == 'concat_z'
+    if getattr(cfg, 'seq_critic', False) and cfg.ali_mode == '3dcnn':       # tflib/ops/conv3d.py:13-31
+        for i, (cin, cout, sl) in enumerate(conv3d_plan(cfg)):
+            fan_in, fan_out = cin * 16 * 4, cout * 16 / 4. * 4 / sl
+            sd = np.sqrt(4. / (fan_in + fan_out))
+            P['Discriminator.%d.Filters' % (i + 1)] = rng.uniform(-sd * np.sqrt(3), sd * np.sqrt(3), size=(4, 4, 4, cin, cout)).astype(np.float32)
+            P['Discriminator.%d.Biases' % (i + 1)] = np.zeros(cout, np.float32)
+        lin('Discriminator.z1', cfg.dim_g + cfg.dim_l * cfg.LEN + cfg.n_c, 512)
+        lin('Discriminator.zx1', cfg.flat + 512, 512)
+        lin('Discriminator.Output', 512, 1)
+        return P
     conv('Discriminator.1', cfg.C * cfg.LEN if seq_x else cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
     conv('Discriminator.4', 4 * d, 8 * d)
     if seq_z:
@@ -221,7 +232,23 @@ def Discriminator(cfg, P, x, z_g, z_l, labels):              # :265-315
     return tp.reshape(N.Linear(P, 'Discriminator.Output', out), (cfg.B * cfg.LEN,))
 
 
+def conv3d_plan(cfg):
+    """(in, out, stride_len) of the four Conv3D layers (:364-384): LEN 16 halves the length every layer, LEN 4 only in layers 1 and 3"""
+    d, s24 = cfg.dim, (2 if cfg.LEN == 16 else 1)
+    return [(1, d, 2), (d, 2 * d, s24), (2 * d, 4 * d, 2), (4 * d, 8 * d, s24)]
+
+
 def SequenceDiscriminator(cfg, P, x, z_g, z_l, labels):
+    if cfg.ali_mode == '3dcnn':         # :352-405: NLHWC volume through four 4x4x4 Conv3D layers (one channel: the transpose is a reshape)
+        out = tp.reshape(x, (cfg.B, cfg.LEN, 64, 64, 1))
+        for i, (_, cout, sl) in enumerate(conv3d_plan(cfg)):
+            nm = 'Discriminator.%d' % (i + 1)
+            out = _lrelu(tp.add(tp.conv3d(out, P[nm + '.Filters'], sl, 2), tp.reshape(P[nm + '.Biases'], (1, 1, 1, 1, cout))))
+        out = tp.reshape(out, (cfg.B, cfg.flat))
+        z = tp.concat([z_g, tp.reshape(z_l, (cfg.B, cfg.LEN * cfg.dim_l)), labels], axis=1)
+        z_out = _lrelu(N.Linear(P, 'Discriminator.z1', z))
+        out = _lrelu(N.Linear(P, 'Discriminator.zx1', tp.concat([out, z_out], axis=1)))
+        return tp.reshape(N.Linear(P, 'Discriminator.Output', out), (cfg.B,))
     if cfg.ali_mode == 'concat_z':      # :451-497: per-frame conv stack, a 4x4 VALID conv to DIM_LATENT_G features per frame, concatenated
         out = _conv_stack(cfg, P, 'Discriminator', tp.reshape(x, (cfg.B * cfg.LEN, cfg.C, 64, 64)))
         out = tp.add(tp.conv2d(out, P['Discriminator.5.Filters'], 1, 'VALID'), tp.reshape(P['Discriminator.5.Biases'], (1, -1, 1, 1)))

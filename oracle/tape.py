@@ -237,6 +237,24 @@ def deconv2d(x, w, stride=2, padding='SAME'):
 
 
 # ---- composites the reference uses ----------------------------------------------------
+def conv3d(x, w, stride_len, stride):
+    """tf.nn.conv3d NDHWC SAME; closed under differentiation through its two gradient maps"""
+    fl, fs = w.v.shape[0], w.v.shape[1]
+    return T(O.conv3d(x.v, w.v, stride_len, stride), (x, w),
+             lambda g: (conv3d_bwd_data(g, w, x.v.shape, stride_len, stride), conv3d_bwd_filter(x, g, fl, fs, stride_len, stride)))
+
+
+def conv3d_bwd_data(gy, w, in_shape, stride_len, stride):
+    fl, fs = w.v.shape[0], w.v.shape[1]
+    return T(O.conv3d_bwd_data(gy.v, w.v, in_shape, stride_len, stride), (gy, w),
+             lambda g: (conv3d(g, w, stride_len, stride), conv3d_bwd_filter(g, gy, fl, fs, stride_len, stride)))
+
+
+def conv3d_bwd_filter(x, gy, fl, fs, stride_len, stride):
+    return T(O.conv3d_bwd_filter(x.v, gy.v, fl, fs, stride_len, stride), (x, gy),
+             lambda g: (conv3d_bwd_data(gy, g, x.v.shape, stride_len, stride), conv3d(x, g, stride_len, stride)))
+
+
 def bce_with_logits(x, z):
     """tf.nn.sigmoid_cross_entropy_with_logits, z a python float 0/1."""
     return add(add(relu(x), scale(x, -float(z))), log1p(exp(neg(absolute(x)))))

@@ -9,7 +9,7 @@ from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
 
 DATASET = 'chairs'  # rotating chairs: 31 RGB views of 64x64 per object, no class labels
 MODE = 'local_ep'  # local_ep, local_epce-z, ali, alice-z
-ALI_MODE = 'concat_x'  # concat_x, concat_z (the 3-D conv critic '3dcnn' is not built)
+ALI_MODE = 'concat_x'  # concat_x, concat_z ('3dcnn' is one-channel, LEN 4 / 16 only: the moving-MNIST script)
 POS_MODE = 'naive_mean_field'  # gsp, naive_mean_field, inverse, forward_inverse
 OP_DYN_MODE = 'res_w'  # res, res_w
 DIM_LATENT_G = 128  # global latent variable

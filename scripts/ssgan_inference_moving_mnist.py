@@ -9,7 +9,7 @@ from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
 
 DATASET = 'moving_mnist'
 MODE = 'local_ep'  # local_ep, local_epce-z, ali, alice-z
-ALI_MODE = 'concat_x'  # concat_x, concat_z (the 3-D conv critic '3dcnn' is not built)
+ALI_MODE = 'concat_x'  # concat_x, concat_z, 3dcnn (Conv3D critic: LEN 4 or 16)
 POS_MODE = 'naive_mean_field'  # gsp, naive_mean_field, inverse, forward_inverse
 OP_DYN_MODE = 'res'  # res, res_w
 DIM_LATENT_G = 128  # global latent variable

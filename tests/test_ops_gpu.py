@@ -905,3 +905,95 @@ def test_mix_rbf_mmd2_fused_op(gpu, m, n, d):
     dx, dy = torch.autograd.grad(v * 3.0, [tx, ty])
     assert _rel(dx.cpu().numpy(), 3.0 * rx.v) < 1e-4 and _rel(dy.cpu().numpy(), 3.0 * ry.v) < 1e-4
     assert abs(float(lib.objs.mmd.mix_rbf_mmd2(tx.detach(), tx.detach()))) < 1e-5
+
+
+@pytest.mark.parametrize('case', [  # (N, L, H, W, Ci, Co, fl, fs, stride_len, stride)
+    (3, 4, 64, 64, 1, 4, 4, 4, 2, 2),     # Discriminator.1 of the 3dcnn critic (LEN 4)
+    (3, 2, 32, 32, 4, 8, 4, 4, 1, 2),     # Discriminator.2, LEN 4 (stride_len 1: pad (1, 2) along the length)
+    (2, 16, 16, 16, 2, 3, 4, 4, 2, 2),    # LEN 16 plan
+    (2, 1, 8, 8, 16, 32, 4, 4, 1, 2),     # Discriminator.4, LEN 4: length 1, three of the four length taps in the padding
+    (2, 5, 7, 6, 3, 5, 3, 2, 2, 1),       # ragged: odd sizes, fl != fs, stride 1
+    (1, 3, 4, 4, 2, 2, 1, 1, 1, 1)])
+def test_conv3d_entry_points(gpu, case):
+    """Conv3D (tflib/ops/conv3d.py:33-48) = ggan_im2col3d + ggan_gemm, gradients through ggan_col2im3d / ggan_gemm, vs the float64
+    oracle (functional.conv3d; bias [1,1,1,1,Co]); the fused LeakyReLU epilogue; im2col / col2im adjointness."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    N, L, H, W, Ci, Co, fl, fs, sl, st = case
+    rng = np.random.default_rng(sum(case))
+    x, w, b = rng.standard_normal((N, L, H, W, Ci)), 0.2 * rng.standard_normal((fl, fs, fs, Ci, Co)), rng.standard_normal(Co)
+    ref = O.conv3d(x, w, sl, st) + b
+    gy = rng.standard_normal(ref.shape)
+    tx, tw, tb = (_t(a, gpu).requires_grad_() for a in (x, w, b.reshape(1, 1, 1, 1, Co)))
+    y = F.conv3d(tx, tw, tb, sl, st)
+    assert tuple(y.shape) == ref.shape
+    assert _rel(y.detach().cpu().numpy(), ref) <= 2e-5
+    gx, gw, gb = torch.autograd.grad(y, (tx, tw, tb), _t(gy, gpu))
+    assert _rel(gx.cpu().numpy(), O.conv3d_bwd_data(gy, w, x.shape, sl, st)) <= 2e-5
+    assert _rel(gw.cpu().numpy(), O.conv3d_bwd_filter(x, gy, fl, fs, sl, st)) <= 2e-5
+    assert gb.shape == tb.shape and _rel(gb.cpu().numpy().reshape(-1), gy.reshape(-1, Co).sum(0)) <= 2e-5
+    # no bias, no input gradient
+    y2 = F.conv3d(_t(x, gpu), tw, None, sl, st)
+    assert _rel(y2.detach().cpu().numpy(), ref - b) <= 2e-5
+    (gw2,) = torch.autograd.grad(y2, (tw,), _t(gy, gpu))
+    assert _rel(gw2.cpu().numpy(), gw.cpu().numpy()) <= 1e-5      # (a different split of the same reduction)
+    # fused activation epilogue and its backward
+    y3 = F.conv3d(tx, tw, tb, sl, st, F.ACT_LRELU, 0.2)
+    assert _rel(y3.detach().cpu().numpy(), np.where(ref > 0, ref, 0.2 * ref)) <= 2e-5
+    (gx3,) = torch.autograd.grad(y3, (tx,), _t(gy, gpu))
+    assert _rel(gx3.cpu().numpy(), O.conv3d_bwd_data(gy * np.where(ref > 0, 1.0, 0.2), w, x.shape, sl, st)) <= 2e-5
+    # <im2col(a), c> == <a, col2im(c)>, and the second derivative path (col2im's backward is im2col again)
+    col = F.Im2Col3d.apply(tx, fl, fs, sl, st)
+    c = torch.randn_like(col)
+    lhs = float((col.detach().double() * c.double()).sum())
+    rhs = float((tx.detach().double() * F.Col2Im3d.apply(c, tuple(tx.shape), fl, fs, sl, st).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    cg = c.clone().requires_grad_()
+    (gc,) = torch.autograd.grad(F.Col2Im3d.apply(cg, tuple(tx.shape), fl, fs, sl, st), (cg,), tx.detach())
+    assert torch.equal(gc, col.detach())
+
+
+def test_conv3d_layer_registers_reference_parameters(gpu):
+    import torch
+    from graphical_gan_amd import tflib as lib
+    lib.delete_all_params()
+    np.random.seed(0)
+    x = torch.randn(2, 4, 8, 8, 1, device=gpu)
+    y = lib.ops.conv3d.Conv3D('T3.1', 4, 1, 6, 4, x, stride=2, stride_len=2)
+    assert tuple(y.shape) == (2, 2, 4, 4, 6)
+    P = lib.named_params()
+    assert tuple(P['T3.1.Filters'].shape) == (4, 4, 4, 1, 6) and tuple(P['T3.1.Biases'].shape) == (1, 1, 1, 1, 6)
+    fan_in, fan_out = 1 * 16 * 4, 6 * 16 / 4. * 4 / 2
+    bound = np.sqrt(4. / (fan_in + fan_out)) * np.sqrt(3)
+    f = P['T3.1.Filters'].detach().cpu().numpy()
+    assert np.abs(f).max() <= bound and np.abs(f).max() > 0.8 * bound
+    y2 = lib.ops.conv3d.Conv3D('T3.nb', 2, 6, 3, 3, y, he_init=False, biases=False)
+    assert tuple(y2.shape) == (2, 2, 4, 4, 3) and 'T3.nb.Biases' not in lib.named_params()
+    lib.delete_all_params()
+
+
+@pytest.mark.parametrize('rows,cols', [(8192, 32), (100000, 33), (524288, 32), (65536, 256), (9000, 1)])
+def test_tall_column_sum_and_tall_linear_backward(gpu, rows, cols):
+    """ggan_colsum_tall (row slabs + fixed-order second stage) and the split-K route Linear backward takes on tall operands."""
+    import torch
+    from graphical_gan_amd import functional as F
+    assert rows >= F.TALL_ROWS
+    g = torch.Generator(device='cpu').manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(gpu)
+    ref = x.double().sum(0)
+    out = F.ColSum.apply(x)
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * float(x.abs().sum(0).max())
+    assert torch.equal(out, F.ColSum.apply(x))            # deterministic
+    if cols >= 32 and rows <= 100000:
+        K = 48
+        a = torch.randn(rows, K, generator=g).to(gpu).requires_grad_()
+        w = (0.1 * torch.randn(K, cols, generator=g)).to(gpu).requires_grad_()
+        b = torch.zeros(cols, device=gpu).requires_grad_()
+        y = F.Gemm.apply(a, w, b, False, False, F.ACT_LRELU, 0.2)
+        ga, gw, gb = torch.autograd.grad(y, (a, w, b), x)
+        pre = a.detach().double() @ w.detach().double()
+        assert float((y.detach().double() - torch.where(pre > 0, pre, 0.2 * pre)).abs().max()) <= 2e-5
+        gm = x.double() * torch.where(y.detach() > 0, 1.0, 0.2)       # (the sign of the fp32 result: pre-activations within rounding of 0)
+        for got, want in ((ga, gm @ w.detach().double().t()), (gw, a.detach().double().t() @ gm), (gb, gm.sum(0))):
+            assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())) * 4

@@ -174,13 +174,42 @@ def test_oracle_reproduces_trajectory_goldens(name):
         assert np.abs(digest(v) - z['p1/' + k]).max() < 1e-7 * max(1.0, np.abs(z['p1/' + k]).max()), k
 
 
-@pytest.mark.parametrize('mode,channels,n_c', [('local_ep', 1, 10), ('local_epce-z', 1, 10), ('alice-z', 1, 10), ('local_ep', 3, 0)])
+def test_conv3d_oracle_known_answers_and_finite_differences():
+    """oracle conv3d (tf.nn.conv3d NDHWC SAME, tflib/ops/conv3d.py:33-39): an all-ones volume / filter counts the taps inside the
+    volume (SAME puts the extra padding at the END), a 1x1x1 filter is a per-voxel matmul, and both gradient maps agree with float64
+    central differences."""
+    from oracle import ops as O, tape as tp
+    y = O.conv3d(np.ones((1, 4, 4, 4, 1)), np.ones((4, 4, 4, 1, 1)), 2, 2)
+    # out 2 per axis, pad (1 before, 1 after): windows [-1..2] and [1..4] -> 3 taps inside each
+    assert y.shape == (1, 2, 2, 2, 1) and np.all(y == 27.0)
+    y = O.conv3d(np.ones((1, 5, 5, 5, 1)), np.ones((4, 4, 4, 1, 1)), 2, 2)       # out 3, pad total 3 -> (1, 2): windows [-1..2], [1..4], [3..6]
+    assert y.shape == (1, 3, 3, 3, 1) and y[0, 0, 0, 0, 0] == 27.0 and y[0, 1, 1, 1, 0] == 64.0 and y[0, 2, 2, 2, 0] == 8.0
+    rng = np.random.default_rng(0)
+    x, w = rng.standard_normal((2, 3, 4, 5, 3)), rng.standard_normal((1, 1, 1, 3, 2))
+    assert np.abs(O.conv3d(x, w, 1, 1) - x @ w[0, 0, 0]).max() < 1e-12
+    for (L, H, W, fl, fs, sl, st) in ((4, 6, 6, 4, 4, 2, 2), (4, 5, 7, 4, 4, 1, 2), (3, 4, 4, 2, 3, 1, 1)):
+        x, w = tp.T(rng.standard_normal((2, L, H, W, 3))), tp.T(0.3 * rng.standard_normal((fl, fs, fs, 3, 2)))
+        y = tp.conv3d(x, w, sl, st)
+        gy = rng.standard_normal(y.v.shape)
+        gx, gw = tp.grad(tp.reduce_sum(tp.mul(y, tp.T(gy))), [x, w])
+        for t, g in ((x, gx), (w, gw)):
+            for _ in range(3):
+                idx = tuple(rng.integers(0, n) for n in t.v.shape)
+                vp, vm = t.v.copy(), t.v.copy()
+                vp[idx] += 1e-6; vm[idx] -= 1e-6
+                f = lambda v: float((O.conv3d(v if t is x else x.v, v if t is w else w.v, sl, st) * gy).sum())
+                assert abs((f(vp) - f(vm)) / 2e-6 - g.v[idx]) < 1e-6, (L, fl, sl, idx)
+
+
+@pytest.mark.parametrize('mode,channels,n_c', [('local_ep', 1, 10), ('local_epce-z', 1, 10), ('alice-z', 1, 10), ('local_ep', 3, 0),
+                                               ('ali:3dcnn', 1, 10)])
 def test_ssgan_oracle_finite_differences(mode, channels, n_c):
     """oracle/ssgan.py (state-space GAN; weighted_local_epce, its reconstruction variant, the sequence-critic modes, the chairs
     shapes): tape gradients vs float64 central differences, and the cost at initialisation ~ 2*ln2."""
     from oracle import ssgan as S, tape as tp
-    cfg = S.Cfg(batch_size=1, length=3, dim=2, dim_op=8, dim_g=4, dim_l=3, pos_mode='gsp', op_dyn_mode='res_w', mode=mode,
-                channels=channels, n_c=n_c)
+    mode, _, ali_mode = mode.partition(':')
+    cfg = S.Cfg(batch_size=1, length=4 if ali_mode else 3, dim=2, dim_op=8, dim_g=4, dim_l=3, pos_mode='gsp', op_dyn_mode='res_w', mode=mode,
+                channels=channels, n_c=n_c, ali_mode=ali_mode or 'concat_x')
     assert abs(cfg.ratio().sum() - 1.0) < 1e-12
     P0 = {k: v.astype(np.float64) for k, v in S.init_params(cfg, 0).items()}
     feed = S.make_feed(cfg, np.random.default_rng(1))

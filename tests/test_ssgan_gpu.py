@@ -34,12 +34,14 @@ def _mk(gpu, pos_mode, op_dyn_mode, graph, B=2, L=3, dim=4, channels=1, n_c=10, 
     ('naive_mean_field', 'res_w', 3, 0, 'local_ep'),            # ssgan_inference_chairs.py
     ('naive_mean_field', 'res', 1, 10, 'local_epce-z'),         # + LAMBDA * l2(real_x, rec_x)
     ('naive_mean_field', 'res', 1, 10, 'ali'), ('gsp', 'res', 1, 10, 'alice-z'),       # one critic on the whole sequence (concat_x)
-    ('naive_mean_field', 'res', 1, 10, 'ali:concat_z')])
+    ('naive_mean_field', 'res', 1, 10, 'ali:concat_z'),
+    ('naive_mean_field', 'res', 1, 10, 'ali:3dcnn'), ('gsp', 'res', 1, 10, 'alice-z:3dcnn')])    # Conv3D critic (LEN 4)
 def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, n_c, mode):
     import torch
     from oracle import ssgan as O, tape as tp
     mode, _, ali_mode = mode.partition(':')
-    ocfg, P0, cfg, tr = _mk(gpu, pos_mode, op_dyn_mode, False, channels=channels, n_c=n_c, mode=mode, ali_mode=ali_mode or 'concat_x')
+    ocfg, P0, cfg, tr = _mk(gpu, pos_mode, op_dyn_mode, False, channels=channels, n_c=n_c, mode=mode, ali_mode=ali_mode or 'concat_x',
+                            **(dict(L=4) if ali_mode == '3dcnn' else {}))
     feed = O.make_feed(ocfg, np.random.default_rng(3))
     Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
     oout = O.forward(ocfg, Pt, feed)
@@ -67,12 +69,14 @@ def test_ssgan_first_step_costs_and_grads(gpu, pos_mode, op_dyn_mode, channels, 
 
 
 @pytest.mark.parametrize('graph,chairs,mode', [(False, False, 'local_ep'), (True, False, 'local_ep'), (True, True, 'local_ep'),
-                                               (True, False, 'local_epce-z'), (True, False, 'alice-z')],
-                         ids=['eager', 'hipgraph', 'hipgraph-chairs', 'hipgraph-epce-z', 'hipgraph-alice-z'])
+                                               (True, False, 'local_epce-z'), (True, False, 'alice-z'), (True, False, 'ali:3dcnn')],
+                         ids=['eager', 'hipgraph', 'hipgraph-chairs', 'hipgraph-epce-z', 'hipgraph-alice-z', 'hipgraph-ali-3dcnn'])
 def test_ssgan_trajectory(gpu, graph, chairs, mode):
     """4 iterations (critic step, then gen + critic) with TF-Adam on both sides: costs and every weight."""
     from oracle import ssgan as O
-    ocfg, P0, cfg, tr = _mk(gpu, 'naive_mean_field', 'res_w' if chairs else 'res', graph, mode=mode, **(dict(channels=3, n_c=0) if chairs else {}))
+    mode, _, ali_mode = mode.partition(':')
+    kw = dict(channels=3, n_c=0) if chairs else (dict(ali_mode=ali_mode, L=4) if ali_mode else {})
+    ocfg, P0, cfg, tr = _mk(gpu, 'naive_mean_field', 'res_w' if chairs else 'res', graph, mode=mode, **kw)
     rng = np.random.default_rng(9)
     feeds = [O.make_feed(ocfg, rng) for _ in range(8)]
     otr = O.Trainer(ocfg, P0, np.float64)
