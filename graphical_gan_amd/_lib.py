@@ -62,6 +62,10 @@ SIGNATURES = {
     'ggan_linear_bwd_data_act': (_I, [_I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_linear_bwd_weight_act': (_I, [_I, _I, _I, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_colsum': (_I, [_P, _P, _I, _I, _P]),
+    'ggan_reparam_fwd': (_I, [_P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_agg_div_fwd': (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    'ggan_agg_div_bwd': (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'ggan_colsum_tall': (_I, [_P, _P, _I, _I, _P, _Z, _P]),
     'ggan_chansum': (_I, [_P, _P, _I, _I, _I, _P, _Z, _P]),
     'ggan_bn_fwd_train': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),

@@ -139,6 +139,177 @@ __global__ void chansum_final_k(const float* __restrict__ part, float* __restric
     out[c] = s;
 }
 
+// ---- stochastic encoder head (TYPE_Q = 'learn_std', gan_inference_cifar10.py:173-188): std = exp(log_std), z = mean + eps * std ----------
+__global__ void reparam_fwd_k(const float* __restrict__ mean, const float* __restrict__ log_std, const float* __restrict__ eps,
+                              float* __restrict__ z, float* __restrict__ sd, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = expf(log_std[i]);
+        sd[i] = s;
+        z[i] = fmaf(eps[i], s, mean[i]);
+    }
+}
+
+__global__ void reparam_bwd_k(const float* __restrict__ gz, const float* __restrict__ gsd, const float* __restrict__ eps,
+                              const float* __restrict__ sd, float* __restrict__ gmean, float* __restrict__ glog, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = gz ? gz[i] : 0.f, b = gsd ? gsd[i] : 0.f;
+        gmean[i] = a;
+        glog[i] = (a * eps[i] + b) * sd[i];
+    }
+}
+
+// ---- tflib/objs/kl_aggregated.py: KL / inverse KL / JSD between the aggregated posterior (equal-weight mixture of the minibatch's nx
+// diagonal Gaussians) and the N(0, I) prior on nz Monte-Carlo samples.  kind 0 kl (samples from q), 1 ikl (samples from p), 2 jsd
+// (both: rows [0, nz) from q, [nz, 2nz) from p).  One block per sample; every reduction in a fixed order.
+struct AggP {
+    const float *mu, *sd, *k, *eps_q, *z_p;
+    int kind, nx, nz, d, n_coms;
+};
+#define GGAN_LOG2PI 1.8378770664093453f
+
+__device__ __forceinline__ float block_max(float v, float* smem) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float t = smem[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, smem[i]);
+    return t;
+}
+
+__global__ __launch_bounds__(128) void agg_div_fwd_k(const AggP P, float* __restrict__ Z, float* __restrict__ A, float* __restrict__ Bv,
+                                                      float* __restrict__ T) {
+    extern __shared__ float zs[];          // d
+    __shared__ float red[20];
+    const int i = blockIdx.x, nx = P.nx, d = P.d;
+    const bool qs = P.kind == 0 || (P.kind == 2 && i < P.nz);
+    const int ip = P.kind == 2 ? i - P.nz : i;
+    float part = 0.f;
+    for (int dd = threadIdx.x; dd < d; dd += blockDim.x) {
+        float z;
+        if (qs) {                           // mixture_gaussian (:6-16): k @ mu + (k @ std) * eps, k one-hot
+            float m = 0.f, sg = 0.f;
+            for (int j = 0; j < nx; ++j) {
+                const float kk = P.k[(size_t)i * nx + j];
+                m = fmaf(kk, P.mu[(size_t)j * d + dd], m);
+                sg = fmaf(kk, P.sd[(size_t)j * d + dd], sg);
+            }
+            z = fmaf(sg, P.eps_q[(size_t)i * d + dd], m);
+        } else {
+            z = P.z_p[(size_t)ip * d + dd];
+        }
+        zs[dd] = z;
+        Z[(size_t)i * d + dd] = z;
+        part += z * z + GGAN_LOG2PI;
+    }
+    const float b = -0.5f * block_sum(part, red);       // log N(z; 0, I)   (also orders the zs writes before the reads below)
+    float lmax = -3.0e38f;
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) {
+        float acc = 0.f;
+        for (int dd = 0; dd < d; ++dd) {
+            const float sg = P.sd[(size_t)j * d + dd], r = (zs[dd] - P.mu[(size_t)j * d + dd]) / sg;
+            acc += r * r + GGAN_LOG2PI + 2.f * logf(sg);
+        }
+        const float a = -0.5f * acc;
+        A[(size_t)i * nx + j] = a;
+        lmax = fmaxf(lmax, a);
+    }
+    float mx = block_max(lmax, red);
+    if (P.kind == 2) mx = fmaxf(mx, b);
+    float se = 0.f;
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) se += expf(A[(size_t)i * nx + j] - mx);
+    const float Sq = block_sum(se, red);
+    if (threadIdx.x == 0) {
+        const float lq = mx + logf(Sq) - logf((float)nx);
+        float t;
+        if (P.kind == 0) t = lq - b;
+        else if (P.kind == 1) t = b - lq;
+        else {
+            const float lm = mx + logf(Sq + (float)P.n_coms * expf(b - mx)) - logf((float)(nx + P.n_coms));
+            t = qs ? 0.5f * (lq - lm) : 0.5f * (b - lm);
+        }
+        T[i] = t;
+        Bv[i] = b;
+    }
+}
+
+__global__ void agg_div_final_k(const float* __restrict__ T, int ns, int nz, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < ns; ++i) s += T[i];           // sample order: deterministic
+        out[0] = s / (float)nz;
+    }
+}
+
+// stage A (block per sample): W[i][j] = dL/da_ij, GZ[i][:] = dL/dz_i for the samples drawn from q (they depend on mu / std)
+__global__ __launch_bounds__(128) void agg_div_bwd_samples_k(const AggP P, const float* __restrict__ Z, const float* __restrict__ A,
+                                                              const float* __restrict__ Bv, const float* __restrict__ gout,
+                                                              float* __restrict__ W, float* __restrict__ GZ) {
+    extern __shared__ float ws[];          // nx
+    __shared__ float red[20];
+    const int i = blockIdx.x, nx = P.nx, d = P.d;
+    const bool qs = P.kind == 0 || (P.kind == 2 && i < P.nz);
+    const float b = Bv[i], gs = gout[0] / (float)P.nz;
+    float lmax = -3.0e38f;
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) lmax = fmaxf(lmax, A[(size_t)i * nx + j]);
+    float mx = block_max(lmax, red);
+    if (P.kind == 2) mx = fmaxf(mx, b);
+    float se = 0.f;
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) se += expf(A[(size_t)i * nx + j] - mx);
+    const float Sq = block_sum(se, red);
+    const float pe = (float)P.n_coms * expf(b - mx), M = Sq + pe;
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) {
+        const float e = expf(A[(size_t)i * nx + j] - mx);
+        float w;
+        if (P.kind == 0) w = e / Sq;
+        else if (P.kind == 1) w = -e / Sq;
+        else w = qs ? 0.5f * (e / Sq - e / M) : -0.5f * e / M;
+        w *= gs;
+        ws[j] = w;
+        W[(size_t)i * nx + j] = w;
+    }
+    __syncthreads();
+    if (!qs) return;
+    const float v = gs * (P.kind == 0 ? -1.f : -0.5f * pe / M);      // dL/db; db/dz = -z
+    for (int dd = threadIdx.x; dd < d; dd += blockDim.x) {
+        const float z = Z[(size_t)i * d + dd];
+        float acc = -v * z;
+        for (int j = 0; j < nx; ++j) {
+            const float sg = P.sd[(size_t)j * d + dd];
+            acc -= ws[j] * (z - P.mu[(size_t)j * d + dd]) / (sg * sg);
+        }
+        GZ[(size_t)i * d + dd] = acc;
+    }
+}
+
+// stage B (block per component j): the direct terms of every sample, then the samples drawn from this component (through z)
+__global__ __launch_bounds__(128) void agg_div_bwd_comps_k(const AggP P, int ns, const float* __restrict__ Z, const float* __restrict__ W,
+                                                            const float* __restrict__ GZ, float* __restrict__ gmu, float* __restrict__ gsd) {
+    const int j = blockIdx.x, nx = P.nx, d = P.d;
+    const int nq = P.kind == 1 ? 0 : P.nz;
+    for (int dd = threadIdx.x; dd < d; dd += blockDim.x) {
+        const float m = P.mu[(size_t)j * d + dd], sg = P.sd[(size_t)j * d + dd], i2 = 1.f / (sg * sg);
+        float gm = 0.f, gsg = 0.f;
+        for (int i = 0; i < ns; ++i) {
+            const float w = W[(size_t)i * nx + j], r = Z[(size_t)i * d + dd] - m;
+            gm = fmaf(w, r * i2, gm);
+            gsg = fmaf(w, r * r * i2 / sg - 1.f / sg, gsg);
+        }
+        for (int i = 0; i < nq; ++i) {
+            const float kk = P.k[(size_t)i * nx + j];
+            if (kk != 0.f) {
+                const float gz = kk * GZ[(size_t)i * d + dd];
+                gm += gz;
+                gsg = fmaf(gz, P.eps_q[(size_t)i * d + dd], gsg);
+            }
+        }
+        gmu[(size_t)j * d + dd] = gm;
+        gsd[(size_t)j * d + dd] = gsg;
+    }
+}
+
 // ---- losses (single block: n is a minibatch of logits) ---------------------------------------------
 __global__ void bce_fwd_k(const float* __restrict__ x, float z, float weight, float* __restrict__ loss, int n,
                           int accumulate) {
@@ -951,6 +1122,56 @@ int ggan_mix_rbf_mmd2_bwd(const float* X, const float* Y, int m, int n, int d, c
     MmdParams P;
     GGAN_CHECK_ARG(mmd_params(P, X, Y, m, n, d, sigmas, wts, ns) == 0 && gout && (dX || dY), "bad argument");
     GGAN_LAUNCH("mmd2_bwd", 5.0 * (m + n) * (m + n) * d, 0, mmd2_bwd_k, dim3(m + n), dim3(256), 0, (hipStream_t)stream, P, gout, dX, dY);
+    return 0;
+}
+
+int ggan_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* z, float* std_out, size_t n, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(mean && log_std && eps && z && std_out, "null pointer");
+    if (n == 0) return 0;
+    GGAN_LAUNCH("reparam_fwd", 0, 20.0 * n, reparam_fwd_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, mean, log_std, eps, z, std_out, n);
+    return 0;
+}
+
+int ggan_reparam_bwd(const float* gz, const float* gstd, const float* eps, const float* std_in, float* gmean, float* glog_std, size_t n,
+                     ggan_stream_t stream) {
+    GGAN_CHECK_ARG((gz || gstd) && eps && std_in && gmean && glog_std, "null pointer");
+    if (n == 0) return 0;
+    GGAN_LAUNCH("reparam_bwd", 0, 24.0 * n, reparam_bwd_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, gz, gstd, eps, std_in, gmean,
+                glog_std, n);
+    return 0;
+}
+
+static int agg_params(AggP& P, int kind, const float* mu, const float* sd, const float* k_onehot, const float* eps_q, const float* z_p, int nx,
+                      int nz, int d, int n_coms) {
+    if (kind < 0 || kind > 2 || !mu || !sd || nx <= 0 || nz <= 0 || d <= 0 || n_coms <= 0 || d > 8192 || nx > 8192) return -1;
+    if (kind != 1 && (!k_onehot || !eps_q)) return -1;
+    if (kind != 0 && !z_p) return -1;
+    P.mu = mu; P.sd = sd; P.k = k_onehot; P.eps_q = eps_q; P.z_p = z_p;
+    P.kind = kind; P.nx = nx; P.nz = nz; P.d = d; P.n_coms = n_coms;
+    return 0;
+}
+
+int ggan_agg_div_fwd(int kind, const float* mu, const float* sd, const float* k_onehot, const float* eps_q, const float* z_p, int nx, int nz,
+                     int d, int n_coms, float* out, float* Z, float* A, float* Bv, float* T, ggan_stream_t stream) {
+    AggP P;
+    GGAN_CHECK_ARG(agg_params(P, kind, mu, sd, k_onehot, eps_q, z_p, nx, nz, d, n_coms) == 0 && out && Z && A && Bv && T, "bad argument");
+    const int ns = kind == 2 ? 2 * nz : nz;
+    GGAN_LAUNCH("agg_div_fwd", 8.0 * ns * nx * d, 0, agg_div_fwd_k, dim3(ns), dim3(128), d * sizeof(float), (hipStream_t)stream, P, Z, A, Bv, T);
+    GGAN_LAUNCH("agg_div_final", 0, 0, agg_div_final_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)T, ns, nz, out);
+    return 0;
+}
+
+int ggan_agg_div_bwd(int kind, const float* mu, const float* sd, const float* k_onehot, const float* eps_q, int nx, int nz, int d, int n_coms,
+                     const float* Z, const float* A, const float* Bv, const float* gout, float* W, float* GZ, float* gmu, float* gsd,
+                     ggan_stream_t stream) {
+    AggP P;
+    GGAN_CHECK_ARG(agg_params(P, kind, mu, sd, k_onehot, eps_q, Z /* unused */, nx, nz, d, n_coms) == 0 && Z && A && Bv && gout && W && GZ && gmu &&
+                       gsd, "bad argument");
+    const int ns = kind == 2 ? 2 * nz : nz;
+    GGAN_LAUNCH("agg_div_bwd_samples", 6.0 * ns * nx * d, 0, agg_div_bwd_samples_k, dim3(ns), dim3(128), nx * sizeof(float), (hipStream_t)stream, P,
+                Z, A, Bv, gout, W, GZ);
+    GGAN_LAUNCH("agg_div_bwd_comps", 8.0 * ns * nx * d, 0, agg_div_bwd_comps_k, dim3(nx), dim3(128), 0, (hipStream_t)stream, P, ns, Z,
+                (const float*)W, (const float*)GZ, gmu, gsd);
     return 0;
 }
 

@@ -858,6 +858,67 @@ class MixRbfMmd2(Function):
         return dx, dy, None, None
 
 
+class Reparam(Function):
+    """(z, std) = (mean + eps * exp(log_std), exp(log_std)): the stochastic encoder head (gan_inference_cifar10.py:173-188)"""
+
+    @staticmethod
+    def forward(ctx, mean, log_std, eps):
+        mean, log_std, eps = _c(mean), _c(log_std), _c(eps)
+        z, sd = torch.empty_like(mean), torch.empty_like(mean)
+        check(_L().ggan_reparam_fwd(_p(mean), _p(log_std), _p(eps), _p(z), _p(sd), mean.numel(), _stream()), 'ggan_reparam_fwd')
+        ctx.save_for_backward(eps, sd)
+        return z, sd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz, gsd):
+        eps, sd = ctx.saved_tensors
+        gmean, glog = torch.empty_like(sd), torch.empty_like(sd)
+        check(_L().ggan_reparam_bwd(_p(_c(gz)) if gz is not None else _p(None), _p(_c(gsd)) if gsd is not None else _p(None), _p(eps), _p(sd),
+                                    _p(gmean), _p(glog), sd.numel(), _stream()), 'ggan_reparam_bwd')
+        return gmean, glog, None
+
+
+AGG_KL, AGG_IKL, AGG_JSD = 0, 1, 2
+
+
+class AggDiv(Function):
+    """Monte-Carlo KL / inverse KL / JSD between the aggregated posterior (mixture of the minibatch's diagonal Gaussians mu, sd [nx, d])
+    and N(0, I) (tflib/objs/kl_aggregated.py:46-74) -> 0-dim tensor.  k_onehot [nz, nx], eps_q [nz, d]: the component draws and noise
+    of the samples from q (kl, jsd); z_p [nz, d]: the samples from the prior (ikl, jsd)."""
+
+    @staticmethod
+    def forward(ctx, mu, sd, k_onehot, eps_q, z_p, kind, n_coms):
+        mu, sd = _c(mu), _c(sd)
+        nx, d = mu.shape
+        nz = (z_p if kind != AGG_KL else eps_q).shape[0]
+        ns = 2 * nz if kind == AGG_JSD else nz
+        k_onehot = _c(k_onehot) if kind != AGG_IKL else None
+        eps_q = _c(eps_q) if kind != AGG_IKL else None
+        z_p = _c(z_p) if kind != AGG_KL else None
+        assert k_onehot is None or (tuple(k_onehot.shape) == (nz, nx) and tuple(eps_q.shape) == (nz, d))
+        assert z_p is None or tuple(z_p.shape) == (nz, d)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=mu.device)
+        out, Z, A, Bv, T = new(), new(ns, d), new(ns, nx), new(ns), new(ns)
+        check(_L().ggan_agg_div_fwd(kind, _p(mu), _p(sd), _p(k_onehot), _p(eps_q), _p(z_p), nx, nz, d, int(n_coms), _p(out), _p(Z), _p(A),
+                                    _p(Bv), _p(T), _stream()), 'ggan_agg_div_fwd')
+        ctx.dims = (kind, nx, nz, d, int(n_coms), ns)
+        ctx.save_for_backward(mu, sd, k_onehot, eps_q, Z, A, Bv)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        mu, sd, k_onehot, eps_q, Z, A, Bv = ctx.saved_tensors
+        kind, nx, nz, d, n_coms, ns = ctx.dims
+        gmu, gsd = torch.empty_like(mu), torch.empty_like(sd)
+        W = torch.empty((ns, nx), dtype=torch.float32, device=mu.device)
+        GZ = torch.empty((nz, d), dtype=torch.float32, device=mu.device)
+        check(_L().ggan_agg_div_bwd(kind, _p(mu), _p(sd), _p(k_onehot), _p(eps_q), nx, nz, d, n_coms, _p(Z), _p(A), _p(Bv), _p(_c(g)),
+                                    _p(W), _p(GZ), _p(gmu), _p(gsd), _stream()), 'ggan_agg_div_bwd')
+        return gmu, gsd, None, None, None, None, None
+
+
 def _dims3(x_shape, fl, fs, Co, stride_len, stride):
     N, L, H, W, Ci = x_shape
     dims = (C.c_int * 10)(N, L, H, W, Ci, Co, fl, fs, int(stride_len), int(stride))

@@ -41,16 +41,21 @@ class Config(object):
         #   alice-z: + l2(real_x, G(q_z));  alice-x: + l2(p_z, E(fake_x));  alice: both;  local_epce: gmgan + l2(real_x, G(q_z))
         #   vegan / vegan-wgan-gp (gan_inference_cifar10.py:192-222,305-322): the critic is an MLP on codes, + l2(real_x, G(q_z))
         #   vegan-mmd (:327-329, tflib/objs/mmd.py): no critic at all -- lamb * MMD^2(q_z, p_z) + l2(real_x, G(q_z)), generator steps only
+        #   vegan-kl / vegan-ikl / vegan-jsd (:331-341, tflib/objs/kl_aggregated.py): no critic, a stochastic encoder (TYPE_Q = 'learn_std',
+        #     :40-43,173-188) and lamb * D(aggregated posterior || N(0, I)) on Z_SAMPLES Monte-Carlo samples + l2(real_x, G(q_z))
         assert self.mode in ('ali', 'local_ep', 'wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce', 'vegan',
-                             'vegan-wgan-gp', 'vegan-mmd')
+                             'vegan-wgan-gp', 'vegan-mmd', 'vegan-kl', 'vegan-ikl', 'vegan-jsd')
+        self.agg = self.mode in ('vegan-kl', 'vegan-ikl', 'vegan-jsd')
+        self.learn_std, self.z_samples = self.agg, 100               # TYPE_Q, Z_SAMPLES (:41-43)
         self.latent_critic = self.mode in ('vegan', 'vegan-wgan-gp')
         self.lamb = 1.0                                                  # LAMBDA (gan_inference_cifar10.py:62)
-        assert not ((self.latent_critic or self.mode == 'vegan-mmd') and n_coms)
+        self.no_critic = self.mode == 'vegan-mmd' or self.agg
+        assert not ((self.latent_critic or self.no_critic) and n_coms)
         self.top = self.dim * 2 ** (self.nl - 1)
         self.flat = 16 * self.top
         self.output_dim = self.C * self.S * self.S
         self.critic_iters = 5 if self.mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else 1   # gan_inference_cifar10.py:53-59
-        if self.mode == 'vegan-mmd':
+        if self.no_critic:
             self.critic_iters = 0          # 'No discriminators' (:52-53)
         self.lr = lr if lr is not None else {'wali-gp': 1e-4, 'wali': 5e-5}.get(self.mode, 2e-4)
         self.beta1 = 0.5
@@ -110,6 +115,11 @@ class GraphicalGAN(object):
             for tag in ('f', 'r') + (('h',) if c.mode == 'vegan-wgan-gp' else ()):
                 for i, w in enumerate((c.dim_latent, 1024, 512, 256)):
                     feed['dn_%s%d' % (tag, i)] = torch.zeros(B, w, device=device)
+        if c.agg:                    # the encoder's eps and the Monte-Carlo draws of tflib/objs/kl_aggregated.py (component one-hots, eps, prior samples)
+            feed['q_eps'] = torch.zeros(B, c.dim_latent, device=device)
+            feed['kl_k'] = torch.zeros(c.z_samples, B, device=device)
+            feed['kl_eps'] = torch.zeros(c.z_samples, c.dim_latent, device=device)
+            feed['kl_zp'] = torch.zeros(c.z_samples, c.dim_latent, device=device)
         return feed
 
     def sample_noise(self, f):
@@ -125,6 +135,9 @@ class GraphicalGAN(object):
         if 'alpha' in f:
             specs.append((f['alpha'], F.NOISE_UNIFORM, 0., 1.))
         specs += [(f[k], F.NOISE_NORMAL, 0., 1.) for k in sorted(f) if k.startswith('dn_')]
+        if c.agg:
+            specs += [(f['q_eps'], F.NOISE_NORMAL, 0., 1.), (f['kl_k'], F.NOISE_ONEHOT, 0., 0.), (f['kl_eps'], F.NOISE_NORMAL, 0., 1.),
+                      (f['kl_zp'], F.NOISE_NORMAL, 0., 1.)]
         if c.dataset == 'face':
             specs.append((f['dequant_u'], F.NOISE_UNIFORM, 0., 1. / 128))
         F.noise_fill_(f['rng_state'], specs)
@@ -194,7 +207,9 @@ class GraphicalGAN(object):
             ch = cout
         return out.reshape(-1, c.output_dim)
 
-    def Extractor(self, inputs, out_slot=None):
+    def Extractor(self, inputs, out_slot=None, eps=None):
+        """eps given (TYPE_Q = 'learn_std', gan_inference_cifar10.py:173-188): returns (mean + eps * std, mean, std), std = exp(Linear
+        'Extractor.Std')"""
         c = self.cfg
         out = inputs.reshape(-1, c.C, c.S, c.S)
         ch = c.C
@@ -208,6 +223,11 @@ class GraphicalGAN(object):
                 out = self._conv(name, ch, cout, out, LRELU)
             ch = cout
         out = out.reshape(-1, c.flat)
+        if eps is not None:
+            log_std = lib.ops.linear.Linear('Extractor.Std', c.flat, c.dim_latent, out)
+            mean = lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out)
+            z, std = F.Reparam.apply(mean, log_std, eps)
+            return z, mean, std
         return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out, out=out_slot)
 
     def Discriminator(self, x, z, grad_rows=None):
@@ -333,6 +353,9 @@ class GraphicalGAN(object):
             with torch.cuda.stream(self._side):
                 fake_x = self.Generator(p_z, xs[0])
         real_x = self.real_x(feed, xs[1])
+        if c.agg:                      # (no critic, no fake_x: TF prunes the Generator(p_z) branch these modes never fetch)
+            q_z, q_mean, q_std = self.Extractor(real_x, eps=feed['q_eps'])
+            return dict(real_x=real_x, q_z=q_z, q_z_mean=q_mean, q_z_std=q_std, p_z=p_z)
         q_z = self.Extractor(real_x, zs[1])
         out = dict(real_x=real_x, q_z=q_z, p_z=p_z)
         if c.K:
@@ -353,6 +376,18 @@ class GraphicalGAN(object):
         out = dict(nets) if nets is not None else self.forward_nets(feed)
         if c.latent_critic:
             return self._forward_latent(feed, which, out)
+        if c.agg:
+            rec = 1. * lib.utils.distance.distance(out['real_x'], self.Generator(out['q_z']), 'l2')
+            gen_params, _ = self._var_lists()
+            K = lib.objs.kl_aggregated
+            args = (out['q_z_mean'], out['q_z_std'], None, None, rec, gen_params, c.z_samples)
+            kw = dict(lr=c.lr, beta1=c.beta1, draws=(feed['kl_k'], feed['kl_eps'], feed['kl_zp']))
+            if c.mode == 'vegan-ikl':
+                gen_cost, gen_op = K.vegan_ikl(*args, c.dim_latent, c.lamb, **kw)
+            else:
+                gen_cost, gen_op = (K.vegan_kl if c.mode == 'vegan-kl' else K.vegan_jsd)(*args, c.B, c.dim_latent, c.lamb, **kw)
+            out.update(rec_penalty=rec, gen_cost=gen_cost, gen_train_op=gen_op, disc_cost=None, disc_train_op=None)
+            return out
         if c.mode == 'vegan-mmd':
             rec = 1. * lib.utils.distance.distance(out['real_x'], self.Generator(out['q_z']), 'l2')
             gen_params, _ = self._var_lists()

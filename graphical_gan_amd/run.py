@@ -79,7 +79,9 @@ def train(S, cfg, model=None, out_dir=None):
             checkpoint.save(os.path.join(out_dir, 'params_%d.npz' % (it + 1)), tr)
             with torch.no_grad():
                 nets = tr.model.forward_nets(tr.feed)
-            fx = nets['fake_x'].detach().float().cpu().numpy()
+                # (the critic-free code-space modes never build Generator(p_z) in a step: samples are drawn here)
+                fx = nets['fake_x'] if 'fake_x' in nets else tr.model.Generator(nets['p_z'])
+            fx = fx.detach().float().cpu().numpy()
             side = getattr(cfg, 'S', 64)
             fx = fx.reshape(-1, getattr(cfg, 'C', 1), side, side)[:64]
             lo = 0.0 if getattr(cfg, 'out_act', 'tanh') == 'sigmoid' else -1.0

@@ -1,1 +1,1 @@
-from . import gan_inference, mmd  # noqa: F401
+from . import gan_inference, mmd, kl_aggregated  # noqa: F401

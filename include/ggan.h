@@ -228,6 +228,24 @@ int ggan_mix_rbf_mmd2_fwd(const float* X, const float* Y, int m, int n, int d, c
 int ggan_mix_rbf_mmd2_bwd(const float* X, const float* Y, int m, int n, int d, const float* sigmas, const float* wts, int ns,
                           const float* gout, float* dX, float* dY, ggan_stream_t stream);
 
+/* Stochastic encoder head, TYPE_Q = 'learn_std' (gan_inference_cifar10.py:173-188): std = exp(log_std), z = mean + eps * std; the backward
+ * takes the gradients arriving at z and at std (either may be NULL). */
+int ggan_reparam_fwd(const float* mean, const float* log_std, const float* eps, float* z, float* std_out, size_t n, ggan_stream_t stream);
+int ggan_reparam_bwd(const float* gz, const float* gstd, const float* eps, const float* std_in, float* gmean, float* glog_std, size_t n,
+                     ggan_stream_t stream);
+
+/* tflib/objs/kl_aggregated.py:46-74 (MODE vegan-kl / vegan-ikl / vegan-jsd): Monte-Carlo divergence between the aggregated posterior -- the
+ * equal-weight mixture of the minibatch's nx diagonal Gaussians (mu, sd: [nx, d]) -- and the N(0, I) prior (gan_inference_cifar10.py:269-270).
+ * kind 0: KL(q||p) on nz samples of q (k_onehot [nz, nx] one-hot component draws, eps_q [nz, d]; z = k @ mu + (k @ sd) * eps, :6-16);
+ * kind 1: KL(p||q) on the nz prior samples z_p [nz, d]; kind 2: JSD on both sets, the mixture m built from the nx components and n_coms
+ * copies of the prior term (:31-44).  out: device scalar.  Z [ns, d], A [ns, nx], Bv [ns], T [ns] (ns = nz, or 2 nz for kind 2) are
+ * caller-owned buffers the forward fills and the backward reads; W [ns, nx] and GZ [nz, d] are backward scratch.  gout: device scalar. */
+int ggan_agg_div_fwd(int kind, const float* mu, const float* sd, const float* k_onehot, const float* eps_q, const float* z_p, int nx, int nz,
+                     int d, int n_coms, float* out, float* Z, float* A, float* Bv, float* T, ggan_stream_t stream);
+int ggan_agg_div_bwd(int kind, const float* mu, const float* sd, const float* k_onehot, const float* eps_q, int nx, int nz, int d, int n_coms,
+                     const float* Z, const float* A, const float* Bv, const float* gout, float* W, float* GZ, float* gmu, float* gsd,
+                     ggan_stream_t stream);
+
 /* All the noise of one session.run in one launch: up to GGAN_NOISE_MAX device tensors, each filled with kind 0 = a + b*N(0,1),
  * 1 = uniform [a, b), 2 = one-hot rows of width `widths[i]` with a uniformly drawn index (the prior's k ~ Cat(1/K)).  Replaces
  * tf.random_normal / tf.random_uniform / Categorical.sample + one_hot of the scripts (gmgan_inference_cifar10.py:115-120,344-346;

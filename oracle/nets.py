@@ -16,13 +16,14 @@ from . import tape as tp
 
 class Cfg(object):
     def __init__(self, dataset='cifar10', batch_size=64, n_coms=0, dim=None, dim_latent=128,
-                 bn=None, mode_k='CONCRETE', temp=0.1, latent_critic=False):
+                 bn=None, mode_k='CONCRETE', temp=0.1, latent_critic=False, learn_std=False, z_samples=100):
         self.dataset = dataset
         self.B = batch_size
         self.K = n_coms                      # 0 => plain gan_inference_* (no GMM prior)
         self.dim_latent = dim_latent
         self.temp = temp
         self.mode_k = mode_k
+        self.learn_std, self.z_samples = learn_std, z_samples   # MODE vegan-kl/ikl/jsd: TYPE_Q = 'learn_std', Z_SAMPLES (gan_inference_cifar10.py:40-43)
         self.latent_critic = latent_critic     # MODE vegan / vegan-wgan-gp: the critic sees codes only (gan_inference_cifar10.py:192-222)
         if dataset == 'cifar10':
             self.C, self.S, self.dim, self.nl, self.bn, self.out_act = 3, 32, 64, 3, True, 'tanh'
@@ -97,6 +98,8 @@ def init_params(cfg, seed=0):
         P['Extractor.%d.Biases' % (i + 1)] = np.zeros(chans[i + 1], 'float32')
         if cfg.bn and i > 0:
             bn('Extractor.BN%d' % (i + 1), chans[i + 1])
+    if getattr(cfg, 'learn_std', False):
+        lin('Extractor.Std', cfg.flat, cfg.dim_latent)            # created before Extractor.Output (gan_inference_cifar10.py:174,181)
     lin('Extractor.Output', cfg.flat, cfg.dim_latent)
     # Generator
     lin('Generator.Input', cfg.dim_latent, cfg.flat)
@@ -182,7 +185,7 @@ def Generator(cfg, P, noise):
     return tp.reshape(out, (-1, cfg.output_dim))
 
 
-def Extractor(cfg, P, x):
+def Extractor(cfg, P, x, eps=None):
     out = tp.reshape(x, (-1, cfg.C, cfg.S, cfg.S))
     for i in range(cfg.nl):
         out = Conv2D(P, 'Extractor.%d' % (i + 1), out)
@@ -190,6 +193,10 @@ def Extractor(cfg, P, x):
             out = Batchnorm(P, 'Extractor.BN%d' % (i + 1), [0, 2, 3], out)
         out = tp.leaky_relu(out)
     out = tp.reshape(out, (-1, cfg.flat))
+    if eps is not None:        # TYPE_Q = 'learn_std' (gan_inference_cifar10.py:173-188): q_z = mean + eps * exp(Linear 'Extractor.Std')
+        std = tp.exp(Linear(P, 'Extractor.Std', out))
+        mean = Linear(P, 'Extractor.Output', out)
+        return tp.add(mean, tp.mul(eps, std)), mean, std
     return Linear(P, 'Extractor.Output', out)
 
 

@@ -97,6 +97,63 @@ def mix_rbf_mmd2(X, Y, sigmas=(2., 5., 10., 20., 40., 80.)):
                   tp.scale(tp.reduce_sum(kxy), -2.0 / (m * n)))
 
 
+# ---- tflib/objs/kl_aggregated.py: divergences between the aggregated posterior (a mixture of the minibatch's diagonal Gaussians) and
+# the prior, estimated on Z_SAMPLES Monte-Carlo samples (MODE vegan-kl / vegan-ikl / vegan-jsd) -------------------------------------
+def mixture_gaussian(k_onehot, mu, std, eps):
+    """:6-16: z = k @ mu + (k @ std) * eps, k one-hot rows drawn uniformly over the components"""
+    return tp.add(tp.matmul(k_onehot, mu), tp.mul(tp.matmul(k_onehot, std), eps))
+
+
+def log_likelihood_diagonal_gaussian(x, mu, std):
+    """:18-20"""
+    r = tp.mul(tp.add(x, tp.neg(mu)), tp.power(std, -1.0))
+    res = tp.scale(tp.add(tp.add(tp.square(r), tp.scale(tp.log(std), 2.0)), tp.T(np.asarray(np.log(2 * np.pi), dtype=x.v.dtype))), -0.5)
+    return tp.reduce_sum(res, (res.v.ndim - 1,))
+
+
+def _log_mean_exp_rows(res_mat):
+    """:26-29 (the subtracted row maximum is an additive constant of the total derivative)"""
+    mx = tp.T(res_mat.v.max(axis=1, keepdims=True))
+    return tp.add(tp.log(tp.reduce_mean(tp.exp(tp.add(res_mat, tp.neg(mx))), (1,))), tp.reshape(mx, (-1,)))
+
+
+def log_likelihood_mixture_gaussian(x, mu, std):
+    """:22-29: x [nz, d] under the equal-weight mixture of the nx components -> [nz]"""
+    nz, d = x.v.shape
+    nx = mu.v.shape[0]
+    return _log_mean_exp_rows(log_likelihood_diagonal_gaussian(tp.reshape(x, (nz, 1, d)), tp.reshape(mu, (1, nx, d)), tp.reshape(std, (1, nx, d))))
+
+
+def log_likelihood_mixture_mixture_gaussian(x, mu_q, std_q, mu_p, std_p, n_coms):
+    """:31-44: the nx posterior components and n_coms copies of the prior term, equally weighted"""
+    nz, d = x.v.shape
+    nx = mu_q.v.shape[0]
+    r1 = log_likelihood_diagonal_gaussian(tp.reshape(x, (nz, 1, d)), tp.reshape(mu_q, (1, nx, d)), tp.reshape(std_q, (1, nx, d)))
+    r2 = log_likelihood_diagonal_gaussian(x, mu_p, std_p)
+    r2 = tp.broadcast_to(tp.reshape(r2, (nz, 1)), (nz, n_coms))
+    return _log_mean_exp_rows(tp.concat([r1, r2], axis=1))
+
+
+def aggregated_divergence(kind, q_mean, q_std, k_onehot, eps_q, z_p, n_coms):
+    """kl / ikl / jsd_q_aggregated_p_diagonal_gaussian (:46-74) with p = N(0, I) (gan_inference_cifar10.py:269-270); the script's
+    random draws (component indices, eps, prior samples) are inputs"""
+    dt = q_mean.v.dtype
+    nz, d = z_p.v.shape
+    p_mean, p_std = tp.T(np.zeros((nz, d), dt)), tp.T(np.ones((nz, d), dt))
+    if kind == 'kl':
+        z = mixture_gaussian(k_onehot, q_mean, q_std, eps_q)
+        return tp.reduce_mean(tp.add(log_likelihood_mixture_gaussian(z, q_mean, q_std), tp.neg(log_likelihood_diagonal_gaussian(z, p_mean, p_std))))
+    if kind == 'ikl':
+        return tp.reduce_mean(tp.add(log_likelihood_diagonal_gaussian(z_p, p_mean, p_std), tp.neg(log_likelihood_mixture_gaussian(z_p, q_mean, q_std))))
+    assert kind == 'jsd'
+    z1 = mixture_gaussian(k_onehot, q_mean, q_std, eps_q)
+    log_q = log_likelihood_mixture_gaussian(z1, q_mean, q_std)
+    log_m1 = log_likelihood_mixture_mixture_gaussian(z1, q_mean, q_std, p_mean, p_std, n_coms)
+    log_p = log_likelihood_diagonal_gaussian(z_p, p_mean, p_std)
+    log_m2 = log_likelihood_mixture_mixture_gaussian(z_p, q_mean, q_std, p_mean, p_std, n_coms)
+    return tp.reduce_mean(tp.scale(tp.add(tp.add(log_q, tp.neg(log_m1)), tp.add(log_p, tp.neg(log_m2))), 0.5))
+
+
 def wali_costs(disc_fake, disc_real):
     """tflib/objs/gan_inference.py:5-6 (the generator cost really is -mean(fake) - mean(real) there)."""
     gen = tp.add(tp.neg(tp.reduce_mean(disc_fake)), tp.neg(tp.reduce_mean(disc_real)))

@@ -14,6 +14,9 @@ from . import nets as N
 from . import objs as J
 
 
+AGG_MODES = ('vegan-kl', 'vegan-ikl', 'vegan-jsd')
+
+
 def make_feed(cfg, rng, mode='ali'):
     """Synthetic inputs for one session.run."""
     f = {}
@@ -33,6 +36,14 @@ def make_feed(cfg, rng, mode='ali'):
         for tag in ('f', 'r') + (('h',) if mode == 'vegan-wgan-gp' else ()):
             for i, w in enumerate((cfg.dim_latent, 1024, 512, 256)):
                 f['dn_%s%d' % (tag, i)] = rng.standard_normal((cfg.B, w), dtype=np.float32)
+    if mode in AGG_MODES:                           # the stochastic encoder's eps and the Monte-Carlo draws of tflib/objs/kl_aggregated.py
+        Z = cfg.z_samples
+        f['q_eps'] = rng.standard_normal((cfg.B, cfg.dim_latent), dtype=np.float32)
+        k = np.zeros((Z, cfg.B), np.float32)
+        k[np.arange(Z), rng.integers(0, cfg.B, size=Z)] = 1
+        f['kl_k'] = k
+        f['kl_eps'] = rng.standard_normal((Z, cfg.dim_latent), dtype=np.float32)
+        f['kl_zp'] = rng.standard_normal((Z, cfg.dim_latent), dtype=np.float32)
     return f
 
 
@@ -49,6 +60,13 @@ def forward(cfg, P, feed, mode='ali'):
     """P: name -> tape.T.  Returns dict of taped tensors incl. gen_cost / disc_cost."""
     dt = next(iter(P.values())).v.dtype.type
     real_x = tp.T(real_x_from_feed(cfg, feed, dt))
+    if mode in AGG_MODES:                           # gan_inference_cifar10.py:263-270,331-341: no critic, stochastic encoder
+        q_z, q_mean, q_std = N.Extractor(cfg, P, real_x, eps=tp.T(feed['q_eps'].astype(dt)))
+        rec = J.distance(real_x, N.Generator(cfg, P, q_z), 'l2')
+        div = J.aggregated_divergence(mode[6:], q_mean, q_std, tp.T(feed['kl_k'].astype(dt)), tp.T(feed['kl_eps'].astype(dt)),
+                                      tp.T(feed['kl_zp'].astype(dt)), cfg.B)
+        return {'real_x': real_x, 'q_z': q_z, 'q_z_mean': q_mean, 'q_z_std': q_std, 'rec_penalty': rec, 'divergence': div,
+                'gen_cost': tp.add(tp.scale(div, 1.0), rec), 'disc_cost': None}
     q_z = N.Extractor(cfg, P, real_x)
     noise = tp.T(feed['p_z_noise'].astype(dt))
     out = {'real_x': real_x, 'q_z': q_z}
@@ -139,7 +157,7 @@ class Trainer(object):
         else:
             self.gen_opt = J.Adam(gen_names, **hp)
             self.disc_opt = J.Adam(disc_names, **hp)
-        self.critic_iters = 5 if mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else (0 if mode == 'vegan-mmd' else 1)   # :52-59
+        self.critic_iters = 5 if mode in ('wali', 'wali-gp', 'vegan', 'vegan-wgan-gp') else (0 if mode == 'vegan-mmd' or mode in AGG_MODES else 1)   # :52-59
 
     def _run(self, feed, which):
         Pt = {k: tp.T(v) for k, v in self.P.items()}

@@ -8,11 +8,11 @@ from graphical_gan_amd import run
 from graphical_gan_amd.models import Config
 
 DATASET = 'face'
-MODE = 'ali'  # ali, alice, alice-z, alice-x, wali, wali-gp, vegan, vegan-wgan-gp, vegan-mmd
+MODE = 'ali'  # ali, alice, alice-z, alice-x, wali, wali-gp, vegan, vegan-wgan-gp, vegan-mmd, vegan-kl, vegan-ikl, vegan-jsd
 
 DIM_LATENT = 128  # latent dimension
 BATCH_SIZE = 128
-CRITIC_ITERS = 0 if MODE == "vegan-mmd" else (5 if MODE in ("wali", "wali-gp", "vegan", "vegan-wgan-gp") else 1)
+CRITIC_ITERS = 0 if MODE in ("vegan-mmd", "vegan-kl", "vegan-ikl", "vegan-jsd") else (5 if MODE in ("wali", "wali-gp", "vegan", "vegan-wgan-gp") else 1)
 LR = {"wali-gp": 1e-4, "wali": 5e-5}.get(MODE, 2e-4)  # the wali objectives ignore the scripts' LR (gan_inference.py:4,28)
 BETA1 = .5
 ITERS = 100000  # number of iterations to train

@@ -233,3 +233,37 @@ def test_ssgan_oracle_finite_differences(mode, channels, n_c):
             Pm[n] = P0[n].copy(); Pm[n][idx] -= eps
             fd = (float(cost(Pp, which).v) - float(cost(Pm, which).v)) / (2 * eps)
             assert abs(fd - g.v[idx]) <= 1e-6 + 1e-5 * abs(fd), (which, n, fd, g.v[idx])
+
+
+@pytest.mark.parametrize('kind', ['kl', 'ikl', 'jsd'])
+def test_aggregated_divergence_oracle_known_answers_and_finite_differences(kind):
+    """oracle restatement of tflib/objs/kl_aggregated.py:46-74: zero when the aggregated posterior IS the prior (every component N(0, I));
+    the closed-form log-likelihoods for one component; JSD <= ln 2; tape gradients vs float64 central differences."""
+    from oracle import objs as J, tape as tp
+    rng = np.random.default_rng(3)
+    nx, nz, d = 4, 9, 3
+    k = np.zeros((nz, nx)); k[np.arange(nz), rng.integers(0, nx, nz)] = 1
+    eps, zp = rng.standard_normal((nz, d)), rng.standard_normal((nz, d))
+    T = tp.T
+    assert abs(float(J.aggregated_divergence(kind, T(np.zeros((nx, d))), T(np.ones((nx, d))), T(k), T(eps), T(zp), nx).v)) < 1e-12
+    # one component N(m, s): log q(z) is the diagonal-Gaussian density itself
+    m, s = rng.standard_normal((1, d)), np.exp(0.3 * rng.standard_normal((1, d)))
+    ll = J.log_likelihood_mixture_gaussian(T(zp), T(m), T(s)).v
+    want = (-0.5 * (((zp - m) / s) ** 2 + np.log(2 * np.pi) + 2 * np.log(s))).sum(1)
+    assert np.abs(ll - want).max() < 1e-12
+    mu, sd = 3.0 * rng.standard_normal((nx, d)), np.exp(0.5 * rng.standard_normal((nx, d)))
+
+    def f(mu_, sd_):
+        return J.aggregated_divergence(kind, T(mu_), T(sd_), T(k), T(eps), T(zp), nx)
+
+    if kind == 'jsd':
+        assert 0.0 < float(f(mu, sd).v) <= np.log(2) + 1e-12
+    tm, ts = T(mu), T(sd)
+    gm, gs = tp.grad(J.aggregated_divergence(kind, tm, ts, T(k), T(eps), T(zp), nx), [tm, ts])
+    for a, g, which in ((mu, gm, 0), (sd, gs, 1)):
+        for _ in range(4):
+            idx = tuple(rng.integers(0, n) for n in a.shape)
+            ap, am = a.copy(), a.copy()
+            ap[idx] += 1e-6; am[idx] -= 1e-6
+            fd = (float((f(ap, sd) if which == 0 else f(mu, ap)).v) - float((f(am, sd) if which == 0 else f(mu, am)).v)) / 2e-6
+            assert abs(fd - g.v[idx]) <= 1e-6 * max(1.0, abs(fd)), (kind, which, idx, fd, g.v[idx])

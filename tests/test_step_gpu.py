@@ -18,11 +18,13 @@ def _fresh():
     lib.delete_all_params()
 
 
-def _mk(dataset, B, K, mode, dim, dl, fuse, graph, gpu):
+def _mk(dataset, B, K, mode, dim, dl, fuse, graph, gpu, z_samples=None, bn=None):
     from graphical_gan_amd.models import Config
     from graphical_gan_amd.engine import Trainer
     from oracle import nets as N
-    ocfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl, latent_critic=mode.startswith('vegan'))
+    agg = mode in ('vegan-kl', 'vegan-ikl', 'vegan-jsd')
+    ocfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl, latent_critic=mode.startswith('vegan') and not agg, learn_std=agg,
+                 z_samples=z_samples or 100, bn=bn)
     P0 = N.init_params(ocfg, seed=0)
     rng = np.random.default_rng(7)
     for k in P0:   # make biases / BN params non-trivial so their gradients paths are exercised
@@ -31,7 +33,9 @@ def _mk(dataset, B, K, mode, dim, dl, fuse, graph, gpu):
         if k.endswith('.scale'):
             P0[k] = (1 + 0.1 * rng.standard_normal(P0[k].shape)).astype(np.float32)
     _fresh()
-    cfg = Config(dataset, batch_size=B, n_coms=K, mode=mode, dim=dim, dim_latent=dl, fuse=fuse)
+    cfg = Config(dataset, batch_size=B, n_coms=K, mode=mode, dim=dim, dim_latent=dl, fuse=fuse, bn=bn)
+    if z_samples:
+        cfg.z_samples = z_samples
     tr = Trainer(cfg, device=gpu, graph=graph, inject_noise=True)
     tr.load_params(P0)
     return ocfg, P0, cfg, tr
@@ -461,3 +465,53 @@ def test_vegan_mmd_mode_generator_only_steps(gpu):
         assert set(ro) == set(rp) == ({'gen_cost'} if it > 0 else set())
         for k in ro:
             assert abs(float(rp[k]) - ro[k]) <= 2e-3 * max(1.0, abs(ro[k])), (it, k, float(rp[k]), ro[k])
+
+
+@pytest.mark.parametrize('mode,z_samples,bn', [('vegan-kl', None, False), ('vegan-ikl', 13, False), ('vegan-jsd', None, False), ('vegan-jsd', 7, True)])
+def test_vegan_aggregated_divergence_modes(gpu, mode, z_samples, bn):
+    """MODE vegan-kl / vegan-ikl / vegan-jsd (gan_inference_cifar10.py:331-341, tflib/objs/kl_aggregated.py; CRITIC_ITERS = 0, stochastic
+    encoder TYPE_Q = 'learn_std'): cost, the divergence alone, every Generator / Extractor gradient and a 4-iteration trajectory
+    (generator steps only) against the oracle, same injected draws."""
+    import torch
+    from oracle import step as S, tape as tp
+    mk = lambda: _mk('cifar10', 8, 0, mode, 8, 8, True, True, gpu, z_samples=z_samples, bn=bn)
+    ocfg, P0, cfg, tr = mk()
+    assert cfg.critic_iters == 0 and cfg.learn_std and 'Extractor.Std.W' in P0
+    feed = S.make_feed(ocfg, np.random.default_rng(11), mode)
+    Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
+    oout = S.forward(ocfg, Pt, feed, mode)
+    tr.set_feed(feed)
+    out = tr.model.forward(tr.feed, 'gen')
+    assert out['disc_cost'] is None
+    for k in ('q_z', 'q_z_mean', 'q_z_std'):
+        assert np.abs(out[k].detach().cpu().numpy() - oout[k].v).max() <= 1e-5 * max(1.0, np.abs(oout[k].v).max()), k
+    oc, c = float(oout['gen_cost'].v), float(out['gen_cost'].detach())
+    od, d = float(oout['divergence'].v), c - float(out['rec_penalty'].detach())
+    assert abs(c - oc) <= 1e-5 * max(1.0, abs(oc)) and abs(d - od) <= 2e-5 * max(1.0, abs(od)), (c, oc, d, od)
+    opt = out['gen_train_op'].optimizer
+    names = [p.param_name for p in opt.params]
+    assert 'Extractor.Std.W' in names and not any(n.startswith('Discriminator') for n in names)
+    grads = torch.autograd.grad(out['gen_cost'], opt.params, allow_unused=True)
+    ogs = tp.grad(oout['gen_cost'], [Pt[n] for n in names])
+    gmax = max(np.abs(og.v).max() for og in ogs if og is not None)
+    for n, g, og in zip(names, grads, ogs):
+        if og is None:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        err = np.abs(g.cpu().numpy().reshape(og.v.shape) - og.v).max()
+        assert err <= 1e-4 * max(np.abs(og.v).max(), 1e-2 * gmax), (n, err)
+    del out, grads, opt
+    ocfg, P0, cfg, tr = mk()
+    otr = S.Trainer(ocfg, P0, mode, np.float64)
+    feeds = [S.make_feed(ocfg, np.random.default_rng(300 + i), mode) for i in range(6)]
+    fo, fp = iter(feeds), iter(feeds)
+    for it in range(4):
+        ro, rp = otr.iteration(it, fo), tr.iteration(it, fp)
+        assert set(ro) == set(rp) == ({'gen_cost'} if it > 0 else set())
+        for k in ro:
+            assert abs(float(rp[k]) - ro[k]) <= 2e-3 * max(1.0, abs(ro[k])), (it, k, float(rp[k]), ro[k])
+    P = tr.get_params()
+    for n, v in otr.P.items():
+        if n.startswith('Discriminator'):
+            continue
+        assert np.abs(P[n].astype(np.float64).reshape(v.shape) - v).max() <= 2e-3 * max(1.0, np.abs(v).max()), n
