@@ -327,8 +327,9 @@ def main():
             'value': round(images_per_s, 1), 'unit': 'sequences/sec' if ssgan else 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('ssgan_inference_%s.py MODE=local_ep POS_MODE=%s LEN=%d BATCH_SIZE=%d sequences '
-                                    '(per GPU) of 64x64x%d frames%s' % (args.dataset, cfg.pos_mode, cfg.LEN, cfg.B, cfg.C,
+            'config': {'workload': ('ssgan_inference_%s.py MODE=%s POS_MODE=%s LEN=%d BATCH_SIZE=%d sequences '
+                                    '(per GPU) of 64x64x%d frames%s' % (args.dataset, cfg.mode + ((' ALI_MODE=' + cfg.ali_mode) if cfg.seq_critic else ''),
+                                                                        cfg.pos_mode, cfg.LEN, cfg.B, cfg.C,
                                                                         ', eager' if args.no_graph else ''))
                        if ssgan else '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
                 'gmgan' if K else 'gan', args.dataset, args.mode, ' N_COMS=%d' % K if K else '', cfg.B, cfg.S, cfg.S, cfg.C,
