@@ -24,7 +24,18 @@ TRAJ = {   # name -> (dataset, B, K, mode, dim, dim_latent, iterations)
     'traj_cifar_wali': ('cifar10', 6, 0, 'wali', 8, 16, 2),         # RMSProp + weight clipping, 5 critic steps
     'traj_cifar_alice': ('cifar10', 6, 0, 'alice', 8, 16, 2),       # both reconstruction terms
     'traj_cifar_vegan': ('cifar10', 4, 0, 'vegan', 8, 16, 2),       # latent critic with BatchNorm + noise layers
+    'traj_cifar_vegan_jsd': ('cifar10', 6, 0, 'vegan-jsd', 8, 8, 4),   # critic-free: stochastic encoder + aggregated-posterior JSD
+    'traj_cifar_vegan_kl': ('cifar10', 6, 0, 'vegan-kl', 8, 8, 3),
+    'traj_cifar_vegan_mmd': ('cifar10', 6, 0, 'vegan-mmd', 8, 16, 3),
 }
+Z_SAMPLES = 12      # Monte-Carlo samples of the aggregated-divergence trajectories (the scripts' 100 would only make the fixture larger)
+
+
+def cfg_for(name):
+    dataset, B, K, mode, dim, dl, iters = TRAJ[name]
+    agg = mode in S.AGG_MODES
+    return N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl, latent_critic=mode in ('vegan', 'vegan-wgan-gp'),
+                 learn_std=agg, z_samples=Z_SAMPLES)
 
 
 def perturbed_params(cfg, seed=0):
@@ -71,7 +82,7 @@ def make_ops():
 
 def make_traj(name):
     dataset, B, K, mode, dim, dl, iters = TRAJ[name]
-    cfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl, latent_critic=mode.startswith('vegan'))
+    cfg = cfg_for(name)
     P0 = perturbed_params(cfg)
     tr = S.Trainer(cfg, P0, mode, np.float64)
     n_feeds = iters * (1 + tr.critic_iters)
@@ -80,7 +91,7 @@ def make_traj(name):
     costs = []
     for it in range(iters):
         r = tr.iteration(it, it_f)
-        costs.append([r.get('gen_cost', np.nan), r['disc_cost']])
+        costs.append([r.get('gen_cost', np.nan), r.get('disc_cost', np.nan)])
     out = {'costs': np.asarray(costs)}
     # initial weights are NOT stored: perturbed_params(cfg) regenerates them (numpy legacy RandomState is
     # stream-stable); final weights are stored as per-tensor digests (sum, abs-sum, first 8 values)

@@ -48,7 +48,8 @@ def test_ops_vs_goldens(gpu):
 
 
 @pytest.mark.parametrize('name', ['traj_cifar_ali', 'traj_cifar_gmgan', 'traj_cifar_wali_gp', 'traj_mnist_gmgan',
-                                  'traj_face_gmgan', 'traj_svhn_gmgan', 'traj_cifar_wali', 'traj_cifar_alice', 'traj_cifar_vegan'])
+                                  'traj_face_gmgan', 'traj_svhn_gmgan', 'traj_cifar_wali', 'traj_cifar_alice', 'traj_cifar_vegan',
+                                  'traj_cifar_vegan_jsd', 'traj_cifar_vegan_kl', 'traj_cifar_vegan_mmd'])
 def test_trajectory_vs_goldens(gpu, name):
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
     import make_golden as MG
@@ -58,23 +59,29 @@ def test_trajectory_vs_goldens(gpu, name):
     from graphical_gan_amd.models import Config
     dataset, B, K, mode, dim, dl, iters = MG.TRAJ[name]
     z = load(name)
-    ocfg = N.Cfg(dataset, batch_size=B, n_coms=K, dim=dim, dim_latent=dl, latent_critic=mode.startswith('vegan'))
+    ocfg = MG.cfg_for(name)
     optim.reset_optimizers(); lib.delete_all_params()
     pmode = 'local_ep' if (K and mode == 'ali') else mode
-    tr = Trainer(Config(dataset, batch_size=B, n_coms=K, mode=pmode, dim=dim, dim_latent=dl), device=gpu, graph=False,
-                 inject_noise=True)
+    cfg = Config(dataset, batch_size=B, n_coms=K, mode=pmode, dim=dim, dim_latent=dl)
+    cfg.z_samples = MG.Z_SAMPLES
+    tr = Trainer(cfg, device=gpu, graph=False, inject_noise=True)
     tr.load_params(MG.perturbed_params(ocfg))
     feeds = iter(traj_feeds(z))
     for it in range(iters):
         r = tr.iteration(it, feeds)
         if it > 0:
             assert abs(float(r['gen_cost']) - z['costs'][it, 0]) <= 2e-3 * max(1.0, abs(z['costs'][it, 0]))
-        assert abs(float(r['disc_cost']) - z['costs'][it, 1]) <= 2e-3 * max(1.0, abs(z['costs'][it, 1]))
+        if tr.cfg.critic_iters:
+            assert abs(float(r['disc_cost']) - z['costs'][it, 1]) <= 2e-3 * max(1.0, abs(z['costs'][it, 1]))
+        else:
+            assert 'disc_cost' not in r and np.isnan(z['costs'][it, 1])
     P = tr.get_params()
     for k in z.files:
         if not k.startswith('p1/'):
             continue
         n = k[3:]
+        if not tr.cfg.critic_iters and n.startswith('Discriminator'):
+            continue   # critic-free modes: the oracle's parameter set carries an unused critic
         if ocfg.bn and (n.endswith('.Biases') or n == 'Generator.Input.b') and not n.startswith('Discriminator') \
                 and n not in ('Extractor.1.Biases', 'Generator.5.Biases'):
             continue
