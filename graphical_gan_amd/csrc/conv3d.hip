@@ -13,36 +13,54 @@ struct C3 {
     int N, L, H, W, Ci, Co, Lo, Ho, Wo, kl, k, sl, s, pl, ph, pw;
 };
 
-// col[(n,ol,oh,ow)][(dl,dh,dw,ci)] = x[n, ol*sl+dl-pl, oh*s+dh-ph, ow*s+dw-pw, ci]  (0 outside the volume)
+template <int V> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<4> { typedef float4 T; };
+template <int V> __device__ __forceinline__ typename VecT<V>::T vzero();
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+template <> __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vacc(float& a, float b) { a += b; }
+__device__ __forceinline__ void vacc(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// col[(n,ol,oh,ow)][(dl,dh,dw,ci)] = x[n, ol*sl+dl-pl, oh*s+dh-ph, ow*s+dw-pw, ci]  (0 outside the volume).  One thread per V
+// consecutive channels (V = 4: 16-byte loads / stores when Ci % 4 == 0); IT = 32-bit index arithmetic whenever the element count
+// allows it (the 64-bit divisions of the general case cost more than the memory traffic).
+template <typename IT, int V>
 __global__ void im2col3d_k(const C3 g, const float* __restrict__ x, float* __restrict__ col) {
-    const size_t K = (size_t)g.kl * g.k * g.k * g.Ci, total = (size_t)g.N * g.Lo * g.Ho * g.Wo * K;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t t = i;
-        const int ci = (int)(t % g.Ci); t /= g.Ci;
-        const int dw = (int)(t % g.k); t /= g.k;
-        const int dh = (int)(t % g.k); t /= g.k;
-        const int dl = (int)(t % g.kl); t /= g.kl;
-        const int ow = (int)(t % g.Wo); t /= g.Wo;
-        const int oh = (int)(t % g.Ho); t /= g.Ho;
-        const int ol = (int)(t % g.Lo);
-        const int n = (int)(t / g.Lo);
+    typedef typename VecT<V>::T VT;
+    const IT Cv = (IT)(g.Ci / V), total = (IT)g.N * g.Lo * g.Ho * g.Wo * g.kl * g.k * g.k * Cv;
+    for (IT i = (IT)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * blockDim.x) {
+        IT t = i;
+        const int cv = (int)(t % Cv); t /= Cv;
+        const int dw = (int)(t % (IT)g.k); t /= (IT)g.k;
+        const int dh = (int)(t % (IT)g.k); t /= (IT)g.k;
+        const int dl = (int)(t % (IT)g.kl); t /= (IT)g.kl;
+        const int ow = (int)(t % (IT)g.Wo); t /= (IT)g.Wo;
+        const int oh = (int)(t % (IT)g.Ho); t /= (IT)g.Ho;
+        const int ol = (int)(t % (IT)g.Lo);
+        const int n = (int)(t / (IT)g.Lo);
         const int l = ol * g.sl + dl - g.pl, h = oh * g.s + dh - g.ph, w = ow * g.s + dw - g.pw;
         const bool in = (unsigned)l < (unsigned)g.L && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-        col[i] = in ? x[((((size_t)n * g.L + l) * g.H + h) * g.W + w) * g.Ci + ci] : 0.f;
+        VT v = vzero<V>();
+        if (in) v = reinterpret_cast<const VT*>(x)[((((size_t)n * g.L + l) * g.H + h) * g.W + w) * Cv + cv];
+        reinterpret_cast<VT*>(col)[i] = v;
     }
 }
 
 // the adjoint as a gather (deterministic): gx[n,l,h,w,ci] = sum over the taps (dl,dh,dw) whose window covers the voxel
+template <typename IT, int V>
 __global__ void col2im3d_k(const C3 g, const float* __restrict__ col, float* __restrict__ gx) {
-    const size_t K = (size_t)g.kl * g.k * g.k * g.Ci, total = (size_t)g.N * g.L * g.H * g.W * g.Ci;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t t = i;
-        const int ci = (int)(t % g.Ci); t /= g.Ci;
-        const int w = (int)(t % g.W); t /= g.W;
-        const int h = (int)(t % g.H); t /= g.H;
-        const int l = (int)(t % g.L);
-        const int n = (int)(t / g.L);
-        float acc = 0.f;
+    typedef typename VecT<V>::T VT;
+    const IT Cv = (IT)(g.Ci / V), total = (IT)g.N * g.L * g.H * g.W * Cv;
+    const size_t Kv = (size_t)g.kl * g.k * g.k * Cv;
+    for (IT i = (IT)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * blockDim.x) {
+        IT t = i;
+        const int cv = (int)(t % Cv); t /= Cv;
+        const int w = (int)(t % (IT)g.W); t /= (IT)g.W;
+        const int h = (int)(t % (IT)g.H); t /= (IT)g.H;
+        const int l = (int)(t % (IT)g.L);
+        const int n = (int)(t / (IT)g.L);
+        VT acc = vzero<V>();
         for (int dl = 0; dl < g.kl; ++dl) {
             const int a = l + g.pl - dl;
             if (a < 0 || a % g.sl) continue;
@@ -58,11 +76,12 @@ __global__ void col2im3d_k(const C3 g, const float* __restrict__ col, float* __r
                     if (c < 0 || c % g.s) continue;
                     const int ow = c / g.s;
                     if (ow >= g.Wo) continue;
-                    acc += col[((((size_t)n * g.Lo + ol) * g.Ho + oh) * g.Wo + ow) * K + (((size_t)dl * g.k + dh) * g.k + dw) * g.Ci + ci];
+                    vacc(acc, reinterpret_cast<const VT*>(col)[((((size_t)n * g.Lo + ol) * g.Ho + oh) * g.Wo + ow) * Kv +
+                                                               (((size_t)dl * g.k + dh) * g.k + dw) * Cv + cv]);
                 }
             }
         }
-        gx[i] = acc;
+        reinterpret_cast<VT*>(gx)[i] = acc;
     }
 }
 
@@ -80,7 +99,7 @@ int fill(C3& g, const int* d) {
 
 int blocks(size_t n) {
     size_t b = (n + 255) / 256;
-    return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+    return (int)(b > 32768 ? 32768 : (b < 1 ? 1 : b));
 }
 
 }  // namespace
@@ -98,7 +117,12 @@ int ggan_im2col3d(const int* dims10, const float* x, float* col, ggan_stream_t s
     C3 g;
     GGAN_CHECK_ARG(dims10 && x && col && fill(g, dims10) == 0, "bad argument");
     const size_t n = (size_t)g.N * g.Lo * g.Ho * g.Wo * g.kl * g.k * g.k * g.Ci;
-    GGAN_LAUNCH("im2col3d", 0, 8.0 * n, im2col3d_k, dim3(blocks(n)), dim3(256), 0, (hipStream_t)stream, g, x, col);
+    const bool v4 = (g.Ci & 3) == 0 && (((uintptr_t)x | (uintptr_t)col) & 15) == 0, i32 = n < 0xF0000000ull;
+    hipStream_t s = (hipStream_t)stream;
+    if (v4 && i32) { GGAN_LAUNCH("im2col3d", 0, 8.0 * n, (im2col3d_k<uint32_t, 4>), dim3(blocks(n / 4)), dim3(256), 0, s, g, x, col); }
+    else if (v4) { GGAN_LAUNCH("im2col3d", 0, 8.0 * n, (im2col3d_k<size_t, 4>), dim3(blocks(n / 4)), dim3(256), 0, s, g, x, col); }
+    else if (i32) { GGAN_LAUNCH("im2col3d", 0, 8.0 * n, (im2col3d_k<uint32_t, 1>), dim3(blocks(n)), dim3(256), 0, s, g, x, col); }
+    else { GGAN_LAUNCH("im2col3d", 0, 8.0 * n, (im2col3d_k<size_t, 1>), dim3(blocks(n)), dim3(256), 0, s, g, x, col); }
     return 0;
 }
 
@@ -106,8 +130,13 @@ int ggan_col2im3d(const int* dims10, const float* col, float* gx, ggan_stream_t 
     C3 g;
     GGAN_CHECK_ARG(dims10 && col && gx && fill(g, dims10) == 0, "bad argument");
     const size_t n = (size_t)g.N * g.L * g.H * g.W * g.Ci;
-    GGAN_LAUNCH("col2im3d", 0, 4.0 * n * (1 + (g.kl / g.sl + 1) * (g.k / g.s + 1) * (g.k / g.s + 1)), col2im3d_k, dim3(blocks(n)), dim3(256),
-                0, (hipStream_t)stream, g, col, gx);
+    const double bytes = 4.0 * n * (1 + (g.kl / g.sl + 1) * (g.k / g.s + 1) * (g.k / g.s + 1));
+    const bool v4 = (g.Ci & 3) == 0 && (((uintptr_t)gx | (uintptr_t)col) & 15) == 0, i32 = n < 0xF0000000ull;
+    hipStream_t s = (hipStream_t)stream;
+    if (v4 && i32) { GGAN_LAUNCH("col2im3d", 0, bytes, (col2im3d_k<uint32_t, 4>), dim3(blocks(n / 4)), dim3(256), 0, s, g, col, gx); }
+    else if (v4) { GGAN_LAUNCH("col2im3d", 0, bytes, (col2im3d_k<size_t, 4>), dim3(blocks(n / 4)), dim3(256), 0, s, g, col, gx); }
+    else if (i32) { GGAN_LAUNCH("col2im3d", 0, bytes, (col2im3d_k<uint32_t, 1>), dim3(blocks(n)), dim3(256), 0, s, g, col, gx); }
+    else { GGAN_LAUNCH("col2im3d", 0, bytes, (col2im3d_k<size_t, 1>), dim3(blocks(n)), dim3(256), 0, s, g, col, gx); }
     return 0;
 }
 
