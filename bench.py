@@ -163,7 +163,10 @@ def main():
         K = ({'svhn': 50, 'face': 100}.get(args.dataset, 30)) if args.mode in ('local_ep', 'local_epce') else 0
         if K and args.n_coms:
             K = args.n_coms
-        cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse)
+        # the code-space objectives run with the scripts' own settings for them: DIM_LATENT = 8, BN_FLAG = False (gan_inference_cifar10.py:72-77)
+        code = args.mode in ('vegan', 'vegan-wgan-gp', 'vegan-kl', 'vegan-ikl', 'vegan-jsd')
+        cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse,
+                     **(dict(dim_latent=8, bn=False) if code else {}))
         tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
     torch.manual_seed(1234 + rank)
     ring = tr.model.synthetic_ring(dev, n=4 if ssgan else 8, seed=1234 + rank)

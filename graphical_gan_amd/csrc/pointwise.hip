@@ -216,18 +216,20 @@ __global__ __launch_bounds__(128) void agg_div_fwd_k(const AggP P, float* __rest
         A[(size_t)i * nx + j] = a;
         lmax = fmaxf(lmax, a);
     }
-    float mx = block_max(lmax, red);
-    if (P.kind == 2) mx = fmaxf(mx, b);
+    // (as the reference: log q is shifted by ITS row maximum (:26-29), the mixture m by the maximum over its own terms (:41-44) -- a
+    // common shift would underflow sum exp(a_j) to 0 wherever the prior term dominates)
+    const float mq = block_max(lmax, red);
     float se = 0.f;
-    for (int j = threadIdx.x; j < nx; j += blockDim.x) se += expf(A[(size_t)i * nx + j] - mx);
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) se += expf(A[(size_t)i * nx + j] - mq);
     const float Sq = block_sum(se, red);
     if (threadIdx.x == 0) {
-        const float lq = mx + logf(Sq) - logf((float)nx);
+        const float lq = mq + logf(Sq) - logf((float)nx);
         float t;
         if (P.kind == 0) t = lq - b;
         else if (P.kind == 1) t = b - lq;
         else {
-            const float lm = mx + logf(Sq + (float)P.n_coms * expf(b - mx)) - logf((float)(nx + P.n_coms));
+            const float mm = fmaxf(mq, b);
+            const float lm = mm + logf(Sq * expf(mq - mm) + (float)P.n_coms * expf(b - mm)) - logf((float)(nx + P.n_coms));
             t = qs ? 0.5f * (lq - lm) : 0.5f * (b - lm);
         }
         T[i] = t;
@@ -254,18 +256,21 @@ __global__ __launch_bounds__(128) void agg_div_bwd_samples_k(const AggP P, const
     const float b = Bv[i], gs = gout[0] / (float)P.nz;
     float lmax = -3.0e38f;
     for (int j = threadIdx.x; j < nx; j += blockDim.x) lmax = fmaxf(lmax, A[(size_t)i * nx + j]);
-    float mx = block_max(lmax, red);
-    if (P.kind == 2) mx = fmaxf(mx, b);
+    const float mq = block_max(lmax, red);
     float se = 0.f;
-    for (int j = threadIdx.x; j < nx; j += blockDim.x) se += expf(A[(size_t)i * nx + j] - mx);
+    for (int j = threadIdx.x; j < nx; j += blockDim.x) se += expf(A[(size_t)i * nx + j] - mq);
     const float Sq = block_sum(se, red);
-    const float pe = (float)P.n_coms * expf(b - mx), M = Sq + pe;
+    const float mm = P.kind == 2 ? fmaxf(mq, b) : mq;                       // shift of the mixture m (jsd)
+    const float pe = (float)P.n_coms * expf(b - mm), M = Sq * expf(mq - mm) + pe;
     for (int j = threadIdx.x; j < nx; j += blockDim.x) {
-        const float e = expf(A[(size_t)i * nx + j] - mx);
+        const float a = A[(size_t)i * nx + j], rq = expf(a - mq) / Sq;      // responsibility under q
         float w;
-        if (P.kind == 0) w = e / Sq;
-        else if (P.kind == 1) w = -e / Sq;
-        else w = qs ? 0.5f * (e / Sq - e / M) : -0.5f * e / M;
+        if (P.kind == 0) w = rq;
+        else if (P.kind == 1) w = -rq;
+        else {
+            const float rm = expf(a - mm) / M;                                // ... under m
+            w = qs ? 0.5f * (rq - rm) : -0.5f * rm;
+        }
         w *= gs;
         ws[j] = w;
         W[(size_t)i * nx + j] = w;

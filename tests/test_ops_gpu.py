@@ -1032,3 +1032,26 @@ def test_aggregated_divergence_fused_op(gpu, kind, nx, nz, d):
         assert torch.equal(a, gz) and _rel(b.cpu().numpy(), ((gz * e + gs) * s.detach()).cpu().numpy()) <= 1e-6
         (b2,) = torch.autograd.grad(F.Reparam.apply(mean, ls, e)[0], (ls,), gz)      # only z used: std's gradient is absent
         assert _rel(b2.cpu().numpy(), (gz * e * s.detach()).cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize('kind', ['kl', 'jsd'])
+def test_aggregated_divergence_stays_finite_when_the_prior_term_dominates(gpu, kind):
+    """wide posterior components (std 50): for samples near a component mean log p(z) exceeds every log q_j(z) by hundreds of nats; the
+    reference shifts log q by its own row maximum, so must the kernel (a shared shift underflows sum_j exp to 0 -> log 0)."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import objs as J, tape as tp
+    rng = np.random.default_rng(5)
+    nx, nz, d = 6, 9, 128
+    mu, sd = 0.01 * rng.standard_normal((nx, d)), np.full((nx, d), 50.0)
+    k = np.zeros((nz, nx)); k[np.arange(nz), rng.integers(0, nx, nz)] = 1
+    eps, zp = 1e-3 * rng.standard_normal((nz, d)), rng.standard_normal((nz, d))
+    tmu, tsd = tp.T(mu), tp.T(sd)
+    ref = J.aggregated_divergence(kind, tmu, tsd, tp.T(k), tp.T(eps), tp.T(zp), nx)
+    rgm, rgs = tp.grad(ref, [tmu, tsd])
+    gmu, gsd = _t(mu, gpu).requires_grad_(), _t(sd, gpu).requires_grad_()
+    out = F.AggDiv.apply(gmu, gsd, _t(k, gpu), _t(eps, gpu), _t(zp, gpu), F.AGG_KL if kind == 'kl' else F.AGG_JSD, nx)
+    assert np.isfinite(float(out.detach())) and abs(float(out.detach()) - float(ref.v)) <= 1e-4 * max(1.0, abs(float(ref.v)))
+    dm, ds = torch.autograd.grad(out, (gmu, gsd))
+    assert bool(torch.isfinite(dm).all() and torch.isfinite(ds).all())
+    assert _rel(dm.cpu().numpy(), rgm.v) <= 1e-3 and _rel(ds.cpu().numpy(), rgs.v) <= 1e-3
