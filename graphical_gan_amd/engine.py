@@ -212,8 +212,9 @@ class Trainer(object):
     def step(self, which):
         """One gen or disc session.run on the current contents of the static buffers -> 0-dim cost tensor."""
         self._calls[which] += 1
-        if self._calls['gen'] >= 2 and self._calls['disc'] >= 2:
-            lib.end_build_phase()        # both step kinds have been built once: from here on the layer calls draw no initial values
+        if self._calls['gen'] >= 2 and (self._calls['disc'] >= 2 or not getattr(self.cfg, 'critic_iters', 1)):
+            lib.end_build_phase()        # both step kinds have been built once (critic-free modes: the generator step): from here on
+                                         # the layer calls draw no initial values
         if not self.graph_enabled:
             return self._eager(which)
         rec = self._graphs.get(which)
