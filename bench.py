@@ -3,13 +3,21 @@
 
 A "step" is one iteration of the reference loop (gmgan_inference_cifar10.py:480-494): one generator+extractor
 session.run followed by CRITIC_ITERS critic session.runs, each on a fresh synthetic minibatch + fresh noise,
-each including forward, backward and the TF-Adam update.  Workload at N=1: BASELINE.json configs[1],
-gan_inference_cifar10.py (32x32x3, BATCH_SIZE=64, MODE='ali'); per-GPU batch stays 64 as N grows (weak scaling).
+each including forward, backward and the TF-Adam update.  Headline workload: BASELINE.json configs[1],
+gan_inference_cifar10.py (32x32x3, BATCH_SIZE=64, MODE='ali' = "G+D"); per-GPU batch stays 64 as N grows (weak scaling).
+
+The one JSON line also carries `variants`: the other BASELINE configurations measured in the same process, each with its
+own ms_per_step, algorithmic GFLOP, roofline (dominant kernel) and cpu_baseline:
+  wali-gp            gan_inference_cifar10.py MODE='wali-gp' ("G+D+GP", CRITIC_ITERS=5, gan_inference_cifar10.py:351-366)
+  gmgan-cifar10-K30  gmgan_inference_cifar10.py with the script's N_COMS=30;  gmgan-cifar10-K10: BASELINE configs[2] (K=10)
+  gan-face           gan_inference_face.py 64x64x3 bs=64 (configs[3])
+  ssgan-moving-mnist ssgan_inference_moving_mnist.py 64x64 T=16 bs=32 (configs[4])
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -19,6 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+VARIANTS = [
+    dict(key='wali-gp', dataset='cifar10', mode='wali-gp'),
+    dict(key='gmgan-cifar10-K30', dataset='cifar10', mode='local_ep', n_coms=30),
+    dict(key='gmgan-cifar10-K10', dataset='cifar10', mode='local_ep', n_coms=10),
+    dict(key='gan-face', dataset='face', mode='ali'),
+    dict(key='ssgan-moving-mnist', dataset='moving_mnist', ssgan_mode='local_ep'),
+]
 
 
 def algorithmic_gflop_per_iteration(cfg):
@@ -93,6 +109,258 @@ def ssgan_gflop_per_iteration(cfg):
     return ((fwd + gen_bwd) + cfg.critic_iters * (fwd + disc_bwd)) / 1e9
 
 
+def _pmc_table(workload_key):
+    """HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same workload,
+    committed by tools/prof_round.sh; counters cannot be read from inside the process.  -> (kernel -> record, tag)"""
+    try:
+        tab = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+    except (OSError, ValueError):
+        return {}, None
+    tag = tab.get('_tag')
+    if workload_key in tab and isinstance(tab[workload_key], dict) and 'traffic_bytes' not in tab[workload_key]:
+        return tab[workload_key], tag
+    if workload_key == 'headline' and '_tag' not in tab:      # round-1 layout: kernel -> record of the headline workload
+        return tab, 'r01l'
+    return {}, tag
+
+
+def cpu_baseline(spec, cfg, K, np, torch, budget_s=float(os.environ.get('GGAN_BENCH_CPU_BUDGET_S', '10'))):
+    """The same step on the host cores (oracle/, test infrastructure; the reference itself is Python 2 + TF1 and cannot run):
+    PyTorch-CPU restatement (oneDNN convolutions, every granted core) for the image scripts, the numpy restatement on a
+    bounded sample for the state-space script."""
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=host_cores())
+    except ImportError:
+        pass
+    if spec['dataset'] in ('moving_mnist', 'chairs'):
+        from oracle import ssgan as OSS
+        ob = 2                                         # bounded sample: 2 sequences per minibatch instead of cfg.B
+        ocfg = OSS.Cfg(batch_size=ob, length=cfg.LEN, n_c=cfg.n_c, channels=cfg.C, op_dyn_mode=cfg.op_dyn_mode)
+        otr = OSS.Trainer(ocfg, OSS.init_params(ocfg, 0), np.float32)
+        feeds = iter([OSS.make_feed(ocfg, np.random.default_rng(i)) for i in range(8)])
+        otr.iteration(1, feeds)
+        t1 = time.perf_counter()
+        otr.iteration(2, feeds)
+        cdt = time.perf_counter() - t1
+        return dict(value=round(ob / cdt, 3), unit='sequences/sec', cores=host_cores(), kind='port',
+                    sample='1 iteration (gen step + critic step) at %d sequences x %d frames per minibatch, numpy fp32 '
+                    'oracle with multi-threaded BLAS' % (ob, cfg.LEN))
+    mode = spec['mode']
+    if mode not in ('ali', 'wali-gp', 'local_ep'):
+        from oracle import nets as ON, step as OS
+        ocfg = ON.Cfg(spec['dataset'], batch_size=cfg.B, n_coms=K)
+        otr = OS.Trainer(ocfg, ON.init_params(ocfg, 0), mode, np.float32)
+        feeds = iter([OS.make_feed(ocfg, np.random.default_rng(i), otr.mode) for i in range(64)])
+        otr.iteration(1, feeds)
+        t1 = time.perf_counter()
+        otr.iteration(2, feeds)
+        cdt = time.perf_counter() - t1
+        return dict(value=round(cfg.B / cdt, 2), unit='images/sec', cores=host_cores(), kind='port',
+                    sample='1 iteration (gen step + %d critic step(s)) of the same workload, numpy fp32 oracle with '
+                    'multi-threaded BLAS' % cfg.critic_iters)
+    from oracle import nets as ON, step as OS, torch_cpu
+    torch.set_num_threads(host_cores())
+    ocfg = ON.Cfg(spec['dataset'], batch_size=cfg.B, n_coms=K)
+    ts = torch_cpu.Step(ocfg, ON.init_params(ocfg, 0), torch.float32, mode)
+    rng = np.random.default_rng(0)
+    omode = 'wali-gp' if mode == 'wali-gp' else 'ali'
+
+    def feeds():
+        while True:
+            yield OS.make_feed(ocfg, rng, omode)
+    fi = feeds()
+    ts.iteration(1, fi)                                # warm-up (thread pool, oneDNN primitive cache)
+    n_cpu, t1 = 0, time.perf_counter()
+    while n_cpu < 1 or (time.perf_counter() - t1 < budget_s and n_cpu < 2000):
+        ts.iteration(2 + n_cpu, fi)
+        n_cpu += 1
+    cdt = time.perf_counter() - t1
+    return dict(value=round(cfg.B * n_cpu / cdt, 1), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                sample='%d iteration(s) (gen step + %d critic step(s)) of the same workload in %.1f s, PyTorch-CPU fp32 restatement '
+                '(oneDNN convolutions, TF-SAME padding and TF-Adam emulated)' % (n_cpu, ts.critic_iters, cdt))
+
+
+def run_workload(spec, args, env, steps, warmup, top_kernels=None):
+    """Build the workload, time `steps` iterations of graph replay, bracket its kernels (eager), time the CPU restatement.
+    -> result dict (rank 0) / None.  Leaves the parameter registry and the optimizers empty."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from graphical_gan_amd import _lib, optim
+    from graphical_gan_amd import tflib as lib
+    from graphical_gan_amd.engine import Trainer, broadcast_params
+    from graphical_gan_amd.models import Config
+    dev, world, rank = env['dev'], env['world'], env['rank']
+    optim.reset_optimizers()
+    lib.delete_all_params()
+    dataset = spec['dataset']
+    ssgan = dataset in ('moving_mnist', 'chairs')
+    batch = spec.get('batch_size') or ((32 if dataset == 'moving_mnist' else 16) if ssgan else 64)
+    np.random.seed(0)                                  # reference initialisers draw from numpy's global RNG
+    if ssgan:                                          # BASELINE configs[4]: ssgan_inference_moving_mnist.py, T=16
+        from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
+        K = 0
+        mode, _, ali_mode = spec.get('ssgan_mode', 'local_ep').partition(':')
+        skw = dict(mode=mode, ali_mode=ali_mode or 'concat_x')
+        if dataset == 'chairs':                        # ssgan_inference_chairs.py: 31 RGB views, no labels, res_w operator
+            cfg = SSConfig(batch_size=batch, fuse=not args.no_fuse, length=31, n_c=0, channels=3, op_dyn_mode='res_w',
+                           dataset='chairs', **skw)
+        else:
+            cfg = SSConfig(batch_size=batch, fuse=not args.no_fuse, **skw)
+        model = StateSpaceGAN(cfg)
+        tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank, model=model)
+    else:
+        mode = spec['mode']
+        # N_COMS of the gmgan scripts: 30 (cifar10 :78, mnist), 50 (svhn :72), 100 (face :68)
+        K = ({'svhn': 50, 'face': 100}.get(dataset, 30)) if mode in ('local_ep', 'local_epce') else 0
+        if K and spec.get('n_coms'):
+            K = spec['n_coms']
+        # the code-space objectives run with the scripts' own settings for them: DIM_LATENT = 8, BN_FLAG = False (gan_inference_cifar10.py:72-77)
+        code = mode in ('vegan', 'vegan-wgan-gp', 'vegan-kl', 'vegan-ikl', 'vegan-jsd')
+        cfg = Config(dataset, batch_size=batch, n_coms=K, mode=mode, fuse=not args.no_fuse,
+                     **(dict(dim_latent=8, bn=False) if code else {}))
+        tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
+    spec = dict(spec, mode=mode)
+    torch.manual_seed(1234 + rank)
+    ring = tr.model.synthetic_ring(dev, n=4 if ssgan else 8, seed=1234 + rank)
+
+    def batches():
+        i = 0
+        while True:
+            yield ring[i % len(ring)]
+            i += 1
+    bi = batches()
+    if args.host_feed:                                 # same minibatches, but every one crosses PCIe (graphical_gan_amd/data.py)
+        from graphical_gan_amd.data import DevicePrefetcher
+        host_ring = [tuple(t.cpu().numpy() for t in b) if isinstance(b, tuple) else b.cpu().numpy() for b in ring]
+        bi = DevicePrefetcher(lambda: iter(host_ring), dev, depth=2)
+    it = 0
+    tr.iteration(it, bi); it += 1                      # creates parameters + optimizers (eager)
+    tr.iteration(it, bi); it += 1
+    broadcast_params(0)
+    for _ in range(max(warmup, 2)):                    # includes graph capture
+        tr.iteration(it, bi); it += 1
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    tr.flush()
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = tr.iteration(it, bi); it += 1
+    tr.flush()                                         # (DP: the last critic step's exchange + Adam belong to the timed work)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = all(np.isfinite(float(v)) for v in last.values())
+
+    ms_per_step = 1e3 * dt / steps
+    units_per_s = cfg.B * world * steps / dt
+    gflop_it = ssgan_gflop_per_iteration(cfg) if ssgan else algorithmic_gflop_per_iteration(cfg)
+    step_tflops = gflop_it * steps / dt / 1e3          # per GPU
+
+    # ---- per-kernel timing of the same step with HIP events (eager, on the launch stream) ---------------------
+    roofline = None
+    kernels = None
+    if not args.no_kernel_profile:
+        # EVERY rank runs these eager iterations (they contain the gradient all-reduce: a collective issued by rank 0 alone
+        # would hang the job); only rank 0 records and reports
+        tr.flush()
+        tr_graph = tr.graph_enabled
+        tr.graph_enabled = False
+        L = _lib.load()
+        for _ in range(2):
+            tr.iteration(it, bi); it += 1
+        torch.cuda.synchronize(dev)
+        L.ggan_prof_reset(); L.ggan_prof_enable(1 if rank == 0 else 0)
+        n_prof = 5 if not ssgan else 3
+        for _ in range(n_prof):
+            tr.iteration(it, bi); it += 1
+        torch.cuda.synchronize(dev)
+        L.ggan_prof_enable(0)
+        recs = _lib.prof_report() if rank == 0 else []
+        L.ggan_prof_reset()
+        tr.graph_enabled = tr_graph
+    if rank == 0 and not args.no_kernel_profile:
+        recs.sort(key=lambda r: -r['total_ms'])
+        kernels = [dict(name=r['name'], launches_per_iter=r['launches'] / n_prof,
+                        ms_per_iter=round(r['total_ms'] / n_prof, 4),
+                        avg_us=round(1e3 * r['total_ms'] / r['launches'], 2),
+                        tflops=round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 2) if r['flops'] else None)
+                   for r in recs]
+        launches_per_iter = sum(r['launches'] for r in recs) / n_prof
+        dom = next((r for r in recs if r['flops'] > 0), None)
+        if dom is not None:
+            ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            tab, tag = _pmc_table(spec.get('key', 'headline'))
+            pmc = tab.get(dom['name'])
+            roofline = dict(bound='mfma', kernel=dom['name'], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
+                            unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                            source='HIP-event bracket around every launch of this kernel on the launch stream, eager replay of '
+                                   'the same step in this process (%d iterations); the timed region above replays HIP graphs, '
+                                   'whose per-kernel durations are in profiles/ (rocprofv3 --kernel-trace)' % n_prof,
+                            traffic=pmc['traffic_bytes'] if pmc else None,
+                            traffic_source=('static: profiles/pmc_traffic.json @%s (separate rocprofv3 --pmc passes of this '
+                                            'workload, bytes/launch, FETCH_SIZE x2 per the gfx950 note)' % tag) if pmc else None,
+                            pmc=pmc,
+                            avg_launch_us=round(1e3 * dom['total_ms'] / dom['launches'], 2),
+                            flop_per_launch=dom['flops'] / dom['launches'],
+                            whole_step_tflops=round(step_tflops, 2),
+                            whole_step_frac=round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                            libggan_launches_per_step=launches_per_iter)
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(spec, cfg, K, np, torch)
+
+    res = None
+    if rank == 0:
+        unit = 'sequences/sec' if ssgan else 'images/sec'
+        if ssgan:
+            metric = 'sequences/sec (G+D step) %s T=%d 64x64 bs=%d' % (dataset, cfg.LEN, cfg.B)
+            workload = ('ssgan_inference_%s.py MODE=%s POS_MODE=%s LEN=%d BATCH_SIZE=%d sequences (per GPU) of 64x64x%d frames%s' % (
+                dataset, cfg.mode + ((' ALI_MODE=' + cfg.ali_mode) if cfg.seq_critic else ''), cfg.pos_mode, cfg.LEN, cfg.B, cfg.C,
+                ', eager' if args.no_graph else ''))
+        else:
+            metric = 'images/sec (G+D%s step) %s %dx%d bs=%d' % ('+GP' if mode == 'wali-gp' else '', dataset, cfg.S, cfg.S, cfg.B)
+            workload = '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
+                'gmgan' if K else 'gan', dataset, mode, ' N_COMS=%d' % K if K else '', cfg.B, cfg.S, cfg.S, cfg.C,
+                cfg.critic_iters, '' if not args.no_graph else ', eager')
+        res = {
+            'metric': metric, 'value': round(units_per_s, 1), 'unit': unit, 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': workload, 'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world,
+                       'hip_graph': not args.no_graph, 'host_feed': bool(args.host_feed), 'fused_epilogues': not args.no_fuse,
+                       'minibatches_per_step': 1 + cfg.critic_iters, 'algorithmic_gflop_per_step': round(gflop_it, 2),
+                       'finite_costs': bool(finite), **({'frames_per_sec': round(units_per_s * cfg.LEN, 1)} if ssgan else {})},
+            'algorithmic_gflop_per_step': round(gflop_it, 2),
+            'whole_step_tflops': round(step_tflops, 2), 'whole_step_frac': round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+            'roofline': roofline, 'cpu_baseline': cpu,
+            'kernels': kernels[:top_kernels] if (kernels and top_kernels) else kernels,
+        }
+    # ---- tear down: graphs, flat optimizer buffers, parameters ------------------------------------------------
+    tr.flush()
+    torch.cuda.synchronize(dev)
+    del tr, ring, bi
+    optim.reset_optimizers()
+    lib.delete_all_params()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -108,12 +376,13 @@ def main():
     ap.add_argument('--no-fuse', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
-    ap.add_argument('--cpu-iters', type=int, default=2)
+    ap.add_argument('--no-variants', action='store_true', help='headline workload only')
+    ap.add_argument('--variants', default=None, help='comma-separated subset of: ' + ', '.join(v['key'] for v in VARIANTS))
+    ap.add_argument('--variant-steps', type=int, default=None, help='timed iterations per variant (default: min(steps, 60))')
     ap.add_argument('--host-feed', action='store_true',
                     help='minibatches start in host memory (pinned double-buffered H->D copies): the PCIe-inclusive rate')
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -138,211 +407,31 @@ def main():
 
     import __graft_entry__ as ge
     ge.build()
-    from graphical_gan_amd import _lib
-    from graphical_gan_amd.engine import Trainer, broadcast_params
-    from graphical_gan_amd.models import Config
+    env = dict(dev=dev, world=world, rank=rank)
 
-    ssgan = args.dataset in ('moving_mnist', 'chairs')
-    if args.batch_size is None:
-        args.batch_size = (32 if args.dataset == 'moving_mnist' else 16) if ssgan else 64
-    np.random.seed(0)                                  # reference initialisers draw from numpy's global RNG
-    if ssgan:                                          # BASELINE configs[4]: ssgan_inference_moving_mnist.py, T=16
-        from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
-        K = 0
-        args.mode, _, ali_mode = args.ssgan_mode.partition(':')
-        skw = dict(mode=args.mode, ali_mode=ali_mode or 'concat_x')
-        if args.dataset == 'chairs':                   # ssgan_inference_chairs.py: 31 RGB views, no labels, res_w operator
-            cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse, length=31, n_c=0, channels=3, op_dyn_mode='res_w',
-                           dataset='chairs', **skw)
-        else:
-            cfg = SSConfig(batch_size=args.batch_size, fuse=not args.no_fuse, **skw)
-        model = StateSpaceGAN(cfg)
-        tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank, model=model)
-    else:
-        # N_COMS of the gmgan scripts: 30 (cifar10 :78, mnist), 50 (svhn :72), 100 (face :68)
-        K = ({'svhn': 50, 'face': 100}.get(args.dataset, 30)) if args.mode in ('local_ep', 'local_epce') else 0
-        if K and args.n_coms:
-            K = args.n_coms
-        # the code-space objectives run with the scripts' own settings for them: DIM_LATENT = 8, BN_FLAG = False (gan_inference_cifar10.py:72-77)
-        code = args.mode in ('vegan', 'vegan-wgan-gp', 'vegan-kl', 'vegan-ikl', 'vegan-jsd')
-        cfg = Config(args.dataset, batch_size=args.batch_size, n_coms=K, mode=args.mode, fuse=not args.no_fuse,
-                     **(dict(dim_latent=8, bn=False) if code else {}))
-        tr = Trainer(cfg, device=dev, graph=not args.no_graph, seed=1234 + rank)
-    torch.manual_seed(1234 + rank)
-    ring = tr.model.synthetic_ring(dev, n=4 if ssgan else 8, seed=1234 + rank)
+    head_spec = dict(key='headline', dataset=args.dataset, mode=args.mode, ssgan_mode=args.ssgan_mode, n_coms=args.n_coms,
+                     batch_size=args.batch_size)
+    out = run_workload(head_spec, args, env, args.steps, args.warmup)
 
-    def batches():
-        i = 0
-        while True:
-            yield ring[i % len(ring)]
-            i += 1
-    bi = batches()
-    if args.host_feed:                                 # same minibatches, but every one crosses PCIe (graphical_gan_amd/data.py)
-        from graphical_gan_amd.data import DevicePrefetcher
-        host_ring = [tuple(t.cpu().numpy() for t in b) if isinstance(b, tuple) else b.cpu().numpy() for b in ring]
-        bi = DevicePrefetcher(lambda: iter(host_ring), dev, depth=2)
-    it = 0
-    tr.iteration(it, bi); it += 1                      # creates parameters + optimizers (eager)
-    tr.iteration(it, bi); it += 1
-    broadcast_params(0)
-    for _ in range(max(args.warmup, 2)):               # includes graph capture
-        tr.iteration(it, bi); it += 1
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    tr.flush()
-    fence()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = tr.iteration(it, bi); it += 1
-    tr.flush()                                         # (DP: the last critic step's exchange + Adam belong to the timed work)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    finite = all(np.isfinite(float(v)) for v in last.values())
-
-    ms_per_step = 1e3 * dt / args.steps
-    images_per_s = cfg.B * world * args.steps / dt
-    gflop_it = ssgan_gflop_per_iteration(cfg) if ssgan else algorithmic_gflop_per_iteration(cfg)
-    step_tflops = gflop_it * args.steps / dt / 1e3      # per GPU
-
-    # ---- per-kernel timing of the same step with HIP events (eager, on the launch stream) ---------------------
-    roofline = None
-    kernels = None
-    if not args.no_kernel_profile:
-        # EVERY rank runs these eager iterations (they contain the gradient all-reduce: a collective issued by rank 0 alone
-        # would hang the job); only rank 0 records and reports
-        tr.flush()
-        tr_graph = tr.graph_enabled
-        tr.graph_enabled = False
-        L = _lib.load()
-        for _ in range(2):
-            tr.iteration(it, bi); it += 1
-        torch.cuda.synchronize(dev)
-        L.ggan_prof_reset(); L.ggan_prof_enable(1 if rank == 0 else 0)
-        n_prof = 5
-        for _ in range(n_prof):
-            tr.iteration(it, bi); it += 1
-        torch.cuda.synchronize(dev)
-        L.ggan_prof_enable(0)
-        recs = _lib.prof_report() if rank == 0 else []
-        L.ggan_prof_reset()
-        tr.graph_enabled = tr_graph
-    if rank == 0 and not args.no_kernel_profile:
-        recs.sort(key=lambda r: -r['total_ms'])
-        kernels = [dict(name=r['name'], launches_per_iter=r['launches'] / n_prof,
-                        ms_per_iter=round(r['total_ms'] / n_prof, 4),
-                        avg_us=round(1e3 * r['total_ms'] / r['launches'], 2),
-                        tflops=round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 2) if r['flops'] else None)
-                   for r in recs]
-        dom = next((r for r in recs if r['flops'] > 0), None)
-        if dom is not None:
-            ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-            # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this same
-            # workload, committed by tools/prof_round.sh; counters cannot be read from inside the process
-            traffic, pmc = None, None
-            try:
-                tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')))
-                pmc = tab.get(dom['name'])
-                traffic = pmc['traffic_bytes'] if pmc else None
-            except (OSError, ValueError):
-                pass
-            roofline = dict(bound='mfma', kernel=dom['name'], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
-                            unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic,
-                            traffic_unit='bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)', pmc=pmc,
-                            avg_launch_us=round(1e3 * dom['total_ms'] / dom['launches'], 2),
-                            flop_per_launch=dom['flops'] / dom['launches'],
-                            whole_step_tflops=round(step_tflops, 2),
-                            whole_step_frac=round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4))
-    if world > 1:
-        dist.barrier()
-
-    # ---- CPU baseline: the numpy oracle (a port; the reference is Python2+TF1 and cannot run) ------------------
-    cpu = None
-    blas_limit = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            from threadpoolctl import threadpool_limits
-            blas_limit = threadpool_limits(limits=host_cores())
-        except ImportError:
-            pass
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and ssgan:
-        from oracle import ssgan as OSS
-        ob = 2                                         # bounded sample: 2 sequences per minibatch instead of cfg.B
-        ocfg = OSS.Cfg(batch_size=ob, length=cfg.LEN, n_c=cfg.n_c, channels=cfg.C, op_dyn_mode=cfg.op_dyn_mode)
-        otr = OSS.Trainer(ocfg, OSS.init_params(ocfg, 0), np.float32)
-        feeds = iter([OSS.make_feed(ocfg, np.random.default_rng(i)) for i in range(8)])
-        otr.iteration(1, feeds)
-        t1 = time.perf_counter()
-        otr.iteration(2, feeds)
-        cdt = time.perf_counter() - t1
-        cpu = dict(value=round(ob / cdt, 3), unit='sequences/sec', cores=host_cores(), kind='port',
-                   sample='1 iteration (gen step + critic step) at %d sequences x 16 frames per minibatch, numpy fp32 '
-                   'oracle with multi-threaded BLAS' % ob)
-    elif rank == 0 and world == 1 and not args.no_cpu_baseline and args.dataset == 'cifar10' and args.mode == 'ali':
-        # the same step on the host cores with PyTorch-CPU (oneDNN convolutions, every core): the closest stand-in for an
-        # optimised TensorFlow-CPU build of the reference, which cannot run here (oracle/torch_cpu.py)
-        from oracle import nets as ON, step as OS, torch_cpu
-        torch.set_num_threads(host_cores())
-        ocfg = ON.Cfg('cifar10', batch_size=cfg.B)
-        ts = torch_cpu.Step(ocfg, ON.init_params(ocfg, 0), torch.float32)
-        rng = np.random.default_rng(0)
-
-        def cpu_iteration():
-            for which in ('gen', 'disc'):
-                f = OS.make_feed(ocfg, rng, 'ali')
-                ts.step(which, OS.real_x_from_feed(ocfg, f, np.float32), f['p_z_noise'])
-        cpu_iteration()                                # warm-up (thread pool, oneDNN primitive cache)
-        n_cpu, t1 = 0, time.perf_counter()
-        while n_cpu < 3 or (time.perf_counter() - t1 < 10.0 and n_cpu < 2000):
-            cpu_iteration()
-            n_cpu += 1
-        cdt = time.perf_counter() - t1
-        cpu = dict(value=round(cfg.B * n_cpu / cdt, 1), unit='images/sec', cores=torch.get_num_threads(), kind='port',
-                   sample='%d iterations (gen step + critic step) of the same workload in %.1f s, PyTorch-CPU fp32 restatement '
-                   '(oneDNN convolutions, TF-SAME padding and TF-Adam emulated)' % (n_cpu, cdt))
-    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import nets as ON, step as OS
-        ocfg = ON.Cfg(args.dataset, batch_size=cfg.B, n_coms=K)
-        otr = OS.Trainer(ocfg, ON.init_params(ocfg, 0), 'wali-gp' if args.mode == 'wali-gp' else 'ali', np.float32)
-        feeds = iter([OS.make_feed(ocfg, np.random.default_rng(i), otr.mode) for i in range(64)])
-        otr.iteration(1, feeds)                        # warm numpy/BLAS
-        t1 = time.perf_counter()
-        for j in range(args.cpu_iters):
-            otr.iteration(2 + j, feeds)
-        cdt = time.perf_counter() - t1
-        cpu = dict(value=round(cfg.B * args.cpu_iters / cdt, 2), unit='images/sec', cores=host_cores(),
-                   kind='port', sample='%d iterations (gen step + %d critic step(s)) of the same workload, numpy fp32 '
-                   'oracle with multi-threaded BLAS' % (args.cpu_iters, cfg.critic_iters))
-
+    # the other BASELINE configurations, same process, same measurement (only next to the default headline workload)
+    default_head = args.dataset == 'cifar10' and args.mode == 'ali' and args.batch_size is None and not args.host_feed
+    variants = []
+    if not args.no_variants and (default_head or args.variants):
+        want = [k.strip() for k in args.variants.split(',')] if args.variants else [v['key'] for v in VARIANTS]
+        vsteps = args.variant_steps or min(args.steps, 60)
+        for v in VARIANTS:
+            if v['key'] not in want:
+                continue
+            t0 = time.perf_counter()
+            r = run_workload(v, args, env, vsteps, min(args.warmup, 5), top_kernels=8)
+            if r is not None:
+                r['key'] = v['key']
+                r['wall_s'] = round(time.perf_counter() - t0, 1)
+                variants.append(r)
     if rank == 0:
-        out = {
-            'metric': ('sequences/sec (G+D step) %s T=%d 64x64 bs=%d' % (args.dataset, cfg.LEN, cfg.B)) if ssgan else
-                      'images/sec (G+D%s step) %s %dx%d bs=%d' % ('+GP' if args.mode == 'wali-gp' else '', args.dataset, cfg.S, cfg.S, cfg.B),
-            'value': round(images_per_s, 1), 'unit': 'sequences/sec' if ssgan else 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('ssgan_inference_%s.py MODE=%s POS_MODE=%s LEN=%d BATCH_SIZE=%d sequences '
-                                    '(per GPU) of 64x64x%d frames%s' % (args.dataset, cfg.mode + ((' ALI_MODE=' + cfg.ali_mode) if cfg.seq_critic else ''),
-                                                                        cfg.pos_mode, cfg.LEN, cfg.B, cfg.C,
-                                                                        ', eager' if args.no_graph else ''))
-                       if ssgan else '%s_inference_%s.py MODE=%s%s BATCH_SIZE=%d (per GPU) %dx%dx%d, CRITIC_ITERS=%d%s' % (
-                'gmgan' if K else 'gan', args.dataset, args.mode, ' N_COMS=%d' % K if K else '', cfg.B, cfg.S, cfg.S, cfg.C,
-                cfg.critic_iters, '' if not args.no_graph else ', eager'),
-                'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world, 'hip_graph': not args.no_graph, 'host_feed': bool(args.host_feed),
-                'fused_epilogues': not args.no_fuse, 'minibatches_per_step': 1 + cfg.critic_iters,
-                'algorithmic_gflop_per_step': round(gflop_it, 2), 'finite_costs': bool(finite),
-                **({'frames_per_sec': round(images_per_s * cfg.LEN, 1)} if ssgan else {})},
-            'roofline': roofline, 'cpu_baseline': cpu, 'kernels': kernels,
-        }
+        if variants or not args.no_variants:
+            out['metric'] = out['metric'] + ('; variants: G+D+GP (wali-gp), gmgan K=30/K=10, face 64x64, ssgan T=16' if variants else '')
+            out['variants'] = variants
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

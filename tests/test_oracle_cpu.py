@@ -115,6 +115,45 @@ def test_full_step_vs_torch_autograd():
         assert np.abs(ts.T[n].detach().numpy() - otr.P[n]).max() < 1e-9, n
 
 
+@pytest.mark.parametrize('dataset,mode,K', [('cifar10', 'wali-gp', 0), ('cifar10', 'local_ep', 5), ('face', 'ali', 0),
+                                            ('face', 'local_ep', 4), ('mnist', 'local_ep', 3), ('svhn', 'ali', 0)])
+def test_torch_restatement_matches_numpy_tape(dataset, mode, K):
+    """oracle/torch_cpu.py generates the full-size golden fixtures (tests/golden/make_golden.py): every configuration it is used
+    for agrees with the numpy tape in float64 at small sizes -- costs, critic logits, every gradient, two iterations of Adam."""
+    import torch
+    from oracle import torch_cpu
+    cfg = N.Cfg(dataset, batch_size=3, n_coms=K, dim=4, dim_latent=6)
+    P0 = {k: v.astype(np.float64) for k, v in N.init_params(cfg, 4).items()}
+    omode = 'wali-gp' if mode == 'wali-gp' else 'ali'
+    ts = torch_cpu.Step(cfg, P0, torch.float64, mode)
+    feed = S.make_feed(cfg, np.random.default_rng(11), omode)
+    Pt = {k: tp.T(v) for k, v in P0.items()}
+    out = S.forward(cfg, Pt, feed, omode)
+    for which in ('gen', 'disc'):
+        tout, cost, tg = ts.grads(feed, which)
+        if not (mode == 'wali-gp' and which == 'gen'):       # (gen run of wali-gp leaves the penalty out of disc_cost)
+            assert abs(float(tout['disc_cost']) - float(out['disc_cost'].v)) < 1e-11
+        assert abs(float(cost) - float(out[which + '_cost'].v)) < 1e-11
+        names = list(tg)
+        og = tp.grad(out[which + '_cost'], [Pt[n] for n in names])
+        for n, b in zip(names, og):
+            a = tg[n]
+            assert (a is None) == (b is None), n
+            if a is not None:
+                assert np.abs(a.numpy() - b.v).max() < 1e-9 * max(1.0, np.abs(b.v).max()), n
+    lf = (lambda t: t) if not K else (lambda t: t[1])
+    assert np.abs(lf(tout['disc_fake']).detach().numpy() - lf(out['disc_fake']).v).max() < 1e-11
+    otr = S.Trainer(cfg, P0, omode, np.float64)
+    fo = iter([S.make_feed(cfg, np.random.default_rng(20 + i), omode) for i in range(16)])
+    ft = iter([S.make_feed(cfg, np.random.default_rng(20 + i), omode) for i in range(16)])
+    for it in range(2):
+        ro, rt = otr.iteration(it, fo), ts.iteration(it, ft)
+        for k in ro:
+            assert abs(ro[k] - rt[k]) < 1e-9 * max(1.0, abs(ro[k])), (it, k)
+    for n in ('Discriminator.zx1.W', 'Generator.3.Filters', 'Extractor.2.Filters'):
+        assert np.abs(ts.T[n].detach().numpy() - otr.P[n]).max() < 1e-8, n
+
+
 # ---- (ii) finite differences ---------------------------------------------------------------------------------
 @pytest.mark.parametrize('mode,K,dataset', [('ali', 0, 'cifar10'), ('wali-gp', 0, 'cifar10'), ('ali', 5, 'cifar10'),
                                             ('ali', 3, 'mnist'), ('ali', 3, 'face'), ('wali', 0, 'cifar10'),

@@ -377,8 +377,9 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '2'], capture_output=True, text=True,
-                       timeout=900, env=env, cwd=root)
+    env['GGAN_BENCH_CPU_BUDGET_S'] = '2'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '2', '--variant-steps', '4'],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
@@ -390,16 +391,26 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
     assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-3
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
+    assert 'source' in d['roofline']
+    # every BASELINE configuration rides along in the same line, each with its own roofline and CPU baseline
+    assert [v['key'] for v in d['variants']] == ['wali-gp', 'gmgan-cifar10-K30', 'gmgan-cifar10-K10', 'gan-face', 'ssgan-moving-mnist']
+    for v in d['variants']:
+        assert v['value'] > 0 and v['ms_per_step'] > 0 and v['algorithmic_gflop_per_step'] > 0, v['key']
+        assert v['roofline'] is not None and v['roofline']['frac'] > 0 and v['cpu_baseline'] is not None and v['cpu_baseline']['value'] > 0, v['key']
+        assert v['config']['finite_costs'], v['key']
+    assert 'G+D+GP' in d['variants'][0]['metric'] and 'N_COMS=10' in d['variants'][2]['config']['workload']
     port = 29700 + (os.getpid() % 200)
     env2 = dict(env, GGAN_DIST_BACKEND='gloo')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2'],
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+                        '--variants', 'gmgan-cifar10-K10', '--variant-steps', '4'],
                        capture_output=True, text=True, timeout=900, env=env2, cwd=root)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1                                  # rank 0 only
     d2 = json.loads(lines[0])
     assert d2['n_gpus'] == 2 and d2['scaling'] == 'weak' and d2['config']['global_batch'] == 128 and d2['value'] > 0
+    assert len(d2['variants']) == 1 and d2['variants'][0]['n_gpus'] == 2 and d2['variants'][0]['value'] > 0
 
 
 @pytest.mark.parametrize('mode,K', [('ali', 0), ('local_ep', 30)])
