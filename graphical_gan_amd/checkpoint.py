@@ -12,10 +12,23 @@ from . import tflib as lib
 
 
 def _roles():
-    return {key[0]: opt for key, opt in optim._optimizers.items()}
+    roles = {}
+    for key, opt in optim._optimizers.items():
+        if key[0] in roles:
+            raise RuntimeError('two live optimizers for role %r: a checkpoint keys optimizer state by role '
+                               '(optim.reset_optimizers() drops stale ones)' % (key[0],))
+        roles[key[0]] = opt
+    return roles
 
 
-def save(path, trainer=None):
+def _npz(path):
+    """np.savez appends '.npz' to a path that lacks it; save and restore agree on the same file name"""
+    path = str(path)
+    return path if path.endswith('.npz') else path + '.npz'
+
+
+def save(path, trainer=None, data_source=None):
+    path = _npz(path)
     if trainer is not None:
         trainer.flush()
     torch.cuda.synchronize()
@@ -25,14 +38,16 @@ def save(path, trainer=None):
         for p, (o, n) in zip(opt.params, opt.slots):
             out['adam/%s/%s/m' % (role, p.param_name)] = opt.m[o:o + n].cpu().numpy().reshape(tuple(p.shape))
             out['adam/%s/%s/v' % (role, p.param_name)] = opt.v[o:o + n].cpu().numpy().reshape(tuple(p.shape))
+    if data_source is not None:
+        out['meta/data_source'] = np.asarray(str(data_source))
     np.savez(path, **out)
     return sorted(out)
 
 
 def restore(path, trainer):
     """Loads parameters (creating registry entries as needed) and the Adam states."""
-    z = np.load(path)
-    params = {k: z[k] for k in z.files if not k.startswith('adam/')}
+    z = np.load(_npz(path))
+    params = {k: z[k] for k in z.files if not k.startswith(('adam/', 'meta/'))}
     trainer.load_params(params)
     state = {}
     for k in z.files:

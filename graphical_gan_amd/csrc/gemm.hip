@@ -47,6 +47,8 @@ struct GemmParams {
     int a_split, lda2;
     float* C2;
     int c_split;
+    unsigned a_bytes, a2_bytes, b_bytes;   // FAST path: buffer sizes of the stored operands
+    int fast;
 };
 
 // Load a [64 rows(r) x 16 k] tile of a matrix into LDS as T[k][r].
@@ -130,6 +132,32 @@ __device__ __forceinline__ void load_step_tile(const float* __restrict__ base, i
     }
 }
 
+// Branch-free variant: raw buffer loads whose out-of-range lanes carry an out-of-bounds offset and return 0 (no scalar
+// fallback path, no waits inside branches -- the generic loader above compiles to a chain of "load; s_waitcnt vmcnt(0)" blocks).
+// Legal when every float4 is 16-byte aligned and wholly inside or outside the matrix (launcher: FAST).
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+constexpr unsigned GOOB = 0x7FFFFFF0u;
+template <bool KCONTIG>
+__device__ __forceinline__ void load_step_tile_fast(__amdgpu_buffer_rsrc_t rs, int ld, int R, int r0, int k0, int kend,
+                                                    float4 (&reg)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int row, k;
+        unsigned off;
+        if (KCONTIG) {
+            const int unit = tid + 256 * u;
+            row = r0 + (unit >> 3); k = k0 + (unit & 7) * 4;
+            off = (unsigned)(row * ld + k) * 4u;
+        } else {
+            row = r0 + (tid & 15) * 4; k = k0 + u * BK + (tid >> 4);
+            off = (unsigned)(k * ld + row) * 4u;
+        }
+        const u32x4g t = __builtin_amdgcn_raw_buffer_load_b128(rs, (row < R && k < kend) ? off : GOOB, 0, 0);
+        reg[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    }
+}
+
 template <bool KCONTIG>
 __device__ __forceinline__ void store_step_tile(float* T, const float4 (&reg)[2]) {
     const int tid = threadIdx.x;
@@ -167,74 +195,116 @@ __device__ __forceinline__ void store_tile(float* T, const float4& reg) {
 // TA: A stored [K,M] (transposed)  => element (m,k) at A[k*lda + m]  => !KCONTIG
 // TB: B stored [N,K] (transposed)  => element (n,k) at B[n*ldb + k]  =>  KCONTIG
 // MASK: 0 none, 1 activation-derivative mask on A, 2 on B
-template <bool TA, bool TB, int MASK = 0>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
+constexpr int TSZ = KSTEP * LDP;                           // one LDS step tile (sized for the wider row)
+
+template <bool TA, bool TB, int MASK, bool FAST>
+__device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, const int by, const int split, float* As, float* Bs) {
     // LDS double-buffered so a step costs ONE barrier: the next step's global loads are issued before the MFMA block, parked in
     // registers, and committed to the other buffer after it
     constexpr bool AK = !TA, BKc = TB;                     // operand is k-contiguous in memory
     constexpr int LA = AK ? LDPK : LDP, LB = BKc ? LDPK : LDP;
-    constexpr int TSZ = KSTEP * LDP;                       // (sized for the wider row)
-    __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1, half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
+    const int m0 = by * BM, n0 = bx * BN;
     const int kb = split * P.kps, ke = min(kb + P.kps, P.K);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool do_colsum = P.colsum != nullptr && blockIdx.y == 0 && tid < BN;   // rows beyond K are zero in the tile
+    const bool do_colsum = P.colsum != nullptr && by == 0 && tid < BN;   // rows beyond K are zero in the tile
     float csum = 0.f;
-    float4 ra[2], rb[2], rma[2], rmb[2];
-    auto load_step = [&](int k0) {
+    // register ring two steps deep: the loads of step k+2 are issued before the MFMA block of step k, the loads of step k+1
+    // (issued one iteration earlier) are committed to the other LDS buffer after it.  A workgroup's step was bound by the
+    // latency of ONE prefetch (~1.3 us per 32-k step measured against 0.43 us of MFMA issue); two in flight cover it.
+    float4 ra[2][2], rb[2][2], rma[2][2], rmb[2][2];
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, (short)0, (int)P.a_bytes, 0x00020000);
+    const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A2 ? P.A2 : P.A), (short)0, (int)(P.A2 ? P.a2_bytes : P.a_bytes), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, (short)0, (int)P.b_bytes, 0x00020000);
+    const auto rsAr = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK == 1 ? P.a_ref : P.A), (short)0, (int)P.a_bytes, 0x00020000);
+    const auto rsBr = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK == 2 ? P.b_ref : P.B), (short)0, (int)P.b_bytes, 0x00020000);
+    auto load_step = [&](int k0, float4 (&xa)[2], float4 (&xb)[2], float4 (&xma)[2], float4 (&xmb)[2]) {
+        if constexpr (FAST) {
+            // (source selection by scalar selects, ONE load sequence: no branches around the loads)
+            const bool second = P.A2 != nullptr && (AK ? k0 >= P.a_split : m0 >= P.a_split);
+            const auto rs = second ? rsA2 : rsA;
+            const int ld = second ? P.lda2 : P.lda;
+            int R = P.M, r0 = m0, kk0 = k0, kke = ke;
+            if (P.A2 != nullptr) {
+                if (AK) { kk0 = second ? k0 - P.a_split : k0; kke = second ? ke - P.a_split : min(ke, P.a_split); }
+                else { R = second ? P.M - P.a_split : P.a_split; r0 = second ? m0 - P.a_split : m0; }
+            }
+            load_step_tile_fast<AK>(rs, ld, R, r0, kk0, kke, xa);
+            if (MASK == 1) load_step_tile_fast<AK>(rsAr, P.lda, P.M, m0, k0, ke, xma);
+            load_step_tile_fast<BKc>(rsB, P.ldb, P.N, n0, k0, ke, xb);
+            if (MASK == 2) load_step_tile_fast<BKc>(rsBr, P.ldb, P.N, n0, k0, ke, xmb);
+            return;
+        }
         if (P.A2 == nullptr) {
-            load_step_tile<AK>(P.A, P.lda, P.M, m0, k0, ke, P.vecA, ra);
+            load_step_tile<AK>(P.A, P.lda, P.M, m0, k0, ke, P.vecA, xa);
         } else if (AK) {        // element (m, k) at A[m*lda + k]: the sources split the k range
             const bool second = k0 >= P.a_split;
             load_step_tile<AK>(second ? P.A2 - P.a_split : P.A, second ? P.lda2 : P.lda, P.M, m0, k0, second ? ke : min(ke, P.a_split),
-                               P.vecA, ra);
+                               P.vecA, xa);
         } else {                // element (m, k) at A[k*lda + m]: the sources split the m range
             const bool second = m0 >= P.a_split;
             load_step_tile<AK>(second ? P.A2 - P.a_split : P.A, second ? P.lda2 : P.lda, second ? P.M : P.a_split, m0, k0, ke,
-                               P.vecA, ra);
+                               P.vecA, xa);
         }
-        if (MASK == 1) load_step_tile<AK>(P.a_ref, P.lda, P.M, m0, k0, ke, P.vecA, rma);
-        load_step_tile<BKc>(P.B, P.ldb, P.N, n0, k0, ke, P.vecB, rb);
-        if (MASK == 2) load_step_tile<BKc>(P.b_ref, P.ldb, P.N, n0, k0, ke, P.vecB, rmb);
+        if (MASK == 1) load_step_tile<AK>(P.a_ref, P.lda, P.M, m0, k0, ke, P.vecA, xma);
+        load_step_tile<BKc>(P.B, P.ldb, P.N, n0, k0, ke, P.vecB, xb);
+        if (MASK == 2) load_step_tile<BKc>(P.b_ref, P.ldb, P.N, n0, k0, ke, P.vecB, xmb);
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf, float4 (&xa)[2], float4 (&xb)[2], float4 (&xma)[2], float4 (&xmb)[2]) {
         if (MASK == 1) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) ra[u] = apply_mask<true>(ra[u], rma[u], P.ref_act, P.ref_alpha);
+            for (int u = 0; u < 2; ++u) xa[u] = apply_mask<true>(xa[u], xma[u], P.ref_act, P.ref_alpha);
         }
         if (MASK == 2) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) rb[u] = apply_mask<true>(rb[u], rmb[u], P.ref_act, P.ref_alpha);
+            for (int u = 0; u < 2; ++u) xb[u] = apply_mask<true>(xb[u], xmb[u], P.ref_act, P.ref_alpha);
         }
-        store_step_tile<AK>(As + buf * TSZ, ra);
-        store_step_tile<BKc>(Bs + buf * TSZ, rb);
+        store_step_tile<AK>(As + buf * TSZ, xa);
+        store_step_tile<BKc>(Bs + buf * TSZ, xb);
     };
-    load_step(kb);
-    store_step(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kb; k0 < ke; k0 += KSTEP, buf ^= 1) {
-        const bool more = k0 + KSTEP < ke;
-        if (more) load_step(k0 + KSTEP);
+    auto mma_step = [&](int buf) {
         const float* Ab = As + buf * TSZ;
         const float* Bb = Bs + buf * TSZ;
         if (do_colsum) {
 #pragma unroll
             for (int kk = 0; kk < KSTEP; ++kk) csum += Bb[kk * LB + tid];
         }
+        // all 32 fragment reads of the step are issued up front and the 16 MFMAs drain them with counted lgkmcnt waits.  The
+        // straightforward loop compiles to "2 ds_read; s_waitcnt lgkmcnt(0); v_mfma" per k-pair: one LDS round trip of matrix-pipe
+        // idle per MFMA (measured 1.07 us per step where the MFMAs need 0.43 us) -- nothing else hides it when the grid puts
+        // one or two workgroups on a CU, which is the regime of the step's Linear layers.
+        float fa[KSTEP / 2], fb[KSTEP / 2];
 #pragma unroll
-        for (int kk = 0; kk < KSTEP; kk += 2) {
-            const float a = Ab[(kk + half) * LA + wm * 32 + l31];
-            const float b = Bb[(kk + half) * LB + wn * 32 + l31];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int i = 0; i < KSTEP / 2; ++i) {
+            fa[i] = Ab[(2 * i + half) * LA + wm * 32 + l31];
+            fb[i] = Bb[(2 * i + half) * LB + wn * 32 + l31];
         }
-        if (more) store_step(buf ^ 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // 12 DS reads first
+#pragma unroll
+        for (int i = 0; i < KSTEP / 2; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // ... then the next two reads still to issue
+        }
+    };
+    load_step(kb, ra[0], rb[0], rma[0], rmb[0]);
+    store_step(0, ra[0], rb[0], rma[0], rmb[0]);
+    if (kb + KSTEP < ke) load_step(kb + KSTEP, ra[1], rb[1], rma[1], rmb[1]);
+    __syncthreads();
+    // two steps per trip so that the register sets are compile-time: even steps multiply buffer 0 and refill set 0
+    for (int k0 = kb; k0 < ke; k0 += 2 * KSTEP) {
+        if (k0 + 2 * KSTEP < ke) load_step(k0 + 2 * KSTEP, ra[0], rb[0], rma[0], rmb[0]);
+        mma_step(0);
+        if (k0 + KSTEP < ke) store_step(1, ra[1], rb[1], rma[1], rmb[1]);
+        __syncthreads();
+        if (k0 + KSTEP >= ke) break;
+        if (k0 + 3 * KSTEP < ke) load_step(k0 + 3 * KSTEP, ra[1], rb[1], rma[1], rmb[1]);
+        mma_step(1);
+        if (k0 + 2 * KSTEP < ke) store_step(0, ra[0], rb[0], rma[0], rmb[0]);
         __syncthreads();
     }
     if (do_colsum && n0 + tid < P.N) P.colsum[n0 + tid] = csum;
@@ -280,6 +350,101 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     }
 }
 
+template <bool TA, bool TB, int MASK = 0, bool FAST = false>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
+    gemm_tile<TA, TB, MASK, FAST>(P, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Independent products in ONE launch (a Linear layer's weight gradient next to its data gradient: both consume the same
+// upstream gradient, neither fills the chip, and every launch of a step graph costs ~5 us before it does any work).
+// Workgroups [first[j], first[j+1]) belong to problem j; FAST operands, no split-K.
+struct GemmGroup {
+    int n;
+    int first[4];
+    int kind[3];        // 0: A^T B (ta)   1: A B^T (tb)   2: A B
+    int gx[3];
+    GemmParams p[3];
+};
+
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
+    int j = 0;
+    if (G.n > 1 && (int)blockIdx.x >= G.first[1]) j = 1;
+    if (G.n > 2 && (int)blockIdx.x >= G.first[2]) j = 2;
+    const int local = blockIdx.x - G.first[j];
+    const int bx = local % G.gx[j], by = local / G.gx[j];
+    const GemmParams& P = G.p[j];
+    switch (G.kind[j]) {
+        case 0: gemm_tile<true, false, 0, true>(P, bx, by, 0, As, Bs); break;
+        case 1: gemm_tile<false, true, 0, true>(P, bx, by, 0, As, Bs); break;
+        default: gemm_tile<false, false, 0, true>(P, bx, by, 0, As, Bs); break;
+    }
+}
+
+// ---- the critics' heads: Linear + LeakyReLU + Linear(H -> 1) -------------------------------------------------------------------
+// forward tail: h = lrelu(sum of the split-K slabs of the first Linear + b), logits = h . w_out + b_out.  One workgroup per two rows.
+__global__ __launch_bounds__(256) void head_out_fwd_k(const float* __restrict__ part, int SK, size_t slab, const float* __restrict__ b,
+                                                      const float* __restrict__ w_out, const float* __restrict__ b_out, float alpha,
+                                                      float* __restrict__ h, float* __restrict__ logits, int M, int H) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, rl = tid >> 7, t = tid & 127;
+    const int row = blockIdx.x * 2 + rl;
+    float dot = 0.f;
+    if (row < M) {
+        for (int c = t * 4; c < H; c += 512) {
+            const size_t o = (size_t)row * H + c;
+            float4 v = *reinterpret_cast<const float4*>(part + o);
+            for (int s = 1; s < SK; ++s) {                       // (slab order: deterministic)
+                const float4 u = *reinterpret_cast<const float4*>(part + (size_t)s * slab + o);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const float4 bb = *reinterpret_cast<const float4*>(b + c);
+            const float4 ww = *reinterpret_cast<const float4*>(w_out + c);
+            v.x = fmaxf(alpha * (v.x + bb.x), v.x + bb.x); v.y = fmaxf(alpha * (v.y + bb.y), v.y + bb.y);
+            v.z = fmaxf(alpha * (v.z + bb.z), v.z + bb.z); v.w = fmaxf(alpha * (v.w + bb.w), v.w + bb.w);
+            *reinterpret_cast<float4*>(h + o) = v;
+            dot = fmaf(v.x, ww.x, fmaf(v.y, ww.y, fmaf(v.z, ww.z, fmaf(v.w, ww.w, dot))));
+        }
+    }
+    dot = wave_sum(dot);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (t == 0 && row < M) logits[row] = (red[2 * rl] + red[2 * rl + 1]) + b_out[0];
+}
+
+// backward head: gh[r,c] = g[r] * w_out[c] * lrelu'(h[r,c]);  d_wout[c] = sum_r g[r] h[r,c];  d_bout = sum_r g[r].
+// One workgroup per 64 columns; 4 row groups, combined in group order (deterministic).
+__global__ __launch_bounds__(256) void head_out_bwd_k(const float* __restrict__ g, const float* __restrict__ h,
+                                                      const float* __restrict__ w_out, float alpha, float* __restrict__ gh,
+                                                      float* __restrict__ d_wout, float* __restrict__ d_bout, int M, int H) {
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f, gs = 0.f;
+    if (c < H) {
+        const float w = w_out[c];
+#pragma unroll 4
+        for (int r = rg; r < M; r += 4) {
+            const float gr = g[r], hv = h[(size_t)r * H + c];
+            gh[(size_t)r * H + c] = gr * w * (hv > 0.f ? 1.f : alpha);
+            acc = fmaf(gr, hv, acc);
+            gs += gr;
+        }
+    }
+    red[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < H && d_wout) d_wout[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (blockIdx.x == 0 && d_bout) {
+        __syncthreads();
+        if (cl == 0) red[rg][0] = gs;
+        __syncthreads();
+        if (tid == 0) d_bout[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    }
+}
+
 // N == 1 (the critics' Output layers, 512 -> 1): a matrix-vector product -- one wave per row, no tiles, no split-K, no reduce
 __global__ __launch_bounds__(256) void gemv_rows_k(const float* __restrict__ A, const float* __restrict__ w, const float* __restrict__ bias,
                                                    float* __restrict__ C, int M, int K, int act, float alpha) {
@@ -303,15 +468,19 @@ size_t ggan_gemm_workspace(int M, int N, int K) {
     return (size_t)64 * M * N * sizeof(float);
 }
 
-static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C,
-                       float* colsum, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s,
-                       const float* a_ref = nullptr, const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f,
-                       const float* A2 = nullptr, int a_split = 0, float* C2 = nullptr, int c_split = 0) {
-    if (N == 1 && !ta && !tb && !colsum && !a_ref && !b_ref) {
-        GGAN_LAUNCH("gemv_rows_k", 2.0 * M * K, 0, gemv_rows_k, dim3(cdiv(M, 4)), dim3(256), 0, s, A, B, bias, C, M, K, act, alpha);
-        return 0;
-    }
+// Fill the parameter block of one product (operand views, float4 legality, split-K choice, FAST path); no launch.
+// mode 0: normal (split-K result reduced by the caller)   1: no split-K (grouped launches, fused column sums)
+struct GemmPlan {
     GemmParams P;
+    int gx, gy;
+    void* ws;
+};
+
+static int gemm_plan(GemmPlan& G, int mode, int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias,
+                     float* C, float* colsum, int act, float alpha, void* ws, size_t ws_bytes, const float* a_ref = nullptr,
+                     const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f, const float* A2 = nullptr,
+                     int a_split = 0, float* C2 = nullptr, int c_split = 0) {
+    GemmParams& P = G.P;
     memset(&P, 0, sizeof(P));
     P.a_ref = a_ref; P.b_ref = b_ref; P.ref_act = ref_act; P.ref_alpha = ref_alpha;
     P.A = A; P.B = B; P.bias = bias; P.C = C;
@@ -335,9 +504,11 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     P.out_elems = (size_t)M * N;
     P.colsum = colsum;
     ws = ws_scratch(ws, ws_bytes);
+    G.ws = ws;
     const int gx = cdiv(N, BN), gy = cdiv(M, BM);
+    G.gx = gx; G.gy = gy;
     int sk = 1;
-    if (!colsum && ws && !C2) {       // (a fused column sum needs the whole K range in one workgroup; so does a split output)
+    if (mode == 0 && !colsum && ws && !C2) {       // (a fused column sum needs the whole K range in one workgroup; so does a split output)
         const char* e = getenv("GGAN_GEMM_SK");
         if (e) sk = atoi(e);
         else {
@@ -351,6 +522,9 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
             const int max_sk = K / BK;
             if (sk > max_sk) sk = max_sk;
             if (sk > (tall ? 256 : 64)) sk = tall ? 256 : 64;
+            // short reductions over a grid that already covers a good part of the chip (the weight gradients of the batch-64
+            // layers): the extra reduce launch costs more than it spreads (5.4 vs 8.4 us measured at 512x512x64)
+            if (K <= 128 && base >= 32) sk = 1;
         }
         if (sk < 1) sk = 1;
         while (sk > 1 && (size_t)sk * P.out_elems * sizeof(float) > ws_bytes) sk /= 2;
@@ -358,18 +532,123 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     P.kps = cdiv(cdiv(K, sk), BK) * BK;
     P.SK = cdiv(K, P.kps);
     if (P.SK > 1) P.C = (float*)ws;
-    const double fl = 2.0 * M * N * (double)K;
-    const dim3 grid(gx, gy, P.SK), block(256);
-    if (a_ref || b_ref) {
-        if (a_ref && !b_ref && !ta && tb) { GGAN_LAUNCH("gemm_kernel<false, true, 1>", fl, 0, (gemm_kernel<false, true, 1>), grid, block, 0, s, P); }
-        else if (b_ref && !a_ref && ta && !tb) { GGAN_LAUNCH("gemm_kernel<true, false, 2>", fl, 0, (gemm_kernel<true, false, 2>), grid, block, 0, s, P); }
+    // branch-free buffer-load path: every operand float4 aligned and wholly in or out of range, byte offsets within 31 bits
+    const size_t szA = (size_t)(A2 ? (ta ? (size_t)K * a_split : (size_t)M * a_split) : (size_t)M * K) * 4;
+    const size_t szA2 = A2 ? (size_t)(ta ? (size_t)K * (M - a_split) : (size_t)M * (K - a_split)) * 4 : 0;
+    const size_t szB = (size_t)N * K * 4;
+    const bool dims4 = (K % 4 == 0) && (P.kps % 4 == 0) && (ta ? (M % 4 == 0 && (!A2 || a_split % 4 == 0)) : true) && (tb ? true : N % 4 == 0);
+    P.fast = P.vecA && P.vecB && dims4 && szA < 0x7FFFFFF0ull && szA2 < 0x7FFFFFF0ull && szB < 0x7FFFFFF0ull && !getenv("GGAN_GEMM_GENERIC");
+    P.a_bytes = (unsigned)szA; P.a2_bytes = (unsigned)szA2; P.b_bytes = (unsigned)szB;
+    return 0;
+}
+
+// launch one planned product (split-K slabs stay in the workspace: the caller reduces or consumes them)
+static int gemm_launch_planned(const GemmPlan& G, int ta, int tb, hipStream_t s) {
+    const GemmParams& P = G.P;
+    const double fl = 2.0 * P.M * P.N * (double)P.K;
+    const dim3 grid(G.gx, G.gy, P.SK), block(256);
+#define GGAN_GEMM_CASE(TA_, TB_, MK_, NAME_)                                                                                      \
+    do {                                                                                                                           \
+        if (P.fast) { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, true>), grid, block, 0, s, P); }                      \
+        else { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, false>), grid, block, 0, s, P); }                            \
+    } while (0)
+    if (P.a_ref || P.b_ref) {
+        if (P.a_ref && !P.b_ref && !ta && tb) GGAN_GEMM_CASE(false, true, 1, "gemm_kernel<false, true, 1>");
+        else if (P.b_ref && !P.a_ref && ta && !tb) GGAN_GEMM_CASE(true, false, 2, "gemm_kernel<true, false, 2>");
         else { set_error("gemm: unsupported mask/transposition combination"); return -1; }
     } else
-    if (!ta && !tb) { GGAN_LAUNCH("gemm_kernel<false, false>", fl, 0, (gemm_kernel<false, false>), grid, block, 0, s, P); }
-    else if (!ta && tb) { GGAN_LAUNCH("gemm_kernel<false, true>", fl, 0, (gemm_kernel<false, true>), grid, block, 0, s, P); }
-    else if (ta && !tb) { GGAN_LAUNCH("gemm_kernel<true, false>", fl, 0, (gemm_kernel<true, false>), grid, block, 0, s, P); }
-    else { GGAN_LAUNCH("gemm_kernel<true, true>", fl, 0, (gemm_kernel<true, true>), grid, block, 0, s, P); }
-    if (P.SK > 1) return launch_splitk_reduce((const float*)ws, P.SK, P.out_elems, C, bias, N, 1, act, alpha, s);
+    if (!ta && !tb) GGAN_GEMM_CASE(false, false, 0, "gemm_kernel<false, false>");
+    else if (!ta && tb) GGAN_GEMM_CASE(false, true, 0, "gemm_kernel<false, true>");
+    else if (ta && !tb) GGAN_GEMM_CASE(true, false, 0, "gemm_kernel<true, false>");
+    else GGAN_GEMM_CASE(true, true, 0, "gemm_kernel<true, true>");
+#undef GGAN_GEMM_CASE
+    return 0;
+}
+
+static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C,
+                       float* colsum, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s,
+                       const float* a_ref = nullptr, const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f,
+                       const float* A2 = nullptr, int a_split = 0, float* C2 = nullptr, int c_split = 0) {
+    if (N == 1 && !ta && !tb && !colsum && !a_ref && !b_ref) {
+        GGAN_LAUNCH("gemv_rows_k", 2.0 * M * K, 0, gemv_rows_k, dim3(cdiv(M, 4)), dim3(256), 0, s, A, B, bias, C, M, K, act, alpha);
+        return 0;
+    }
+    GemmPlan G;
+    int rc = gemm_plan(G, 0, ta, tb, M, N, K, A, B, bias, C, colsum, act, alpha, ws, ws_bytes, a_ref, b_ref, ref_act, ref_alpha, A2,
+                       a_split, C2, c_split);
+    if (rc) return rc;
+    rc = gemm_launch_planned(G, ta, tb, s);
+    if (rc) return rc;
+    if (G.P.SK > 1) return launch_splitk_reduce((const float*)G.ws, G.P.SK, G.P.out_elems, C, bias, N, 1, act, alpha, s);
+    return 0;
+}
+
+// Linear + LeakyReLU + Linear(H -> 1): the tail of the joint critic (gan_inference_cifar10.py:244-255: zx1 on
+// tf.concat([conv features, latent features]) -> lrelu -> Output) and of the code-space critics (Hyper3 -> HyperOutput,
+// gmgan_inference_cifar10.py:282-301).  Forward = the split-K GEMM of the first Linear with its slabs left in the workspace +
+// ONE tail kernel (slab sum, bias, LeakyReLU, the H -> 1 product) instead of reduce + gemv launches.
+int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* b,
+                         const float* w_out, const float* b_out, float alpha, float* h, float* logits, void* ws, size_t ws_bytes,
+                         ggan_stream_t stream) {
+    GGAN_CHECK_ARG(a1 && w && b && w_out && b_out && h && logits, "null pointer");
+    GGAN_CHECK_ARG(M > 0 && K1 > 0 && K2 >= 0 && H > 0 && (H % 4) == 0 && (a2 || K2 == 0), "bad shape");
+    GGAN_CHECK_ARG(al16(b) && al16(w_out) && al16(h), "b, w_out, h must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    GemmPlan G;
+    int rc = gemm_plan(G, 0, 0, 0, M, H, K1 + K2, a1, w, nullptr, h, nullptr, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
+                       K2 ? a2 : nullptr, K2 ? K1 : 0);
+    if (rc) return rc;
+    rc = gemm_launch_planned(G, 0, 0, s);
+    if (rc) return rc;
+    const float* part = G.P.SK > 1 ? (const float*)G.ws : h;          // (SK == 1: the product already sits in h; summed "slab" of one)
+    GGAN_LAUNCH("head_out_fwd_k", 2.0 * M * H, 4.0 * M * H * (G.P.SK + 1), head_out_fwd_k, dim3(cdiv(M, 2)), dim3(256), 0, s, part,
+                G.P.SK, G.P.out_elems, b, w_out, b_out, alpha, h, logits, M, H);
+    return 0;
+}
+
+// Backward of the same head from g = d cost / d logits [M]:
+//   gh = g w_out^T * lrelu'(h)                      (scratch [M,H], caller-owned: also what the two products below consume)
+//   d_wout[H] = h^T g, d_bout = sum g               (NULL: not wanted)
+//   d_w[K1+K2,H] = [a1|a2]^T gh, d_b[H] = colsum gh (d_w NULL in generator steps: the critic's weights are not in the var_list)
+//   [d_a1 | d_a2] = gh w^T                          (NULL: the inputs need no gradient)
+// head kernel + ONE grouped launch for the two products (separate launches when an operand does not take the FAST loads).
+int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const float* a1, const float* a2, const float* w, const float* h,
+                         const float* w_out, float alpha, float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b, float* d_wout,
+                         float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(g && a1 && w && h && w_out && gh, "null pointer");
+    GGAN_CHECK_ARG(M > 0 && K1 > 0 && K2 >= 0 && H > 0 && (a2 || K2 == 0), "bad shape");
+    GGAN_CHECK_ARG(!d_a1 || K2 == 0 || d_a2, "d_a2 missing");
+    GGAN_CHECK_ARG(!d_b || d_w, "d_b comes out of the weight-gradient product");
+    hipStream_t s = (hipStream_t)stream;
+    const int K = K1 + K2;
+    GGAN_LAUNCH("head_out_bwd_k", 3.0 * M * H, 8.0 * M * H, head_out_bwd_k, dim3(cdiv(H, 64)), dim3(256), 0, s, g, h, w_out, alpha, gh,
+                d_wout, d_bout, M, H);
+    GemmPlan Gw, Ga;
+    int nw = 0, na = 0;
+    if (d_w) {      // d_w[K,H] = [a1|a2]^T gh: A stored [M,K] read transposed, sources split the OUTPUT rows; column sums of gh -> d_b
+        int rc = gemm_plan(Gw, 1, 1, 0, K, H, M, a1, gh, nullptr, d_w, d_b, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
+                           K2 ? a2 : nullptr, K2 ? K1 : 0);
+        if (rc) return rc;
+        nw = 1;
+    }
+    if (d_a1) {     // [d_a1 | d_a2] = gh w^T: B = w stored [K,H] read transposed, output columns split at K1
+        int rc = gemm_plan(Ga, 1, 0, 1, M, K, H, gh, w, nullptr, d_a1, nullptr, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
+                           nullptr, 0, K2 ? d_a2 : nullptr, K2 ? K1 : 0);
+        if (rc) return rc;
+        na = 1;
+    }
+    if (nw && na && Gw.P.fast && Ga.P.fast && !getenv("GGAN_NO_GEMM_GROUP")) {
+        GemmGroup GG;
+        memset(&GG, 0, sizeof(GG));
+        GG.n = 2;
+        GG.kind[0] = 0; GG.gx[0] = Gw.gx; GG.p[0] = Gw.P; GG.first[0] = 0;
+        GG.kind[1] = 1; GG.gx[1] = Ga.gx; GG.p[1] = Ga.P; GG.first[1] = Gw.gx * Gw.gy;
+        GG.first[2] = GG.first[1] + Ga.gx * Ga.gy;
+        GGAN_LAUNCH("gemm_group_kernel", 4.0 * M * K * (double)H, 0, gemm_group_kernel, dim3(GG.first[2]), dim3(256), 0, s, GG);
+        return 0;
+    }
+    if (nw) { int rc = gemm_launch_planned(Gw, 1, 0, s); if (rc) return rc; }
+    if (na) { int rc = gemm_launch_planned(Ga, 0, 1, s); if (rc) return rc; }
     return 0;
 }
 

@@ -162,10 +162,15 @@ class Trainer(object):
         with torch.cuda.stream(s):
             # (the optimizers exist: the first call of each kind ran eagerly)
             snap = [(o, o.theta.clone(), o.m.clone(), o.v.clone(), o.step.clone()) for o in self._optimizers()]
+            # (the device noise state too: a graph=True and a graph=False run with the same seed draw the same noise sequence)
+            rng = self.feed.get('rng_state') if isinstance(self.feed, dict) else None
+            rng_snap = rng.clone() if torch.is_tensor(rng) else None
             for _ in range(2):
                 self._eager(which)
             for o, th, m, v, st in snap:
                 o.theta.copy_(th); o.m.copy_(m); o.v.copy_(v); o.step.copy_(st)
+            if rng_snap is not None:
+                rng.copy_(rng_snap)
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         g1 = torch.cuda.CUDAGraph()

@@ -8,6 +8,7 @@ is itself built from these Functions, so the gradient-penalty double backward (S
 There is no CPU path: tensors must live on a HIP device and libggan.so must load.
 """
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -140,6 +141,10 @@ def _geom(t):
 # ---------------------------------------------------------------------------------------------------
 # convolution family
 # ---------------------------------------------------------------------------------------------------
+# tests: rows of a data-gradient that a grad_rows backward leaves unwritten are filled with NaN, so any consumer shows up
+DEBUG_POISON_CHECK = bool(os.environ.get('GGAN_POISON_UNWRITTEN'))
+
+
 class ConvFwd(Function):
     """y = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) + bias  (tf.nn.conv2d + bias_add; also the Deconv2D data-gradient)."""
 
@@ -212,6 +217,8 @@ def _fused_conv_backward(ctx, gy, x, w, y):
         gx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gy.device)
         if ctx.grad_rows and ctx.grad_rows < N and gw is None and gb is None:
             g = _geom((ctx.grad_rows,) + tuple(geom[1:]))      # leading images only (contiguous NCHW prefix of gy, y, gx)
+            if DEBUG_POISON_CHECK:                               # tests: the unwritten rows must never be read downstream
+                gx[ctx.grad_rows:].fill_(float('nan'))
         check(L.ggan_conv2d_bwd_data_act(C.byref(g), _p(gy), yref, act, ctx.alpha, _p(w), _p(gx), _p(ws), ws.numel(), _stream()),
               'ggan_conv2d_bwd_data_act')
     return gx, gw, gb, None, None, None
@@ -457,6 +464,56 @@ class Gemm2(Function):
             check(L.ggan_gemm_split(0, 1, M, K, N, _p(g), _p(None), 0, _p(w), _p(None), _p(da1), _p(da2), K1, _p(None), ACT_NONE, 0.0,
                                     _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
         return da1, da2, dw, db if (ctx.has_bias and ctx.needs_input_grad[3]) else None, None, None
+
+
+class CriticHead(Function):
+    """logits[M] = Linear(H -> 1)(lrelu(Linear([a1 | a2] -> H))): the tail of a critic as one op (ggan_critic_head_fwd/bwd:
+    split-K slabs summed by the tail kernel that also forms the logits; backward = one head kernel + one grouped launch for
+    the weight- and the data-gradient product).  a2 may be None.  Not differentiable twice: the gradient-penalty pass of
+    wali-gp composes the layers instead (tflib.ops.linear.LinearLReLULinear(differentiable=True))."""
+
+    @staticmethod
+    def forward(ctx, a1, a2, w, b, w_out, b_out, alpha):
+        a1, w, b, w_out, b_out = _c(a1), _c(w), _c(b), _c(w_out), _c(b_out)
+        a2 = _c(a2) if a2 is not None else None
+        M, K1 = a1.shape
+        K2 = a2.shape[1] if a2 is not None else 0
+        H = w.shape[1]
+        assert w.shape[0] == K1 + K2 and w_out.numel() == H and b.numel() == H, (a1.shape, w.shape, w_out.shape)
+        h = torch.empty((M, H), dtype=torch.float32, device=a1.device)
+        logits = torch.empty((M,), dtype=torch.float32, device=a1.device)
+        ws = workspace(a1.device)
+        check(_L().ggan_critic_head_fwd(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(b), _p(w_out), _p(b_out), float(alpha), _p(h),
+                                        _p(logits), _p(ws), ws.numel(), _stream()), 'ggan_critic_head_fwd')
+        ctx.alpha, ctx.has_a2 = float(alpha), a2 is not None
+        ctx.save_for_backward(a1, a2, w, w_out, h)
+        return logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a1, a2, w, w_out, h = ctx.saved_tensors
+        g = _c(g)
+        M, K1 = a1.shape
+        K2 = a2.shape[1] if a2 is not None else 0
+        H = w.shape[1]
+        need = ctx.needs_input_grad
+        dev = g.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        gh = new(M, H)
+        want_a = need[0] or (a2 is not None and need[1])
+        d_a1 = new(M, K1) if want_a else None
+        d_a2 = new(M, K2) if (want_a and a2 is not None) else None
+        d_w = new(K1 + K2, H) if (need[2] or need[3]) else None
+        d_b = new(H) if need[3] else None
+        d_wout = new(*w_out.shape) if need[4] else None
+        d_bout = new(1) if need[5] else None
+        ws = workspace(dev)
+        check(_L().ggan_critic_head_bwd(M, K1, K2, H, _p(g), _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1),
+                                        _p(d_a2), _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(ws), ws.numel(), _stream()),
+              'ggan_critic_head_bwd')
+        return (d_a1 if need[0] else None, d_a2 if (a2 is not None and need[1]) else None, d_w if need[2] else None, d_b, d_wout,
+                d_bout, None)
 
 
 def gemm_colsum_(a, g, ta):

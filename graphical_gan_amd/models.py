@@ -230,8 +230,9 @@ class GraphicalGAN(object):
             return z, mean, std
         return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out, out=out_slot)
 
-    def Discriminator(self, x, z, grad_rows=None):
-        """grad_rows: only the first grad_rows images of x carry a gradient (generator steps: [fake; real])"""
+    def Discriminator(self, x, z, grad_rows=None, twice=False):
+        """grad_rows: only the first grad_rows images of x carry a gradient (generator steps: [fake; real]); twice: the result
+        will be differentiated twice (gradient-penalty pass): plain layer composition instead of the fused critic tail"""
         c = self.cfg
         out = x.reshape(-1, c.C, c.S, c.S)
         ch = c.C
@@ -241,6 +242,10 @@ class GraphicalGAN(object):
             ch = cout
         out = out.reshape(-1, c.flat)
         z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
+        if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):
+            # Linear on concat([out, z_out], 1) + LeakyReLU + the 512 -> 1 Output layer as one op
+            return lib.ops.linear.LinearLReLULinear('Discriminator.zx1', c.flat + 512, 512, 'Discriminator.Output', (out, z_out),
+                                                    differentiable=twice)
         out = self._lin('Discriminator.zx1', c.flat + 512, 512, (out, z_out), LRELU)     # Linear on concat([out, z_out], 1)
         out = lib.ops.linear.Linear('Discriminator.Output', 512, 1, out)
         return out.reshape(-1)
@@ -294,6 +299,8 @@ class GraphicalGAN(object):
         c = self.cfg
         out = self._lin('Discriminator.HyperInput', c.dim_latent + c.K, 512, (z, k), LRELU)     # Linear on concat([z, k], 1)
         out = self._lin('Discriminator.Hyper2', 512, 512, out, LRELU)
+        if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):
+            return lib.ops.linear.LinearLReLULinear('Discriminator.Hyper3', 512, 512, 'Discriminator.HyperOutput', out)
         out = self._lin('Discriminator.Hyper3', 512, 512, out, LRELU)
         out = lib.ops.linear.Linear('Discriminator.HyperOutput', 512, 1, out)
         return out.reshape(-1)
@@ -427,7 +434,7 @@ class GraphicalGAN(object):
             if which == 'gen':
                 gp = None                # not part of gen_cost; TF prunes the third critic pass
             else:
-                gp = J.gradient_penalty(self.Discriminator, real_x, fake_x.detach() if batched else fake_x,
+                gp = J.gradient_penalty(lambda xx, zz: self.Discriminator(xx, zz, twice=True), real_x, fake_x.detach() if batched else fake_x,
                                         q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
             res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
             out['gradient_penalty'] = gp
@@ -453,6 +460,8 @@ class GraphicalGAN(object):
             fake_x, p_z, q_z = fake_x.detach(), p_z.detach(), q_z.detach()
             q_k = q_k.detach() if c.K else None
         B = fake_x.shape[0]
+        # grad_rows leaves the real rows of the image gradient unwritten: legal only while the real half is data
+        assert detach or not real_x.requires_grad, 'batched critic with grad_rows: real_x must not require a gradient'
         x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
         d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B)
         if c.K:

@@ -254,6 +254,7 @@ class StateSpaceGAN(object):
         J.ONLY[0] = which
         with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
             if which in ('gen', 'disc'):
+                assert which == 'disc' or not real_x.requires_grad, 'grad_rows: the real sequences must be data'
                 d = self.SequenceDiscriminator(torch.cat([fake_x, real_x], 0), torch.cat([p_z_g, q_z_g], 0), torch.cat([p_z_l, q_z_l], 0),
                                                torch.cat([p_y, real_y], 0), grad_rows=c.B if which == 'gen' else None)
                 d_fake, d_real = F.SplitRows.apply(d, c.B)
@@ -323,6 +324,7 @@ class StateSpaceGAN(object):
                 # every critic once, on [fake; real] (rows are independent: no BatchNorm); in generator steps the conv
                 # data-gradient is needed for the fake frames only
                 nf = c.B * c.LEN
+                assert which == 'disc' or not real_x.requires_grad, 'grad_rows: the real frames must be data'
                 (af, bf), (ar, br) = self._pairs(p_z_l), self._pairs(q_z_l)
                 t = self.DynamicDiscrminator(torch.cat([af, ar], 0), torch.cat([bf, br], 0))
                 zg = self.ZGDiscrminator(torch.cat([p_z_g, q_z_g], 0))

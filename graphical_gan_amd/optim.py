@@ -187,10 +187,13 @@ def load_adam_state(opt, state):
                     buf[o:o + n].copy_(torch.as_tensor(a, dtype=torch.float32).reshape(-1))
 
 
-def reset_optimizers():
+def reset_optimizers(keep_params=True):
+    """Drop every optimizer (their flat theta / m / v / g buffers go with them).  keep_params: the parameters move back into
+    storage of their own; False when the registry is being emptied anyway (tflib.delete_all_params)."""
     for opt in _optimizers.values():
         for p in opt.params:
-            p.data = p.data.clone()
+            if keep_params:
+                p.data = p.data.clone()
             p._flat_owner = None
     _optimizers.clear()
     _pending_state.clear()

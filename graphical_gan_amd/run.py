@@ -15,9 +15,13 @@ from .engine import Trainer
 
 
 def _batches(S, model, device):
-    """real data through the py3 loaders when it is on disk, synthetic minibatches of the same shape otherwise"""
+    """real data through the py3 loaders.  A missing dataset raises, as the reference scripts do; the synthetic ring of the
+    same shapes is an explicit opt-in (S['SYNTHETIC'] = True or GGAN_SYNTHETIC=1: smoke runs, benchmarks)."""
     ds = S['DATASET']
+    synthetic_ok = bool(S.get('SYNTHETIC')) or os.environ.get('GGAN_SYNTHETIC', '') not in ('', '0')
     try:
+        if synthetic_ok and S.get('SYNTHETIC') == 'force':
+            raise FileNotFoundError('synthetic data requested')
         if ds == 'mnist':
             train, _, _ = lib.mnist.load(S['BATCH_SIZE'], S['BATCH_SIZE'])
             return DevicePrefetcher(train, device, pick=[0]), 'mnist.pkl.gz'
@@ -43,7 +47,10 @@ def _batches(S, model, device):
             train, _ = lib.chairs.load(S['LEN'], S['BATCH_SIZE'], 64, S.get('DATA_DIR', ''))
             return DevicePrefetcher(train, device), S.get('DATA_DIR')
     except FileNotFoundError as e:
-        print('[run] %s -> synthetic minibatches' % e)
+        if not synthetic_ok:
+            raise FileNotFoundError("%s -- dataset %r not found (DATA_DIR=%r); set S['SYNTHETIC'] = True or GGAN_SYNTHETIC=1 to "
+                                    "train on synthetic minibatches instead" % (e, ds, S.get('DATA_DIR', '')))
+        print('[run] %s -> synthetic minibatches (opt-in)' % e)
     ring = model.synthetic_ring(device, n=8)
 
     def forever():
@@ -66,6 +73,8 @@ def train(S, cfg, model=None, out_dir=None):
     out_dir = out_dir or S.get('OUT_DIR')
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'logfile.txt'), 'a') as f:
+            f.write('data source: %s\n' % source)
     t0 = time.time()
     for it in range(S['ITERS']):
         res = tr.iteration(it, batches)
@@ -76,7 +85,7 @@ def train(S, cfg, model=None, out_dir=None):
             lib.plot.flush(out_dir, os.path.join(out_dir, 'logfile.txt') if out_dir else None)
         lib.plot.tick()
         if out_dir and S.get('SAVE_EVERY') and (it + 1) % S['SAVE_EVERY'] == 0:
-            checkpoint.save(os.path.join(out_dir, 'params_%d.npz' % (it + 1)), tr)
+            checkpoint.save(os.path.join(out_dir, 'params_%d.npz' % (it + 1)), tr, data_source=source)
             with torch.no_grad():
                 nets = tr.model.forward_nets(tr.feed)
                 # (the critic-free code-space modes never build Generator(p_z) in a step: samples are drawn here)

@@ -78,6 +78,10 @@ def named_params():
 
 
 def delete_all_params():
+    """tflib/__init__.py:44-45.  The optimizers built over these parameters own flat device buffers (theta, m, v, g) and mark
+    the parameters as theirs: registry and optimizer lifetimes stay in sync."""
+    from .. import optim
+    optim.reset_optimizers(keep_params=False)
     _params.clear()
     _build_phase[0] = True
 

@@ -91,3 +91,25 @@ def Linear(name, input_dim, output_dim, inputs, biases=True, initialization=None
     if inputs.dim() != 2:
         result = result.reshape(tuple(inputs.shape[:-1]) + (output_dim,))
     return result
+
+
+def LinearLReLULinear(name1, input_dim, hidden_dim, name2, inputs, alpha=0.2, differentiable=False):
+    """Extension: Linear(name1, input_dim, hidden_dim) -> LeakyReLU(alpha) -> Linear(name2, hidden_dim, 1), the tail of every
+    critic of the scripts (gan_inference_cifar10.py:246-254 'Discriminator.zx1' / 'Discriminator.Output',
+    gmgan_inference_cifar10.py:288-291 'Discriminator.Hyper3' / 'Discriminator.HyperOutput'), as ONE op
+    (functional.CriticHead).  Same registry keys, shapes and initial-value draws (in the same order) as the two Linear calls.
+    inputs: a tensor or a pair standing for tf.concat([x1, x2], 1).  differentiable=True composes the plain layers (needed
+    where the result is differentiated twice: the gradient-penalty pass).  Returns the logits [rows]."""
+    pair = isinstance(inputs, (tuple, list))
+    x1, x2 = inputs if pair else (inputs, None)
+    usable = (not differentiable and x1.dim() == 2 and hidden_dim % 4 == 0
+              and (x2 is None or (x2.dim() == 2 and F.Gemm2.usable(x1, x2))))
+    if not usable:
+        h = Linear(name1, input_dim, hidden_dim, inputs, activation=F.ACT_LRELU, alpha=alpha)
+        return Linear(name2, hidden_dim, 1, h).reshape(-1)
+    w1 = _param(name1 + '.W', _initial(None, input_dim, hidden_dim) if _draw(name1 + '.W') else None)
+    b1 = _param(name1 + '.b', np.zeros((hidden_dim,), dtype='float32'))
+    w2 = _param(name2 + '.W', _initial(None, hidden_dim, 1) if _draw(name2 + '.W') else None)
+    b2 = _param(name2 + '.b', np.zeros((1,), dtype='float32'))
+    assert x1.shape[1] + (x2.shape[1] if x2 is not None else 0) == input_dim, (name1, x1.shape, input_dim)
+    return F.CriticHead.apply(x1, x2, w1, b1, w2, b2, float(alpha))

@@ -110,6 +110,23 @@ int ggan_gemm_split(int ta, int tb, int M, int N, int K, const float* A, const f
                     const float* bias, float* C, float* C2, int c_split, float* colsum_b, int act, float alpha, void* ws,
                     size_t ws_bytes, ggan_stream_t stream);
 
+/* The tail of a critic as ONE op: Linear ([a1 | a2] -> H) + LeakyReLU(alpha) + Linear (H -> 1).
+ * Replaces, for the joint critic, tf.concat + lib.ops.linear.Linear('Discriminator.zx1') + LeakyReLU +
+ * lib.ops.linear.Linear('Discriminator.Output') (/root/reference/gan_inference_cifar10.py:246-254,
+ * gmgan_inference_cifar10.py:294-300) and, with a2 == NULL, 'Discriminator.Hyper3' + 'Discriminator.HyperOutput'
+ * (gmgan_inference_cifar10.py:288-291) and the state-space critics' last two layers.
+ *   forward:  h[M,H] = lrelu([a1|a2] w + b) (kept: the backward's activation reference), logits[M] = h w_out + b_out.
+ *             a1 [M,K1], a2 [M,K2] (NULL when K2 == 0; K1 a multiple of 64 otherwise), w [K1+K2,H], b [H], w_out [H], b_out [1].
+ *   backward: from g[M] = d cost / d logits: gh[M,H] = g w_out^T * lrelu'(h) (caller-owned scratch), d_wout[H], d_bout[1],
+ *             d_w[K1+K2,H], d_b[H], d_a1[M,K1], d_a2[M,K2]; every output pointer may be NULL (not wanted), d_b needs d_w,
+ *             d_a2 goes with d_a1.  Launches: one head kernel + one grouped product launch. */
+int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* b,
+                         const float* w_out, const float* b_out, float alpha, float* h, float* logits, void* ws, size_t ws_bytes,
+                         ggan_stream_t stream);
+int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const float* a1, const float* a2, const float* w, const float* h,
+                         const float* w_out, float alpha, float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b, float* d_wout,
+                         float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream);
+
 /* ---- dense -------------------------------------------------------------------------------
  * C[M,N] = op(A) * op(B) (+ bias[N]) (+act), row-major, ta/tb = 1 reads the operand transposed
  * (A stored [K,M] / B stored [N,K]).  tf.matmul + bias_add of tflib/ops/linear.py:133-146 is

@@ -118,15 +118,24 @@ def absolute(a):
     return T(np.abs(a.v), (a,), lambda g: (mul(g, s),))
 
 
+KINK_LOG = None      # tests: set to [] to collect the 2-D (Linear-layer) ReLU / LeakyReLU inputs of a forward pass
+
+
 def relu(a):
     """tf.nn.relu; gradient g*(x>0)."""
+    if KINK_LOG is not None and a.v.ndim == 2:
+        KINK_LOG.append(a.v)
     m = T((a.v > 0).astype(a.v.dtype))
     return T(np.maximum(a.v, 0), (a,), lambda g: (mul(g, m),))
+
+
 
 
 def leaky_relu(a, alpha=0.2):
     """tf.maximum(alpha*x, x) (gmgan_inference_cifar10.py:122-123).  Piecewise linear:
     slope 1 for x>0 else alpha; second derivative zero a.e."""
+    if KINK_LOG is not None and a.v.ndim == 2:
+        KINK_LOG.append(a.v)
     m = T(np.where(a.v > 0, 1.0, alpha).astype(a.v.dtype))
     return T(O.leaky_relu(a.v, alpha), (a,), lambda g: (mul(g, m),))
 

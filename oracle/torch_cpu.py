@@ -35,6 +35,9 @@ class Step(object):
         self.critic_iters = 5 if mode == 'wali-gp' else 1
         # tflib/objs/gan_inference.py:34-43 (wali_gp: 1e-4, .5, .9) vs the scripts' LR / BETA1 with the default beta2
         self.hp = dict(lr=1e-4, b1=0.5, b2=0.9) if mode == 'wali-gp' else dict(lr=2e-4, b1=0.5, b2=0.999)
+        # margins: set to [] to record, per ReLU / LeakyReLU on a Linear-layer output, (kind, min |pre-activation| / rms(row)): how far the
+        # forward pass stays from a kink where fp32 rounding could pick the other branch (tests/golden/make_golden_full.py)
+        self.margins = None
 
     # ---- layers -----------------------------------------------------------------------------------------------------
     def conv(self, x, name):
@@ -59,8 +62,14 @@ class Step(object):
         return x @ self.T[name + '.W'] + self.T[name + '.b']
 
     # ---- nets -------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def lrelu(x):
+    def _margin(self, tag, x):
+        if self.margins is not None and x.dim() == 2:
+            with torch.no_grad():
+                rms = x.pow(2).mean(1, keepdim=True).sqrt() + 1e-30
+                self.margins.append((tag, float((x.abs() / rms).min())))
+
+    def lrelu(self, x):
+        self._margin('lrelu', x)
         return torch.maximum(0.2 * x, x)
 
     def Extractor(self, x):
@@ -78,6 +87,7 @@ class Step(object):
         g = self.lin(z, 'Generator.Input')
         if c.bn:
             g = self.bn(g, 'Generator.BN1', (0,))
+        self._margin('relu', g)
         g = torch.relu(g).view(-1, c.top, 4, 4)
         names = ['2', '3', '4', '5'] if c.nl == 4 else ['2', '3', '5']
         for i, nm in enumerate(names):

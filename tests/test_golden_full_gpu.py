@@ -1,0 +1,110 @@
+"""-m gpu: the HIP path at BASELINE sizes against the committed full-size fixtures (tests/golden/full_*.npz: float64 first-step
+costs, critic logits and per-parameter gradient digests of every BASELINE configuration, generated offline by
+tests/golden/make_golden_full.py).  Nothing of the oracle's arithmetic runs here: only its deterministic initial-weight and
+feed generators, checked against the checksums in the fixture.  The fixtures' feeds keep every LeakyReLU input of the critics'
+MLP layers clear of its kink (margin stored in the fixture), so the tolerances below carry no allowance for branch flips."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from _golden import load
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+
+
+def _check_grads(z, which, names, grads, tol):
+    import make_golden_full as MG
+    refs = {n: z['%s/g/%s' % (which, n)] for n in names if '%s/g/%s' % (which, n) in z.files}
+    gmax = max(r[1] for r in refs.values())
+    for n, g in zip(names, grads):
+        if n not in refs:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        assert g is not None, n
+        ref = refs[n]
+        f = g.detach().cpu().numpy().astype(np.float64).reshape(-1)
+        scale = max(ref[1], 1e-2 * gmax)          # (floor: mathematically-zero gradients, e.g. a bias that feeds a BatchNorm)
+        idx = MG.sample_index(n, f.size)
+        err = np.abs(f[idx] - ref[2:]).max()
+        assert err <= tol * scale, (which, n, 'entries', err, scale)
+        assert abs(np.linalg.norm(f) - ref[0]) <= tol * max(ref[0], 1e-2 * gmax * np.sqrt(f.size)), (which, n, 'l2', np.linalg.norm(f), ref[0])
+
+
+@pytest.mark.parametrize('name', ['full_cifar_ali', 'full_cifar_wali_gp', 'full_cifar_gmgan_k30', 'full_cifar_gmgan_k10',
+                                  'full_face_ali', 'full_face_gmgan_k100'])
+def test_full_size_first_step_vs_fixture(gpu, name):
+    import torch
+    import make_golden_full as MG
+    from oracle import nets as N, step as S
+    from graphical_gan_amd import tflib as lib, optim
+    from graphical_gan_amd.engine import Trainer
+    from graphical_gan_amd.models import Config
+    z = load(name)
+    dataset, B, K, mode = MG.FULL[name]
+    ocfg = N.Cfg(dataset, batch_size=B, n_coms=K)
+    P0 = MG.perturbed_params(ocfg)
+    feed = S.make_feed(ocfg, np.random.default_rng(int(z['feed_seed'])), MG.omode_of(mode))
+    assert MG.feed_checksum(feed) == int(z['feed_crc']), 'feed generator drifted from the one that made the fixture'
+    assert float(z['margin']) >= MG.MARGIN and float(z['margin_relu']) >= MG.MARGIN_RELU
+    optim.reset_optimizers()
+    lib.delete_all_params()
+    tr = Trainer(Config(dataset, batch_size=B, n_coms=K, mode=mode), device=gpu, graph=False, inject_noise=True)
+    tr.load_params(P0)
+    tr.set_feed(feed)
+    for which in ('gen', 'disc'):
+        out = tr.model.forward(tr.feed, which)
+        ref = float(z[which + '/cost'])
+        c = float(out[which + '_cost'].detach())
+        assert abs(c - ref) <= 1e-5 * max(1.0, abs(ref)), (which, c, ref)
+        df, dr = (out['disc_fake'], out['disc_real']) if not K else (out['disc_fake'][1], out['disc_real'][1])
+        for key, t in (('disc_fake', df), ('disc_real', dr)) + ((('hyper_fake', out['disc_fake'][0]), ('hyper_real', out['disc_real'][0])) if K else ()):
+            r = z['%s/%s' % (which, key)]
+            assert np.abs(t.detach().cpu().numpy() - r).max() <= 2e-5 * max(1.0, np.abs(r).max()), (which, key)
+        opt = out[which + '_train_op'].optimizer
+        names = [p.param_name for p in opt.params]
+        grads = torch.autograd.grad(out[which + '_cost'], opt.params, allow_unused=True)
+        # tolerances (relative to the tensor's max |g|): 1e-4; 1e-3 for the double backward of the gradient penalty; 3e-4 with the
+        # mixture prior, whose Gumbel-softmax assignment divides 128-term squared distances (|logit| ~ 1e2, fp32 rounding ~1e-5)
+        # by TEMP = 0.1 before exponentiating them
+        _check_grads(z, which, names, grads, 1e-3 if (mode == 'wali-gp' and which == 'disc') else (3e-4 if K else 1e-4))
+    optim.reset_optimizers()
+    lib.delete_all_params()
+
+
+def test_full_size_ssgan_first_step_vs_fixture(gpu):
+    """ssgan_inference_moving_mnist.py at BASELINE configs[4]: 32 sequences x 16 frames of 64x64"""
+    import torch
+    import make_golden_full as MG
+    from oracle import ssgan as O
+    from graphical_gan_amd import tflib as lib, optim
+    from graphical_gan_amd.engine import Trainer
+    from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
+    name = 'full_ssgan_b32_t16'
+    z = load(name)
+    ocfg = O.Cfg(**MG.SSGAN[name])
+    P0 = MG.ssgan_params(ocfg)
+    feed = O.make_feed(ocfg, np.random.default_rng(int(z['feed_seed'])))
+    assert MG.feed_checksum(feed) == int(z['feed_crc'])
+    optim.reset_optimizers()
+    lib.delete_all_params()
+    cfg = SSConfig(**MG.SSGAN[name])
+    tr = Trainer(cfg, device=gpu, graph=False, inject_noise=True, model=StateSpaceGAN(cfg))
+    tr.load_params(P0)
+    tr.set_feed(feed)
+    fx = tr.model.forward_nets(tr.feed)['fake_x'].detach().cpu().numpy().astype(np.float64).reshape(-1)
+    ref = z['fake_x_digest']
+    assert np.abs(fx[MG.sample_index('fake_x', fx.size)] - ref[2:]).max() <= 2e-5 and abs(np.linalg.norm(fx) - ref[0]) <= 1e-5 * ref[0]
+    for which in ('gen', 'disc'):
+        out = tr.model.forward(tr.feed, which)
+        refc = float(z[which + '/cost'])
+        c = float(out[which + '_cost'].detach())
+        assert abs(c - refc) <= 1e-5 * max(1.0, abs(refc)), (which, c, refc)
+        opt = out[which + '_train_op'].optimizer
+        names = [p.param_name for p in opt.params]
+        grads = torch.autograd.grad(out[which + '_cost'], opt.params, allow_unused=True)
+        _check_grads(z, which, names, grads, 5e-4)       # (filter gradients here are fp32 sums over up to 5e5 pixels)
+    optim.reset_optimizers()
+    lib.delete_all_params()

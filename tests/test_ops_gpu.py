@@ -1055,3 +1055,44 @@ def test_aggregated_divergence_stays_finite_when_the_prior_term_dominates(gpu, k
     dm, ds = torch.autograd.grad(out, (gmu, gsd))
     assert bool(torch.isfinite(dm).all() and torch.isfinite(ds).all())
     assert _rel(dm.cpu().numpy(), rgm.v) <= 1e-3 and _rel(ds.cpu().numpy(), rgs.v) <= 1e-3
+
+
+@pytest.mark.parametrize('M,K1,K2,H,need', [(128, 4096, 512, 512, 'all'), (128, 4096, 512, 512, 'data'), (64, 512, 0, 512, 'all'),
+                                            (6, 64, 24, 16, 'all'), (5, 40, 0, 8, 'all'), (128, 2048, 512, 512, 'weights')])
+def test_critic_head(gpu, M, K1, K2, H, need):
+    """ggan_critic_head_fwd/bwd (Linear on [a1 | a2] + LeakyReLU + Linear H -> 1, functional.CriticHead): logits and every gradient vs
+    numpy float64, for the critic-step case (all gradients), the generator-step case (data gradients only, frozen weights) and
+    the single-source / odd-size cases."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(M + K1 + K2 + H)
+    a1 = rng.standard_normal((M, K1)).astype(np.float32)
+    a2 = rng.standard_normal((M, K2)).astype(np.float32) if K2 else None
+    w = (rng.standard_normal((K1 + K2, H)) / np.sqrt(K1 + K2)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    wo = (rng.standard_normal((H, 1)) / np.sqrt(H)).astype(np.float32)
+    bo = rng.standard_normal(1).astype(np.float32)
+    g = rng.standard_normal(M).astype(np.float32)
+    A = np.concatenate([a1, a2], 1).astype(np.float64) if K2 else a1.astype(np.float64)
+    pre = A @ w.astype(np.float64) + b
+    h = np.maximum(0.2 * pre, pre)
+    logits = (h @ wo.astype(np.float64)).reshape(-1) + bo
+    gh = g.astype(np.float64)[:, None] * wo.astype(np.float64).reshape(1, -1) * np.where(pre > 0, 1.0, 0.2)
+    ref = dict(a=gh @ w.astype(np.float64).T, w=A.T @ gh, b=gh.sum(0), wo=h.T @ g.astype(np.float64), bo=g.astype(np.float64).sum())
+    wt_grad, in_grad = need in ('all', 'weights'), need in ('all', 'data')
+    t = lambda v, rg: None if v is None else _t(v, gpu).requires_grad_(rg)
+    ta1, ta2 = t(a1, in_grad), t(a2, in_grad)
+    tw, tb, two, tbo = t(w, wt_grad), t(b, wt_grad), t(wo, wt_grad), t(bo, wt_grad)
+    out = F.CriticHead.apply(ta1, ta2, tw, tb, two, tbo, 0.2)
+    assert np.abs(out.detach().cpu().numpy() - logits).max() <= 2e-5 * max(1.0, np.abs(logits).max())
+    ins = [x for x in (ta1, ta2, tw, tb, two, tbo) if x is not None and x.requires_grad]
+    grads = dict(zip([id(x) for x in ins], torch.autograd.grad(out, ins, grad_outputs=_t(g, gpu))))
+    if in_grad:
+        assert _rel(grads[id(ta1)].cpu().numpy(), ref['a'][:, :K1]) < 2e-5
+        if K2:
+            assert _rel(grads[id(ta2)].cpu().numpy(), ref['a'][:, K1:]) < 2e-5
+    if wt_grad:
+        assert _rel(grads[id(tw)].cpu().numpy(), ref['w']) < 2e-5
+        assert _rel(grads[id(tb)].cpu().numpy(), ref['b']) < 2e-5
+        assert _rel(grads[id(two)].cpu().numpy().reshape(-1), ref['wo'].reshape(-1)) < 2e-5
+        assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))

@@ -72,7 +72,11 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
     omode = mode if mode in ('wali', 'wali-gp', 'alice', 'alice-z', 'alice-x', 'local_epce', 'vegan', 'vegan-wgan-gp') else 'ali'
     feed = S.make_feed(ocfg, np.random.default_rng(11), omode)
     Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
-    oout = S.forward(ocfg, Pt, feed, omode)
+    tp.KINK_LOG = kink_log = []
+    try:
+        oout = S.forward(ocfg, Pt, feed, omode)
+    finally:
+        tp.KINK_LOG = None
     tr.set_feed(feed)
     out = tr.model.forward(tr.feed)
     for which in ('gen', 'disc'):
@@ -95,12 +99,27 @@ def test_first_step_costs_and_grads(gpu, case, fuse):
             if err.max() <= tol * scale:
                 continue
             # LeakyReLU/ReLU kinks: a pre-activation within fp32 rounding of 0 takes the other branch in fp32 than in
-            # the fp64 oracle.  In a late critic layer that re-weights ONE sample's whole backward signal (observed:
-            # sample 60 of the full-size case, identical with the plain kernels and with torch-fp64 agreeing with the
-            # oracle to 1e-15), i.e. a rank-1 perturbation of every weight gradient.  Accept it only in that form:
-            # typical entry still within tol, whole tensor within 2e-3 in L2.
+            # the fp64 oracle.  In a late critic layer that re-weights ONE sample's whole backward signal, i.e. a rank-1
+            # perturbation of every weight gradient; in the Generator's first layer (ReLU on a Linear output, 64 terms per
+            # weight-gradient entry) it changes one column of that gradient.  The allowance below is granted only when
+            # the oracle's own forward pass PROVES that such near-kinks exist in the Linear-layer activations and that they
+            # are a handful (_kink_samples); the committed full-size fixtures pick feeds that avoid the situation
+            # altogether and are checked without any allowance (tests/test_golden_full_gpu.py).
+            kinks = _kink_samples(kink_log)
+            assert 1 <= len(kinks) <= 8, (which, n, err.max(), scale, 'deviation without a provable (and rare) near-kink', kinks)
             l2 = np.linalg.norm(err) / (np.linalg.norm(ref) + 1e-30)
             assert np.median(err) <= tol * scale and l2 <= 2e-3, (which, n, err.max(), np.median(err), l2, scale)
+
+
+def _kink_samples(log, margin=1e-5):
+    """(layer call, row) pairs whose Linear-layer ReLU / LeakyReLU inputs come within `margin` (relative to the row's rms) of zero
+    in the float64 oracle forward pass (oracle.tape.KINK_LOG): the places where an fp32 evaluation can legitimately take the other
+    branch for a unit that carries a macroscopic share of a weight-gradient entry"""
+    rows = []
+    for i, x in enumerate(log):
+        rms = np.sqrt((x ** 2).mean(1, keepdims=True)) + 1e-30
+        rows += [(i, int(r)) for r in np.nonzero((np.abs(x) / rms).min(1) < margin)[0]]
+    return rows
 
 
 @pytest.mark.parametrize("case", CASES[:13], ids=lambda c: '-'.join(str(x) for x in c))
