@@ -428,7 +428,27 @@ def main():
                 r['key'] = v['key']
                 r['wall_s'] = round(time.perf_counter() - t0, 1)
                 variants.append(r)
+    # N > 1: the same headline step (a) without its gradient exchange -> what the exchange costs a step once overlap is
+    # accounted for, (b) strong scaling: the reference's global batch of 64 split over the replicas
+    dp_extra = None
+    if world > 1 and default_head and not args.no_variants:
+        os.environ['GGAN_SKIP_ALLREDUCE'] = '1'
+        r0 = run_workload(head_spec, args, env, min(args.steps, 100), min(args.warmup, 5), top_kernels=1)
+        del os.environ['GGAN_SKIP_ALLREDUCE']
+        dp_extra = {}
+        if rank == 0:
+            dp_extra['ms_per_step_without_exchange'] = r0['ms_per_step']
+            dp_extra['exposed_exchange_ms_per_step'] = round(out['ms_per_step'] * args.steps / args.steps - r0['ms_per_step'], 4)
+        if 64 % world == 0 and 64 // world >= 4:
+            sargs = argparse.Namespace(**dict(vars(args), no_kernel_profile=True, no_cpu_baseline=True))
+            r1 = run_workload(dict(head_spec, batch_size=64 // world), sargs, env, min(args.steps, 100), min(args.warmup, 5))
+            if rank == 0:
+                dp_extra['strong_scaling'] = {'global_batch': 64, 'per_gpu_batch': 64 // world, 'images_per_sec': r1['value'],
+                                              'ms_per_step': r1['ms_per_step']}
     if rank == 0:
+        if dp_extra is not None:
+            out['data_parallel'] = dict(dp_extra, exchange='captured in the step graph' if os.environ.get('GGAN_DP_GRAPH', '1') != '0'
+                                        else 'host-issued between cut graphs', weak_scaling_per_gpu_batch=64)
         if variants or not args.no_variants:
             out['metric'] = out['metric'] + ('; variants: G+D+GP (wali-gp), gmgan K=30/K=10, face 64x64, ssgan T=16' if variants else '')
             out['variants'] = variants

@@ -48,6 +48,7 @@ struct WgradParams {
     float gy_alpha;
     float* gbias;          // optional: sum over n,oh,ow of the (masked) gy
     int dbg_nostore;
+    unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
 };
 
 __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
@@ -57,6 +58,10 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     const int l15 = lane & 15, qq = lane >> 4;
     const int ci0 = blockIdx.x * TCI, co0 = blockIdx.y * TCO, split = blockIdx.z;
 
+    const int wg_lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const bool stamping = P.stamps != nullptr && tid == 0;
+    auto stamp = [&](int i) { if (stamping) P.stamps[(size_t)wg_lin * 16 + i] = __builtin_readcyclecounter(); };
+    stamp(0);
     float* xs = smem;                      // [TCI][CS]
     float* gs = smem + TCI * P.CS;         // [TCO][PCp]
     const int HW = P.H * P.W, HoWo = P.Ho * P.Wo, F4 = P.W >> 2;
@@ -158,11 +163,14 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
 
     const int c_begin = split * P.chunks_per_split;
     const int c_end = min(c_begin + P.chunks_per_split, P.chunks_total);
+    stamp(1);
     if (c_begin < c_end) prefetch(c_begin);
     for (int ch = c_begin; ch < c_end; ++ch) {
         __syncthreads();
         commit();
         __syncthreads();
+        if (ch == c_begin) stamp(2);
+        if (ch - c_begin >= 1 && ch - c_begin < 9) stamp(3 + ch - c_begin);
         if (ch + 1 < c_end) prefetch(ch + 1);
         // ---- MFMA: this wave's pixel quads; the 26 fragment reads of the NEXT quad are issued before the 25 MFMAs
         //      of the current one (one wave per SIMD: nothing else hides the LDS latency) ---------------------------
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
         }
     }
 
+    stamp(12);
     if (do_bias) {
         // threads gcol*(PC/4) .. +PC/4-1 hold the partial sums of channel gcol: xor-shuffle within that lane group
         const int grp = P.PC >> 2;
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
             for (int r = 0; r < 4; ++r) red[(wave * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
     }
     __syncthreads();
+    stamp(13);
     if (P.dbg_nostore) return;
     // element (t, ci_l, co_l) sits at red[w][(t*4 + (ci_l&3))*64 + (ci_l>>2)*16 + co_l]
     float* outp = P.out + (size_t)split * P.slab_stride;
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
             if (co + 3 < P.Co) dst[3] = v.w;
         }
     }
+    stamp(14);
 }
 
 int env_int(const char* name, int dflt) {
@@ -291,6 +302,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     if (m.act != GGAN_ACT_NONE) { P.gy_ref = m.ref; P.gy_act = m.act; P.gy_alpha = m.alpha; }
     P.gbias = gbias;
     P.dbg_nostore = env_int("GGAN_DBG", 0) & 8;
+    const bool want_stamps = (env_int("GGAN_DBG", 0) & 4) != 0;
     P.x_bytes = (unsigned)xb; P.gy_bytes = (unsigned)gb;
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo;
     P.pad_t = g.pad_t;
@@ -341,6 +353,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     }
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     if (parts && ws_bytes < P.slab_stride * sizeof(float)) { set_error("conv_wgrad: partial-slab buffer too small"); return -1; }
+    if (want_stamps && !parts && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     GGAN_LAUNCH("wgrad_kernel", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P);
     if (parts) {
         parts->n = P.SK;

@@ -26,6 +26,45 @@ from .models import GraphicalGAN
 _CAPTURE_MODE = os.environ.get('GGAN_CAPTURE_MODE', 'thread_local')
 
 
+_DP_GRAPH_OK = {}
+
+
+def dp_graph_selftest(device):
+    """Can this process group's all-reduce be captured in a HIP graph and replayed?  Every rank captures a tiny sum-all-reduce,
+    replays it twice and checks the result; the verdicts are combined with an ordinary (eager) MIN all-reduce so that all
+    replicas take the same path.  Cached per device."""
+    key = str(device)
+    if key in _DP_GRAPH_OK:
+        return _DP_GRAPH_OK[key]
+    ok = 1.0
+    try:
+        world = dist.get_world_size()
+        t = torch.ones(256, device=device)
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            dist.all_reduce(t.clone())                    # (communicator warm-up outside the capture)
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
+                u = t * 1.0
+                dist.all_reduce(u)
+                v = u + 1.0
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize(device)
+            if abs(float(v[0]) - (world + 1.0)) > 1e-6:
+                ok = 0.0
+        torch.cuda.current_stream(device).wait_stream(s)
+    except Exception as e:                                # noqa: BLE001 (any capture failure selects the cut graphs)
+        print('[engine] all-reduce capture self-test failed (%s): falling back to cut graphs' % (str(e).splitlines()[0] if str(e) else type(e).__name__))
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    _DP_GRAPH_OK[key] = bool(float(flag[0]) > 0.5)
+    return _DP_GRAPH_OK[key]
+
+
 class Trainer(object):
     def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None, sync_bn=False):
         """sync_bn: BatchNorm statistics over the global batch of all replicas (N GPUs x B/N then reproduce
@@ -50,7 +89,16 @@ class Trainer(object):
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # data-parallel runs split the step graph around the gradient all-reduce; the flag lets a single GPU exercise
         # exactly that code path (the collective is then a 1-rank no-op)
-        self.split_graph = self.world > 1 or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
+        # data-parallel steps: by default the gradient exchange is captured INSIDE the step graph (one graph per step again:
+        # RCCL's kernels become graph nodes on the process group's stream, joined before the update), so a replica's step is the
+        # single-GPU step plus the exposed part of the exchange.  GGAN_DP_GRAPH=0 restores the cut graphs
+        # ([nets] [critic+backward+pack] -> host-issued all-reduce -> [update]) with the exchange overlapped across steps.
+        dp = self.world > 1 or bool(os.environ.get('GGAN_FORCE_ALLREDUCE')) and dist.is_available() and dist.is_initialized()
+        self.dp_graph = (dp and os.environ.get('GGAN_DP_GRAPH', '1') != '0' and not os.environ.get('GGAN_FORCE_SPLIT_GRAPH')
+                         and dist.get_backend() == 'nccl')      # (gloo stages device tensors through the host: not capturable)
+        if self.dp_graph and graph and not dp_graph_selftest(self.device):
+            self.dp_graph = False
+        self.split_graph = (self.world > 1 and not self.dp_graph) or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
         self.sync_bn = bool(sync_bn) and self.world > 1
         if self.sync_bn:
             lib.ops.batchnorm.set_sync_group(True)
@@ -176,7 +224,28 @@ class Trainer(object):
         g1 = torch.cuda.CUDAGraph()
         if not self.split_graph:
             with torch.cuda.graph(g1, stream=s, capture_error_mode=_CAPTURE_MODE):
-                cost, opt, keep = self._fwd_bwd(which)
+                st = None
+                if self.dp_graph and which == 'gen':
+                    # two gradient buckets inside the one graph: the Generator's bucket is on the wire (the process group's
+                    # stream: a parallel branch of the graph) while the Extractor's backward pass still runs
+                    nets = self._nets()
+                    cut = self.model.cut_tensors(nets) if hasattr(self.model, 'cut_tensors') else None
+                    st = self._bwd_phase1(nets) if (cut and not os.environ.get('GGAN_ONE_BUCKET')) else None
+                    if st is not None:
+                        opt, cost = st['opt'], st['cost']
+                        w1 = opt.all_reduce(async_op=True, lo=0, hi=st['off'])
+                        keep = (st['keep'], self._bwd_phase2(st), st, nets)
+                        w2 = opt.all_reduce(async_op=True, lo=st['off'], hi=None)
+                        for w in (w1, w2):
+                            if w is not None:
+                                w.wait()
+                    else:
+                        cost, opt, keep = self._fwd_bwd(which, nets)
+                        opt.all_reduce()
+                else:
+                    cost, opt, keep = self._fwd_bwd(which)
+                    if self.dp_graph:
+                        opt.all_reduce()
                 opt.update()
             return dict(g0=None, g1=g1, g1b=None, split=None, g2=None, cost=cost, opt=opt, keep=keep)
         # data parallel: [forward + backward + pack] -> all-reduce -> [Adam].  Every step is cut once more, after the

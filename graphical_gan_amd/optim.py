@@ -44,6 +44,8 @@ class GradBucket(object):
         """async_op: returns the torch.distributed work handle (None when there is nothing to exchange); the caller
         calls .wait() before the bucket is read -- lets the exchange overlap kernels issued in between.
         lo/hi: exchange only flat[lo:hi] (a sub-bucket whose gradients are complete before the rest)."""
+        if _os.environ.get('GGAN_SKIP_ALLREDUCE'):        # measurement only (bench.py: a step without its exchange; replicas drift apart)
+            return None
         if self.world > 1 or (_os.environ.get('GGAN_FORCE_ALLREDUCE') and dist.is_available() and dist.is_initialized()):
             buf = self.flat if (lo == 0 and hi is None) else self.flat[lo:hi]
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)

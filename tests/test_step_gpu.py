@@ -280,14 +280,20 @@ def test_driver_loop_and_counterpart_script(gpu, tmp_path):
     _fresh()
     cfg = Config('cifar10', batch_size=8, mode='ali', dim=8, dim_latent=16)
     S = dict(DATASET='cifar10', BATCH_SIZE=8, ITERS=4, SAVE_EVERY=2, LOG_EVERY=2, OUT_DIR=str(tmp_path), DATA_DIR='/nonexistent')
+    with pytest.raises(FileNotFoundError):          # a missing dataset raises, as the reference scripts do ...
+        run.train(S, cfg)
+    _fresh()
+    S['SYNTHETIC'] = True                            # ... the synthetic ring is an explicit opt-in
     run.train(S, cfg)
+    assert 'data source: synthetic' in open(str(tmp_path / 'logfile.txt')).read()
     names = sorted(os.listdir(str(tmp_path)))
     assert 'params_2.npz' in names and 'params_4.npz' in names and 'samples_4.png' in names and 'logfile.txt' in names
     z = np.load(str(tmp_path / 'params_4.npz'))
     assert 'Discriminator.zx1.W' in z.files and int(z['adam/disc/step'][0]) == 4 and int(z['adam/gen/step'][0]) == 3
+    assert str(z['meta/data_source']) == 'synthetic'
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'gmgan_inference_cifar10.py'), '3'], capture_output=True,
-                       text=True, timeout=600, env=dict(os.environ, GGAN_DATA_DIR='/nonexistent'))
+                       text=True, timeout=600, env=dict(os.environ, GGAN_DATA_DIR='/nonexistent', GGAN_SYNTHETIC='1'))
     assert r.returncode == 0, r.stderr[-2000:]
     assert 'iter 2' in r.stdout and 'disc cost' in r.stdout
 

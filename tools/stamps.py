@@ -7,12 +7,14 @@ from graphical_gan_amd import functional as F, _lib
 dev = torch.device('cuda:0')
 op = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
 ci, h, co = (64, 16, 128) if (len(sys.argv) < 3 or sys.argv[2] == 'B') else (128, 8, 256)
-N = 64
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 geom = F.conv_geom(N, ci, h, h, co, 5, 2)
 x = torch.randn(N, ci, h, h, device=dev); w = torch.randn(5, 5, ci, co, device=dev) * .05
 gy = torch.randn(N, co, geom[5], geom[6], device=dev); b = torch.randn(co, device=dev)
 ws = F.workspace(dev)
-fn = (lambda: F.ConvFwd.apply(x, w, b, geom, 1, 0.2)) if op == 'fwd' else (lambda: F.ConvDgrad.apply(gy, w, None, geom, 0, 0.0))
+fn = {'fwd': lambda: F.ConvFwd.apply(x, w, b, geom, 1, 0.2), 'dgrad': lambda: F.ConvDgrad.apply(gy, w, None, geom, 0, 0.0),
+      'wgrad': lambda: F.ConvWgrad.apply(x, gy, geom)}[op]
+if len(sys.argv) > 3: N = int(sys.argv[3])
 for _ in range(3): fn()
 torch.cuda.synchronize()
 st = ws[-(32 << 20):].view(torch.int64)
@@ -22,7 +24,8 @@ a = st.cpu().numpy().reshape(-1, 16)
 a = a[a[:, 0] != 0]
 print(op, sys.argv[2:] , 'workgroups', len(a))
 t0 = a[:, 0].min()
-names = ['start', 'descr', 'commit0', 'bar0'] + ['chunk%d' % i for i in range(8)] + ['loop_end', 'reduced', 'stored']
+names = (['start', 'descr', 'commit0', 'bar0'] + ['chunk%d' % i for i in range(8)] + ['loop_end', 'reduced', 'stored']) if op != 'wgrad' else \
+    (['start', 'descr', 'commit0'] + ['x', 'chunk1', 'chunk2', 'chunk3', 'chunk4', 'chunk5', 'chunk6', 'chunk7', 'chunk8'] + ['loop_end', 'reduced', 'stored'])
 print('WG start skew vs first WG: median %d max %d' % (np.median(a[:, 0] - t0), (a[:, 0] - t0).max()))
 for i, nme in enumerate(names):
     col = a[:, i]
