@@ -496,7 +496,7 @@ int env_int(const char* name, int dflt) {
 struct WaveCfg { int WM, WN, KS, PW; };
 // fwd: 25 taps per chunk-channel-pair; dgrad class pairs carry only 12-13 taps, so they stage twice as many channels per
 // chunk (PW doubled) to keep ~25+ MFMAs per wave between barriers
-const WaveCfg kCfgsFwd[8] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}, {1, 1, 4, 2}, {2, 1, 4, 1}, {1, 1, 8, 1}, {2, 2, 2, 1}, {2, 1, 4, 2}};
+const WaveCfg kCfgsFwd[9] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}, {1, 1, 4, 2}, {2, 1, 4, 1}, {1, 1, 8, 1}, {2, 2, 2, 1}, {2, 1, 4, 2}, {4, 1, 2, 2}};
 const WaveCfg kCfgsDgrad[7] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}, {1, 1, 4, 4}, {2, 1, 4, 2}, {1, 1, 8, 1}, {2, 2, 2, 2}};
 
 // pixel tile TI x TR x TC <= TM whose CK-channel slab fits the per-thread staging budget
@@ -541,6 +541,7 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         allow_big_lds(corr_kernel<2, 2, 2, 1, 2>); allow_big_lds(corr_kernel<2, 2, 1, 2, 2>); allow_big_lds(corr_kernel<2, 1, 1, 4, 1>);
         allow_big_lds(corr_kernel<2, 1, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 1>); allow_big_lds(corr_kernel<2, 1, 1, 8, 1>);
         allow_big_lds(corr_kernel<2, 2, 2, 2, 1>); allow_big_lds(corr_kernel<0, 2, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 2>);
+        allow_big_lds(corr_kernel<0, 4, 1, 2, 2>); allow_big_lds(corr_kernel<2, 4, 1, 2, 2>);
         once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
@@ -553,7 +554,8 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
             case 4: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 1>" : "corr_kernel<2, 2, 1, 4, 1>"), fl, 0, (corr_kernel<MODE, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
             case 5: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 8, 1>" : "corr_kernel<2, 1, 1, 8, 1>"), fl, 0, (corr_kernel<MODE, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
             case 6: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 2, 1>" : "corr_kernel<2, 2, 2, 2, 1>"), fl, 0, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 2>" : "corr_kernel<2, 2, 1, 4, 2>"), fl, 0, (corr_kernel<MODE, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
+            case 7: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 2>" : "corr_kernel<2, 2, 1, 4, 2>"), fl, 0, (corr_kernel<MODE, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 4, 1, 2, 2>" : "corr_kernel<2, 4, 1, 2, 2>"), fl, 0, (corr_kernel<MODE, 4, 1, 2, 2>), grid, dim3(512), shmem, s, P); break;
         }
     } else {
         switch (cfg) {
@@ -577,21 +579,28 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const int target = env_int("GGAN_TARGET_WGS", 200);
     const WaveCfg* kCfgs = MODE == 1 ? kCfgsDgrad : kCfgsFwd;
     int cfg = env_int(cfg_env, -1);
-    if (cfg < 0 || cfg > 7) {
+    if (cfg < 0 || cfg > (MODE == 1 ? 6 : 8)) {
         // 8 waves per workgroup (two per SIMD: one wave's LDS / barrier stalls hide under the other's MFMAs; measured
         // 12-19 % faster than the 4-wave layouts).  Largest tile that still yields ~one workgroup per CU.
-        static const int order[3] = {6, 4, 5};          // 64x64, 64x32, 32x32 (pixels x channels)
+        // 128x32, 64x64, 64x32, 32x32 (pixels x channels).  The filter slice is 2/3 of what a 64x32 workgroup stages per chunk and
+        // is the same for every pixel tile: the 128-pixel layout stages it once for twice the MFMA work (forward kinds only:
+        // measured 43.2 vs 47.9 us on the critic's 64->128 layer at 128 images, slower for the data-gradient kinds)
+        static const int order[4] = {8, 6, 4, 5};
+        const int first = (MODE == 0 && !getenv("GGAN_NO_WIDE_TILE")) ? 0 : 1;
         cfg = 5;
-        for (int oi = 0; oi < 3; ++oi) {
+        for (int oi = first; oi < 4; ++oi) {
             const int c = order[oi];
             const WaveCfg& wc = kCfgs[c];
             const int CK = 2 * wc.KS * wc.PW, TM = 32 * wc.WM, TNW = 32 * wc.WN;
             if (P.CNtot <= 32 && TNW > 32) continue;                               // don't pad tiny channel counts to 64
             CorrParams T = P;
             if (!pick_tile(T, Hu, Wv, TM, CK, su, ext_r, ext_c)) continue;
-            if (oi < 2 && T.TI * T.TR * T.TC * 2 <= TM && Hu * Wv * P.N >= TM) continue;   // staging budget forced a half-empty tile
+            if (oi < 3 && T.TI * T.TR * T.TC * 2 <= TM && Hu * Wv * P.N >= TM) continue;   // staging budget forced a half-empty tile
             const int wgs = cdiv(P.N, T.TI) * cdiv(Hu, T.TR) * cdiv(Wv, T.TC) * cdiv(P.CNtot, TNW) * groups;
-            if (wgs >= target || oi == 2) { cfg = c; break; }
+            // (the 128-pixel layout pays only while the grid is about one workgroup per CU: with several rounds of 64x64 tiles --
+            //  the 512-frame launches of the state-space scripts -- those stay faster, 200 vs 190+ us measured)
+            if (oi == 0 && wgs >= 2 * target) continue;
+            if (wgs >= target || oi == 3) { cfg = c; break; }
         }
         if (P.CKtot < 8) cfg = P.CNtot <= 32 ? 1 : 6;                              // 3-channel inputs: smallest chunks
     }
