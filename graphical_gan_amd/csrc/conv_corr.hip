@@ -57,6 +57,7 @@ struct CorrParams {
     float alpha;
     unsigned in_bytes, w_bytes;
     int dbg;
+    int dma;                      // forward kinds: stage the slab and the filter slice by LDS-DMA (buffer_load ... lds)
     unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
     const float* in_ref;     // optional: slab values are in[i] * act'(in_ref[i]) (fused activation backward)
     int in_act;
@@ -152,9 +153,11 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 
     // two staging buffers: [CK][CS] slab + [NTT][CK][TNW] filter slice each
     // (+1 / +4 rows: trash slots that absorb the commit of staging elements beyond the tile, so commits are branch-free)
-    const int XS_SZ = (CK * P.CS + 1 + 3) & ~3;
+    // (forward kinds: the slab region is padded to whole 64-float wave-instructions and the filter slice gets a 256-float tail,
+    //  so the zero fill of an LDS-DMA instruction's unused lanes lands in padding)
+    const int XS_SZ = KIND == 0 ? ((CK * P.CS + 64) & ~63) : ((CK * P.CS + 1 + 3) & ~3);
     constexpr int WS_USED = NTT * CK * RS;
-    const int STAGE = XS_SZ + ((WS_USED + 4 * RS + 3) & ~3);
+    const int STAGE = XS_SZ + ((WS_USED + (KIND == 0 ? 256 : 4 * RS) + 3) & ~3);
 
     const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, (short)0, (int)P.in_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)P.w_bytes, 0x00020000);
@@ -286,17 +289,61 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         }
     };
 
+    // LDS-DMA staging (forward kinds): the same per-lane offsets, but the loads land in LDS directly -- lane l of a
+    // wave-instruction writes LDS[M0 base + l * size], which is exactly how the slab (element e = tid + j*NTHR) and the filter slice
+    // (float4 unit u = tid + q*NTHR, LDS float index 4u) are laid out; halo / tail lanes carry the out-of-bounds offset and write
+    // zeros.  No staging registers, no ds_write traffic competing with the fragment reads of the MFMA loop.
+    const bool dma = KIND == 0 && P.dma != 0;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage_dma = [&](int ck0, int buf) {
+        float* xsb = smem + buf * STAGE;
+        float* wsb = xsb + XS_SZ;
+        const int soff_x = ck0 * HWin * 4;
+        const int soff_w = ck0 * P.w_sk * 4;
+#pragma unroll
+        for (int j = 0; j < XE; ++j) {
+            const int e0 = wave_u * 64 + j * NTHR;           // first slab element of this wave-instruction
+            if (e0 < xe_cnt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(xsb + e0), 4, xvo[j], soff_x, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < WE; ++q) {
+            const int u0 = wave_u * 64 + q * NTHR;
+            const unsigned vo = (ck0 + w_ck(tid + q * NTHR) < ck_end) ? wvo[q] : OOB;
+            if (u0 < WUNITS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wsb + 4 * u0), 16, vo, soff_w, 0, 0);
+        }
+    };
+
     // ---- main loop over reduction-channel chunks: chunk c is multiplied out of buffer c&1 while chunk c+1 is committed
     //      to the other buffer and chunk c+2's global loads are in flight; ONE barrier per chunk ---------------------
     stamp(1);
+    int buf = 0;
+    int it_ = 0;
+    if (dma) {
+        // chunk c+1 is in flight into the other buffer while chunk c is multiplied: the wait + barrier at the end of the chunk
+        // retires it for every wave (RAW), and every wave's fragment reads of that buffer were retired one barrier earlier (WAR)
+        stage_dma(ck_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp(3);
+        for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
+            if (ck0 + CK < ck_end) stage_dma(ck0 + CK, buf ^ 1);
+            const float* xs = smem + buf * STAGE;
+            const float* ws = xs + XS_SZ;
+            mma_taps<CL::th(0), CL::tw(0), DI, PW, CK, RS>(xs, ws, xfrag[0], wfrag, P.CS, P.SCp, acc[0]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (it_ < 8) stamp(4 + it_);
+            ++it_;
+        }
+    } else {
     prefetch(ck_begin);
     commit(0);
     stamp(2);
     if (ck_begin + CK < ck_end) prefetch(ck_begin + CK);
     __syncthreads();
     stamp(3);
-    int buf = 0;
-    int it_ = 0;
     // The two waves that share a SIMD run the chunk in OPPOSITE order: waves of the first half stage chunk c+1 (LDS commit +
     // global prefetch of c+2) and then multiply chunk c, waves of the second half multiply first and stage afterwards.  The
     // vector-memory / LDS-write burst of one half therefore overlaps the MFMA phase of the other (with every wave in the
@@ -326,6 +373,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         __syncthreads();
         if (!fine && it_ < 8) stamp(4 + it_);
         ++it_;
+    }
     }
     stamp(12);
 
@@ -632,7 +680,9 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     P.dbg = env_int("GGAN_DBG", 0);
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     const int RS = TNW + (MODE != 0 ? 2 : 0);     // filter row stride in LDS (corr_body: padded for the k-contiguous staging)
-    size_t stage = 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
+    size_t stage = MODE == 0 ? 2 * ((size_t)((CK * P.CS + 64) & ~63) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3))
+                             : 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
+    P.dma = MODE == 0 && env_int("GGAN_CORR_DMA", 1) && (P.dbg & 3) == 0;
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
