@@ -100,6 +100,8 @@ SIGNATURES = {
     'ggan_adam_step_counted': (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P]),
     'ggan_pack': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), _I, _P, _P]),
     'ggan_pack_parts': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), _I, _P, _P, _P]),
+    'ggan_pack_parts2': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), C.POINTER(_P), C.POINTER(_I),
+                              C.POINTER(_Z), _I, _P, _P, _P]),
     'ggan_prof_enable': (_I, [_I]),
     'ggan_prof_reset': (_I, []),
     'ggan_prof_report': (_I, [C.POINTER(ProfRec), _I]),

@@ -511,6 +511,9 @@ struct PackTable {
     size_t off[GGAN_PACK_MAX];
     size_t pstride[GGAN_PACK_MAX];   // floats between the partial slabs of source k
     int parts[GGAN_PACK_MAX];        // number of slabs to sum (1 = plain copy)
+    const float* src2[GGAN_PACK_MAX];  // optional SECOND gradient contribution of the same tensor (a parameter used by two passes of a
+    size_t pstride2[GGAN_PACK_MAX];    // step, e.g. the critic's main pass and its gradient-penalty pass), added after the first
+    int parts2[GGAN_PACK_MAX];
     int count;
     int32_t* bump;                   // optional: counter incremented once per launch (the optimizer's step ordinal)
 };
@@ -520,13 +523,14 @@ struct PackTable {
 __global__ void pack_k(PackTable t, float* __restrict__ flat) {
     const int k = blockIdx.y;
     const float* s = t.src[k];
+    const float* s2 = t.src2[k];
     float* d = flat + t.off[k];
     const size_t n = t.size[k];
-    const int np = t.parts[k];
-    const size_t ps = t.pstride[k];
+    const int np = t.parts[k], np2 = s2 ? t.parts2[k] : 0;
+    const size_t ps = t.pstride[k], ps2 = t.pstride2[k];
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     if (t.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) t.bump[0] += 1;
-    if (s && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0 && (np == 1 || (ps & 3) == 0)) {
+    if (s && ((((uintptr_t)s) | ((uintptr_t)d) | ((uintptr_t)s2)) & 15) == 0 && (np == 1 || (ps & 3) == 0) && (np2 <= 1 || (ps2 & 3) == 0)) {
         const size_t n4 = n >> 2;
         float4* d4 = reinterpret_cast<float4*>(d);
         for (size_t i = i0; i < n4; i += stride) {
@@ -536,11 +540,17 @@ __global__ void pack_k(PackTable t, float* __restrict__ flat) {
                 const float4 b = reinterpret_cast<const float4*>(s + (size_t)p * ps)[i];
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
+#pragma unroll 8
+            for (int p = 0; p < np2; ++p) {
+                const float4 b = reinterpret_cast<const float4*>(s2 + (size_t)p * ps2)[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
             d4[i] = a;
         }
         for (size_t i = (n4 << 2) + i0; i < n; i += stride) {
             float a = s[i];
             for (int p = 1; p < np; ++p) a += s[(size_t)p * ps + i];
+            for (int p = 0; p < np2; ++p) a += s2[(size_t)p * ps2 + i];
             d[i] = a;
         }
     } else {
@@ -550,6 +560,7 @@ __global__ void pack_k(PackTable t, float* __restrict__ flat) {
                 a = s[i];
                 for (int p = 1; p < np; ++p) a += s[(size_t)p * ps + i];
             }
+            for (int p = 0; p < np2; ++p) a += s2[(size_t)p * ps2 + i];
             d[i] = a;
         }
     }
@@ -1037,8 +1048,9 @@ int ggan_adam_advance(int32_t* step, ggan_stream_t stream) {
     return 0;
 }
 
-int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts,
-                    const size_t* strides, int count, float* flat, int32_t* bump, ggan_stream_t stream) {
+int ggan_pack_parts2(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts, const size_t* strides,
+                     const float* const* srcs2, const int* parts2, const size_t* strides2, int count, float* flat, int32_t* bump,
+                     ggan_stream_t stream) {
     GGAN_CHECK_ARG(srcs && sizes && offsets && flat, "null pointer");
     GGAN_CHECK_ARG(count > 0 && count <= GGAN_PACK_MAX, "count out of range");
     PackTable t;
@@ -1047,9 +1059,12 @@ int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t*
         t.src[i] = srcs[i]; t.size[i] = sizes[i]; t.off[i] = offsets[i];
         t.parts[i] = parts ? parts[i] : 1;
         t.pstride[i] = strides ? strides[i] : 0;
-        GGAN_CHECK_ARG(t.parts[i] >= 1, "parts must be >= 1");
+        t.src2[i] = srcs2 ? srcs2[i] : nullptr;
+        t.parts2[i] = (srcs2 && parts2) ? parts2[i] : 1;
+        t.pstride2[i] = (srcs2 && strides2) ? strides2[i] : 0;
+        GGAN_CHECK_ARG(t.parts[i] >= 1 && t.parts2[i] >= 1, "parts must be >= 1");
         if (sizes[i] > mx) mx = sizes[i];
-        tot += sizes[i] * (size_t)t.parts[i];
+        tot += sizes[i] * (size_t)(t.parts[i] + (t.src2[i] ? t.parts2[i] : 0));
     }
     t.count = count;
     t.bump = bump;
@@ -1058,6 +1073,11 @@ int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t*
     if (gx > 512) gx = 512;
     GGAN_LAUNCH("pack", 0, 4.0 * tot + 4.0 * mx, pack_k, dim3(gx, count), dim3(kBlock), 0, (hipStream_t)stream, t, flat);
     return 0;
+}
+
+int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts,
+                    const size_t* strides, int count, float* flat, int32_t* bump, ggan_stream_t stream) {
+    return ggan_pack_parts2(srcs, sizes, offsets, parts, strides, nullptr, nullptr, nullptr, count, flat, bump, stream);
 }
 
 int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offsets, int count, float* flat, ggan_stream_t stream) {

@@ -58,6 +58,29 @@ FUSED_CONV_BWD = _os.environ.get('GGAN_NO_FUSED_BWD') is None
 _DEFER = [None]
 
 
+def _skip_undefined(cls):
+    """Single-output Functions: an undefined incoming gradient means "no gradient", not a zero tensor to push through the layer.
+    The tape reaches a forward node whenever the graph has an edge to it, also when every edge delivers None at run time -- the
+    gradient-penalty pass is the case that matters: its first-order backward reads the forward activations only as LeakyReLU
+    sign references (derivative zero a.e., returned as None), so in the final backward the critic's forward nodes of that pass
+    become ready with an undefined gradient.  torch materialises it as zeros by default and the node then runs its whole backward
+    on zeros (measured: three conv layers' filter- and data-gradient kernels per critic step of wali-gp, all on zero input)."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx.set_materialize_grads(False)
+        ctx._n_in = len(args)
+        return fwd(ctx, *args)
+
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * ctx._n_in
+        return bwd(ctx, g)
+    cls.forward = staticmethod(forward)
+    cls.backward = staticmethod(backward)
+    return cls
+
+
 class defer_wgrad_reduce(object):
     def __init__(self, enabled=True):
         self.enabled = bool(enabled) and _os.environ.get('GGAN_NO_DEFER_WGRAD') is None
@@ -70,7 +93,7 @@ class defer_wgrad_reduce(object):
     def __exit__(self, et, ev, tb):
         reg, _DEFER[0] = _DEFER[0], None
         if self.enabled and et is None and reg:
-            raise _lib.GganError('%d deferred filter-gradient slab sets were never packed' % len(reg))
+            raise _lib.GganError('%d deferred filter-gradient slab sets were never packed: %s' % (len(reg), sorted((v[0], v[1]) for v in reg.values())))
 
 
 def _wgrad_parts(x, gy, y, act, alpha, geom, with_bias):
@@ -145,6 +168,7 @@ def _geom(t):
 DEBUG_POISON_CHECK = bool(os.environ.get('GGAN_POISON_UNWRITTEN'))
 
 
+@_skip_undefined
 class ConvFwd(Function):
     """y = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) + bias  (tf.nn.conv2d + bias_add; also the Deconv2D data-gradient)."""
 
@@ -224,6 +248,7 @@ def _fused_conv_backward(ctx, gy, x, w, y):
     return gx, gw, gb, None, None, None
 
 
+@_skip_undefined
 class ConvDgrad(Function):
     """gx[N,Ci,H,W] = conv^T(gy[N,Co,Ho,Wo], w) + bias[Ci]  (Conv2DBackpropInput; also the Deconv2D forward)."""
 
@@ -258,6 +283,7 @@ class ConvDgrad(Function):
         return (d_gy, d_w, d_b) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
+@_skip_undefined
 class ConvWgrad(Function):
     """gw[k,k,Ci,Co] = sum_n,oh,ow x (*) gy  (Conv2DBackpropFilter)."""
 
@@ -286,6 +312,7 @@ class ConvWgrad(Function):
         return d_x, d_gy, None
 
 
+@_skip_undefined
 class ChanSum(Function):
     """out[c] = sum_{n,h,w} x[n,c,h,w]  (BiasAddGrad, NCHW)."""
 
@@ -312,6 +339,7 @@ class ChanSum(Function):
 TALL_ROWS = 8192
 
 
+@_skip_undefined
 class ColSum(Function):
     """out[c] = sum_r x[r,c]  (BiasAddGrad of Linear)."""
 
@@ -336,6 +364,7 @@ class ColSum(Function):
 # ---------------------------------------------------------------------------------------------------
 # dense
 # ---------------------------------------------------------------------------------------------------
+@_skip_undefined
 class Gemm(Function):
     """C[M,N] = op(A) op(B) + bias[N]; ta/tb read the stored operand transposed."""
 
@@ -406,6 +435,7 @@ def _fused_linear_backward(ctx, g, x, w, y):
     return (dx, dw, db) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
+@_skip_undefined
 class Gemm2(Function):
     """[a1 | a2] @ w + bias without materialising the concatenation (tf.concat + Linear of the joint critic,
     gan_inference_cifar10.py:246-248): the GEMM reads its A operand from two buffers, its weight gradient likewise, and its
@@ -466,6 +496,7 @@ class Gemm2(Function):
         return da1, da2, dw, db if (ctx.has_bias and ctx.needs_input_grad[3]) else None, None, None
 
 
+@_skip_undefined
 class CriticHead(Function):
     """logits[M] = Linear(H -> 1)(lrelu(Linear([a1 | a2] -> H))): the tail of a critic as one op (ggan_critic_head_fwd/bwd:
     split-K slabs summed by the tail kernel that also forms the logits; backward = one head kernel + one grouped launch for
@@ -537,6 +568,7 @@ def linear(x, w, bias=None, act=ACT_NONE, alpha=0.0):
 # ---------------------------------------------------------------------------------------------------
 # pointwise
 # ---------------------------------------------------------------------------------------------------
+@_skip_undefined
 class ActFwd(Function):
     @staticmethod
     def forward(ctx, x, act, alpha):
@@ -553,6 +585,7 @@ class ActFwd(Function):
         return ActBwd.apply(gy, ref, ctx.act, ctx.alpha), None, None
 
 
+@_skip_undefined
 class ActBwd(Function):
     """gx = gy * act'(ref); ref = forward input (lrelu/relu: only its sign is used, so the forward output
     works too) or forward output (tanh/sigmoid)."""
@@ -597,6 +630,7 @@ def sigmoid(x):
     return ActFwd.apply(x, ACT_SIGMOID, 0.0)
 
 
+@_skip_undefined
 class BatchNormTrain(Function):
     """Training-mode BN over all axes but channel axis 1 (NCHW) or over axis 0 of [N,C]."""
 
@@ -807,6 +841,7 @@ class SplitRows(Function):
         return torch.cat([ga, gb], 0), None
 
 
+@_skip_undefined
 class CastScaleI32(Function):
     """real_x = mul*(float(x)/div - .5) + noise  (no gradient: the input is data)."""
 
@@ -825,6 +860,7 @@ class CastScaleI32(Function):
         return (None,) * len(ctx.needs_input_grad)
 
 
+@_skip_undefined
 class Axpby(Function):
     """out = a*x + b*y + c"""
 
@@ -1027,6 +1063,7 @@ def conv3d(x, w, bias, stride_len, stride, act=ACT_NONE, alpha=0.2):
     return y.view(x.shape[0], Lo, Ho, Wo, Co)
 
 
+@_skip_undefined
 class RowLerp(Function):
     """out[r,:] = x[r,:] + alpha[r]*(y[r,:]-x[r,:])  (the wali-gp interpolates)."""
 
@@ -1221,17 +1258,29 @@ def noise_fill_(state, specs):
 
 def pack_(tensors, offsets, flat, bump=None):
     """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros); tensors registered by `defer_wgrad_reduce` are
-    summed over their split-K slabs on the way.  bump: int32 device counter incremented once (the Adam step ordinal)."""
+    summed over their split-K slabs on the way.  An entry may be a pair (t, t2): two gradient contributions of one parameter
+    (either may be None), summed here.  bump: int32 device counter incremented once (the Adam step ordinal)."""
     L = _L()
     reg = _DEFER[0]
     for i0 in range(0, len(tensors), _lib.PACK_MAX):
-        chunk = tensors[i0:i0 + _lib.PACK_MAX]
+        chunk = [(t if isinstance(t, tuple) else (t, None)) for t in tensors[i0:i0 + _lib.PACK_MAX]]
+        chunk = [((b, None) if a is None else (a, b)) for a, b in chunk]        # a lone second contribution is the first
         n = len(chunk)
-        srcs = (C.c_void_p * n)(*[t.data_ptr() if t is not None else 0 for t in chunk])
         sizes = (C.c_size_t * n)(*[int(s) for s in [o[1] for o in offsets[i0:i0 + n]]])
         offs = (C.c_size_t * n)(*[int(o[0]) for o in offsets[i0:i0 + n]])
-        info = [reg.pop(t.data_ptr(), None) if (reg and t is not None) else None for t in chunk]
-        parts = (C.c_int * n)(*[(e[0] if e else 1) for e in info])
-        strides = (C.c_size_t * n)(*[(e[1] if e else 0) for e in info])
-        check(L.ggan_pack_parts(srcs, sizes, offs, parts, strides, n, _p(flat), _p(bump if i0 == 0 else None), _stream()),
-              'ggan_pack_parts')
+
+        def table(col):
+            ts = [c[col] for c in chunk]
+            srcs = (C.c_void_p * n)(*[t.data_ptr() if t is not None else 0 for t in ts])
+            info = [reg.pop(t.data_ptr(), None) if (reg and t is not None) else None for t in ts]
+            parts = (C.c_int * n)(*[(e[0] if e else 1) for e in info])
+            strides = (C.c_size_t * n)(*[(e[1] if e else 0) for e in info])
+            return srcs, parts, strides
+        s1, p1, st1 = table(0)
+        if any(c[1] is not None for c in chunk):
+            s2, p2, st2 = table(1)
+            check(L.ggan_pack_parts2(s1, sizes, offs, p1, st1, s2, p2, st2, n, _p(flat), _p(bump if i0 == 0 else None), _stream()),
+                  'ggan_pack_parts2')
+        else:
+            check(L.ggan_pack_parts(s1, sizes, offs, p1, st1, n, _p(flat), _p(bump if i0 == 0 else None), _stream()),
+                  'ggan_pack_parts')

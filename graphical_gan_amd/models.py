@@ -83,7 +83,9 @@ class GraphicalGAN(object):
     def single_contribution(self):
         """every parameter receives exactly one gradient contribution per backward pass (critic evaluated once on
         [fake; real]; the wali-gp penalty re-enters the critic)"""
-        return bool(self.cfg.batch_critic) and self.cfg.mode in ('ali', 'local_ep', 'wali')   # (reconstruction terms reuse G / E)
+        # (reconstruction terms reuse G / E; the wali-gp penalty pass uses second leaves of the critic's weights, see forward)
+        return bool(self.cfg.batch_critic) and (self.cfg.mode in ('ali', 'local_ep', 'wali') or
+                                                (self.cfg.mode == 'wali-gp' and not os.environ.get('GGAN_NO_SECOND_LEAF')))
 
     def cut_tensors(self, nets):
         """tensors through which EVERY gradient of the Extractor's parameters flows (None if there is no such cut: the
@@ -434,8 +436,11 @@ class GraphicalGAN(object):
             if which == 'gen':
                 gp = None                # not part of gen_cost; TF prunes the third critic pass
             else:
-                gp = J.gradient_penalty(lambda xx, zz: self.Discriminator(xx, zz, twice=True), real_x, fake_x.detach() if batched else fake_x,
-                                        q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
+                # (the penalty pass reaches the critic's weights through second autograd leaves: the optimizer sums the two
+                #  gradient contributions of every weight where it packs the bucket, not with an addition launch per weight)
+                with (lib.second_leaf() if (batched and not os.environ.get('GGAN_NO_SECOND_LEAF')) else lib.frozen()):
+                    gp = J.gradient_penalty(lambda xx, zz: self.Discriminator(xx, zz, twice=True), real_x, fake_x.detach() if batched else fake_x,
+                                            q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
             res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
             out['gradient_penalty'] = gp
         else:

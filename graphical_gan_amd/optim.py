@@ -89,12 +89,26 @@ class AdamOptimizer(object):
 
     # -- one optimizer step ---------------------------------------------------------------------------
     def compute_gradients(self, cost):
+        """-> one entry per parameter: its gradient, or a pair (gradient, gradient through the parameter's second leaf) when a
+        second pass of the step used tflib.second_leaf (summed by pack)"""
+        from . import tflib as lib
         if self._one is None or self._one.shape != cost.shape:
             self._one = torch.ones_like(cost)            # persistent d(cost)/d(cost) seed (no fill launch per step)
-        return torch.autograd.grad(cost, self.params, grad_outputs=self._one, allow_unused=True)
+        extra = [lib.second_leaf_for(p) for p in self.params]
+        idx = [i for i, e in enumerate(extra) if e is not None]
+        if not idx:
+            return torch.autograd.grad(cost, self.params, grad_outputs=self._one, allow_unused=True)
+        g = torch.autograd.grad(cost, list(self.params) + [extra[i] for i in idx], grad_outputs=self._one, allow_unused=True)
+        out = list(g[:len(self.params)])
+        for j, i in enumerate(idx):
+            g2 = g[len(self.params) + j]
+            if g2 is not None:
+                out[i] = (out[i], g2)
+        return out
 
     def pack(self, grads):
-        gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
+        cc = lambda g: None if g is None else (g if g.is_contiguous() else g.contiguous())
+        gs = [(cc(g[0]), cc(g[1])) if isinstance(g, tuple) else cc(g) for g in grads]
         F.pack_(gs, self.slots, self.g, bump=self.step)     # also advances the step counter (read by update())
         return gs  # keep alive until the kernel ran (stream-ordered)
 

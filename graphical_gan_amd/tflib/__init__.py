@@ -45,7 +45,41 @@ def param(name, *args, **kwargs):
         result = _param_aliases[id(result)]
     if _frozen and any(f in name for f in _frozen):
         return result.detach()
+    if _second[0] is not None and result.requires_grad:
+        return _second_leaf_of(name, result)
     return result
+
+
+# A parameter that two passes of ONE step reach (the critic's weights: its main pass and its gradient-penalty pass) would get
+# two gradient contributions that the tape adds with one launch per parameter.  Inside `with second_leaf():` the ops receive a
+# second autograd leaf on the SAME storage instead; the optimizer asks the tape for both gradients and sums them where it packs
+# the bucket (optim.AdamOptimizer.compute_gradients / functional.pack_).  Host logic only: values are shared, nothing is copied.
+_second = [None]
+_second_leaves = {}
+
+
+class second_leaf(object):
+    def __enter__(self):
+        self.prev, _second[0] = _second[0], True
+        return self
+
+    def __exit__(self, *a):
+        _second[0] = self.prev
+
+
+def _second_leaf_of(name, p):
+    t = _second_leaves.get(name)
+    if t is None or t.data_ptr() != p.data_ptr() or t.shape != p.shape:       # (re-homed into an optimizer's flat buffer since)
+        t = p.detach().requires_grad_(True)
+        t.param_name = name
+        _second_leaves[name] = t
+    return t
+
+
+def second_leaf_for(p):
+    """the second leaf last handed out for registry parameter p, if any (a leaf the current tape does not contain simply gets no
+    gradient; one created before an optimizer re-homed p is still the leaf the tape of THAT forward pass holds)"""
+    return _second_leaves.get(getattr(p, 'param_name', None))
 
 
 _frozen = []
@@ -83,6 +117,7 @@ def delete_all_params():
     from .. import optim
     optim.reset_optimizers(keep_params=False)
     _params.clear()
+    _second_leaves.clear()
     _build_phase[0] = True
 
 

@@ -323,6 +323,13 @@ int ggan_pack(const float* const* srcs, const size_t* sizes, const size_t* offse
  * bump (may be NULL): an int32 incremented once by this launch. */
 int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts,
                     const size_t* strides, int count, float* flat, int32_t* bump, ggan_stream_t stream);
+/* ggan_pack_parts with an optional SECOND contribution per tensor (srcs2[i] may be NULL; parts2 / strides2 as parts / strides):
+ * flat[off_i ..] = sum of the slabs of srcs[i] (zeros if NULL) + sum of the slabs of srcs2[i].  A parameter that two passes of one
+ * step reach (the critic's main pass and its gradient-penalty pass, gan_inference_cifar10.py:351-366) gets its two gradient
+ * contributions summed here instead of by an addition launch per parameter. */
+int ggan_pack_parts2(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts, const size_t* strides,
+                     const float* const* srcs2, const int* parts2, const size_t* strides2, int count, float* flat, int32_t* bump,
+                     ggan_stream_t stream);
 
 /* ---- per-kernel timing (bench.py roofline leg) -----------------------------------------------
  * When enabled every launch is bracketed by hipEvents on its own stream.  ggan_prof_report
