@@ -59,6 +59,8 @@ SIGNATURES = {
     'ggan_gmm_latent_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'ggan_gemm_split': (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _F, _P, _Z, _P]),
     'ggan_gemm_colsum': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_dyn_scan_fwd': (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
+    'ggan_dyn_scan_bwd': (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     'ggan_critic_head_fwd': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _Z, _P]),
     'ggan_critic_head_bwd': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_linear_bwd_data_act': (_I, [_I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),

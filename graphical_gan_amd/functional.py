@@ -547,6 +547,56 @@ class CriticHead(Function):
                 d_bout, None)
 
 
+class DynScan(Function):
+    """zs[B, T+1, dl]: the transition operator of the state-space scripts applied T times (ggan_dyn_scan_fwd / _bwd: one scan
+    launch per direction, the weight gradients as products over all T*B rows).  zw / b_zw None: OP_DYN_MODE 'res'."""
+
+    @staticmethod
+    def usable(z0, eps, w_1):
+        return w_1.shape[0] == 256 and w_1.shape[1] == 256 and z0.shape[1] <= 16 and eps.shape[1] <= 16
+
+    @staticmethod
+    def forward(ctx, z0, eps, w_in, b_in, w_1, b_1, w_out, b_out, zw, b_zw, T, alpha):
+        z0, eps, w_in, b_in, w_1, b_1, w_out, b_out = (_c(t) for t in (z0, eps, w_in, b_in, w_1, b_1, w_out, b_out))
+        zw, b_zw = (_c(zw), _c(b_zw)) if zw is not None else (None, None)
+        B, dl = z0.shape
+        dt, Hd = eps.shape[1], w_1.shape[0]
+        assert w_in.shape == (dl + dt, Hd) and w_out.shape == (Hd, dl), (w_in.shape, w_out.shape)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=z0.device)
+        zs, h1, h2 = new(B, T + 1, dl), new(T, B, Hd), new(T, B, Hd)
+        check(_L().ggan_dyn_scan_fwd(B, T, dl, dt, Hd, _p(z0), _p(eps), _p(w_in), _p(b_in), _p(w_1), _p(b_1), _p(w_out), _p(b_out),
+                                     _p(zw), _p(b_zw), float(alpha), _p(zs), _p(h1), _p(h2), _stream()), 'ggan_dyn_scan_fwd')
+        ctx.T, ctx.alpha = T, float(alpha)
+        ctx.save_for_backward(eps, w_in, w_1, w_out, zw, zs, h1, h2)
+        return zs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_zs):
+        eps, w_in, w_1, w_out, zw, zs, h1, h2 = ctx.saved_tensors
+        g_zs = _c(g_zs)
+        B, T1, dl = zs.shape
+        T, dt, Hd = T1 - 1, eps.shape[1], w_1.shape[0]
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=zs.device)
+        G1, G2, Go, Xin = new(T * B, Hd), new(T * B, Hd), new(T * B, dl), new(T * B, dl + dt)
+        d_z0, d_eps = new(B, dl), new(B, dt)
+        check(_L().ggan_dyn_scan_bwd(B, T, dl, dt, Hd, _p(g_zs), _p(zs), _p(eps), _p(h1), _p(h2), _p(w_in), _p(w_1), _p(w_out), _p(zw),
+                                     ctx.alpha, _p(G1), _p(G2), _p(Go), _p(Xin), _p(d_z0), _p(d_eps), _stream()), 'ggan_dyn_scan_bwd')
+        need = ctx.needs_input_grad
+        d_win = d_bin = d_w1 = d_b1 = d_wout = d_bout = d_zw = d_bzw = None
+        if need[2] or need[3]:
+            d_win, d_bin = gemm_colsum_(Xin, G1, True)                      # [dl+dt, H], [H]
+        if need[4] or need[5]:
+            d_w1, d_b1 = gemm_colsum_(h1.view(T * B, Hd), G2, True)         # [H, H], [H]
+        if need[6] or need[7] or need[9]:
+            d_wout, d_bout = gemm_colsum_(h2.view(T * B, Hd), Go, True)     # [H, dl], [dl]
+        if zw is not None and need[8]:
+            d_zw = Gemm.apply(Xin[:, :dl].contiguous(), Go, None, True, False, ACT_NONE, 0.0)
+            d_bzw = d_bout
+        return (d_z0 if need[0] else None, d_eps if need[1] else None, d_win, d_bin, d_w1, d_b1, d_wout, d_bout, d_zw, d_bzw,
+                None, None)
+
+
 def gemm_colsum_(a, g, ta):
     """C = op(A) @ g and colsum[n] = sum_k g[k, n] in one kernel (no autograd: used inside plain backward passes)."""
     a, g = _c(a), _c(g)

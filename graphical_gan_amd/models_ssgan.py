@@ -14,6 +14,8 @@ What is done differently from a literal transcription (same arithmetic):
     hand the critics their weights without gradient edges (tflib.frozen), as TF's var_list does, and run the frame
     critic's conv data-gradient on the fake frames only (grad_rows).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -148,6 +150,18 @@ class StateSpaceGAN(object):
 
     def DynamicGenerator(self, z_l_0, epsilon):
         c, zs = self.cfg, [z_l_0]
+        name = 'Generator.Dynamic'
+        P = lib.ops.linear.linear_params
+        if (c.fuse and c.dim_op == 256 and c.dim_l <= 16 and c.dim_t <= 16 and z_l_0.is_cuda
+                and not os.environ.get('GGAN_NO_DYN_SCAN')):
+            # the LEN-1 applications of the shared-weight operator as ONE scan launch per direction (functional.DynScan)
+            # (while the graph is being built every application draws its initial values, as in the reference: same RNG stream)
+            for _ in range(c.LEN - 1 if lib.initial_values_needed(name + '.Input.W') else 1):
+                w_in, b_in = P(name + '.Input', c.dim_l + c.dim_t, c.dim_op)
+                w_1, b_1 = P(name + '.1', c.dim_op, c.dim_op)
+                w_out, b_out = P(name + '.Output', c.dim_op, c.dim_l)
+                zw, b_zw = P(name + '.ZW', c.dim_l, c.dim_l) if c.op_dyn_mode != 'res' else (None, None)
+            return F.DynScan.apply(z_l_0, epsilon, w_in, b_in, w_1, b_1, w_out, b_out, zw, b_zw, c.LEN - 1, 0.2)
         for _ in range(c.LEN - 1):
             zs.append(self.ImplicitOperator(zs[-1], epsilon, 'Generator.Dynamic'))
         return torch.stack(zs, 1)

@@ -113,3 +113,10 @@ def LinearLReLULinear(name1, input_dim, hidden_dim, name2, inputs, alpha=0.2, di
     b2 = _param(name2 + '.b', np.zeros((1,), dtype='float32'))
     assert x1.shape[1] + (x2.shape[1] if x2 is not None else 0) == input_dim, (name1, x1.shape, input_dim)
     return F.CriticHead.apply(x1, x2, w1, b1, w2, b2, float(alpha))
+
+
+def linear_params(name, input_dim, output_dim):
+    """(W, b) of Linear(name, input_dim, output_dim) without applying it: same registry keys, shapes and initial-value draws"""
+    w = _param(name + '.W', _initial(None, input_dim, output_dim) if _draw(name + '.W') else None)
+    b = _param(name + '.b', np.zeros((output_dim,), dtype='float32'))
+    return w, b

@@ -110,6 +110,23 @@ int ggan_gemm_split(int ta, int tb, int M, int N, int K, const float* A, const f
                     const float* bias, float* C, float* C2, int c_split, float* colsum_b, int act, float alpha, void* ws,
                     size_t ws_bytes, ggan_stream_t stream);
 
+/* The state-space scripts' transition operator unrolled over a sequence, as ONE scan per direction
+ * (/root/reference/ssgan_inference_moving_mnist.py:98-114 ImplicitOperator, :134-141 DynamicGenerator; 'res_w' variant:
+ * ssgan_inference_chairs.py): z_{t+1} = Linear_out(lrelu(Linear_1(lrelu(Linear_in([z_t | eps]))))) + z_t   (zw == NULL)
+ *                                      ... + z_t zw + b_zw                                                 (zw != NULL)
+ * for t = 0 .. T-1 (T = LEN-1), one workgroup per sequence.  H (DIM_OP) must be 256, dl, dt <= 16.
+ *   forward : zs[B, T+1, dl] (zs[:, 0] = z0), h1 / h2 [T, B, H] = the two hidden activations (kept for the backward).
+ *   backward: from g_zs[B, T+1, dl] = d cost / d zs: the masked hidden-layer gradients G1, G2 [T, B, H], the gradient at every
+ *             operator output Go[T, B, dl], the operator inputs Xin[T, B, dl+dt], d_z0[B, dl], d_eps[B, dt] (may be NULL).  The
+ *             weight gradients are products over all T*B rows: dW_in = Xin^T G1, dW_1 = h1^T G2, dW_out = h2^T Go,
+ *             dZW = Xin[:, :dl]^T Go, biases = column sums (ggan_gemm_colsum). */
+int ggan_dyn_scan_fwd(int B, int T, int dl, int dt, int H, const float* z0, const float* eps, const float* w_in, const float* b_in,
+                      const float* w_1, const float* b_1, const float* w_out, const float* b_out, const float* zw, const float* b_zw,
+                      float alpha, float* zs, float* h1, float* h2, ggan_stream_t stream);
+int ggan_dyn_scan_bwd(int B, int T, int dl, int dt, int H, const float* g_zs, const float* zs, const float* eps, const float* h1,
+                      const float* h2, const float* w_in, const float* w_1, const float* w_out, const float* zw, float alpha, float* G1,
+                      float* G2, float* Go, float* Xin, float* d_z0, float* d_eps, ggan_stream_t stream);
+
 /* The tail of a critic as ONE op: Linear ([a1 | a2] -> H) + LeakyReLU(alpha) + Linear (H -> 1).
  * Replaces, for the joint critic, tf.concat + lib.ops.linear.Linear('Discriminator.zx1') + LeakyReLU +
  * lib.ops.linear.Linear('Discriminator.Output') (/root/reference/gan_inference_cifar10.py:246-254,

@@ -1096,3 +1096,42 @@ def test_critic_head(gpu, M, K1, K2, H, need):
         assert _rel(grads[id(tb)].cpu().numpy(), ref['b']) < 2e-5
         assert _rel(grads[id(two)].cpu().numpy().reshape(-1), ref['wo'].reshape(-1)) < 2e-5
         assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
+
+
+@pytest.mark.parametrize('res_w', [False, True], ids=['res', 'res_w'])
+@pytest.mark.parametrize('B,T,dl,dt', [(5, 4, 8, 8), (32, 15, 8, 8), (3, 30, 8, 8), (2, 3, 4, 6)])
+def test_dyn_scan(gpu, B, T, dl, dt, res_w):
+    """ggan_dyn_scan_fwd/bwd (functional.DynScan: the transition operator of the state-space scripts applied T times,
+    ssgan_inference_moving_mnist.py:98-141) vs the layer-by-layer recurrence in float64 torch-CPU autograd: the sequence, and the
+    gradient of a random linear functional of it w.r.t. z0, eps and every weight."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(B * 100 + T)
+    Hd = 256
+    mk = lambda *s, sc=1.0: (sc * rng.standard_normal(s)).astype(np.float32)
+    z0, eps = mk(B, dl), mk(B, dt)
+    w_in, b_in = mk(dl + dt, Hd, sc=0.3), mk(Hd, sc=0.1)
+    w_1, b_1 = mk(Hd, Hd, sc=0.08), mk(Hd, sc=0.1)
+    w_out, b_out = mk(Hd, dl, sc=0.08), mk(dl, sc=0.1)
+    zw, b_zw = (mk(dl, dl, sc=0.3), mk(dl, sc=0.1)) if res_w else (None, None)
+    gz = mk(B, T + 1, dl)
+    names = ['z0', 'eps', 'w_in', 'b_in', 'w_1', 'b_1', 'w_out', 'b_out'] + (['zw', 'b_zw'] if res_w else [])
+    vals = [z0, eps, w_in, b_in, w_1, b_1, w_out, b_out] + ([zw, b_zw] if res_w else [])
+    ref = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in vals]
+    r = dict(zip(names, ref))
+    lre = lambda x: torch.maximum(0.2 * x, x)
+    zs = [r['z0']]
+    for _ in range(T):
+        h = lre(torch.cat([zs[-1], r['eps']], 1) @ r['w_in'] + r['b_in'])
+        h = lre(h @ r['w_1'] + r['b_1'])
+        o = h @ r['w_out'] + r['b_out']
+        zs.append(o + (zs[-1] @ r['zw'] + r['b_zw'] if res_w else zs[-1]))
+    zs = torch.stack(zs, 1)
+    gref = torch.autograd.grad((zs * torch.tensor(gz, dtype=torch.float64)).sum(), ref)
+    dev = [_t(v, gpu).requires_grad_(True) for v in vals]
+    d = dict(zip(names, dev))
+    out = F.DynScan.apply(d['z0'], d['eps'], d['w_in'], d['b_in'], d['w_1'], d['b_1'], d['w_out'], d['b_out'], d.get('zw'), d.get('b_zw'), T, 0.2)
+    assert _rel(out.detach().cpu().numpy(), zs.detach().numpy()) < 2e-5
+    g = torch.autograd.grad(out, dev, grad_outputs=_t(gz, gpu))
+    for n, a, b in zip(names, g, gref):
+        assert _rel(a.cpu().numpy(), b.numpy()) < 5e-5, n
