@@ -72,7 +72,7 @@ __global__ __launch_bounds__(H) void dyn_scan_fwd_k(const ScanParams P) {
         float s[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s[u] = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int k = 0; k < H; k += 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) s[u] = fmaf(h_s[k + u], P.w_1[(size_t)(k + u) * H + n], s[u]);
@@ -144,11 +144,23 @@ __global__ __launch_bounds__(H) void dyn_scan_bwd_k(const ScanParams P) {
             gq = *reinterpret_cast<const float4*>(g1_s + 4 * lane);
             __syncthreads();      // (g1_s is reused for g_h1 below)
         }
-        for (int k = wave; k < H; k += 4) {
-            const float4 w = *reinterpret_cast<const float4*>(P.w_1 + (size_t)k * H + 4 * lane);
-            float v = fmaf(gq.x, w.x, fmaf(gq.y, w.y, fmaf(gq.z, w.z, gq.w * w.w)));
-            v = wave_sum(v);
-            if (lane == 0) g1_s[k] = v;
+        // (8 rows per trip: the eight 1 KB row loads are in flight together and the eight shuffle reductions interleave)
+        for (int k0 = wave; k0 < H; k0 += 32) {
+            float4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(P.w_1 + (size_t)(k0 + 4 * u) * H + 4 * lane);
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = fmaf(gq.x, w[u].x, fmaf(gq.y, w[u].y, fmaf(gq.z, w[u].z, gq.w * w[u].w)));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] += __shfl_xor(v[u], o, 64);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g1_s[k0 + 4 * u] = v[u];
+            }
         }
         __syncthreads();
         const float g1 = g1_s[n] * (P.h1[row + n] > 0.f ? 1.f : P.alpha);
