@@ -640,10 +640,12 @@ int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const flo
     if (nw && na && Gw.P.fast && Ga.P.fast && !getenv("GGAN_NO_GEMM_GROUP")) {
         GemmGroup GG;
         memset(&GG, 0, sizeof(GG));
+        // (the data-gradient product first: its workgroups walk K = H in 16 serial steps, the weight-gradient's only M / 32 --
+        //  dispatched first, the long pole starts at once and the short workgroups fill in around it)
         GG.n = 2;
-        GG.kind[0] = 0; GG.gx[0] = Gw.gx; GG.p[0] = Gw.P; GG.first[0] = 0;
-        GG.kind[1] = 1; GG.gx[1] = Ga.gx; GG.p[1] = Ga.P; GG.first[1] = Gw.gx * Gw.gy;
-        GG.first[2] = GG.first[1] + Ga.gx * Ga.gy;
+        GG.kind[0] = 1; GG.gx[0] = Ga.gx; GG.p[0] = Ga.P; GG.first[0] = 0;
+        GG.kind[1] = 0; GG.gx[1] = Gw.gx; GG.p[1] = Gw.P; GG.first[1] = Ga.gx * Ga.gy;
+        GG.first[2] = GG.first[1] + Gw.gx * Gw.gy;
         GGAN_LAUNCH("gemm_group_kernel", 4.0 * M * K * (double)H, 0, gemm_group_kernel, dim3(GG.first[2]), dim3(256), 0, s, GG);
         return 0;
     }
