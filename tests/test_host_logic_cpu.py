@@ -225,3 +225,56 @@ def test_api_surface_matches_reference_signatures():
     assert str(inspect.signature(lib.param)) == '(name, *args, **kwargs)'
     for name in ('enable_default_weightnorm', 'disable_default_weightnorm', 'set_weights_stdev', 'unset_weights_stdev'):
         assert callable(getattr(lib.ops.linear, name))
+
+
+def test_second_leaf_shares_storage_and_keeps_gradients_apart(lib):
+    """tflib.second_leaf: a second pass of a step sees the same weight VALUES through a second autograd leaf, so the tape returns
+    two gradient contributions per weight instead of adding them (the optimizer sums them where it packs the bucket); frozen
+    parameters and non-trainable entries are not affected; delete_all_params drops the leaves."""
+    import torch
+    w = lib.param('Discriminator.1.W', np.arange(6, dtype='float32').reshape(2, 3))
+    mv = lib.param('Discriminator.BN.moving_mean', np.zeros(3, 'float32'), trainable=False)
+    x = torch.ones(4, 2)
+    y1 = (x @ lib.param('Discriminator.1.W', None)).sum()
+    with lib.second_leaf():
+        w2 = lib.param('Discriminator.1.W', None)
+        assert lib.param('Discriminator.BN.moving_mean', None) is mv
+        y2 = (2.0 * x @ w2).sum()
+        with lib.frozen('Discriminator'):
+            assert not lib.param('Discriminator.1.W', None).requires_grad
+    assert w2 is not w and w2.is_leaf and w2.requires_grad and w2.data_ptr() == w.data_ptr()
+    assert lib.param('Discriminator.1.W', None) is w                       # outside the context: the registry parameter again
+    assert lib.second_leaf_for(w) is w2
+    g1, g2 = torch.autograd.grad(y1 + y2, [w, w2])
+    assert torch.equal(g1, torch.full((2, 3), 4.0)) and torch.equal(g2, torch.full((2, 3), 8.0))
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert torch.equal(w2.detach(), w.detach())                            # same storage: values follow
+    with lib.second_leaf():
+        assert lib.param('Discriminator.1.W', None) is w2                  # cached while the storage is unchanged
+    w.data = w.data.clone()                                                # (what an optimizer does when it re-homes a parameter)
+    with lib.second_leaf():
+        w3 = lib.param('Discriminator.1.W', None)
+    assert w3 is not w2 and w3.data_ptr() == w.data_ptr()
+    lib.delete_all_params()
+    assert lib.second_leaf_for(w) is None
+
+
+def test_optimizer_returns_contribution_pairs(lib):
+    """optim.AdamOptimizer.compute_gradients: a parameter that a second-leaf pass reached comes back as (gradient, second
+    gradient); others as a plain tensor or None"""
+    import torch
+    from graphical_gan_amd import optim
+
+    class Opt(optim.AdamOptimizer):          # (CPU: no flat device buffers, only the gradient bookkeeping under test)
+        def __init__(self, params):
+            self.params, self._one = list(params), None
+    a = lib.param('Discriminator.a', np.ones(3, 'float32'))
+    b = lib.param('Discriminator.b', np.ones(3, 'float32'))
+    c = lib.param('Discriminator.c', np.ones(3, 'float32'))
+    cost = (a * 2).sum() + (b * 3).sum()
+    with lib.second_leaf():
+        cost = cost + (lib.param('Discriminator.a', None) * 5).sum()
+    g = Opt([a, b, c]).compute_gradients(cost)
+    assert isinstance(g[0], tuple) and float(g[0][0][0]) == 2.0 and float(g[0][1][0]) == 5.0
+    assert torch.is_tensor(g[1]) and float(g[1][0]) == 3.0 and g[2] is None
