@@ -71,11 +71,12 @@ class GraphicalGAN(object):
     def __init__(self, cfg):
         self.cfg = cfg
         self._side = None                                     # second stream of forward_nets
-        # two-stream Extractor / Generator passes: measured +3 % (ali, face, mnist), -5..7 % with the mixture prior or the
-        # gradient penalty (more cross-stream edges than overlap), so only the plain joint-critic modes ask for it; the Trainer
+        # two-stream Extractor / Generator passes: measured +3 % (ali, face, mnist), -5..7 % with the gradient penalty (more
+        # cross-stream edges than overlap), so the joint-critic modes without a penalty ask for it; the Trainer
         # turns it on while it builds a single-graph step (fork_now) -- eager steps are host-bound and gain nothing
-        self.fork_nets = (not os.environ.get('GGAN_NO_FORK_NETS') and not cfg.K
-                          and cfg.mode in ('ali', 'alice', 'alice-z', 'alice-x', 'wali'))
+        # (round 2, after the kernels got shorter: +1.5 % with the mixture prior too; still -6.6 % for wali-gp)
+        self.fork_nets = (not os.environ.get('GGAN_NO_FORK_NETS')
+                          and cfg.mode in ('ali', 'alice', 'alice-z', 'alice-x', 'wali', 'local_ep', 'local_epce')) or bool(os.environ.get('GGAN_FORCE_FORK_NETS'))
         self.fork_now = False
 
     # ---- engine hooks: the static inputs of one session.run (what the reference feeds / samples) -----------------
