@@ -58,6 +58,24 @@ FUSED_CONV_BWD = _os.environ.get('GGAN_NO_FUSED_BWD') is None
 _DEFER = [None]
 
 
+# ctx.needs_input_grad says whether an input REQUIRES grad, not whether the running torch.autograd.grad call asked for it.  The
+# gradient-penalty construction differentiates the critic w.r.t. its INPUT only (create_graph=True); without a hint every layer's
+# first-order backward would also form its weight and bias gradients there -- three filter-gradient launches, two weight-gradient
+# products and their reduce / column-sum launches per critic step of wali-gp (~150 us), all discarded by the tape.
+_DATA_ONLY = [False]
+
+
+class data_grad_only(object):
+    """with data_grad_only(): torch.autograd.grad(out, [x], create_graph=True) -- layer backwards skip parameter gradients"""
+
+    def __enter__(self):
+        self.prev, _DATA_ONLY[0] = _DATA_ONLY[0], True
+        return self
+
+    def __exit__(self, *a):
+        _DATA_ONLY[0] = self.prev
+
+
 def _skip_undefined(cls):
     """Single-output Functions: an undefined incoming gradient means "no gradient", not a zero tensor to push through the layer.
     The tape reaches a forward node whenever the graph has an edge to it, also when every edge delivers None at run time -- the
@@ -202,10 +220,10 @@ class ConvFwd(Function):
         if ctx.act != ACT_NONE:
             gy = ActBwd.apply(gy, y, ctx.act, ctx.alpha)       # lrelu/relu: sign(y) == sign(pre-activation)
         gx = gw = gb = None
-        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        if ctx.needs_input_grad[1]:
+        params = not _DATA_ONLY[0]
+        if ctx.needs_input_grad[1] and params:
             gw = ConvWgrad.apply(x, gy, ctx.geom)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and params:
             gb = ChanSum.apply(gy)
         if ctx.needs_input_grad[0]:
             gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
@@ -394,7 +412,9 @@ class Gemm(Function):
         if ctx.act != ACT_NONE:
             g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
         da = db = dbias = None
-        if (ctx.needs_input_grad[1] and not tb and ctx.has_bias and ctx.needs_input_grad[2]
+        if _DATA_ONLY[0]:
+            pass                                                               # (parameter gradients not wanted by this grad call)
+        elif (ctx.needs_input_grad[1] and not tb and ctx.has_bias and ctx.needs_input_grad[2]
                 and not torch.is_grad_enabled() and g.shape[0] < TALL_ROWS):
             db, dbias = gemm_colsum_(a, g, not ta)                             # dW and db in ONE launch
         else:
@@ -467,10 +487,10 @@ class Gemm2(Function):
         if torch.is_grad_enabled():          # differentiable composition (second derivatives: wali-gp)
             if ctx.act != ACT_NONE:
                 g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
-            a = torch.cat([a1, a2], 1)
+            params = not _DATA_ONLY[0]
             da = Gemm.apply(g, w, None, False, True, ACT_NONE, 0.0) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
-            dw = Gemm.apply(a, g, None, True, False, ACT_NONE, 0.0) if ctx.needs_input_grad[2] else None
-            db = ColSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+            dw = Gemm.apply(torch.cat([a1, a2], 1), g, None, True, False, ACT_NONE, 0.0) if (ctx.needs_input_grad[2] and params) else None
+            db = ColSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[3] and params) else None
             return (da[:, :K1] if da is not None else None, da[:, K1:] if da is not None else None, dw, db, None, None)
         g = _c(g)
         if ctx.act != ACT_NONE:
