@@ -262,6 +262,16 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     finite = all(np.isfinite(float(v)) for v in last.values())
+    # run-to-run spread of the same K-step window (not part of `value`: the contract's timed region is the one above)
+    repeats = []
+    for _ in range(args.repeats if spec.get('key') == 'headline' else 0):
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            tr.iteration(it, bi); it += 1
+        tr.flush()
+        fence()
+        repeats.append(1e3 * (time.perf_counter() - t1) / steps)
 
     ms_per_step = 1e3 * dt / steps
     units_per_s = cfg.B * world * steps / dt
@@ -348,6 +358,7 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
             'algorithmic_gflop_per_step': round(gflop_it, 2),
             'whole_step_tflops': round(step_tflops, 2), 'whole_step_frac': round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4),
             'roofline': roofline, 'cpu_baseline': cpu,
+            **({'repeat_ms_per_step': [round(x, 4) for x in repeats]} if repeats else {}),
             'kernels': kernels[:top_kernels] if (kernels and top_kernels) else kernels,
         }
     # ---- tear down: graphs, flat optimizer buffers, parameters ------------------------------------------------
@@ -377,6 +388,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='headline workload only')
+    ap.add_argument('--repeats', type=int, default=3, help='extra repetitions of the K-step window after the timed one (spread; headline only)')
     ap.add_argument('--variants', default=None, help='comma-separated subset of: ' + ', '.join(v['key'] for v in VARIANTS))
     ap.add_argument('--variant-steps', type=int, default=None, help='timed iterations per variant (default: min(steps, 60))')
     ap.add_argument('--host-feed', action='store_true',
