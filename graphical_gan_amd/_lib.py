@@ -82,6 +82,7 @@ SIGNATURES = {
     'ggan_bn_sync_bwd_apply': (_I, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     'ggan_act_fwd': (_I, [_P, _P, _Z, _I, _F, _P]),
     'ggan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
+    'ggan_act_bwd_chansum': (_I, [_P, _P, _P, _P, _I, C.POINTER(_I), _I, _I, _I, _I, _F, _P]),
     'ggan_bias_add': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'ggan_cast_scale_i32': (_I, [_P, _P, _P, _Z, _F, _F, _P]),
     'ggan_axpby': (_I, [_P, _P, _P, _Z, _F, _F, _F, _P]),

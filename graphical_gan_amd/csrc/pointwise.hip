@@ -45,6 +45,45 @@ __global__ void act_bwd_k(const float* __restrict__ gy, const float* __restrict_
     for (size_t j = (n4 << 2) + i; j < n; j += stride) gx[j] = act_grad(gy[j], ref[j], act, alpha);
 }
 
+// act_bwd + the bias gradient of the layer in one pass: workgroup (c, s) handles channel c of the images [s*ipb, (s+1)*ipb),
+// writes gx = gy * act'(ref) and its partial sum to parts[s*C + c] (slab s of a "parts" gradient: the pack kernel or a split-K
+// reduce adds the slabs in order -- deterministic, no second reduction launch).  Replaces act_bwd + chansum_part + chansum_final
+// in the backward of a Deconv2D / Conv2D whose bias does not feed a BatchNorm.
+__global__ __launch_bounds__(256) void act_bwd_chansum_k(const float* __restrict__ gy, const float* __restrict__ ref, float* __restrict__ gx,
+                                                         float* __restrict__ parts, int N, int C, int HW, int ipb, int act, float alpha) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x;
+    const int n0 = sidx * ipb, n1 = min(n0 + ipb, N);
+    float acc = 0.f;
+    const int hw4 = HW >> 2;
+    for (int n = n0; n < n1; ++n) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        if ((HW & 3) == 0) {
+            const float4* g4 = reinterpret_cast<const float4*>(gy + base);
+            const float4* r4 = reinterpret_cast<const float4*>(ref + base);
+            float4* o4 = reinterpret_cast<float4*>(gx + base);
+            for (int j = tid; j < hw4; j += 256) {
+                const float4 g = g4[j], r = r4[j];
+                float4 o;
+                o.x = act_grad(g.x, r.x, act, alpha); o.y = act_grad(g.y, r.y, act, alpha);
+                o.z = act_grad(g.z, r.z, act, alpha); o.w = act_grad(g.w, r.w, act, alpha);
+                o4[j] = o;
+                acc += (o.x + o.y) + (o.z + o.w);
+            }
+        } else {
+            for (int j = tid; j < HW; j += 256) {
+                const float o = act_grad(gy[base + j], ref[base + j], act, alpha);
+                gx[base + j] = o;
+                acc += o;
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) parts[(size_t)sidx * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void bias_add_k(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
                            size_t total, int C, int HW) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -855,6 +894,25 @@ int ggan_act_bwd(const float* gy, const float* ref, float* gx, size_t n, int act
     hipStream_t s = (hipStream_t)stream;
     GGAN_CHECK_ARG(aligned16(gy) && aligned16(ref) && aligned16(gx), "buffers must be 16-byte aligned");
     GGAN_LAUNCH("act_bwd", 0, 12.0 * n, act_bwd_k, dim3(grid_for(n, 16)), dim3(kBlock), 0, s, gy, ref, gx, n, act, alpha);
+    return 0;
+}
+
+int ggan_act_bwd_chansum(const float* gy, const float* ref, float* gx, float* parts, int parts_cap, int* n_parts, int N, int C, int HW,
+                         int act, float alpha, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(gy && ref && gx && parts && n_parts, "null pointer");
+    GGAN_CHECK_ARG(N > 0 && C > 0 && HW > 0 && parts_cap >= C, "bad shape");
+    GGAN_CHECK_ARG(aligned16(gy) && aligned16(ref) && aligned16(gx), "buffers must be 16-byte aligned");
+    // enough workgroups to cover the chip, at most one slab per image and at most parts_cap / C slabs
+    int S = (512 + C - 1) / C;
+    if (S > N) S = N;
+    if (S > parts_cap / C) S = parts_cap / C;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    const int ipb = (N + S - 1) / S;
+    S = (N + ipb - 1) / ipb;
+    *n_parts = S;
+    GGAN_LAUNCH("act_bwd_chansum", 0, 12.0 * N * C * HW, act_bwd_chansum_k, dim3(C, S), dim3(256), 0, (hipStream_t)stream, gy, ref, gx, parts,
+                N, C, HW, ipb, act, alpha);
     return 0;
 }
 

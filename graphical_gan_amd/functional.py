@@ -287,13 +287,30 @@ class ConvDgrad(Function):
     @staticmethod
     def backward(ctx, h):
         gy, w, out = ctx.saved_tensors
-        if ctx.act != ACT_NONE:
-            h = ActBwd.apply(h, out, ctx.act, ctx.alpha)
         d_gy = d_w = d_b = None
+        reg = _DEFER[0]
+        if (ctx.act != ACT_NONE and ctx.has_bias and ctx.needs_input_grad[2] and reg is not None and not torch.is_grad_enabled()
+                and not _os.environ.get('GGAN_NO_ACT_CHANSUM')):
+            # activation derivative and the bias gradient in ONE pass: the channel sums leave as partial slabs for the pack kernel
+            h = _c(h)
+            N, Cc = h.shape[0], h.shape[1]
+            HW = h.numel() // (N * Cc)
+            cap = min(64, max(1, -(-512 // Cc))) * Cc
+            part = torch.empty((cap,), dtype=torch.float32, device=h.device)
+            hm = torch.empty_like(h)
+            n = C.c_int(0)
+            check(_L().ggan_act_bwd_chansum(_p(h), _p(out), _p(hm), _p(part), cap, C.byref(n), N, Cc, HW, ctx.act, ctx.alpha, _stream()),
+                  'ggan_act_bwd_chansum')
+            h = hm
+            d_b = part[:Cc]
+            if n.value > 1:
+                reg[d_b.data_ptr()] = (n.value, Cc, part)
+        elif ctx.act != ACT_NONE:
+            h = ActBwd.apply(h, out, ctx.act, ctx.alpha)
         if ctx.needs_input_grad[1]:
             parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None
             d_w = parts[0] if parts is not None else ConvWgrad.apply(h, gy, ctx.geom)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and d_b is None:
             pre = getattr(h, '_ggan_chansum', None) if not torch.is_grad_enabled() else None
             d_b = pre if (pre is not None and pre.numel() == h.shape[1]) else ChanSum.apply(h)
         if ctx.needs_input_grad[0]:

@@ -210,6 +210,12 @@ int ggan_bn_sync_bwd_apply(const float* x, const float* gy, const float* y, int 
 int ggan_act_fwd(const float* x, float* y, size_t n, int act, float alpha, ggan_stream_t stream);
 int ggan_act_bwd(const float* gy, const float* ref, float* gx, size_t n, int act, float alpha,
                  ggan_stream_t stream);
+/* ggan_act_bwd that also emits the bias gradient of the layer as partial slabs: gx = gy * act'(ref) over [N, C, HW] and
+ * parts[s*C + c] = sum of gx over channel c of the s-th image range, s < *n_parts (<= parts_cap / C); the slabs are summed by
+ * ggan_pack_parts (stride C).  One launch for what tf.nn.bias_add's BiasAddGrad and the activation's gradient op are in the
+ * backward of Deconv2D / Conv2D + activation (tflib/ops/deconv2d.py:110-116 followed by tf.nn.relu / tanh in the scripts). */
+int ggan_act_bwd_chansum(const float* gy, const float* ref, float* gx, float* parts, int parts_cap, int* n_parts, int N, int C, int HW,
+                         int act, float alpha, ggan_stream_t stream);
 /* y = x + bias broadcast: NCHW bias[C] (HW>1) or [rows,C] (HW=1).  tf.nn.bias_add. */
 int ggan_bias_add(const float* x, const float* bias, float* y, int N, int C, int HW, ggan_stream_t stream);
 /* real_x = mul*(float(int32)/div - .5) (+ noise) (gmgan_inference_cifar10.py:342; face :242-243). */
