@@ -618,7 +618,10 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         slabs = (float*)ws;
         cap_slabs = ws ? ws_bytes / (P.slab_stride * sizeof(float)) : 0;
     }
-    int sk = P.items < 64 ? P.items : 64;
+    // (slab cap 64 keeps the consumer of the slabs cheap; with thousands of items -- the 512..1024-frame launches of the
+    //  state-space scripts, 134 MB of gy to stream -- 64 x Co/16 workgroups leave half the chip idle: 256 small slabs then)
+    const int max_sk = (P.items >= 2048 && P.slab_stride <= 8192) ? 256 : 64;
+    int sk = P.items < max_sk ? P.items : max_sk;
     if ((size_t)sk > cap_slabs) sk = (int)cap_slabs;
     if (sk < 1) sk = 1;
     P.ipw = cdiv(P.items, sk);

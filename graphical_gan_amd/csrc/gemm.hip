@@ -49,6 +49,7 @@ struct GemmParams {
     int c_split;
     unsigned a_bytes, a2_bytes, b_bytes;   // FAST path: buffer sizes of the stored operands
     int fast;
+    size_t slab_stride;    // split-K: floats between partial slabs (out_elems, + N when the column sums ride along as a tail)
 };
 
 // Load a [64 rows(r) x 16 k] tile of a matrix into LDS as T[k][r].
@@ -137,7 +138,10 @@ __device__ __forceinline__ void load_step_tile(const float* __restrict__ base, i
 // Legal when every float4 is 16-byte aligned and wholly inside or outside the matrix (launcher: FAST).
 typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
 constexpr unsigned GOOB = 0x7FFFFFF0u;
-template <bool KCONTIG>
+// VEC == false: the same unit as four dword loads, each with its own range test -- operands whose rows are not 16-byte aligned
+// (leading dimension or extent not a multiple of 4: the state-space critics' Linear on [features | latent | 10 labels], K = 4618)
+// stay on the branch-free path instead of the generic loader.
+template <bool KCONTIG, bool VEC>
 __device__ __forceinline__ void load_step_tile_fast(__amdgpu_buffer_rsrc_t rs, int ld, int R, int r0, int k0, int kend,
                                                     float4 (&reg)[2]) {
     const int tid = threadIdx.x;
@@ -153,8 +157,18 @@ __device__ __forceinline__ void load_step_tile_fast(__amdgpu_buffer_rsrc_t rs, i
             row = r0 + (tid & 15) * 4; k = k0 + u * BK + (tid >> 4);
             off = (unsigned)(k * ld + row) * 4u;
         }
-        const u32x4g t = __builtin_amdgcn_raw_buffer_load_b128(rs, (row < R && k < kend) ? off : GOOB, 0, 0);
-        reg[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+        if (VEC) {
+            const u32x4g t = __builtin_amdgcn_raw_buffer_load_b128(rs, (row < R && k < kend) ? off : GOOB, 0, 0);
+            reg[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+        } else {
+            unsigned v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = KCONTIG ? (row < R && k + j < kend) : (row + j < R && k < kend);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? off + 4u * j : GOOB, 0, 0);
+            }
+            reg[u] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
     }
 }
 
@@ -197,7 +211,7 @@ __device__ __forceinline__ void store_tile(float* T, const float4& reg) {
 // MASK: 0 none, 1 activation-derivative mask on A, 2 on B
 constexpr int TSZ = KSTEP * LDP;                           // one LDS step tile (sized for the wider row)
 
-template <bool TA, bool TB, int MASK, bool FAST>
+template <bool TA, bool TB, int MASK, int FAST>
 __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, const int by, const int split, float* As, float* Bs) {
     // LDS double-buffered so a step costs ONE barrier: the next step's global loads are issued before the MFMA block, parked in
     // registers, and committed to the other buffer after it
@@ -223,7 +237,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     const auto rsAr = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK == 1 ? P.a_ref : P.A), (short)0, (int)P.a_bytes, 0x00020000);
     const auto rsBr = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK == 2 ? P.b_ref : P.B), (short)0, (int)P.b_bytes, 0x00020000);
     auto load_step = [&](int k0, float4 (&xa)[2], float4 (&xb)[2], float4 (&xma)[2], float4 (&xmb)[2]) {
-        if constexpr (FAST) {
+        if constexpr (FAST != 0) {
+            constexpr bool V = FAST == 1;
             // (source selection by scalar selects, ONE load sequence: no branches around the loads)
             const bool second = P.A2 != nullptr && (AK ? k0 >= P.a_split : m0 >= P.a_split);
             const auto rs = second ? rsA2 : rsA;
@@ -233,10 +248,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
                 if (AK) { kk0 = second ? k0 - P.a_split : k0; kke = second ? ke - P.a_split : min(ke, P.a_split); }
                 else { R = second ? P.M - P.a_split : P.a_split; r0 = second ? m0 - P.a_split : m0; }
             }
-            load_step_tile_fast<AK>(rs, ld, R, r0, kk0, kke, xa);
-            if (MASK == 1) load_step_tile_fast<AK>(rsAr, P.lda, P.M, m0, k0, ke, xma);
-            load_step_tile_fast<BKc>(rsB, P.ldb, P.N, n0, k0, ke, xb);
-            if (MASK == 2) load_step_tile_fast<BKc>(rsBr, P.ldb, P.N, n0, k0, ke, xmb);
+            load_step_tile_fast<AK, V>(rs, ld, R, r0, kk0, kke, xa);
+            if (MASK == 1) load_step_tile_fast<AK, V>(rsAr, P.lda, P.M, m0, k0, ke, xma);
+            load_step_tile_fast<BKc, V>(rsB, P.ldb, P.N, n0, k0, ke, xb);
+            if (MASK == 2) load_step_tile_fast<BKc, V>(rsBr, P.ldb, P.N, n0, k0, ke, xmb);
             return;
         }
         if (P.A2 == nullptr) {
@@ -307,7 +322,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
         if (k0 + 2 * KSTEP < ke) store_step(0, ra[0], rb[0], rma[0], rmb[0]);
         __syncthreads();
     }
-    if (do_colsum && n0 + tid < P.N) P.colsum[n0 + tid] = csum;
+    if (do_colsum && n0 + tid < P.N) P.colsum[(P.SK > 1 ? (size_t)split * P.slab_stride : 0) + n0 + tid] = csum;   // (split-K: a partial sum in the slab's tail)
     // epilogue: global stores are issue-bound (16 dword stores per lane took longer than the k-loop of the short-K layers), so
     // the tile goes through LDS and leaves as one float4 row segment per thread and pass (4 passes)
     constexpr int LC = BN + 4;
@@ -319,7 +334,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     }
     __syncthreads();
     const bool direct = P.SK == 1;
-    float* Cp = direct ? P.C : P.C + (size_t)split * P.out_elems;
+    float* Cp = direct ? P.C : P.C + (size_t)split * P.slab_stride;
     int ldc = P.N, ncol0 = 0, nend = P.N;       // output columns [ncol0, nend) live in Cp with leading dimension ldc
     if (P.C2 != nullptr) {
         if (n0 >= P.c_split) { Cp = P.C2; ldc = P.N - P.c_split; ncol0 = P.c_split; }
@@ -350,7 +365,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     }
 }
 
-template <bool TA, bool TB, int MASK = 0, bool FAST = false>
+template <bool TA, bool TB, int MASK = 0, int FAST = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
@@ -378,9 +393,9 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
     const int bx = local % G.gx[j], by = local / G.gx[j];
     const GemmParams& P = G.p[j];
     switch (G.kind[j]) {
-        case 0: gemm_tile<true, false, 0, true>(P, bx, by, 0, As, Bs); break;
-        case 1: gemm_tile<false, true, 0, true>(P, bx, by, 0, As, Bs); break;
-        default: gemm_tile<false, false, 0, true>(P, bx, by, 0, As, Bs); break;
+        case 0: gemm_tile<true, false, 0, 1>(P, bx, by, 0, As, Bs); break;
+        case 1: gemm_tile<false, true, 0, 1>(P, bx, by, 0, As, Bs); break;
+        default: gemm_tile<false, false, 0, 1>(P, bx, by, 0, As, Bs); break;
     }
 }
 
@@ -508,7 +523,7 @@ static int gemm_plan(GemmPlan& G, int mode, int ta, int tb, int M, int N, int K,
     const int gx = cdiv(N, BN), gy = cdiv(M, BM);
     G.gx = gx; G.gy = gy;
     int sk = 1;
-    if (mode == 0 && !colsum && ws && !C2) {       // (a fused column sum needs the whole K range in one workgroup; so does a split output)
+    if (mode == 0 && ws && !C2) {       // (a split output needs the whole K range in one workgroup; column sums ride along as slab tails)
         const char* e = getenv("GGAN_GEMM_SK");
         if (e) sk = atoi(e);
         else {
@@ -527,17 +542,25 @@ static int gemm_plan(GemmPlan& G, int mode, int ta, int tb, int M, int N, int K,
             if (K <= 128 && base >= 32) sk = 1;
         }
         if (sk < 1) sk = 1;
-        while (sk > 1 && (size_t)sk * P.out_elems * sizeof(float) > ws_bytes) sk /= 2;
+        // with column sums the unsplit product is one launch and the split one two: split only where the serial chain is long
+        // and the grid small (the weight gradients of the 1024-row critics: 8..24 workgroups walking 32 steps, 40 us)
+        if (colsum && !(gx * gy < 64 && K >= 512)) sk = 1;
+        while (sk > 1 && (size_t)sk * (P.out_elems + (colsum ? N : 0)) * sizeof(float) > ws_bytes) sk /= 2;
     }
     P.kps = cdiv(cdiv(K, sk), BK) * BK;
     P.SK = cdiv(K, P.kps);
-    if (P.SK > 1) P.C = (float*)ws;
+    P.slab_stride = P.out_elems + ((colsum && P.SK > 1) ? (size_t)N : 0);
+    if (P.SK > 1) {
+        P.C = (float*)ws;
+        if (colsum) P.colsum = (float*)ws + P.out_elems;      // slab s: [out_elems product | N column sums]
+    }
     // branch-free buffer-load path: every operand float4 aligned and wholly in or out of range, byte offsets within 31 bits
     const size_t szA = (size_t)(A2 ? (ta ? (size_t)K * a_split : (size_t)M * a_split) : (size_t)M * K) * 4;
     const size_t szA2 = A2 ? (size_t)(ta ? (size_t)K * (M - a_split) : (size_t)M * (K - a_split)) * 4 : 0;
     const size_t szB = (size_t)N * K * 4;
     const bool dims4 = (K % 4 == 0) && (P.kps % 4 == 0) && (ta ? (M % 4 == 0 && (!A2 || a_split % 4 == 0)) : true) && (tb ? true : N % 4 == 0);
-    P.fast = P.vecA && P.vecB && dims4 && szA < 0x7FFFFFF0ull && szA2 < 0x7FFFFFF0ull && szB < 0x7FFFFFF0ull && !getenv("GGAN_GEMM_GENERIC");
+    const bool small = szA < 0x7FFFFFF0ull && szA2 < 0x7FFFFFF0ull && szB < 0x7FFFFFF0ull && !getenv("GGAN_GEMM_GENERIC");
+    P.fast = !small ? 0 : ((P.vecA && P.vecB && dims4) ? 1 : 2);        // 1: 16-byte loads, 2: dword loads (any alignment / extent)
     P.a_bytes = (unsigned)szA; P.a2_bytes = (unsigned)szA2; P.b_bytes = (unsigned)szB;
     return 0;
 }
@@ -549,8 +572,9 @@ static int gemm_launch_planned(const GemmPlan& G, int ta, int tb, hipStream_t s)
     const dim3 grid(G.gx, G.gy, P.SK), block(256);
 #define GGAN_GEMM_CASE(TA_, TB_, MK_, NAME_)                                                                                      \
     do {                                                                                                                           \
-        if (P.fast) { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, true>), grid, block, 0, s, P); }                      \
-        else { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, false>), grid, block, 0, s, P); }                            \
+        if (P.fast == 1) { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 1>), grid, block, 0, s, P); }                    \
+        else if (P.fast == 2) { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 2>), grid, block, 0, s, P); }               \
+        else { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 0>), grid, block, 0, s, P); }                                \
     } while (0)
     if (P.a_ref || P.b_ref) {
         if (P.a_ref && !P.b_ref && !ta && tb) GGAN_GEMM_CASE(false, true, 1, "gemm_kernel<false, true, 1>");
@@ -579,7 +603,9 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     if (rc) return rc;
     rc = gemm_launch_planned(G, ta, tb, s);
     if (rc) return rc;
-    if (G.P.SK > 1) return launch_splitk_reduce((const float*)G.ws, G.P.SK, G.P.out_elems, C, bias, N, 1, act, alpha, s);
+    if (G.P.SK > 1)
+        return launch_splitk_reduce((const float*)G.ws, G.P.SK, G.P.out_elems, C, bias, N, 1, act, alpha, s, G.P.slab_stride, colsum,
+                                    colsum ? (size_t)N : 0);
     return 0;
 }
 
@@ -602,7 +628,7 @@ int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const fl
     if (rc) return rc;
     const float* part = G.P.SK > 1 ? (const float*)G.ws : h;          // (SK == 1: the product already sits in h; summed "slab" of one)
     GGAN_LAUNCH("head_out_fwd_k", 2.0 * M * H, 4.0 * M * H * (G.P.SK + 1), head_out_fwd_k, dim3(cdiv(M, 2)), dim3(256), 0, s, part,
-                G.P.SK, G.P.out_elems, b, w_out, b_out, alpha, h, logits, M, H);
+                G.P.SK, G.P.slab_stride, b, w_out, b_out, alpha, h, logits, M, H);
     return 0;
 }
 
@@ -637,7 +663,7 @@ int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const flo
         if (rc) return rc;
         na = 1;
     }
-    if (nw && na && Gw.P.fast && Ga.P.fast && !getenv("GGAN_NO_GEMM_GROUP")) {
+    if (nw && na && Gw.P.fast == 1 && Ga.P.fast == 1 && !getenv("GGAN_NO_GEMM_GROUP")) {
         GemmGroup GG;
         memset(&GG, 0, sizeof(GG));
         // (the data-gradient product first: its workgroups walk K = H in 16 serial steps, the weight-gradient's only M / 32 --
