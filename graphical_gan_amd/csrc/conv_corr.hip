@@ -66,13 +66,22 @@ struct CorrParams {
     CorrClass cls[4];
 };
 
+#ifndef GGAN_ABL
+#define GGAN_ABL 0
+#endif
 // One chunk's MFMAs for one class.  hipcc emits "ds_read; s_waitcnt lgkmcnt(0); v_mfma; v_mfma" for the straightforward loop
 // (operands fetched right before use into the same four registers), which leaves the matrix pipe idle for one LDS latency
 // per MFMA pair (measured: 5300 cycles per chunk where the MFMAs need 3200).  Here the operands of MFMA pair s+2,s+3 are
 // read BEFORE MFMA pair s,s+1 is issued, and sched_group_barrier pins that interleave (<= 4 LDS reads in flight).
-template <int TH, int TW, int DI, int PW, int CK, int RS>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// `hook(step)` runs after MFMA pair number `step` of the chunk (STEP0 = pairs of the classes before this one): the staging
+// instructions of the next chunk are dealt out between the pairs, one or two per pair.  Eight waves issuing their whole share
+// of a chunk at once back up the CU's vector-memory path, and every wave then sits in the issue queue instead of multiplying
+// (measured on the 64->128 data gradient: 5640 cycles per chunk with the burst, 4750 with the filter slice dealt out).
+template <int TH, int TW, int DI, int PW, int CK, int RS, int STEP0 = 0, class Hook = NoHook>
 __device__ __forceinline__ void mma_taps(const float* __restrict__ xs, const float* __restrict__ ws, int xfrag, int wfrag,
-                                         int CS, int SCp, f32x16& acc) {
+                                         int CS, int SCp, f32x16& acc, Hook&& hook = Hook()) {
     constexpr int NS = TH * TW * PW;
     float a[NS], b[NS];
     auto load = [&](int s) {
@@ -89,8 +98,64 @@ __device__ __forceinline__ void mma_taps(const float* __restrict__ xs, const flo
         if (s + 3 < NS) load(s + 3);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
         if (s + 1 < NS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], b[s + 1], acc, 0, 0, 0);
+        hook(STEP0 + s / 2);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS reads of the NEXT pair first
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // then this pair's two MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);   // then the staging instructions dealt to this pair
+    }
+}
+
+// Same product out of the DMA-staged filter image of the data-gradient kinds (corr_body, WD): per tap and block of 16 output
+// channels the image holds [k quad][channel][4 k] floats exactly as an LDS-DMA wave-instruction of 16-byte lanes lays them down
+// (258-float block stride: the two channel blocks a wave reads sit 2 banks apart, so the 4-float channel pitch is conflict free).
+// PW == 1: one float per MFMA (k = 2*ks + half).  PW == 2: a lane's two k of a tap are adjacent -> one 8-byte read feeds both
+// MFMAs (k = 4*ks + 2*half + p; the slab rows are addressed to match).
+template <int TH, int TW, int DI, int PW, int TS, int STEP0, class Hook>
+__device__ __forceinline__ void mma_taps_wd(const float* __restrict__ xs, const float* __restrict__ ws, int xfrag, int wfrag,
+                                            int CS, int SCp, f32x16& acc, Hook&& hook) {
+    constexpr int NT = TH * TW;
+    if constexpr (PW == 1) {
+        float a[NT], b[NT];
+        auto load = [&](int s) {
+            const int i = s / TW, j = s - i * TW;
+            if (GGAN_ABL & 4) { a[s] = __int_as_float(wfrag + s); b[s] = __int_as_float(xfrag + s); return; }
+            a[s] = ws[s * TS + wfrag];
+            b[s] = xs[xfrag + DI * (i * SCp + j)];
+        };
+        load(0);
+        if (NT > 1) load(1);
+#pragma unroll
+        for (int s = 0; s < NT; s += 2) {
+            if (s + 2 < NT) load(s + 2);
+            if (s + 3 < NT) load(s + 3);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+            if (s + 1 < NT) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], b[s + 1], acc, 0, 0, 0);
+            hook(STEP0 + s / 2);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+        }
+    } else {
+        static_assert(PW == 2, "one 8-byte filter read per tap");
+        float2 a[NT];
+        float b0[NT], b1[NT];
+        auto load = [&](int t) {
+            const int i = t / TW, j = t - i * TW;
+            a[t] = *reinterpret_cast<const float2*>(ws + t * TS + wfrag);
+            b0[t] = xs[xfrag + DI * (i * SCp + j)];
+            b1[t] = xs[CS + xfrag + DI * (i * SCp + j)];
+        };
+        load(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) load(t + 1);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b0[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b1[t], acc, 0, 0, 0);
+            hook(STEP0 + t);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+        }
     }
 }
 
@@ -126,6 +191,10 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     constexpr int NTT = NT0 + NT1 + NT2 + NT3;
     constexpr int WUNITS = NTT * CK * (TNW / 4);
     constexpr int NTHR = 64 * WM * WN * KS;
+    // WD: the data-gradient kinds with 16-channel chunks stage the filter slice by LDS-DMA (see mma_taps_wd); P.dma selects it
+    constexpr bool WD = KIND != 0 && CK == 16 && (PW == 1 || PW == 2);
+    constexpr int NCB = TNW / 16, WBLK = 258, NBLK = NTT * NCB, NWAVE = NTHR / 64;
+    constexpr int WQ = (NBLK + NWAVE - 1) / NWAVE;
     constexpr int WE = (WUNITS + NTHR - 1) / NTHR;
     constexpr int XE = (KIND == 0 ? XE_MAX : XE_MAX / 2) * 256 / NTHR;   // per-thread slab elements (4096 / 2048 budget)
     static_assert(NTHR == 256 || NTHR == 512, "4 or 8 waves per workgroup");
@@ -186,6 +255,19 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         }
         xvo[j] = off;
     }
+    // (filter base of each class of the list, fetched with STATIC kernel-argument offsets: indexing P.cls by a run-time class
+    //  number turns into one dependent scalar / vector load + wait per use -- measured 6.5 k cycles of prologue)
+    int cls_wb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cls_wb[c] = P.cls[CL::cls(c)].wbase;
+    auto wbase_of = [&](int ci_) {
+        int v = cls_wb[0];
+        if (NC > 1 && ci_ == 1) v = cls_wb[1];
+        if (NC > 2 && ci_ == 2) v = cls_wb[2];
+        if (NC > 3 && ci_ == 3) v = cls_wb[3];
+        return v;
+    };
+    auto tw_of = [](int ci_) { return ci_ == 0 ? CL::tw(0) : ci_ == 1 ? CL::tw(1) : ci_ == 2 ? CL::tw(2) : CL::tw(3); };
     unsigned wvo[WE];
     // unit -> (tap group, first reduction channel, output channel) and its LDS float index
     //   !WK: unit = (tap, ck, cn4): 4 consecutive cn in memory => every wave-load is a run of whole 128-B filter rows
@@ -194,6 +276,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     auto w_ck = [](int u) { return WK ? (u % (CK / 4)) * 4 : (u / (TNW / 4)) % CK; };
     auto w_cn = [](int u) { return WK ? (u / (CK / 4)) % TNW : (u % (TNW / 4)) * 4; };
     auto w_lds = [&](int u) { return (w_tap(u) * CK + w_ck(u)) * RS + w_cn(u); };
+    if (!(WD && P.dma)) {
 #pragma unroll
     for (int q = 0; q < WE; ++q) {
         const int u = tid + q * NTHR;
@@ -206,13 +289,13 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
             if (NC > 1 && tap >= NT0) { tap -= NT0; ci_ = 1; }
             if (NC > 2 && ci_ == 1 && tap >= NT1) { tap -= NT1; ci_ = 2; }
             if (NC > 3 && ci_ == 2 && tap >= NT2) { tap -= NT2; ci_ = 3; }
-            const int tw = CL::tw(ci_);
-            const int i = tap / tw, j = tap - i * tw;
-            const int wb = P.cls[CL::cls(ci_)].wbase;
+            const int i = tw_of(ci_) == 3 ? tap / 3 : (tw_of(ci_) == 2 ? tap / 2 : tap / 5), j = tap - i * tw_of(ci_);
+            const int wb = wbase_of(ci_);
             if (cn0 + cn < P.CNtot)
                 off = (unsigned)(wb + i * P.w_si + j * P.w_sj + ckl * P.w_sk + (cn0 + cn) * P.w_sn) * 4u;
         }
         wvo[q] = off;
+    }
     }
 
     // ---- per-lane MFMA fragment bases ----------------------------------------------------------------------
@@ -224,7 +307,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         const int ur = fdiv(rem, P.d_TC);
         const int vc = rem - ur * P.TC;
         const bool in_tile = img < P.TI && (n0 + img) < P.N;
-        const int kbase = (ks * PW * 2 + half) * P.CS;
+        const int kbase = (WD && PW == 2 && P.dma) ? (ks * 4 + 2 * half) * P.CS : (ks * PW * 2 + half) * P.CS;
         const int b = in_tile ? img * (P.SR * P.SCp) + SU * ur * P.SCp + SU * vc : 0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -233,6 +316,9 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         }
     }
     const int wfrag = (ks * PW * 2 + half) * RS + wn * 32 + l31;
+    // (WD image: block of 16 channels, k quad, channel, element)
+    const int wfrag_wd = (wn * 2 + (l31 >> 4)) * WBLK + ((PW == 2 ? ks : (ks >> 1)) * 16 + (l31 & 15)) * 4 +
+                         (PW == 2 ? 2 * half : (ks & 1) * 2 + half);
 
     f32x16 acc[NC];
 #pragma unroll
@@ -245,7 +331,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     for (int j = 0; j < XE; ++j) xref[j] = 0x3f800000u;      // 1.0f: "positive" reference = identity mask when unmasked
     u32x4 wreg[WE];
 
-    auto prefetch = [&](int ck0) {
+    auto prefetch = [&](int ck0, bool with_w = true) {
         const int soff_x = ck0 * HWin * 4;
         const int soff_w = ck0 * P.w_sk * 4;
         if (!(P.dbg & 512)) {
@@ -256,7 +342,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 #pragma unroll
             for (int j = 0; j < XE; ++j) xref[j] = __builtin_amdgcn_raw_buffer_load_b32(rref, xvo[j], soff_x, 0);
         }
-        if (!(P.dbg & 256)) {
+        if (with_w && !(P.dbg & 256)) {
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
             const unsigned vo = (ck0 + w_ck(tid + q * NTHR) < ck_end) ? wvo[q] : OOB;     // reduction-channel tail -> zero filter rows
@@ -265,7 +351,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         }
     };
 
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, bool with_w = true) {
         float* xsb = smem + buf * STAGE;
         float* wsb = xsb + XS_SZ;
         // straight-line: elements beyond the tile (their loads returned 0) land in a trash slot instead of being predicated
@@ -276,6 +362,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
             if (CAN_MASK) v = __uint_as_float(xref[j]) > 0.f ? v : v * mslope;
             xsb[min(e, xe_cnt)] = v;
         }
+        if (with_w)
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
             const int u = tid + q * NTHR;
@@ -315,6 +402,56 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         }
     };
 
+    // WD: this wave's filter blocks (tap, 16 output channels) of a chunk -- lane = (k quad, channel) reads 16 bytes = 4 consecutive
+    // reduction channels of its output channel; the block part of the address is wave-uniform (SGPR offset)
+    const bool wdma = WD && P.dma != 0;
+    int wso[WQ];
+    unsigned wd_lane = 0;
+    int wd_cnlim = 0;
+    if (WD) {
+        wd_lane = (unsigned)((lane >> 4) * 4 * P.w_sk + (cn0 + (lane & 15)) * P.w_sn) * 4u;
+        wd_cnlim = P.CNtot - cn0 - (lane & 15);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int b = wave_u + q * NWAVE;
+            int tap = b / NCB, ci_ = 0;
+            const int cnb = b - tap * NCB;
+            if (NC > 1 && tap >= NT0) { tap -= NT0; ci_ = 1; }
+            if (NC > 2 && ci_ == 1 && tap >= NT1) { tap -= NT1; ci_ = 2; }
+            if (NC > 3 && ci_ == 2 && tap >= NT2) { tap -= NT2; ci_ = 3; }
+            const int i = tw_of(ci_) == 3 ? tap / 3 : (tw_of(ci_) == 2 ? tap / 2 : tap / 5), j = tap - i * tw_of(ci_);
+            const int wb = wbase_of(ci_);
+            wso[q] = __builtin_amdgcn_readfirstlane(b < NBLK ? (wb + i * P.w_si + j * P.w_sj + cnb * 16 * P.w_sn) * 4 : -1);
+        }
+    }
+    auto stage_w1 = [&](int q, int ck0, int buf) {                 // one wave-instruction of the filter slice
+        float* wsb = smem + buf * STAGE + XS_SZ;
+        const bool k_ok = ck0 + (lane >> 4) * 4 < ck_end;            // reduction-channel tail -> zero filter rows
+        const int b = wave_u + q * NWAVE;
+        const unsigned vo = (k_ok && (b % NCB) * 16 < wd_cnlim) ? wd_lane : OOB;
+        const int so = wso[q] + ck0 * P.w_sk * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wsb + b * WBLK), 16, vo, so, 0, 0);
+    };
+    auto stage_w = [&](int ck0, int buf) {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            if (wso[q] >= 0) stage_w1(q, ck0, buf);
+    };
+
+    auto dma_x1 = [&](int j, int ck0, int buf) {                   // forward kinds: one wave-instruction of the slab
+        float* xsb = smem + buf * STAGE;
+        const int e0 = wave_u * 64 + j * NTHR;
+        if (e0 < xe_cnt)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(xsb + e0), 4, xvo[j], ck0 * HWin * 4, 0, 0);
+    };
+    auto dma_w1 = [&](int q, int ck0, int buf) {                   // ... of the filter slice
+        float* wsb = smem + buf * STAGE + XS_SZ;
+        const int u0 = wave_u * 64 + q * NTHR;
+        const unsigned vo = (ck0 + w_ck(tid + q * NTHR) < ck_end) ? wvo[q] : OOB;
+        if (u0 < WUNITS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wsb + 4 * u0), 16, vo, ck0 * P.w_sk * 4, 0, 0);
+    };
+
     // ---- main loop over reduction-channel chunks: chunk c is multiplied out of buffer c&1 while chunk c+1 is committed
     //      to the other buffer and chunk c+2's global loads are in flight; ONE barrier per chunk ---------------------
     stamp(1);
@@ -327,12 +464,77 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         stamp(3);
+        constexpr int NSTEP = (NT0 * PW + 1) / 2, NITEM = XE + WE;
+        constexpr int IPS = (NITEM + NSTEP - 3) / (NSTEP - 2);      // items per MFMA pair: all issued two pairs before the chunk ends
         for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
-            if (ck0 + CK < ck_end) stage_dma(ck0 + CK, buf ^ 1);
+            const int ckn = ck0 + CK;
+            const bool more = ckn < ck_end;
+            auto hook = [&](int g) {
+#pragma unroll
+                for (int it = g * IPS; it < (g + 1) * IPS; ++it) {
+                    if (more && it < XE) dma_x1(it, ckn, buf ^ 1);
+                    if (more && it >= XE && it < NITEM) dma_w1(it - XE, ckn, buf ^ 1);
+                }
+            };
             const float* xs = smem + buf * STAGE;
             const float* ws = xs + XS_SZ;
-            mma_taps<CL::th(0), CL::tw(0), DI, PW, CK, RS>(xs, ws, xfrag[0], wfrag, P.CS, P.SCp, acc[0]);
+            mma_taps<CL::th(0), CL::tw(0), DI, PW, CK, RS, 0>(xs, ws, xfrag[0], wfrag, P.CS, P.SCp, acc[0], hook);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (it_ < 8) stamp(4 + it_);
+            ++it_;
+        }
+    } else if (wdma) {
+        // the slab still goes through registers (it may carry the fused activation mask); the filter slice of chunk c+1 is in flight
+        // into the other buffer while chunk c is multiplied, retired by the wait + barrier at the end of the chunk
+        constexpr int TS = NCB * WBLK;
+        constexpr int WD_STEPS = (NT0 * (PW == 2 ? 2 : 1) + 1) / 2 + (NT1 * (PW == 2 ? 2 : 1) + 1) / 2 +
+                                 (NT2 * (PW == 2 ? 2 : 1) + 1) / 2 + (NT3 * (PW == 2 ? 2 : 1) + 1) / 2;
+        // (a filter block is 1 KB: eight waves x one block per MFMA pair is what the CU's 64 B/clk vector-memory path moves in the
+        //  128 cycles of a pair -- more per pair and the waves queue up at the issue port again)
+        constexpr int WD_DPS = (WQ + WD_STEPS - 2) / (WD_STEPS - 1);                      // filter blocks per pair
+        constexpr int WD_S0 = (WQ + WD_DPS - 1) / WD_DPS < WD_STEPS - 1 ? (WQ + WD_DPS - 1) / WD_DPS : WD_STEPS - 1;   // first slab pair
+        constexpr int WD_SPS = (XE + WD_STEPS - WD_S0 - 1) / (WD_STEPS - WD_S0);          // slab loads per pair
+        prefetch(ck_begin, false);
+        stage_w(ck_begin, 0);
+        commit(0, false);
+        if (ck_begin + CK < ck_end) prefetch(ck_begin + CK, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp(3);
+        for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf ^= 1) {
+            const int ckn = ck0 + CK;       // (beyond the last chunk every lane is out of range: zero rows into the idle buffer)
+            commit(buf ^ 1, false);
+            const float* xs = smem + buf * STAGE;
+            const float* ws = xs + XS_SZ;
+            // dealt out between the MFMA pairs: first the filter blocks of chunk c+1 (deadline: the end of this chunk), then the slab
+            // loads of chunk c+2 (beyond the last chunk every lane is out of range and nothing is fetched).  Vector-memory loads
+            // retire in issue order, so the wait at the end of the chunk leaves the slab loads in flight across the barrier.
+            const int ck2 = ck0 + 2 * CK;
+            const bool more2 = ck2 < ck_end;
+            auto hook = [&](int g) {
+#pragma unroll
+                for (int q = g * WD_DPS; q < (g + 1) * WD_DPS; ++q)
+                    if (q < WQ && (q < WQ - 1 || wso[WQ - 1] >= 0)) stage_w1(q, ckn, buf ^ 1);
+#pragma unroll
+                for (int j = (g - WD_S0) * WD_SPS; j < (g - WD_S0 + 1) * WD_SPS; ++j)
+                    if (j >= 0 && j < XE) {
+                        xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
+                        if (masked) xref[j] = __builtin_amdgcn_raw_buffer_load_b32(rref, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
+                    }
+            };
+            if constexpr (WD) {
+                constexpr int S1 = (CL::th(0) * CL::tw(0) * (PW == 2 ? 2 : 1) + 1) / 2;
+                constexpr int S2 = NC > 1 ? (CL::th(1) * CL::tw(1) * (PW == 2 ? 2 : 1) + 1) / 2 : 0;
+                constexpr int S3 = NC > 2 ? (CL::th(2) * CL::tw(2) * (PW == 2 ? 2 : 1) + 1) / 2 : 0;
+                mma_taps_wd<CL::th(0), CL::tw(0), DI, PW, TS, 0>(xs, ws, xfrag[0], wfrag_wd, P.CS, P.SCp, acc[0], hook);
+                if constexpr (NC > 1) mma_taps_wd<CL::th(1), CL::tw(1), DI, PW, TS, S1>(xs, ws + NT0 * TS, xfrag[1], wfrag_wd, P.CS, P.SCp, acc[1], hook);
+                if constexpr (NC > 2) mma_taps_wd<CL::th(2), CL::tw(2), DI, PW, TS, S1 + S2>(xs, ws + (NT0 + NT1) * TS, xfrag[2], wfrag_wd, P.CS, P.SCp, acc[2], hook);
+                if constexpr (NC > 3) mma_taps_wd<CL::th(3), CL::tw(3), DI, PW, TS, S1 + S2 + S3>(xs, ws + (NT0 + NT1 + NT2) * TS, xfrag[3], wfrag_wd, P.CS, P.SCp, acc[3], hook);
+            }
+            static_assert(2 * XE < 64, "vmcnt field");
+            if (masked) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XE) : "memory");
             __syncthreads();
             if (it_ < 8) stamp(4 + it_);
             ++it_;
@@ -682,7 +884,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const int RS = TNW + (MODE != 0 ? 2 : 0);     // filter row stride in LDS (corr_body: padded for the k-contiguous staging)
     size_t stage = MODE == 0 ? 2 * ((size_t)((CK * P.CS + 64) & ~63) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3))
                              : 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
-    P.dma = MODE == 0 && env_int("GGAN_CORR_DMA", 1) && (P.dbg & 3) == 0;
+    P.dma = (MODE == 0 ? env_int("GGAN_CORR_DMA", 1) : (CK == 16 && env_int("GGAN_DGRAD_DMA", 1))) && (P.dbg & 3) == 0;
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
