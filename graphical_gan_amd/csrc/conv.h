@@ -59,4 +59,24 @@ inline FastDiv make_fastdiv(uint32_t d) {
 }
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.d <= 1 ? n : __umulhi(n, f.mul); }
 
+// Division of SMALL numerators (n <= nmax, a few thousand: element / pixel indices inside one tile) by a run-time divisor as one
+// full-rate 24-bit multiply and a shift: v_mul_hi_u32 is a quarter-rate instruction (16 cycles per wave), and the per-thread
+// staging descriptors of the conv kernels are a few hundred such instructions executed once per launch.
+struct FastDiv24 {
+    uint32_t mul, shift;
+};
+inline bool make_fastdiv24(uint32_t d, uint32_t nmax, FastDiv24* out) {
+    if (d <= 1) { out->mul = 1; out->shift = 0; return true; }
+    for (int s = 31; s >= 1; --s) {
+        const uint64_t m = ((1ull << s) + d - 1) / d;
+        if (m >= (1ull << 24) || m * nmax >= (1ull << 32)) continue;
+        const uint64_t err = m * d - (1ull << s);               // q(n) = floor(n/d) for every n with n * err < 2^s
+        if ((uint64_t)nmax * err >= (1ull << s)) return false;
+        out->mul = (uint32_t)m; out->shift = (uint32_t)s;
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ uint32_t fdiv24(uint32_t n, FastDiv24 f) { return __umul24(n, f.mul) >> f.shift; }
+
 }  // namespace ggan

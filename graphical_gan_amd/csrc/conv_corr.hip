@@ -50,7 +50,7 @@ struct CorrParams {
     int TR, TC, TI;
     int SR, SCp, CS;
     int row0, col0;
-    FastDiv d_CS, d_SRSC, d_SCp, d_TRTC, d_TC;
+    FastDiv24 d_CS, d_SRSC, d_SCp, d_TRTC, d_TC;   // numerators <= XE_MAX * 256
     int img_groups, tiles_r, tiles_c;
     int cps, SK;
     int act;
@@ -235,37 +235,48 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     const float mslope = P.in_act == GGAN_ACT_LRELU ? P.in_alpha : 0.f;   // lrelu / relu only (launcher checks)
     const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(masked ? P.in_ref : P.in), (short)0, (int)P.in_bytes, 0x00020000);
 
+    const bool dma = KIND == 0 && P.dma != 0;        // forward kinds: slab and filter slice by LDS-DMA
+    const bool wdma = WD && P.dma != 0;             // data-gradient kinds: filter slice by LDS-DMA, slab through registers
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned xreg[XE], xref[XE];
+#pragma unroll
+    for (int j = 0; j < XE; ++j) xref[j] = 0x3f800000u;      // 1.0f: "positive" reference = identity mask when unmasked
+
     // ---- per-thread staging descriptors (fixed across chunks) ---------------------------------------------
+    // (the forward DMA path issues the first chunk's loads as soon as each descriptor exists: part of their latency runs under
+    //  the rest of the descriptor arithmetic; measured neutral-to-worse for the data-gradient kinds, which keep them together)
     unsigned xvo[XE];
-    const int xe_cnt = CK * P.CS;
+    const int xe_cnt = CK * P.CS, srsc = P.SR * P.SCp;
 #pragma unroll
     for (int j = 0; j < XE; ++j) {
         const int e = tid + j * NTHR;
         unsigned off = OOB;
         if (e < xe_cnt) {
-            const int ckl = fdiv(e, P.d_CS);
-            const int r1 = e - ckl * P.CS;
-            const int img = fdiv(r1, P.d_SRSC);
-            const int r2 = r1 - img * (P.SR * P.SCp);
-            const int r = fdiv(r2, P.d_SCp);
-            const int cc = r2 - r * P.SCp;
+            // (every factor below is < 2^24 and every product < 2^32: full-rate 24-bit multiplies)
+            const int ckl = fdiv24(e, P.d_CS);
+            const int r1 = e - __umul24(ckl, P.CS);
+            const int img = fdiv24(r1, P.d_SRSC);
+            const int r2 = r1 - __umul24(img, srsc);
+            const int r = fdiv24(r2, P.d_SCp);
+            const int cc = r2 - __umul24(r, P.SCp);
             const int ih = in_row0 + r, iw = in_col0 + cc, n = n0 + img;
             if (n < P.N && ih >= 0 && ih < P.Hin && iw >= 0 && iw < P.Win)
-                off = (unsigned)(((n * P.CKtot + ckl) * P.Hin + ih) * P.Win + iw) * 4u;
+                off = (__umul24(__umul24(__umul24(n, P.CKtot) + ckl, P.Hin) + ih, P.Win) + iw) * 4u;
         }
         xvo[j] = off;
+        if (dma) {
+            const int e0 = wave_u * 64 + j * NTHR;
+            if (e0 < xe_cnt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + e0), 4, off, ck_begin * HWin * 4, 0, 0);
+        }
     }
+    stamp(2);
     // (filter base of each class of the list, fetched with STATIC kernel-argument offsets: indexing P.cls by a run-time class
     //  number turns into one dependent scalar / vector load + wait per use -- measured 6.5 k cycles of prologue)
-    int cls_wb[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) cls_wb[c] = P.cls[CL::cls(c)].wbase;
-    auto wbase_of = [&](int ci_) {
-        int v = cls_wb[0];
-        if (NC > 1 && ci_ == 1) v = cls_wb[1];
-        if (NC > 2 && ci_ == 2) v = cls_wb[2];
-        if (NC > 3 && ci_ == 3) v = cls_wb[3];
-        return v;
+    const int cls_wb0 = P.cls[CL::cls(0)].wbase, cls_wb1 = P.cls[CL::cls(NC > 1 ? 1 : 0)].wbase;
+    const int cls_wb2 = P.cls[CL::cls(NC > 2 ? 2 : 0)].wbase, cls_wb3 = P.cls[CL::cls(NC > 3 ? 3 : 0)].wbase;
+    auto wbase_of = [&](int ci_) {      // (separate scalars, not an array: a run-time index would send it to scratch memory)
+        return ci_ == 0 ? cls_wb0 : ci_ == 1 ? cls_wb1 : ci_ == 2 ? cls_wb2 : cls_wb3;
     };
     auto tw_of = [](int ci_) { return ci_ == 0 ? CL::tw(0) : ci_ == 1 ? CL::tw(1) : ci_ == 2 ? CL::tw(2) : CL::tw(3); };
     unsigned wvo[WE];
@@ -295,16 +306,23 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
                 off = (unsigned)(wb + i * P.w_si + j * P.w_sj + ckl * P.w_sk + (cn0 + cn) * P.w_sn) * 4u;
         }
         wvo[q] = off;
+        if (dma) {
+            const int u0 = wave_u * 64 + q * NTHR;
+            const unsigned vo = (ck_begin + w_ck(u) < ck_end) ? off : OOB;
+            if (u0 < WUNITS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + XS_SZ + 4 * u0), 16, vo, ck_begin * P.w_sk * 4, 0, 0);
+        }
     }
     }
 
+    stamp(15);
     // ---- per-lane MFMA fragment bases ----------------------------------------------------------------------
     int xfrag[NC];
     {
         const int p = wm * 32 + l31;
-        const int img = fdiv(p, P.d_TRTC);
+        const int img = fdiv24(p, P.d_TRTC);
         const int rem = p - img * (P.TR * P.TC);
-        const int ur = fdiv(rem, P.d_TC);
+        const int ur = fdiv24(rem, P.d_TC);
         const int vc = rem - ur * P.TC;
         const bool in_tile = img < P.TI && (n0 + img) < P.N;
         const int kbase = (WD && PW == 2 && P.dma) ? (ks * 4 + 2 * half) * P.CS : (ks * PW * 2 + half) * P.CS;
@@ -326,9 +344,6 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-    unsigned xreg[XE], xref[XE];
-#pragma unroll
-    for (int j = 0; j < XE; ++j) xref[j] = 0x3f800000u;      // 1.0f: "positive" reference = identity mask when unmasked
     u32x4 wreg[WE];
 
     auto prefetch = [&](int ck0, bool with_w = true) {
@@ -380,31 +395,9 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     // wave-instruction writes LDS[M0 base + l * size], which is exactly how the slab (element e = tid + j*NTHR) and the filter slice
     // (float4 unit u = tid + q*NTHR, LDS float index 4u) are laid out; halo / tail lanes carry the out-of-bounds offset and write
     // zeros.  No staging registers, no ds_write traffic competing with the fragment reads of the MFMA loop.
-    const bool dma = KIND == 0 && P.dma != 0;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto stage_dma = [&](int ck0, int buf) {
-        float* xsb = smem + buf * STAGE;
-        float* wsb = xsb + XS_SZ;
-        const int soff_x = ck0 * HWin * 4;
-        const int soff_w = ck0 * P.w_sk * 4;
-#pragma unroll
-        for (int j = 0; j < XE; ++j) {
-            const int e0 = wave_u * 64 + j * NTHR;           // first slab element of this wave-instruction
-            if (e0 < xe_cnt)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(xsb + e0), 4, xvo[j], soff_x, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < WE; ++q) {
-            const int u0 = wave_u * 64 + q * NTHR;
-            const unsigned vo = (ck0 + w_ck(tid + q * NTHR) < ck_end) ? wvo[q] : OOB;
-            if (u0 < WUNITS)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wsb + 4 * u0), 16, vo, soff_w, 0, 0);
-        }
-    };
 
     // WD: this wave's filter blocks (tap, 16 output channels) of a chunk -- lane = (k quad, channel) reads 16 bytes = 4 consecutive
     // reduction channels of its output channel; the block part of the address is wave-uniform (SGPR offset)
-    const bool wdma = WD && P.dma != 0;
     int wso[WQ];
     unsigned wd_lane = 0;
     int wd_cnlim = 0;
@@ -460,8 +453,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     if (dma) {
         // chunk c+1 is in flight into the other buffer while chunk c is multiplied: the wait + barrier at the end of the chunk
         // retires it for every wave (RAW), and every wave's fragment reads of that buffer were retired one barrier earlier (WAR)
-        stage_dma(ck_begin, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (chunk 0 was issued with the descriptors)
         __syncthreads();
         stamp(3);
         constexpr int NSTEP = (NT0 * PW + 1) / 2, NITEM = XE + WE;
@@ -631,9 +623,9 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         const CorrClass& B = P.cls[CL::cls(cb)];
         // first pixel of the quad
         const int p = 4 * p4;
-        const int img = fdiv(p, P.d_TRTC);
+        const int img = fdiv24(p, P.d_TRTC);
         const int rem = p - img * (P.TR * P.TC);
-        const int ur = fdiv(rem, P.d_TC);
+        const int ur = fdiv24(rem, P.d_TC);
         const int vc = rem - ur * P.TC;
         const bool img_ok = img < P.TI && (n0 + img) < P.N;
         const size_t cbase = ((size_t)(n0 + img) * P.CNtot + cn) * chw;
@@ -663,9 +655,9 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int pj = p + j;
-                const int im = fdiv(pj, P.d_TRTC);
+                const int im = fdiv24(pj, P.d_TRTC);
                 const int rm = pj - im * (P.TR * P.TC);
-                const int urj = fdiv(rm, P.d_TC);
+                const int urj = fdiv24(rm, P.d_TC);
                 const int vcj = rm - urj * P.TC;
                 if (!(im < P.TI && (n0 + im) < P.N)) continue;
                 const size_t cb2 = ((size_t)(n0 + im) * P.CNtot + cn) * chw;
@@ -683,6 +675,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 template <int MODE, int WM, int WN, int KS, int PW>
 __global__ __launch_bounds__(64 * WM * WN * KS) void corr_kernel(const CorrParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    warm_kernarg(P);
     const int grp = blockIdx.z / P.SK, split = blockIdx.z - grp * P.SK;
     if (MODE == 0) {
         corr_body<0, 2, 1, WM, WN, KS, PW>(P, split, smem);
@@ -766,11 +759,14 @@ bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r,
     }
 }
 
-void finish_tile(CorrParams& P, int Hu, int Wv) {
-    P.d_CS = make_fastdiv(P.CS); P.d_SRSC = make_fastdiv(P.SR * P.SCp); P.d_SCp = make_fastdiv(P.SCp);
-    P.d_TRTC = make_fastdiv(P.TR * P.TC); P.d_TC = make_fastdiv(P.TC);
+bool finish_tile(CorrParams& P, int Hu, int Wv) {
+    const uint32_t nmax = XE_MAX * 256;
+    if (!make_fastdiv24(P.CS, nmax, &P.d_CS) || !make_fastdiv24(P.SR * P.SCp, nmax, &P.d_SRSC) || !make_fastdiv24(P.SCp, nmax, &P.d_SCp) ||
+        !make_fastdiv24(P.TR * P.TC, nmax, &P.d_TRTC) || !make_fastdiv24(P.TC, nmax, &P.d_TC))
+        return false;
     P.img_groups = cdiv(P.N, P.TI);
     P.tiles_r = cdiv(Hu, P.TR); P.tiles_c = cdiv(Wv, P.TC);
+    return true;
 }
 
 template <typename K>
@@ -857,7 +853,8 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const WaveCfg& wc = kCfgs[cfg];
     const int CK = 2 * wc.KS * wc.PW, TM = 32 * wc.WM, TNW = 32 * wc.WN;
     if (!pick_tile(P, Hu, Wv, TM, CK, su, ext_r, ext_c)) return 1;
-    finish_tile(P, Hu, Wv);
+    if (!finish_tile(P, Hu, Wv)) return 1;
+    if ((size_t)P.N * P.CKtot * P.Hin >= (1u << 24)) return 1;      // the staging descriptors use 24-bit multiplies
     const int gx = P.img_groups * P.tiles_r * P.tiles_c, gy = cdiv(P.CNtot, TNW);
     int sk = env_int(sk_env, 0);
     if (sk <= 0) {

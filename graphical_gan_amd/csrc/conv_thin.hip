@@ -55,6 +55,7 @@ struct ThinDgradParams {
 
 template <int NT, bool TWO>
 __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams P) {
+    warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: keeps the MFMA blocks out of exec-mask branches)
@@ -204,6 +205,7 @@ constexpr int XU_MAX = 3, GU_MAX = 2;
 // groups' partial tiles are added in group order through LDS at the end.
 template <int MPW, int NG>
 __global__ __launch_bounds__(NTHR * NG) void thin_wgrad_kernel(const ThinWgradParams P) {
+    warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int MG = 4;
     const int tid = threadIdx.x & (NTHR - 1), lane = tid & 63;
@@ -409,6 +411,7 @@ struct ThinFwdParams {
 
 template <int NTN, int MPW>
 __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
+    warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -52,6 +52,7 @@ struct WgradParams {
 };
 
 __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
+    warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 5, NT = 25;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

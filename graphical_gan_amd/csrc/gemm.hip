@@ -367,6 +367,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
 
 template <bool TA, bool TB, int MASK = 0, int FAST = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
+    warm_kernarg(P);
     __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
     gemm_tile<TA, TB, MASK, FAST>(P, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
@@ -384,6 +385,7 @@ struct GemmGroup {
 };
 
 __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
+    warm_kernarg(G);
     __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
     int j = 0;
