@@ -20,10 +20,13 @@ using namespace ggan;
 
 namespace {
 
+#ifndef GGAN_ABL
+#define GGAN_ABL 0
+#endif
 constexpr int TCI = 16, TCO = 16;
 constexpr int NW = 8;                      // waves per workgroup: two per SIMD, pixel quads dealt round-robin
 constexpr int NTHR = 64 * NW;
-constexpr int XU_MAX = 4;                  // float4 slab units per thread per chunk (2048 per workgroup)
+constexpr int XU_MAX = 6;                  // float4 slab units per thread per chunk (3072 per workgroup)
 constexpr unsigned OOB = 0x7FFFFFF0u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -63,8 +66,10 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     const bool stamping = P.stamps != nullptr && tid == 0;
     auto stamp = [&](int i) { if (stamping) P.stamps[(size_t)wg_lin * 16 + i] = __builtin_readcyclecounter(); };
     stamp(0);
-    float* xs = smem;                      // [TCI][CS]
-    float* gs = smem + TCI * P.CS;         // [TCO][PCp]
+    // two staging buffers, each [TCI][CS] x slab + [TCO][PCp] gy tile: chunk c is multiplied out of buffer c&1 while chunk c+1 is
+    // committed to the other one (ONE barrier per chunk; with a single buffer the commit sat between two barriers with every
+    // matrix pipe idle: 5700 cycles per chunk where the MFMAs need 3200)
+    const int STG = TCI * P.CS + TCO * P.PCp;
     const int HW = P.H * P.W, HoWo = P.Ho * P.Wo, F4 = P.W >> 2;
 
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, (int)P.x_bytes, 0x00020000);
@@ -108,8 +113,8 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     }
     const bool gvalid = gcol < TCO && (co0 + gcol) < P.Co;
 
-    // zero the slab once: halo columns and padded channels are never written again
-    for (int e = tid; e < TCI * P.CS; e += NTHR) xs[e] = 0.f;
+    // zero the slabs once: halo columns and padded channels are never written again
+    for (int e = tid; e < TCI * P.CS; e += NTHR) { smem[e] = 0.f; smem[STG + e] = 0.f; }
 
     f32x4 acc[NT];
 #pragma unroll
@@ -139,7 +144,9 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
         if (masked) gref = __builtin_amdgcn_raw_buffer_load_b128(rr, gvo, 0, 0);
     };
 
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        float* xs = smem + buf * STG;
+        float* gs = xs + TCI * P.CS;
 #pragma unroll
         for (int j = 0; j < XU_MAX; ++j) {
             if (tid + j * NTHR < P.xunits) {
@@ -166,19 +173,32 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     const int c_end = min(c_begin + P.chunks_per_split, P.chunks_total);
     stamp(1);
     if (c_begin < c_end) prefetch(c_begin);
+    __syncthreads();                        // (slabs zeroed)
+    if (c_begin < c_end) commit(0);
+    if (c_begin + 1 < c_end) prefetch(c_begin + 1);
+    __syncthreads();
+    stamp(2);
+    // the two waves that share a SIMD run the chunk in opposite order (stage-then-multiply / multiply-then-stage): the LDS-write
+    // and vector-memory burst of one overlaps the MFMA phase of the other
+    const bool stage_first = wave < NW / 2;
     for (int ch = c_begin; ch < c_end; ++ch) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (ch == c_begin) stamp(2);
-        if (ch - c_begin >= 1 && ch - c_begin < 9) stamp(3 + ch - c_begin);
-        if (ch + 1 < c_end) prefetch(ch + 1);
+        const int buf = (ch - c_begin) & 1;
+        const float* xs = smem + buf * STG;
+        const float* gs = xs + TCI * P.CS;
+        auto stage_next = [&]() {
+            if (!(GGAN_ABL & 1) && ch + 1 < c_end) {
+                commit(buf ^ 1);
+                if (ch + 2 < c_end) prefetch(ch + 2);
+            }
+        };
+        if (stage_first) stage_next();
         // ---- MFMA: this wave's pixel quads; the 26 fragment reads of the NEXT quad are issued before the 25 MFMAs
-        //      of the current one (one wave per SIMD: nothing else hides the LDS latency) ---------------------------
+        //      of the current one ---------------------------------------------------------------------------------------
         const int nq = P.PC >> 2;
         float av[2][NT], bv[2];
         auto load_quad = [&](int qd, float* a, float& b) {
             const int p0 = qd * 4;
+            if (GGAN_ABL & 4) { b = __int_as_float(gb + qd); for (int t = 0; t < NT; ++t) a[t] = __int_as_float(xa + t); return; }
             const int img = fdiv(p0, P.d_TRWo);
             const int rem = p0 - img * (P.TR * P.Wo);
             const int r = fdiv(rem, P.d_Wo);
@@ -192,20 +212,33 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
                     a[kh * KS + kw] = xp[kh * P.SCp + ((kw + 3) & 1) * P.SCh + ((kw + 3) >> 1)];
         };
         if (wave < nq) load_quad(wave, av[0], bv[0]);
+        // the 26 fragment reads of the next quad are dealt out between the 25 MFMAs of the current one (a burst of 26 reads in
+        // front of the MFMA block costs the wave ~200 issue cycles per quad with the matrix pipe waiting on the other wave alone)
+        auto interleave = [&]() {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        };
         for (int qd = wave; qd < nq; qd += 2 * NW) {
-            if (qd + NW < nq) load_quad(qd + NW, av[1], bv[1]);
-            __builtin_amdgcn_sched_barrier(0);
+            // (unconditional: reads and MFMAs must sit in one basic block to be interleaved; beyond the last quad the wave re-reads
+            //  its current one and the values are dropped)
+            load_quad(qd + NW < nq ? qd + NW : qd, av[1], bv[1]);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][t], bv[0], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            interleave();
             if (qd + NW < nq) {
-                if (qd + 2 * NW < nq) load_quad(qd + 2 * NW, av[0], bv[0]);
-                __builtin_amdgcn_sched_barrier(0);
+                load_quad(qd + 2 * NW < nq ? qd + 2 * NW : qd, av[0], bv[0]);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][t], bv[1], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                interleave();
             }
         }
+        if (!stage_first) stage_next();
+        __syncthreads();
+        if (ch - c_begin < 8) stamp(4 + ch - c_begin);
     }
 
     stamp(12);
@@ -307,24 +340,31 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     P.x_bytes = (unsigned)xb; P.gy_bytes = (unsigned)gb;
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo;
     P.pad_t = g.pad_t;
-    P.TR = 64 / g.Wo; if (P.TR > g.Ho) P.TR = g.Ho;
-    P.TI = 64 / (P.TR * g.Wo); if (P.TI < 1) P.TI = 1; if (P.TI > g.N) P.TI = g.N;
-    for (;;) {
-        P.SR = 2 * (P.TR - 1) + 5;
-        P.SCp = g.W + 8;
-        P.xunits = TCI * P.TI * P.SR * (g.W / 4);
-        if (P.xunits <= XU_MAX * NTHR && P.TI < 256 && P.SR < 256) break;
-        if (P.TI > 1) P.TI = (P.TI + 1) / 2;
-        else if (P.TR > 1) P.TR = (P.TR + 1) / 2;
-        else return 1;
-    }
-    P.SCh = P.SCp / 2;
-    P.CS = P.TI * P.SR * P.SCp;
-    while ((P.CS & 31) != 2) P.CS += 1;     // == 2 (mod 32): conflict-free 16ci x 2px fragment reads; even for b64 stores
-    P.PC = P.TI * P.TR * g.Wo;
-    P.PCp = P.PC + 4;
-    if ((P.PC & 3) || TCO * (P.PC / 4) > 256) return 1;
-    if (gbias && ((P.PC / 4) & (P.PC / 4 - 1))) return 1;      // lane-group shuffle needs a power-of-two group
+    // pixel chunk: after every barrier all eight waves fetch their first quad's fragments at once (~800 cycles of LDS pipe with the
+    // matrix pipes idle); 128 pixels per chunk instead of 64 halves the number of those bursts per MFMA (when two such staging
+    // buffers fit the LDS)
+    auto plan_chunk = [&](int pcmax) {
+        P.TR = pcmax / g.Wo; if (P.TR > g.Ho) P.TR = g.Ho;
+        P.TI = pcmax / (P.TR * g.Wo); if (P.TI < 1) P.TI = 1; if (P.TI > g.N) P.TI = g.N;
+        for (;;) {
+            P.SR = 2 * (P.TR - 1) + 5;
+            P.SCp = g.W + 8;
+            P.xunits = TCI * P.TI * P.SR * (g.W / 4);
+            if (P.xunits <= XU_MAX * NTHR && P.TI < 256 && P.SR < 256) break;
+            if (P.TI > 1) P.TI = (P.TI + 1) / 2;
+            else if (P.TR > 1) P.TR = (P.TR + 1) / 2;
+            else return false;
+        }
+        P.SCh = P.SCp / 2;
+        P.CS = P.TI * P.SR * P.SCp;
+        while ((P.CS & 31) != 2) P.CS += 1;     // == 2 (mod 32): conflict-free 16ci x 2px fragment reads; even for b64 stores
+        P.PC = P.TI * P.TR * g.Wo;
+        P.PCp = P.PC + 4;
+        if ((P.PC & 3) || TCO * (P.PC / 4) > NTHR) return false;
+        if (gbias && ((P.PC / 4) & (P.PC / 4 - 1))) return false;      // lane-group shuffle needs a power-of-two group
+        return 2 * ((size_t)TCI * P.CS + (size_t)TCO * P.PCp) * sizeof(float) <= 160 * 1024;
+    };
+    if (!(env_int("GGAN_WGRAD_PC", 128) >= 128 && plan_chunk(128)) && !plan_chunk(64)) return 1;
     P.d_F4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR); P.d_TI = make_fastdiv(P.TI);
     P.d_PC4 = make_fastdiv(P.PC / 4); P.d_TRWo = make_fastdiv(P.TR * g.Wo); P.d_Wo = make_fastdiv(g.Wo);
     P.row_tiles = cdiv(g.Ho, P.TR);
@@ -343,7 +383,7 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     P.chunks_per_split = cdiv(P.chunks_total, sk);
     P.SK = cdiv(P.chunks_total, P.chunks_per_split);
     P.out = P.SK > 1 ? (float*)ws : gw;
-    size_t stage = (size_t)TCI * P.CS + (size_t)TCO * P.PCp;
+    size_t stage = 2 * ((size_t)TCI * P.CS + (size_t)TCO * P.PCp);      // double-buffered
     size_t red = (size_t)(NW / 2) * 100 * 64;
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     if (shmem > 160 * 1024) return 1;

@@ -24,8 +24,7 @@ a = st.cpu().numpy().reshape(-1, 16)
 a = a[a[:, 0] != 0]
 print(op, sys.argv[2:] , 'workgroups', len(a))
 t0 = a[:, 0].min()
-names = (['start', 'descr', 'commit0', 'bar0'] + ['chunk%d' % i for i in range(8)] + ['loop_end', 'reduced', 'stored', 'x15']) if op != 'wgrad' else \
-    (['start', 'descr', 'commit0'] + ['x', 'chunk1', 'chunk2', 'chunk3', 'chunk4', 'chunk5', 'chunk6', 'chunk7', 'chunk8'] + ['loop_end', 'reduced', 'stored'])
+names = ['start', 'descr', 'commit0', 'bar0'] + ['chunk%d' % i for i in range(8)] + ['loop_end', 'reduced', 'stored', 'x15']
 print('WG start skew vs first WG: median %d max %d' % (np.median(a[:, 0] - t0), (a[:, 0] - t0).max()))
 for i, nme in enumerate(names):
     col = a[:, i]
