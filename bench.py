@@ -239,6 +239,15 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
     tr.iteration(it, bi); it += 1                      # creates parameters + optimizers (eager)
     tr.iteration(it, bi); it += 1
     broadcast_params(0)
+    feed_mode = 'host' if args.host_feed else 'staging buffer (one device copy per step)'
+    if not args.host_feed and not args.no_ring and not ssgan:
+        # the synthetic minibatches already sit in HBM: the steps read them in place (ring index = the optimizers' device-side step
+        # counts) instead of through a staging buffer, and one iteration is one graph replay (Trainer.use_ring)
+        try:
+            tr.use_ring(ring)
+            feed_mode = 'device-resident ring, read in place' + ('; one graph per iteration' if (world == 1 and not args.no_graph) else '')
+        except (ValueError, RuntimeError):
+            pass
     for _ in range(max(warmup, 2)):                    # includes graph capture
         tr.iteration(it, bi); it += 1
 
@@ -352,7 +361,7 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'parallelism': 'dp%d' % world, 'global_batch': cfg.B * world,
-                       'hip_graph': not args.no_graph, 'host_feed': bool(args.host_feed), 'fused_epilogues': not args.no_fuse,
+                       'hip_graph': not args.no_graph, 'host_feed': bool(args.host_feed), 'minibatch_feed': feed_mode, 'fused_epilogues': not args.no_fuse,
                        'minibatches_per_step': 1 + cfg.critic_iters, 'algorithmic_gflop_per_step': round(gflop_it, 2),
                        'finite_costs': bool(finite), **({'frames_per_sec': round(units_per_s * cfg.LEN, 1)} if ssgan else {})},
             'algorithmic_gflop_per_step': round(gflop_it, 2),
@@ -391,6 +400,7 @@ def main():
     ap.add_argument('--repeats', type=int, default=3, help='extra repetitions of the K-step window after the timed one (spread; headline only)')
     ap.add_argument('--variants', default=None, help='comma-separated subset of: ' + ', '.join(v['key'] for v in VARIANTS))
     ap.add_argument('--variant-steps', type=int, default=None, help='timed iterations per variant (default: min(steps, 60))')
+    ap.add_argument('--no-ring', action='store_true', help='minibatches through the staging buffer (one device copy per step) instead of read in place from the resident ring')
     ap.add_argument('--host-feed', action='store_true',
                     help='minibatches start in host memory (pinned double-buffered H->D copies): the PCIe-inclusive rate')
     args = ap.parse_args()

@@ -104,6 +104,21 @@ __global__ void cast_scale_k(const int32_t* __restrict__ x, const float* __restr
     }
 }
 
+__global__ void cast_scale_ring_k(const int32_t* __restrict__ ring, int nslots, const int32_t* __restrict__ ctr_a,
+                                  const int32_t* __restrict__ ctr_b, int offset, const float* __restrict__ noise,
+                                  float* __restrict__ y, size_t n, float div, float mul) {
+    // (nothing in this launch writes the counters: every workgroup sees the same slot)
+    long long c = (long long)offset + (ctr_a ? *ctr_a : 0) + (ctr_b ? *ctr_b : 0);
+    const int slot = (int)(((c % nslots) + nslots) % nslots);
+    const int32_t* x = ring + (size_t)slot * n;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i; j < n; j += stride) {
+        float v = mul * (((float)x[j] / div) - 0.5f);
+        if (noise) v += noise[j];
+        y[j] = v;
+    }
+}
+
 __global__ void axpby_k(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
                         size_t n, float a, float b, float c) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -928,6 +943,15 @@ int ggan_cast_scale_i32(const int32_t* x, const float* noise, float* y, size_t n
     GGAN_CHECK_ARG(x && y, "null pointer");
     if (n == 0) return 0;
     GGAN_LAUNCH("cast_scale_i32", 0, 8.0 * n, cast_scale_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, noise, y, n, div, mul);
+    return 0;
+}
+
+int ggan_cast_scale_ring_i32(const int32_t* ring, int nslots, const int32_t* ctr_a, const int32_t* ctr_b, int offset,
+                             const float* noise, float* y, size_t n, float div, float mul, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(ring && y && nslots > 0, "bad argument");
+    if (n == 0) return 0;
+    GGAN_LAUNCH("cast_scale_ring_i32", 0, 8.0 * n, cast_scale_ring_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, ring,
+                nslots, ctr_a, ctr_b, offset, noise, y, n, div, mul);
     return 0;
 }
 

@@ -126,11 +126,36 @@ class Trainer(object):
     def set_batch(self, batch):
         self.model.set_batch(self.feed, batch)
 
+    def use_ring(self, batches):
+        """batches: equal-shape int32 device minibatches (model.synthetic_ring, or a loader's staging slots).  From here on every
+        step reads its minibatch from this ring inside its own launches -- slot (generator steps taken + critic steps taken) mod R,
+        counted by the optimizers' device-side step counts -- instead of a staging buffer the host copies the next minibatch
+        into: nothing is issued between two step graphs, and iteration() can replay a whole iteration as ONE graph.  Needs both
+        step kinds to have run once (the optimizers must exist); int32 image scripts only (MNIST feeds floats: unchanged)."""
+        from .optim import _optimizers
+        ring = torch.stack(list(batches)).contiguous()
+        if ring.dtype != torch.int32 or 'real_x_int' not in self.feed or ring[0].numel() != self.feed['real_x_int'].numel():
+            raise ValueError('use_ring: int32 minibatches of the shape of the real_x_int placeholder')
+        ctr = {}
+        for key, o in _optimizers.items():
+            if key[0] in ('gen', 'disc'):
+                ctr[key[0]] = o.step
+        if 'gen' not in ctr:
+            raise RuntimeError('use_ring: run one eager iteration first (the optimizers own the step counters)')
+        self.flush()
+        torch.cuda.synchronize(self.device)
+        taken = sum(int(t.item()) for t in ctr.values())
+        self.feed['ring'] = (ring, ctr['gen'], ctr.get('disc'), -taken)
+        self._graphs = {}                      # (captured steps read the staging buffer)
+        self._iter_graph = None
+
     def _sample_noise(self):
         self.model.sample_noise(self.feed)
 
     # ---- one session.run ------------------------------------------------------------------------------
     def _nets(self):
+        if hasattr(self.model, 'begin_nets'):
+            self.model.begin_nets(self.feed)
         if not self.inject_noise:
             self._sample_noise()
         return self.model.forward_nets(self.feed)
@@ -334,9 +359,64 @@ class Trainer(object):
             self.set_feed(feed)
         return self.step('disc')
 
+    def _capture_iteration(self, kinds):
+        """one HIP graph for a whole iteration (ring mode, one GPU): [generator step, critic step x CRITIC_ITERS], each
+        forward + backward + pack + Adam -- no graph-launch gap between the steps"""
+        forkable = hasattr(self.model, 'fork_now') and not self.sync_bn
+        if forkable:
+            self.model.fork_now = True
+        try:
+            if getattr(self, '_cap_stream', None) is None:
+                self._cap_stream = torch.cuda.Stream(device=self.device)
+            s = self._cap_stream
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                snap = [(o, o.theta.clone(), o.m.clone(), o.v.clone(), o.step.clone()) for o in self._optimizers()]
+                rng = self.feed.get('rng_state') if isinstance(self.feed, dict) else None
+                rng_snap = rng.clone() if torch.is_tensor(rng) else None
+                for _ in range(2):
+                    for k in kinds:
+                        self._eager(k)
+                for o, th, m, v, st in snap:
+                    o.theta.copy_(th); o.m.copy_(m); o.v.copy_(v); o.step.copy_(st)
+                if rng_snap is not None:
+                    rng.copy_(rng_snap)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            costs, keeps = {}, []
+            with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
+                for k in kinds:
+                    cost, opt, keep = self._fwd_bwd(k)
+                    opt.update()
+                    costs[k + '_cost'] = cost
+                    keeps.append((opt, keep))
+            return dict(g=g, costs=costs, keep=keeps, kinds=tuple(kinds))
+        finally:
+            if forkable:
+                self.model.fork_now = False
+
     def iteration(self, it, batches):
-        """batches: iterator of device minibatches (or feed dicts when inject_noise)."""
+        """batches: iterator of device minibatches (or feed dicts when inject_noise); ignored in ring mode (use_ring)."""
         res = {}
+        if isinstance(self.feed, dict) and self.feed.get('ring') is not None:
+            kinds = (['gen'] if it > 0 else []) + ['disc'] * self.cfg.critic_iters
+            one_graph = (self.graph_enabled and it > 0 and self.world == 1 and not self.split_graph and not self.sync_bn
+                         and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
+            if not one_graph:
+                for k in kinds:
+                    res[k + '_cost'] = self.step(k)
+                return res
+            for k in kinds:
+                self._calls[k] += 1
+            if all(self._calls[k] >= 2 for k in set(kinds)):
+                lib.end_build_phase()        # (as step(): every kind has been built once)
+            rec = getattr(self, '_iter_graph', None)
+            if rec is None or rec['kinds'] != tuple(kinds):
+                self.flush()
+                rec = self._iter_graph = self._capture_iteration(kinds)
+            rec['g'].replay()
+            return dict(rec['costs'])
 
         def load(b):
             if isinstance(b, dict):

@@ -935,13 +935,21 @@ class CastScaleI32(Function):
     """real_x = mul*(float(x)/div - .5) + noise  (no gradient: the input is data)."""
 
     @staticmethod
-    def forward(ctx, x_int, noise, div, mul, slot=None):
+    def forward(ctx, x_int, noise, div, mul, slot=None, ring=None):
+        """ring: (int32 [R, ...] tensor of pre-staged minibatches, counter a, counter b, offset) -- the minibatch is slot
+        (a + b + offset) mod R of the ring instead of x_int (ggan_cast_scale_ring_i32)"""
         _dev(x_int)
         assert x_int.dtype == torch.int32
         x_int = x_int.contiguous()
         y = _new_out(slot, x_int.shape, x_int.device)
-        check(_L().ggan_cast_scale_i32(_p(x_int), _p(_c(noise)) if noise is not None else _p(None), _p(y), x_int.numel(),
-                                       div, mul, _stream()), 'ggan_cast_scale_i32')
+        nz = _p(_c(noise)) if noise is not None else _p(None)
+        if ring is not None:
+            rt, ca, cb, off = ring
+            assert rt.dtype == torch.int32 and rt.is_contiguous() and rt[0].numel() == x_int.numel()
+            check(_L().ggan_cast_scale_ring_i32(_p(rt), rt.shape[0], _p(ca), _p(cb), int(off), nz, _p(y), x_int.numel(), div, mul,
+                                                _stream()), 'ggan_cast_scale_ring_i32')
+            return y
+        check(_L().ggan_cast_scale_i32(_p(x_int), nz, _p(y), x_int.numel(), div, mul, _stream()), 'ggan_cast_scale_i32')
         return y
 
     @staticmethod

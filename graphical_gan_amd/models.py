@@ -71,6 +71,8 @@ class GraphicalGAN(object):
     def __init__(self, cfg):
         self.cfg = cfg
         self._side = None                                     # second stream of forward_nets
+        self._early = False                                   # begin_nets() forked it before the noise launch
+        self._pending_join = None                             # [stream, event after real_x, event at the branch's end]
         # two-stream Extractor / Generator passes: measured +3 % (ali, face, mnist), -5..7 % with the gradient penalty (more
         # cross-stream edges than overlap), so the joint-critic modes without a penalty ask for it; the Trainer
         # turns it on while it builds a single-graph step (fork_now) -- eager steps are host-bound and gain nothing
@@ -233,7 +235,7 @@ class GraphicalGAN(object):
             return z, mean, std
         return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out, out=out_slot)
 
-    def Discriminator(self, x, z, grad_rows=None, twice=False):
+    def Discriminator(self, x, z, grad_rows=None, twice=False, before_z=None):
         """grad_rows: only the first grad_rows images of x carry a gradient (generator steps: [fake; real]); twice: the result
         will be differentiated twice (gradient-penalty pass): plain layer composition instead of the fused critic tail"""
         c = self.cfg
@@ -244,6 +246,8 @@ class GraphicalGAN(object):
             out = self._conv('Discriminator.%d' % (i + 1), ch, cout, out, LRELU, grad_rows)   # dropout == identity
             ch = cout
         out = out.reshape(-1, c.flat)
+        if before_z is not None:
+            before_z()               # (forward_nets: z's second half may still be in flight on the other stream)
         z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
         if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):
             # Linear on concat([out, z_out], 1) + LeakyReLU + the 512 -> 1 Output layer as one op
@@ -334,9 +338,39 @@ class GraphicalGAN(object):
         c = self.cfg
         if c.dataset == 'mnist':
             return feed['real_x']
+        ring = feed.get('ring')            # Trainer.use_ring: minibatches pre-staged in HBM, walked by the optimizers' step counts
         if c.dataset == 'face':
-            return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'], out=out_slot)
-        return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2., out=out_slot)
+            return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'], out=out_slot, ring=ring)
+        return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2., out=out_slot, ring=ring)
+
+    def begin_nets(self, feed):
+        """Called by the Trainer BEFORE the noise launch of a step.  When the two nets passes are going to run as parallel
+        branches and the Extractor pass needs no noise, the second stream is forked here, with nothing in front of it."""
+        c = self.cfg
+        self._early = False
+        if not (self.fork_nets and self.fork_now) or c.K or c.agg or c.dataset in ('face', 'mnist') or os.environ.get('GGAN_NO_EARLY_FORK'):
+            return
+        dev = feed['p_z_noise'].device
+        if dev.type != 'cuda' or not (c.batch_critic and 'z_pair' in feed):
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        self._side.wait_stream(torch.cuda.current_stream(dev))
+        self._early = True
+
+    def join_side(self, x_only=False):
+        """make the current stream wait for the second stream's real_x (x_only) or for everything it produced"""
+        pj = self._pending_join
+        if pj is None:
+            return
+        cur, ev_x, ev_end = pj
+        if x_only:
+            if ev_x is not None:
+                cur.wait_event(ev_x)
+                pj[1] = None
+            return
+        cur.wait_event(ev_end)
+        self._pending_join = None
 
     def forward_nets(self, feed):
         """Extractor and Generator passes: everything of a session.run that does not read a critic variable."""
@@ -356,6 +390,23 @@ class GraphicalGAN(object):
         # chains of a generator step overlap the same way.  (Requested by the Trainer for single-graph steps only.)
         p_z = self.HyperGenerator(feed['k_onehot'], feed['p_z_noise'], zs[0]) if c.K else feed['p_z_noise']
         fork = self.fork_nets and self.fork_now and p_z.is_cuda
+        early, self._early = self._early, False
+        if fork and early:
+            # begin_nets() forked before the noise launch: the Extractor pass (which reads no noise) is a ROOT branch of the step
+            # graph on the second stream, the Generator pass follows the noise launch on this one.  The branches are joined
+            # where their results are first read (join_side): real_x before the critic's first layer, q_z before its z path --
+            # a cross-queue dependency that completed long ago costs nothing, one that completes last costs ~11 us of idle chip
+            cur = torch.cuda.current_stream(p_z.device)
+            with torch.cuda.stream(self._side):
+                real_x = self.real_x(feed, xs[1])
+                ev_x = torch.cuda.Event()
+                ev_x.record(self._side)
+                q_z = self.Extractor(real_x, zs[1])
+                ev_end = torch.cuda.Event()
+                ev_end.record(self._side)
+            self._pending_join = [cur, ev_x, ev_end]
+            fake_x = self.Generator(p_z, xs[0])
+            return dict(real_x=real_x, q_z=q_z, p_z=p_z, fake_x=fake_x)
         if fork:
             cur = torch.cuda.current_stream(p_z.device)
             if self._side is None:
@@ -385,6 +436,9 @@ class GraphicalGAN(object):
         is not part of gen_cost); None builds everything.  nets: a forward_nets() result to continue from."""
         c = self.cfg
         out = dict(nets) if nets is not None else self.forward_nets(feed)
+        defer = c.batch_critic and which in ('gen', 'disc') and not (c.latent_critic or c.agg or c.mode == 'vegan-mmd')
+        if not defer:
+            self.join_side()
         if c.latent_critic:
             return self._forward_latent(feed, which, out)
         if c.agg:
@@ -469,8 +523,9 @@ class GraphicalGAN(object):
         B = fake_x.shape[0]
         # grad_rows leaves the real rows of the image gradient unwritten: legal only while the real half is data
         assert detach or not real_x.requires_grad, 'batched critic with grad_rows: real_x must not require a gradient'
+        self.join_side(x_only=True)
         x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
-        d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B)
+        d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=self.join_side)
         if c.K:
             h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
             (hf, hr), (df, dr) = F.SplitRows.apply(h, B), F.SplitRows.apply(d, B)

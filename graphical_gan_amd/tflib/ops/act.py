@@ -28,6 +28,7 @@ def dropout(x, rate=0.0, training=False):
     return x
 
 
-def cast_scale(x_int, div=255., mul=2., noise=None, out=None):
-    """2*((float(x)/255.)-.5) (+ dequantisation noise for the 64x64 scripts).  out: optional functional.RowSlot."""
-    return F.CastScaleI32.apply(x_int, noise, float(div), float(mul), out)
+def cast_scale(x_int, div=255., mul=2., noise=None, out=None, ring=None):
+    """2*((float(x)/255.)-.5) (+ dequantisation noise for the 64x64 scripts).  out: optional functional.RowSlot.
+    ring: read the minibatch from a device-resident ring instead of x_int (functional.CastScaleI32)."""
+    return F.CastScaleI32.apply(x_int, noise, float(div), float(mul), out, ring)

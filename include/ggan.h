@@ -221,6 +221,13 @@ int ggan_bias_add(const float* x, const float* bias, float* y, int N, int C, int
 /* real_x = mul*(float(int32)/div - .5) (+ noise) (gmgan_inference_cifar10.py:342; face :242-243). */
 int ggan_cast_scale_i32(const int32_t* x, const float* noise /* may be NULL */, float* y, size_t n,
                         float div, float mul, ggan_stream_t stream);
+/* The same op reading its minibatch from a device-resident ring of `nslots` pre-staged minibatches of n int32 each: slot
+ * (*ctr_a + *ctr_b + offset) mod nslots (either counter may be NULL).  The counters are device integers that other launches of
+ * the step advance (the optimizers' step counts), so a replayed HIP graph walks the ring without a host-side copy of the next
+ * minibatch into a staging buffer -- what the feed_dict of session.run is to the reference (gan_inference_cifar10.py:392-401),
+ * with the data already in HBM. */
+int ggan_cast_scale_ring_i32(const int32_t* ring, int nslots, const int32_t* ctr_a, const int32_t* ctr_b, int offset,
+                             const float* noise /* may be NULL */, float* y, size_t n, float div, float mul, ggan_stream_t stream);
 /* out = a*x + b*y (+c) elementwise (interpolates, residuals). */
 int ggan_axpby(const float* x, const float* y, float* out, size_t n, float a, float b, float c,
                ggan_stream_t stream);

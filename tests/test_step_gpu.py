@@ -551,3 +551,40 @@ def test_vegan_aggregated_divergence_modes(gpu, mode, z_samples, bn):
         if n.startswith('Discriminator'):
             continue
         assert np.abs(P[n].astype(np.float64).reshape(v.shape) - v).max() <= 2e-3 * max(1.0, np.abs(v).max()), n
+
+
+@pytest.mark.parametrize('mode,crit', [('ali', 1), ('wali-gp', 5)])
+def test_ring_feed_one_graph_per_iteration_matches_staging_buffer(gpu, mode, crit):
+    """Trainer.use_ring: the steps read their minibatch in place from the device-resident ring (slot = the optimizers' step
+    counts) and a whole iteration is ONE graph replay.  Same seeds, same minibatch order => bit-identical weights to the path
+    that copies every minibatch into the staging buffer and replays one graph per step."""
+    import torch
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    finals = []
+    for use_ring in (False, True):
+        _fresh()
+        np.random.seed(0)
+        cfg = Config('cifar10', batch_size=16, n_coms=0, mode=mode, dim=16, dim_latent=32)
+        assert cfg.critic_iters == crit
+        tr = Trainer(cfg, device=gpu, graph=True, seed=4321)
+        ring = tr.model.synthetic_ring(gpu, n=5, seed=99)
+        batches = iter(ring * 40)
+        taken = 0
+        for it in range(2):                       # eager: parameters + optimizers
+            tr.iteration(it, batches)
+            taken += (1 if it > 0 else 0) + crit
+        if use_ring:
+            k = taken % len(ring)
+            tr.use_ring(ring[k:] + ring[:k])      # the ring continues where the iterator stands
+        for it in range(2, 7):
+            res = tr.iteration(it, batches)
+        if use_ring:
+            assert tr._iter_graph is not None and not tr._graphs, 'one graph per iteration expected'
+        tr.flush()
+        torch.cuda.synchronize()
+        assert all(np.isfinite(float(v)) for v in res.values())
+        finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}))
+    assert finals[0][1] == finals[1][1]
+    for k in finals[0][0]:
+        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
