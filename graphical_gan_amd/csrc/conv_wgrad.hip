@@ -252,32 +252,33 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
         }
     }
 
-    // ---- combine the NW pixel-split waves: halve through LDS down to two partial tiles, then ALL waves add those two and
-    //      store float4 runs along co (one wave storing 100 dwords per lane is a ~50k-cycle issue-bound tail) -------------
+    // ---- combine the NW pixel-split waves.  One halving round with 16-byte accesses (wave w+4 parks its 25 accumulator quads,
+    //      wave w adds them: any layout serves, the two waves hold the same elements in the same lanes), then the four
+    //      remaining partial tiles go to LDS transposed for the store phase, where ALL waves add the four and store float4 runs
+    //      along co (one wave storing 100 dwords per lane is a ~50k-cycle issue-bound tail).  Three barriers; the previous
+    //      three halving rounds of dword accesses (seven barriers, two waves busy in the last ones) took 9400 cycles.
     __syncthreads();
     float* red = smem;                     // [NW/2][NT*4][64]
+    static_assert(NW == 8, "one halving round, four partial tiles");
+    {
+        f32x4* slab = reinterpret_cast<f32x4*>(red) + (size_t)(wave & 3) * NT * 64 + lane;
+        if (wave >= 4) {
 #pragma unroll
-    for (int h = NW / 2; h >= 2; h >>= 1) {
-        if (wave >= h && wave < 2 * h) {
+            for (int t = 0; t < NT; ++t) slab[t * 64] = acc[t];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 o = slab[t * 64];
+                acc[t][0] += o[0]; acc[t][1] += o[1]; acc[t][2] += o[2]; acc[t][3] += o[3];
+            }
+            // (slab w is read and rewritten by wave w alone: no barrier between the two)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[((wave - h) * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
+                for (int r = 0; r < 4; ++r) red[(wave * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
         }
-        __syncthreads();
-        if (wave < h) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] += red[(wave * NT * 4 + t * 4 + r) * 64 + lane];
-        }
-        __syncthreads();
-    }
-    if (wave < 2) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * NT * 4 + t * 4 + r) * 64 + lane] = acc[t][r];
     }
     __syncthreads();
     stamp(13);
@@ -290,7 +291,11 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
         const int idx = (t * 4 + (cil & 3)) * 64 + (cil >> 2) * 16 + c4 * 4;
         const float4 a = *reinterpret_cast<const float4*>(red + idx);
         const float4 b2 = *reinterpret_cast<const float4*>(red + NT * 4 * 64 + idx);
-        const float4 v = make_float4(a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w);
+        const float4 c2 = *reinterpret_cast<const float4*>(red + 2 * NT * 4 * 64 + idx);
+        const float4 d2 = *reinterpret_cast<const float4*>(red + 3 * NT * 4 * 64 + idx);
+        // ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7)): the order of the halving rounds this replaces
+        const float4 v = make_float4((a.x + c2.x) + (b2.x + d2.x), (a.y + c2.y) + (b2.y + d2.y), (a.z + c2.z) + (b2.z + d2.z),
+                                     (a.w + c2.w) + (b2.w + d2.w));
         const int ci = ci0 + cil, co = co0 + c4 * 4;
         if (ci >= P.Ci || co >= P.Co) continue;
         float* dst = outp + ((size_t)t * P.Ci + ci) * P.Co + co;
