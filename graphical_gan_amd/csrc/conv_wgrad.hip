@@ -54,6 +54,11 @@ struct WgradParams {
     unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
 };
 
+// NIT: pairs of pixel quads per wave and chunk when that is a compile-time number (1: 64-pixel chunks, 2: 128), 0: any chunk size.
+// With NIT > 0 the quad loop unrolls into 2*NIT straight-line MFMA blocks and the global loads of the chunk after next are dealt
+// out between their MFMAs (as in the correlation kernels: eight waves issuing 7 KB each at once queue up at the CU's 64 B/clk
+// vector-memory path while the matrix pipes wait).
+template <int NIT>
 __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -126,22 +131,35 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     u32x4 xreg[XU_MAX];
     u32x4 greg, gref;
 
-    auto prefetch = [&](int ch) {
+    // loads of one chunk: XU_MAX slab units, the gy quad, its mask reference -- `live` false: every lane out of range (nothing fetched)
+    struct ChunkBase { int n0, oh0, in_row0, xbase; bool live; };
+    auto chunk_base = [&](int ch, bool live) {
+        ChunkBase b;
         const int ig = ch / P.row_tiles, rt = ch - ig * P.row_tiles;
-        const int n0 = ig * P.TI, oh0 = rt * P.TR;
-        const int in_row0 = 2 * oh0 - P.pad_t;
-        const int xbase = (n0 * P.Ci + ci0) * HW + in_row0 * P.W;
-#pragma unroll
-        for (int j = 0; j < XU_MAX; ++j) {
-            const int r = xinfo[j] & 255, img = (xinfo[j] >> 8) & 255;
-            const bool ok = xinfo[j] >= 0 && (unsigned)(in_row0 + r) < (unsigned)P.H && (n0 + img) < P.N;
-            const unsigned vo = ok ? (unsigned)(xbase + xrel[j]) * 4u : OOB;
-            xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+        b.n0 = ig * P.TI; b.oh0 = rt * P.TR;
+        b.in_row0 = 2 * b.oh0 - P.pad_t;
+        b.xbase = (b.n0 * P.Ci + ci0) * HW + b.in_row0 * P.W;
+        b.live = live;
+        return b;
+    };
+    auto pf_item = [&](const ChunkBase& b, int i) {
+        if (i < XU_MAX) {
+            const int r = xinfo[i] & 255, img = (xinfo[i] >> 8) & 255;
+            const bool ok = b.live && xinfo[i] >= 0 && (unsigned)(b.in_row0 + r) < (unsigned)P.H && (b.n0 + img) < P.N;
+            const unsigned vo = ok ? (unsigned)(b.xbase + xrel[i]) * 4u : OOB;
+            xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+        } else {
+            const bool gok = b.live && gvalid && (b.n0 + gimg) < P.N && (b.oh0 + gr) < P.Ho;
+            const unsigned gvo = gok ? (unsigned)((b.n0 * P.Co + co0) * HoWo + b.oh0 * P.Wo + grel) * 4u : OOB;
+            if (i == XU_MAX) greg = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo, 0, 0);
+            else gref = __builtin_amdgcn_raw_buffer_load_b128(rr, masked ? gvo : OOB, 0, 0);   // (unmasked: no fetch, the value is unused)
         }
-        const bool gok = gvalid && (n0 + gimg) < P.N && (oh0 + gr) < P.Ho;
-        const unsigned gvo = gok ? (unsigned)((n0 * P.Co + co0) * HoWo + oh0 * P.Wo + grel) * 4u : OOB;
-        greg = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo, 0, 0);
-        if (masked) gref = __builtin_amdgcn_raw_buffer_load_b128(rr, gvo, 0, 0);
+    };
+    auto prefetch = [&](int ch) {
+        const ChunkBase b = chunk_base(ch, true);
+#pragma unroll
+        for (int i = 0; i < XU_MAX + 1; ++i) pf_item(b, i);
+        if (masked) pf_item(b, XU_MAX + 1);
     };
 
     auto commit = [&](int buf) {
@@ -181,21 +199,15 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     // the two waves that share a SIMD run the chunk in opposite order (stage-then-multiply / multiply-then-stage): the LDS-write
     // and vector-memory burst of one overlaps the MFMA phase of the other
     const bool stage_first = wave < NW / 2;
+    const int nq = P.PC >> 2;
     for (int ch = c_begin; ch < c_end; ++ch) {
         const int buf = (ch - c_begin) & 1;
         const float* xs = smem + buf * STG;
         const float* gs = xs + TCI * P.CS;
-        auto stage_next = [&]() {
-            if (!(GGAN_ABL & 1) && ch + 1 < c_end) {
-                commit(buf ^ 1);
-                if (ch + 2 < c_end) prefetch(ch + 2);
-            }
-        };
-        if (stage_first) stage_next();
-        // ---- MFMA: this wave's pixel quads; the 26 fragment reads of the NEXT quad are issued before the 25 MFMAs
-        //      of the current one ---------------------------------------------------------------------------------------
-        const int nq = P.PC >> 2;
         float av[2][NT], bv[2];
+        // ---- MFMA: this wave's pixel quads; the 26 fragment reads of the NEXT quad are dealt out between the 25 MFMAs of the
+        //      current one (a burst of 26 reads in front of the MFMA block costs the wave ~200 issue cycles per quad with the
+        //      matrix pipe waiting on the other wave alone) -----------------------------------------------------------------------
         auto load_quad = [&](int qd, float* a, float& b) {
             const int p0 = qd * 4;
             if (GGAN_ABL & 4) { b = __int_as_float(gb + qd); for (int t = 0; t < NT; ++t) a[t] = __int_as_float(xa + t); return; }
@@ -211,32 +223,69 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
                 for (int kw = 0; kw < KS; ++kw)   // slab col = 2*ow+kw+3 -> parity plane (kw+3)&1, index ow+((kw+3)>>1)
                     a[kh * KS + kw] = xp[kh * P.SCp + ((kw + 3) & 1) * P.SCh + ((kw + 3) >> 1)];
         };
-        if (wave < nq) load_quad(wave, av[0], bv[0]);
-        // the 26 fragment reads of the next quad are dealt out between the 25 MFMAs of the current one (a burst of 26 reads in
-        // front of the MFMA block costs the wave ~200 issue cycles per quad with the matrix pipe waiting on the other wave alone)
-        auto interleave = [&]() {
+        if constexpr (NIT > 0) {
+            // every wave commits chunk ch+1 first (its registers were filled during chunk ch-1), then multiplies; the loads of
+            // chunk ch+2 ride in the MFMA blocks, IPB per block, one every few MFMAs
+            constexpr int NB = 2 * NIT, NITEM = XU_MAX + 2, IPB = (NITEM + NB - 1) / NB;
+            if (!(GGAN_ABL & 1) && ch + 1 < c_end) commit(buf ^ 1);
+            const ChunkBase nb = chunk_base(ch + 2, ch + 2 < c_end && !(GGAN_ABL & 1));
+            auto block = [&](int bi, const float* a, float bq) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                for (int i = bi * IPB; i < (bi + 1) * IPB; ++i)
+                    if (i < NITEM) pf_item(nb, i);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bq, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (t % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            };
+            load_quad(wave, av[0], bv[0]);
+#pragma unroll
+            for (int itq = 0; itq < NIT; ++itq) {
+                const int qd = wave + itq * 2 * NW;
+                load_quad(qd + NW, av[1], bv[1]);
+                block(2 * itq, av[0], bv[0]);
+                load_quad(itq + 1 < NIT ? qd + 2 * NW : qd, av[0], bv[0]);     // (after the last pair: re-read, dropped)
+                block(2 * itq + 1, av[1], bv[1]);
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        };
-        for (int qd = wave; qd < nq; qd += 2 * NW) {
-            // (unconditional: reads and MFMAs must sit in one basic block to be interleaved; beyond the last quad the wave re-reads
-            //  its current one and the values are dropped)
-            load_quad(qd + NW < nq ? qd + NW : qd, av[1], bv[1]);
+        } else {
+            auto stage_next = [&]() {
+                if (!(GGAN_ABL & 1) && ch + 1 < c_end) {
+                    commit(buf ^ 1);
+                    if (ch + 2 < c_end) prefetch(ch + 2);
+                }
+            };
+            // the two waves that share a SIMD run the chunk in opposite order (stage-then-multiply / multiply-then-stage)
+            if (stage_first) stage_next();
+            auto interleave = [&]() {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][t], bv[0], acc[t], 0, 0, 0);
-            interleave();
-            if (qd + NW < nq) {
-                load_quad(qd + 2 * NW < nq ? qd + 2 * NW : qd, av[0], bv[0]);
+                for (int t = 0; t < NT; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            };
+            if (wave < nq) load_quad(wave, av[0], bv[0]);
+            for (int qd = wave; qd < nq; qd += 2 * NW) {
+                // (unconditional: reads and MFMAs must sit in one basic block to be interleaved; beyond the last quad the wave
+                //  re-reads its current one and the values are dropped)
+                load_quad(qd + NW < nq ? qd + NW : qd, av[1], bv[1]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][t], bv[1], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][t], bv[0], acc[t], 0, 0, 0);
                 interleave();
+                if (qd + NW < nq) {
+                    load_quad(qd + 2 * NW < nq ? qd + 2 * NW : qd, av[0], bv[0]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][t], bv[1], acc[t], 0, 0, 0);
+                    interleave();
+                }
             }
+            if (!stage_first) stage_next();
         }
-        if (!stage_first) stage_next();
         __syncthreads();
         if (ch - c_begin < 8) stamp(4 + ch - c_begin);
     }
@@ -394,13 +443,18 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     if (shmem > 160 * 1024) return 1;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    const int nit = env_int("GGAN_WGRAD_DEAL", 1) ? (P.PC == 128 ? 2 : (P.PC == 64 ? 1 : 0)) : 0;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     if (parts && ws_bytes < P.slab_stride * sizeof(float)) { set_error("conv_wgrad: partial-slab buffer too small"); return -1; }
     if (want_stamps && !parts && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
-    GGAN_LAUNCH("wgrad_kernel", fl, 0, wgrad_kernel, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P);
+    if (nit == 2) { GGAN_LAUNCH("wgrad_kernel", fl, 0, wgrad_kernel<2>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
+    else if (nit == 1) { GGAN_LAUNCH("wgrad_kernel", fl, 0, wgrad_kernel<1>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
+    else { GGAN_LAUNCH("wgrad_kernel", fl, 0, wgrad_kernel<0>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
     if (parts) {
         parts->n = P.SK;
         parts->stride = P.slab_stride;
