@@ -831,7 +831,10 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
         // 128x32, 64x64, 64x32, 32x32 (pixels x channels).  The filter slice is 2/3 of what a 64x32 workgroup stages per chunk and
         // is the same for every pixel tile: the 128-pixel layout stages it once for twice the MFMA work (forward kinds only:
         // measured 43.2 vs 47.9 us on the critic's 64->128 layer at 128 images, slower for the data-gradient kinds)
-        static const int order[4] = {8, 6, 4, 5};
+        // (all-class data gradient: the 64x32 tile with two accumulator pairs per wave = 16-channel chunks, so that its filter slice
+        //  goes by LDS-DMA with 8-byte fragment reads: 47.4 vs 53.9 us on the 64->128 layer at 128 images)
+        static const int order_fwd[4] = {8, 6, 4, 5}, order_all[4] = {8, 6, 7, 5};
+        const int* order = MODE == 2 ? order_all : order_fwd;
         const int first = (MODE == 0 && !getenv("GGAN_NO_WIDE_TILE")) ? 0 : 1;
         cfg = 5;
         for (int oi = first; oi < 4; ++oi) {
