@@ -192,8 +192,9 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     constexpr int WUNITS = NTT * CK * (TNW / 4);
     constexpr int NTHR = 64 * WM * WN * KS;
     // WD: the data-gradient kinds with 16-channel chunks stage the filter slice by LDS-DMA (see mma_taps_wd); P.dma selects it
-    constexpr bool WD = KIND != 0 && CK == 16 && (PW == 1 || PW == 2);
-    constexpr int NCB = TNW / 16, WBLK = 258, NBLK = NTT * NCB, NWAVE = NTHR / 64;
+    constexpr bool WD = KIND != 0 && CK % 16 == 0 && (PW == 1 || PW == 2);
+    constexpr int GH = CK / 16 > 0 ? CK / 16 : 1;      // 16-channel groups of a chunk: a DMA block is (tap, group, 16 output channels)
+    constexpr int NCB = TNW / 16, WBLK = 258, NBLK = NTT * GH * NCB, NWAVE = NTHR / 64;
     constexpr int WQ = (NBLK + NWAVE - 1) / NWAVE;
     constexpr int WE = (WUNITS + NTHR - 1) / NTHR;
     constexpr int XE = (KIND == 0 ? XE_MAX : XE_MAX / 2) * 256 / NTHR;   // per-thread slab elements (4096 / 2048 budget)
@@ -335,7 +336,8 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     }
     const int wfrag = (ks * PW * 2 + half) * RS + wn * 32 + l31;
     // (WD image: block of 16 channels, k quad, channel, element)
-    const int wfrag_wd = (wn * 2 + (l31 >> 4)) * WBLK + ((PW == 2 ? ks : (ks >> 1)) * 16 + (l31 & 15)) * 4 +
+    const int wd_quad = PW == 2 ? ks : (ks >> 1);                 // this wave's k quad of the chunk
+    const int wfrag_wd = ((wd_quad >> 2) * NCB + wn * 2 + (l31 >> 4)) * WBLK + ((wd_quad & 3) * 16 + (l31 & 15)) * 4 +
                          (PW == 2 ? 2 * half : (ks & 1) * 2 + half);
 
     f32x16 acc[NC];
@@ -407,20 +409,20 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 #pragma unroll
         for (int q = 0; q < WQ; ++q) {
             const int b = wave_u + q * NWAVE;
-            int tap = b / NCB, ci_ = 0;
-            const int cnb = b - tap * NCB;
+            const int cnb = b % NCB, gh = (b / NCB) % GH;
+            int tap = b / (NCB * GH), ci_ = 0;
             if (NC > 1 && tap >= NT0) { tap -= NT0; ci_ = 1; }
             if (NC > 2 && ci_ == 1 && tap >= NT1) { tap -= NT1; ci_ = 2; }
             if (NC > 3 && ci_ == 2 && tap >= NT2) { tap -= NT2; ci_ = 3; }
             const int i = tw_of(ci_) == 3 ? tap / 3 : (tw_of(ci_) == 2 ? tap / 2 : tap / 5), j = tap - i * tw_of(ci_);
             const int wb = wbase_of(ci_);
-            wso[q] = __builtin_amdgcn_readfirstlane(b < NBLK ? (wb + i * P.w_si + j * P.w_sj + cnb * 16 * P.w_sn) * 4 : -1);
+            wso[q] = __builtin_amdgcn_readfirstlane(b < NBLK ? (wb + i * P.w_si + j * P.w_sj + gh * 16 * P.w_sk + cnb * 16 * P.w_sn) * 4 : -1);
         }
     }
     auto stage_w1 = [&](int q, int ck0, int buf) {                 // one wave-instruction of the filter slice
         float* wsb = smem + buf * STAGE + XS_SZ;
-        const bool k_ok = ck0 + (lane >> 4) * 4 < ck_end;            // reduction-channel tail -> zero filter rows
         const int b = wave_u + q * NWAVE;
+        const bool k_ok = ck0 + ((b / NCB) % GH) * 16 + (lane >> 4) * 4 < ck_end;            // reduction-channel tail -> zero filter rows
         const unsigned vo = (k_ok && (b % NCB) * 16 < wd_cnlim) ? wd_lane : OOB;
         const int so = wso[q] + ck0 * P.w_sk * 4;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wsb + b * WBLK), 16, vo, so, 0, 0);
@@ -479,7 +481,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     } else if (wdma) {
         // the slab still goes through registers (it may carry the fused activation mask); the filter slice of chunk c+1 is in flight
         // into the other buffer while chunk c is multiplied, retired by the wait + barrier at the end of the chunk
-        constexpr int TS = NCB * WBLK;
+        constexpr int TS = GH * NCB * WBLK;
         constexpr int WD_STEPS = (NT0 * (PW == 2 ? 2 : 1) + 1) / 2 + (NT1 * (PW == 2 ? 2 : 1) + 1) / 2 +
                                  (NT2 * (PW == 2 ? 2 : 1) + 1) / 2 + (NT3 * (PW == 2 ? 2 : 1) + 1) / 2;
         // (a filter block is 1 KB: eight waves x one block per MFMA pair is what the CU's 64 B/clk vector-memory path moves in the
@@ -740,7 +742,7 @@ struct WaveCfg { int WM, WN, KS, PW; };
 // fwd: 25 taps per chunk-channel-pair; dgrad class pairs carry only 12-13 taps, so they stage twice as many channels per
 // chunk (PW doubled) to keep ~25+ MFMAs per wave between barriers
 const WaveCfg kCfgsFwd[9] = {{2, 2, 1, 2}, {2, 1, 2, 2}, {1, 1, 4, 1}, {1, 1, 4, 2}, {2, 1, 4, 1}, {1, 1, 8, 1}, {2, 2, 2, 1}, {2, 1, 4, 2}, {4, 1, 2, 2}};
-const WaveCfg kCfgsDgrad[7] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}, {1, 1, 4, 4}, {2, 1, 4, 2}, {1, 1, 8, 1}, {2, 2, 2, 2}};
+const WaveCfg kCfgsDgrad[9] = {{2, 2, 1, 4}, {2, 1, 2, 4}, {1, 1, 4, 2}, {1, 1, 4, 4}, {2, 1, 4, 2}, {1, 1, 8, 1}, {2, 2, 2, 2}, {1, 1, 8, 2}, {1, 1, 8, 2}};
 
 // pixel tile TI x TR x TC <= TM whose CK-channel slab fits the per-thread staging budget
 bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r, int ext_c) {
@@ -787,7 +789,7 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         allow_big_lds(corr_kernel<2, 2, 2, 1, 2>); allow_big_lds(corr_kernel<2, 2, 1, 2, 2>); allow_big_lds(corr_kernel<2, 1, 1, 4, 1>);
         allow_big_lds(corr_kernel<2, 1, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 1>); allow_big_lds(corr_kernel<2, 1, 1, 8, 1>);
         allow_big_lds(corr_kernel<2, 2, 2, 2, 1>); allow_big_lds(corr_kernel<0, 2, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 2>);
-        allow_big_lds(corr_kernel<0, 4, 1, 2, 2>); allow_big_lds(corr_kernel<2, 4, 1, 2, 2>);
+        allow_big_lds(corr_kernel<0, 4, 1, 2, 2>); allow_big_lds(corr_kernel<2, 4, 1, 2, 2>); allow_big_lds(corr_kernel<1, 1, 1, 8, 2>);
         once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
@@ -811,7 +813,8 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
             case 3: GGAN_LAUNCH("corr_kernel<1, 1, 1, 4, 4>", fl, 0, (corr_kernel<1, 1, 1, 4, 4>), grid, dim3(256), shmem, s, P); break;
             case 4: GGAN_LAUNCH("corr_kernel<1, 2, 1, 4, 2>", fl, 0, (corr_kernel<1, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
             case 5: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 1>", fl, 0, (corr_kernel<1, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH("corr_kernel<1, 2, 2, 2, 2>", fl, 0, (corr_kernel<1, 2, 2, 2, 2>), grid, dim3(512), shmem, s, P); break;
+            case 6: GGAN_LAUNCH("corr_kernel<1, 2, 2, 2, 2>", fl, 0, (corr_kernel<1, 2, 2, 2, 2>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 2>", fl, 0, (corr_kernel<1, 1, 1, 8, 2>), grid, dim3(512), shmem, s, P); break;
         }
     }
     return 0;
@@ -825,7 +828,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const int target = env_int("GGAN_TARGET_WGS", 200);
     const WaveCfg* kCfgs = MODE == 1 ? kCfgsDgrad : kCfgsFwd;
     int cfg = env_int(cfg_env, -1);
-    if (cfg < 0 || cfg > (MODE == 1 ? 6 : 8)) {
+    if (cfg < 0 || cfg > (MODE == 1 ? 7 : 8)) {
         // 8 waves per workgroup (two per SIMD: one wave's LDS / barrier stalls hide under the other's MFMAs; measured
         // 12-19 % faster than the 4-wave layouts).  Largest tile that still yields ~one workgroup per CU.
         // 128x32, 64x64, 64x32, 32x32 (pixels x channels).  The filter slice is 2/3 of what a 64x32 workgroup stages per chunk and
@@ -835,6 +838,10 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
         //  goes by LDS-DMA with 8-byte fragment reads: 47.4 vs 53.9 us on the 64->128 layer at 128 images)
         static const int order_fwd[4] = {8, 6, 4, 5}, order_all[4] = {8, 6, 7, 5};
         const int* order = MODE == 2 ? order_all : order_fwd;
+        // class pairs: 32x32 tiles with 32-channel chunks (13 / 12 taps leave room for them in LDS).  Measured equal to the
+        // 16-channel chunks (33.6 vs 33.9 us on the 128->256 layer: the time per chunk follows the staged bytes, not the barriers),
+        // so it stays an option
+        const bool deep_pairs = MODE == 1 && getenv("GGAN_DEEP_PAIRS");
         const int first = (MODE == 0 && !getenv("GGAN_NO_WIDE_TILE")) ? 0 : 1;
         cfg = 5;
         for (int oi = first; oi < 4; ++oi) {
@@ -850,6 +857,11 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
             //  the 512-frame launches of the state-space scripts -- those stay faster, 200 vs 190+ us measured)
             if (oi == 0 && wgs >= 2 * target) continue;
             if (wgs >= target || oi == 3) { cfg = c; break; }
+        }
+        if (deep_pairs && cfg == 5 && P.CKtot >= 64) {
+            // 13 / 12 taps per chunk-channel leave room for 32-channel chunks in LDS: twice the MFMAs per barrier
+            CorrParams T = P;
+            if (pick_tile(T, Hu, Wv, 32, 32, su, ext_r, ext_c) && !(T.TI * T.TR * T.TC * 2 <= 32 && Hu * Wv * P.N >= 32)) cfg = 7;
         }
         if (P.CKtot < 8) cfg = P.CNtot <= 32 ? 1 : 6;                              // 3-channel inputs: smallest chunks
     }
@@ -884,7 +896,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const int RS = TNW + (MODE != 0 ? 2 : 0);     // filter row stride in LDS (corr_body: padded for the k-contiguous staging)
     size_t stage = MODE == 0 ? 2 * ((size_t)((CK * P.CS + 64) & ~63) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3))
                              : 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
-    P.dma = (MODE == 0 ? env_int("GGAN_CORR_DMA", 1) : (CK == 16 && env_int("GGAN_DGRAD_DMA", 1))) && (P.dbg & 3) == 0;
+    P.dma = (MODE == 0 ? env_int("GGAN_CORR_DMA", 1) : (CK % 16 == 0 && wc.PW <= 2 && env_int("GGAN_DGRAD_DMA", 1))) && (P.dbg & 3) == 0;
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
