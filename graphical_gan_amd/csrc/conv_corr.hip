@@ -66,6 +66,9 @@ struct CorrParams {
     CorrClass cls[4];
 };
 
+// Compile-time ablations for timing experiments (tools/variant_lib.sh builds a second libggan.so with -DGGAN_ABL=bits and
+// tools/stamps.py prints the per-workgroup phase times): 1 = no staging inside the chunk loop, 4 = MFMAs on register constants
+// instead of LDS fragments.  0 in the product build: the branches fold away.
 #ifndef GGAN_ABL
 #define GGAN_ABL 0
 #endif
