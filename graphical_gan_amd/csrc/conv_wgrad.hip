@@ -121,9 +121,6 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     }
     const bool gvalid = gcol < TCO && (co0 + gcol) < P.Co;
 
-    // zero the slabs once: halo columns and padded channels are never written again
-    for (int e = tid; e < TCI * P.CS; e += NTHR) { smem[e] = 0.f; smem[STG + e] = 0.f; }
-
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -194,6 +191,15 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     const int c_end = min(c_begin + P.chunks_per_split, P.chunks_total);
     stamp(1);
     if (c_begin < c_end) prefetch(c_begin);
+    // zero the slabs once (halo columns and padded channels are never written again) -- under the latency of the first loads;
+    // float4 stores (CS is even, the slab base 16-byte aligned: pairs of channels)
+    {
+        const int n4 = (TCI * P.CS) >> 2;
+        float4* z0 = reinterpret_cast<float4*>(smem);
+        float4* z1 = reinterpret_cast<float4*>(smem + STG);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < n4; e += NTHR) { z0[e] = z; z1[e] = z; }
+    }
     __syncthreads();                        // (slabs zeroed)
     if (c_begin < c_end) commit(0);
     if (c_begin + 1 < c_end) prefetch(c_begin + 1);
