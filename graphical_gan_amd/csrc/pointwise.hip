@@ -412,9 +412,12 @@ __global__ void bce_multi_fwd_k(BceTable t, float* __restrict__ loss) {
         const float* x = t.x[k];
         const float z = t.z[k];
         float s = 0.f;
+        float* gx = t.gx[k];                 // optional: the gradient for a unit upstream gradient (bce_multi_bwd_k with gloss == 1)
+        const float g = 1.f * t.w[k] / (float)t.n[k];
         for (int i = threadIdx.x; i < t.n[k]; i += blockDim.x) {
             float v = x[i];
             s += fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)));
+            if (gx) gx[i] = g * (1.f / (1.f + expf(-v)) - z);
         }
         s = block_sum(s, sm);
         const float r = t.w[k] * (s / (float)t.n[k]);
@@ -1043,6 +1046,17 @@ int ggan_bce_logits_multi_fwd(const float* const* xs, const float* labels, const
     int mx;
     GGAN_CHECK_ARG(bce_table(t, xs, nullptr, labels, weights, ns, count, &mx) == 0, "bad term");
     GGAN_LAUNCH("bce_logits_fwd", 0, 4.0 * mx * count, bce_multi_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, t, loss);
+    return 0;
+}
+
+int ggan_bce_logits_multi_fwd_grad(const float* const* xs, const float* labels, const float* weights, const int* ns, int count,
+                                   float* loss, float* const* gxs, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(xs && labels && weights && ns && loss && gxs, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_BCE_MAX, "count out of range");
+    BceTable t;
+    int mx;
+    GGAN_CHECK_ARG(bce_table(t, xs, gxs, labels, weights, ns, count, &mx) == 0, "bad term");
+    GGAN_LAUNCH("bce_logits_fwd_grad", 0, 8.0 * mx * count, bce_multi_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, t, loss);
     return 0;
 }
 

@@ -189,7 +189,7 @@ class Trainer(object):
             return None
         k, off, cut = plan
         if opt._one is None or opt._one.shape != op.cost.shape:
-            opt._one = torch.ones_like(op.cost)
+            opt._one = F.unit_seed(op.cost)
         with F.defer_wgrad_reduce(self.single_contrib):
             g = torch.autograd.grad(op.cost, list(opt.params[:k]) + cut, grad_outputs=opt._one, allow_unused=True)
             keep = opt.pack_subset(g[:k], 0, k, bump=True)

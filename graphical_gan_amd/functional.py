@@ -1185,6 +1185,18 @@ class RowLerp(Function):
 # ---------------------------------------------------------------------------------------------------
 # losses
 # ---------------------------------------------------------------------------------------------------
+UNIT_SEEDS = {}         # data pointer -> the all-ones tensor an optimizer seeds d(cost)/d(cost) with (kept alive here: an address
+                        # in this table can never belong to another tensor); emptied by optim.reset_optimizers
+
+
+def unit_seed(like):
+    """the persistent ones tensor an optimizer differentiates its cost with; registered so that ops whose forward already
+    produced the gradients for a unit upstream gradient (BceSum) can recognise it"""
+    one = torch.ones_like(like)
+    UNIT_SEEDS[one.data_ptr()] = one
+    return one
+
+
 class BceSum(Function):
     """sum_i weight_i * mean(sigmoid_cross_entropy_with_logits(x_i, label_i)) -> 0-dim tensor; one launch forward and one
     backward for all terms."""
@@ -1197,28 +1209,44 @@ class BceSum(Function):
                 (C.c_float * n)(*[float(w) for w in weights]), (C.c_int * n)(*[x.numel() for x in logits]), n)
 
     @staticmethod
+    def _grad_buffers(logits, device):
+        # one gradient buffer; terms that are adjacent rows of one tensor (the critic evaluated on [fake; real]) get adjacent
+        # slices, so SplitRows.backward can hand the buffer on without a concatenation
+        sizes = [x.numel() for x in logits]
+        buf = torch.empty((sum(sizes),), dtype=torch.float32, device=device)
+        outs, o = [], 0
+        for nn in sizes:
+            outs.append(buf[o:o + nn])
+            o += nn
+        return outs
+
+    @staticmethod
     def forward(ctx, labels, weights, *logits):
         logits = [_c(x).reshape(-1) for x in logits]
         loss = torch.empty((1,), dtype=torch.float32, device=logits[0].device)
         xs, zs, ws, ns, n = BceSum._tables(logits, labels, weights)
-        check(_L().ggan_bce_logits_multi_fwd(xs, zs, ws, ns, n, _p(loss), _stream()), 'ggan_bce_logits_multi_fwd')
         ctx.labels, ctx.weights = labels, weights
+        ctx.unit_grads = None
+        if any(ctx.needs_input_grad[2:]) and not os.environ.get('GGAN_NO_BCE_FWD_GRAD'):
+            # a train op differentiates its cost with a unit seed (UNIT_SEEDS): the gradients for that case leave with the forward
+            # launch; any other upstream gradient takes the backward kernel
+            outs = BceSum._grad_buffers(logits, loss.device)
+            gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+            check(_L().ggan_bce_logits_multi_fwd_grad(xs, zs, ws, ns, n, _p(loss), gxs, _stream()), 'ggan_bce_logits_multi_fwd_grad')
+            ctx.unit_grads = outs
+        else:
+            check(_L().ggan_bce_logits_multi_fwd(xs, zs, ws, ns, n, _p(loss), _stream()), 'ggan_bce_logits_multi_fwd')
         ctx.save_for_backward(*logits)
         return loss.reshape(())
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if ctx.unit_grads is not None and g.data_ptr() in UNIT_SEEDS:
+            return (None, None) + tuple(ctx.unit_grads)
         g = _c(g.reshape(1))
         logits = ctx.saved_tensors
-        # one gradient buffer; terms that are adjacent rows of one tensor (the critic evaluated on [fake; real]) get adjacent
-        # slices, so SplitRows.backward can hand the buffer on without a concatenation
-        sizes = [x.numel() for x in logits]
-        buf = torch.empty((sum(sizes),), dtype=torch.float32, device=g.device)
-        outs, o = [], 0
-        for nn in sizes:
-            outs.append(buf[o:o + nn])
-            o += nn
+        outs = BceSum._grad_buffers(logits, g.device)
         xs, zs, ws, ns, n = BceSum._tables(logits, ctx.labels, ctx.weights)
         gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
         check(_L().ggan_bce_logits_multi_bwd(xs, zs, ws, ns, n, _p(g), gxs, _stream()), 'ggan_bce_logits_multi_bwd')

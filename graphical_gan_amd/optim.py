@@ -93,7 +93,7 @@ class AdamOptimizer(object):
         second pass of the step used tflib.second_leaf (summed by pack)"""
         from . import tflib as lib
         if self._one is None or self._one.shape != cost.shape:
-            self._one = torch.ones_like(cost)            # persistent d(cost)/d(cost) seed (no fill launch per step)
+            self._one = F.unit_seed(cost)            # persistent d(cost)/d(cost) seed (no fill launch per step)
         extra = [lib.second_leaf_for(p) for p in self.params]
         idx = [i for i, e in enumerate(extra) if e is not None]
         if not idx:
@@ -213,3 +213,4 @@ def reset_optimizers(keep_params=True):
             p._flat_owner = None
     _optimizers.clear()
     _pending_state.clear()
+    F.UNIT_SEEDS.clear()

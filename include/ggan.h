@@ -251,6 +251,11 @@ int ggan_bce_logits_multi_fwd(const float* const* xs, const float* labels, const
                               int count, float* loss, ggan_stream_t stream);
 int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns,
                               int count, const float* gloss, float* const* gxs, ggan_stream_t stream);
+/* forward AND the gradients for an upstream gradient of exactly 1 in one launch: gxs[i][j] = weights[i]*(sigmoid(x)-z)/n, bit for
+ * bit what ggan_bce_logits_multi_bwd writes for gloss[0] == 1.  The cost of a train op is differentiated with a unit seed
+ * (tf.gradients(cost, var_list), gan_inference.py:108-117), so the backward launch of the cost disappears from the step. */
+int ggan_bce_logits_multi_fwd_grad(const float* const* xs, const float* labels, const float* weights, const int* ns,
+                                   int count, float* loss, float* const* gxs, ggan_stream_t stream);
 /* loss[0] (+)= weight*mean(x); bwd gx[i] = gloss[0]*weight/n  (wali_gp, gan_inference.py:29-30). */
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
