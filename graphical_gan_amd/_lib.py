@@ -95,6 +95,7 @@ SIGNATURES = {
     'ggan_bce_logits_multi_fwd_grad': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _I, _P, C.POINTER(_P), _P]),
     'ggan_mean_fwd': (_I, [_P, _F, _P, _I, _I, _P]),
     'ggan_mean_bwd': (_I, [_P, _F, _P, _I, _P]),
+    'ggan_mean_multi_fwd_grad': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_I), _I, _P, C.POINTER(_P), _P]),
     'ggan_dist_fwd': (_I, [_P, _P, _P, _Z, _I, _F, _I, _P]),
     'ggan_dist_bwd': (_I, [_P, _P, _P, _P, _P, _Z, _I, _F, _P]),
     'ggan_gp_penalty_fwd': (_I, [_P, _P, _P, _I, _I, _F, _P]),

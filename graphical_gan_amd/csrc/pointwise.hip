@@ -477,6 +477,25 @@ __global__ void mean_fwd_k(const float* __restrict__ x, float weight, float* __r
     }
 }
 
+__global__ void mean_multi_fwd_k(BceTable t, float* __restrict__ loss) {
+    __shared__ float sm[32];
+    float tot = 0.f;
+    for (int k = 0; k < t.count; ++k) {      // terms in order: the same summation order as one accumulating launch per term
+        const float* x = t.x[k];
+        float* gx = t.gx[k];                 // optional: the gradient for a unit upstream gradient (mean_bwd_k with gloss == 1)
+        const float g = 1.f * t.w[k] / (float)t.n[k];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < t.n[k]; i += blockDim.x) {
+            s += x[i];
+            if (gx) gx[i] = g;
+        }
+        s = block_sum(s, sm);
+        const float r = t.w[k] * (s / (float)t.n[k]);
+        tot = k ? tot + r : r;
+    }
+    if (threadIdx.x == 0) loss[0] = tot;
+}
+
 __global__ void mean_bwd_k(const float* __restrict__ gloss, float weight, float* __restrict__ gx, int n) {
     const float g = gloss[0] * weight / (float)n;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) gx[i] = g;
@@ -1088,6 +1107,18 @@ int ggan_dist_bwd(const float* x, const float* y, const float* gout, float* gx, 
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream) {
     GGAN_CHECK_ARG(x && loss && n > 0, "bad argument");
     GGAN_LAUNCH("mean_fwd", 0, 4.0 * n, mean_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, x, weight, loss, n, accumulate);
+    return 0;
+}
+
+int ggan_mean_multi_fwd_grad(const float* const* xs, const float* weights, const int* ns, int count, float* loss, float* const* gxs,
+                             ggan_stream_t stream) {
+    GGAN_CHECK_ARG(xs && weights && ns && loss, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_BCE_MAX, "count out of range");
+    BceTable t;
+    int mx;
+    float zeros[GGAN_BCE_MAX] = {0.f};
+    GGAN_CHECK_ARG(bce_table(t, xs, gxs, zeros, weights, ns, count, &mx) == 0, "bad term");
+    GGAN_LAUNCH("mean_multi_fwd", 0, 8.0 * mx * count, mean_multi_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, t, loss);
     return 0;
 }
 

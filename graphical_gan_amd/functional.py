@@ -1288,16 +1288,31 @@ class MeanSum(Function):
     def forward(ctx, weights, *xs):
         xs = [_c(x).reshape(-1) for x in xs]
         loss = torch.empty((1,), dtype=torch.float32, device=xs[0].device)
-        for i, (x, w) in enumerate(zip(xs, weights)):
-            check(_L().ggan_mean_fwd(_p(x), float(w), _p(loss), x.numel(), int(i > 0), _stream()), 'ggan_mean_fwd')
         ctx.weights = weights
         ctx.sizes = [x.numel() for x in xs]
         ctx.dev = xs[0].device
+        ctx.unit_grads = None
+        n = len(xs)
+        if n <= _lib.BCE_MAX and not os.environ.get('GGAN_NO_BCE_FWD_GRAD'):
+            # one launch for all terms; with it (as BceSum) the gradients for the unit seed of a train op, in ONE buffer so that
+            # the halves of a batched critic's logits get adjacent slices (SplitRows.backward: no concatenation)
+            outs = BceSum._grad_buffers(xs, ctx.dev) if any(ctx.needs_input_grad[1:]) else None
+            px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+            pw = (C.c_float * n)(*[float(w) for w in weights])
+            pn = (C.c_int * n)(*ctx.sizes)
+            pg = (C.c_void_p * n)(*[t.data_ptr() for t in outs]) if outs is not None else None
+            check(_L().ggan_mean_multi_fwd_grad(px, pw, pn, n, _p(loss), pg, _stream()), 'ggan_mean_multi_fwd_grad')
+            ctx.unit_grads = outs
+            return loss.reshape(())
+        for i, (x, w) in enumerate(zip(xs, weights)):
+            check(_L().ggan_mean_fwd(_p(x), float(w), _p(loss), x.numel(), int(i > 0), _stream()), 'ggan_mean_fwd')
         return loss.reshape(())
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if ctx.unit_grads is not None and g.data_ptr() in UNIT_SEEDS:
+            return (None,) + tuple(ctx.unit_grads)
         g = _c(g.reshape(1))
         outs = []
         for n, w in zip(ctx.sizes, ctx.weights):

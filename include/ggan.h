@@ -259,6 +259,11 @@ int ggan_bce_logits_multi_fwd_grad(const float* const* xs, const float* labels, 
 /* loss[0] (+)= weight*mean(x); bwd gx[i] = gloss[0]*weight/n  (wali_gp, gan_inference.py:29-30). */
 int ggan_mean_fwd(const float* x, float weight, float* loss, int n, int accumulate, ggan_stream_t stream);
 int ggan_mean_bwd(const float* gloss, float weight, float* gx, int n, ggan_stream_t stream);
+/* every term of a Wasserstein cost in one launch: loss = sum_i weights[i]*mean(xs[i]) (terms added in index order, as
+ * ggan_mean_fwd with accumulate), and -- gxs non-NULL -- the gradients for an upstream gradient of exactly 1,
+ * gxs[i][:] = weights[i]/ns[i] (what ggan_mean_bwd writes for gloss[0] == 1).  count <= GGAN_BCE_MAX. */
+int ggan_mean_multi_fwd_grad(const float* const* xs, const float* weights, const int* ns, int count, float* loss,
+                             float* const* gxs /* may be NULL */, ggan_stream_t stream);
 
 /* Conv3D of the '3dcnn' sequence critic (tflib/ops/conv3d.py:6-51: tf.nn.conv3d, data NDHWC [N,L,H,W,C], filter [fl,fs,fs,in,out],
  * strides (stride_len, stride, stride), SAME padding; ssgan_inference_moving_mnist.py:352-405).  The filter is already the [K, Co]
