@@ -58,6 +58,7 @@ struct CorrParams {
     unsigned in_bytes, w_bytes;
     int dbg;
     int dma;                      // forward kinds: stage the slab and the filter slice by LDS-DMA (buffer_load ... lds)
+    int xq;                       // 4: the slab is staged in 16-byte units of image rows (forward DMA path, see plan_and_launch), else 1
     unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
     const float* in_ref;     // optional: slab values are in[i] * act'(in_ref[i]) (fused activation backward)
     int in_act;
@@ -176,7 +177,7 @@ template <> struct ClassList<2> { static constexpr int NC = 2; static constexpr 
 template <> struct ClassList<3> { static constexpr int NC = 4; static constexpr int cls(int i) { return i; }
                                   static constexpr int th(int i) { return i < 2 ? 3 : 2; } static constexpr int tw(int i) { return (i & 1) ? 2 : 3; } };
 
-template <int KIND, int SU, int DI, int WM, int WN, int KS, int PW>
+template <int KIND, int SU, int DI, int WM, int WN, int KS, int PW, bool X4 = false>
 __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, float* smem) {
     using CL = ClassList<KIND>;
     constexpr int NC = CL::NC;
@@ -228,7 +229,8 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     // (+1 / +4 rows: trash slots that absorb the commit of staging elements beyond the tile, so commits are branch-free)
     // (forward kinds: the slab region is padded to whole 64-float wave-instructions and the filter slice gets a 256-float tail,
     //  so the zero fill of an LDS-DMA instruction's unused lanes lands in padding)
-    const int XS_SZ = KIND == 0 ? ((CK * P.CS + 64) & ~63) : ((CK * P.CS + 1 + 3) & ~3);
+    constexpr int xq = (KIND == 0 && X4) ? 4 : 1;       // (compile-time: a run-time choice of the DMA size would put branches between the MFMAs)
+    const int XS_SZ = KIND == 0 ? (xq == 4 ? ((CK * P.CS + 511) & ~255) : ((CK * P.CS + 64) & ~63)) : ((CK * P.CS + 1 + 3) & ~3);
     constexpr int WS_USED = NTT * CK * RS;
     const int STAGE = XS_SZ + ((WS_USED + (KIND == 0 ? 256 : 4 * RS) + 3) & ~3);
 
@@ -250,7 +252,10 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     // (the forward DMA path issues the first chunk's loads as soon as each descriptor exists: part of their latency runs under
     //  the rest of the descriptor arithmetic; measured neutral-to-worse for the data-gradient kinds, which keep them together)
     unsigned xvo[XE];
-    const int xe_cnt = CK * P.CS, srsc = P.SR * P.SCp;
+    // (xq == 4: the "elements" are 16-byte units -- 4 consecutive floats of an image row, wholly inside or outside the image --
+    //  and the divisors in P are those of the unit grid)
+    const int CSu = P.CS / xq, SCpu = P.SCp / xq;
+    const int xe_cnt = CK * CSu, srsc = P.SR * SCpu;
 #pragma unroll
     for (int j = 0; j < XE; ++j) {
         const int e = tid + j * NTHR;
@@ -258,11 +263,11 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         if (e < xe_cnt) {
             // (every factor below is < 2^24 and every product < 2^32: full-rate 24-bit multiplies)
             const int ckl = fdiv24(e, P.d_CS);
-            const int r1 = e - __umul24(ckl, P.CS);
+            const int r1 = e - __umul24(ckl, CSu);
             const int img = fdiv24(r1, P.d_SRSC);
             const int r2 = r1 - __umul24(img, srsc);
             const int r = fdiv24(r2, P.d_SCp);
-            const int cc = r2 - __umul24(r, P.SCp);
+            const int cc = (r2 - __umul24(r, SCpu)) * xq;
             const int ih = in_row0 + r, iw = in_col0 + cc, n = n0 + img;
             if (n < P.N && ih >= 0 && ih < P.Hin && iw >= 0 && iw < P.Win)
                 off = (__umul24(__umul24(__umul24(n, P.CKtot) + ckl, P.Hin) + ih, P.Win) + iw) * 4u;
@@ -270,8 +275,12 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         xvo[j] = off;
         if (dma) {
             const int e0 = wave_u * 64 + j * NTHR;
-            if (e0 < xe_cnt)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + e0), 4, off, ck_begin * HWin * 4, 0, 0);
+            if (e0 < xe_cnt) {
+                float* dst = smem + e0 * xq;
+                const int so = ck_begin * HWin * 4;
+                if (xq == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 16, off, so, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 4, off, so, 0, 0);
+            }
         }
     }
     stamp(2);
@@ -439,8 +448,13 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     auto dma_x1 = [&](int j, int ck0, int buf) {                   // forward kinds: one wave-instruction of the slab
         float* xsb = smem + buf * STAGE;
         const int e0 = wave_u * 64 + j * NTHR;
-        if (e0 < xe_cnt)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(xsb + e0), 4, xvo[j], ck0 * HWin * 4, 0, 0);
+        if (e0 < xe_cnt) {
+            float* dst = xsb + e0 * xq;
+            const int so = ck0 * HWin * 4;
+            const unsigned vo = xvo[j];
+            if (xq == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 4, vo, so, 0, 0);
+        }
     };
     auto dma_w1 = [&](int q, int ck0, int buf) {                   // ... of the filter slice
         float* wsb = smem + buf * STAGE + XS_SZ;
@@ -677,14 +691,14 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 }
 
 // MODE 0: fwd.  MODE 1: dgrad class pairs, blockIdx.z = pair * SK + split.  MODE 2: dgrad, all four classes per workgroup.
-template <int MODE, int WM, int WN, int KS, int PW>
+template <int MODE, int WM, int WN, int KS, int PW, bool X4 = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void corr_kernel(const CorrParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     warm_kernarg(P);
     const int grp = blockIdx.z / P.SK, split = blockIdx.z - grp * P.SK;
-    if (MODE == 0) {
-        corr_body<0, 2, 1, WM, WN, KS, PW>(P, split, smem);
-    } else if (MODE == 2) {
+    if constexpr (MODE == 0) {
+        corr_body<0, 2, 1, WM, WN, KS, PW, X4>(P, split, smem);
+    } else if constexpr (MODE == 2) {
         corr_body<3, 1, -1, WM, WN, KS, PW>(P, split, smem);
     } else if (grp == 0) {
         corr_body<1, 1, -1, WM, WN, KS, PW>(P, split, smem);
@@ -766,7 +780,8 @@ bool pick_tile(CorrParams& P, int Hu, int Wv, int TM, int CK, int su, int ext_r,
 
 bool finish_tile(CorrParams& P, int Hu, int Wv) {
     const uint32_t nmax = XE_MAX * 256;
-    if (!make_fastdiv24(P.CS, nmax, &P.d_CS) || !make_fastdiv24(P.SR * P.SCp, nmax, &P.d_SRSC) || !make_fastdiv24(P.SCp, nmax, &P.d_SCp) ||
+    const int xq = P.xq == 4 ? 4 : 1;
+    if (!make_fastdiv24(P.CS / xq, nmax, &P.d_CS) || !make_fastdiv24(P.SR * P.SCp / xq, nmax, &P.d_SRSC) || !make_fastdiv24(P.SCp / xq, nmax, &P.d_SCp) ||
         !make_fastdiv24(P.TR * P.TC, nmax, &P.d_TRTC) || !make_fastdiv24(P.TC, nmax, &P.d_TC))
         return false;
     P.img_groups = cdiv(P.N, P.TI);
@@ -793,9 +808,24 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         allow_big_lds(corr_kernel<2, 1, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 1>); allow_big_lds(corr_kernel<2, 1, 1, 8, 1>);
         allow_big_lds(corr_kernel<2, 2, 2, 2, 1>); allow_big_lds(corr_kernel<0, 2, 1, 4, 2>); allow_big_lds(corr_kernel<2, 2, 1, 4, 2>);
         allow_big_lds(corr_kernel<0, 4, 1, 2, 2>); allow_big_lds(corr_kernel<2, 4, 1, 2, 2>); allow_big_lds(corr_kernel<1, 1, 1, 8, 2>);
+        allow_big_lds(corr_kernel<0, 2, 1, 4, 1, true>); allow_big_lds(corr_kernel<0, 1, 1, 8, 1, true>); allow_big_lds(corr_kernel<0, 2, 2, 2, 1, true>);
+        allow_big_lds(corr_kernel<0, 2, 1, 4, 2, true>); allow_big_lds(corr_kernel<0, 4, 1, 2, 2, true>);
         once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
+    if constexpr (MODE == 0) {
+        if (P.xq == 4) {       // slab staged in 16-byte units (the 8-wave layouts only: plan_and_launch)
+            switch (cfg) {
+                case 4: GGAN_LAUNCH("corr_kernel<0, 2, 1, 4, 1>", fl, 0, (corr_kernel<0, 2, 1, 4, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 5: GGAN_LAUNCH("corr_kernel<0, 1, 1, 8, 1>", fl, 0, (corr_kernel<0, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 6: GGAN_LAUNCH("corr_kernel<0, 2, 2, 2, 1>", fl, 0, (corr_kernel<0, 2, 2, 2, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 7: GGAN_LAUNCH("corr_kernel<0, 2, 1, 4, 2>", fl, 0, (corr_kernel<0, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
+                case 8: GGAN_LAUNCH("corr_kernel<0, 4, 1, 2, 2>", fl, 0, (corr_kernel<0, 4, 1, 2, 2, true>), grid, dim3(512), shmem, s, P); break;
+                default: set_error("%s: no 16-byte-unit variant of wave layout %d", name, cfg); return -3;
+            }
+            return 0;
+        }
+    }
     if constexpr (MODE == 0 || MODE == 2) {
         switch (cfg) {
             case 0: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 1, 2>" : "corr_kernel<2, 2, 2, 1, 2>"), fl, 0, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
@@ -871,6 +901,31 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     const WaveCfg& wc = kCfgs[cfg];
     const int CK = 2 * wc.KS * wc.PW, TM = 32 * wc.WM, TNW = 32 * wc.WN;
     if (!pick_tile(P, Hu, Wv, TM, CK, su, ext_r, ext_c)) return 1;
+    P.dbg = env_int("GGAN_DBG", 0);
+    P.dma = (MODE == 0 ? env_int("GGAN_CORR_DMA", 1) : (CK % 16 == 0 && wc.PW <= 2 && env_int("GGAN_DGRAD_DMA", 1))) && (P.dbg & 3) == 0;
+    const int RS = TNW + (MODE != 0 ? 2 : 0);     // filter row stride in LDS (corr_body: padded for the k-contiguous staging)
+    P.xq = 1;
+    if (MODE == 0 && cfg >= 4 && P.dma && (P.Win & 3) == 0 && (((uintptr_t)P.in) & 15) == 0 && ((su * P.TC) & 3) == 0 && env_int("GGAN_CORR_X4", 1)) {
+        // Slab rows in 16-byte units of the image rows: a dword-gather DMA instruction costs the texture path ~64 cycles (a lane
+        // per cycle) and the slab took 6 of them per wave and chunk -- as much texture-path time as the chunk has MFMA time.  With
+        // the slab columns shifted so that LDS column c holds image column (unit-aligned start) + c, a lane moves 4 floats, and
+        // units wholly outside the image (left / right halo) are the out-of-range lanes that arrive as zeros.
+        const int shift = ((P.col0 % 4) + 4) % 4;
+        const int scp4 = (P.SCp + shift + 3) & ~3;
+        const size_t cs4 = (size_t)P.TI * P.SR * scp4;
+        const size_t stage4 = 2 * ((size_t)((CK * cs4 + 511) & ~(size_t)255) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3));
+        // (not where the wider slab rows push a workgroup over half of the CU's LDS: two forward workgroups of the two graph
+        //  branches then no longer share a CU -- measured +0.8 % on the iteration although the kernel alone is 1.6 % faster)
+        const size_t stage1 = 2 * ((size_t)((CK * P.CS + 64) & ~63) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3));
+        const bool crosses = stage1 * sizeof(float) <= 80 * 1024 && stage4 * sizeof(float) > 80 * 1024;
+        if (stage4 * sizeof(float) <= 160 * 1024 && CK * cs4 / 4 <= (size_t)XE_MAX * 256 && (!crosses || env_int("GGAN_CORR_X4", 1) > 1)) {
+            P.xq = 4;
+            P.col0 -= shift;
+            for (int c = 0; c < 4; ++c) P.cls[c].coff += shift;
+            P.SCp = scp4;
+            P.CS = (int)cs4;
+        }
+    }
     if (!finish_tile(P, Hu, Wv)) return 1;
     if ((size_t)P.N * P.CKtot * P.Hin >= (1u << 24)) return 1;      // the staging descriptors use 24-bit multiplies
     const int gx = P.img_groups * P.tiles_r * P.tiles_c, gy = cdiv(P.CNtot, TNW);
@@ -894,12 +949,9 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     }
     P.out = P.SK > 1 ? (float*)ws : dst;
     P.bias = bias; P.act = act; P.alpha = alpha;
-    P.dbg = env_int("GGAN_DBG", 0);
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
-    const int RS = TNW + (MODE != 0 ? 2 : 0);     // filter row stride in LDS (corr_body: padded for the k-contiguous staging)
-    size_t stage = MODE == 0 ? 2 * ((size_t)((CK * P.CS + 64) & ~63) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3))
+    size_t stage = MODE == 0 ? 2 * ((size_t)(P.xq == 4 ? ((CK * P.CS + 511) & ~255) : ((CK * P.CS + 64) & ~63)) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3))
                              : 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
-    P.dma = (MODE == 0 ? env_int("GGAN_CORR_DMA", 1) : (CK % 16 == 0 && wc.PW <= 2 && env_int("GGAN_DGRAD_DMA", 1))) && (P.dbg & 3) == 0;
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
