@@ -30,6 +30,14 @@ constexpr int XE_MAX = 24;                 // slab elements staged per thread pe
 constexpr unsigned OOB = 0x7FFFFFF0u;      // voffset >= num_records: the buffer load returns 0
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// LDS floats of the forward kinds' staging regions: the data plus the zero fill of the last DMA wave-instruction's unused lanes
+// (exact: the 64x32 layout with 16-byte slab units then needs 2 x 40 KB = exactly half of a CU's LDS), at least 4 floats (the
+// register-staged path parks out-of-tile elements there)
+__host__ __device__ inline int fwd_region(int data_floats, int lanes_used, int floats_per_lane) {
+    const int tail = (((lanes_used + 63) & ~63) - lanes_used) * floats_per_lane;
+    return (data_floats + (tail > 4 ? tail : 4) + 3) & ~3;
+}
+
 struct CorrClass {
     int Hu, Wv;        // pixel grid of this class
     int roff, coff;    // slab row/col of tap (0,0) for pixel (0,0)
@@ -230,9 +238,9 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     // (forward kinds: the slab region is padded to whole 64-float wave-instructions and the filter slice gets a 256-float tail,
     //  so the zero fill of an LDS-DMA instruction's unused lanes lands in padding)
     constexpr int xq = (KIND == 0 && X4) ? 4 : 1;       // (compile-time: a run-time choice of the DMA size would put branches between the MFMAs)
-    const int XS_SZ = KIND == 0 ? (xq == 4 ? ((CK * P.CS + 511) & ~255) : ((CK * P.CS + 64) & ~63)) : ((CK * P.CS + 1 + 3) & ~3);
+    const int XS_SZ = KIND == 0 ? fwd_region(CK * P.CS, CK * P.CS / xq, xq) : ((CK * P.CS + 1 + 3) & ~3);
     constexpr int WS_USED = NTT * CK * RS;
-    const int STAGE = XS_SZ + ((WS_USED + (KIND == 0 ? 256 : 4 * RS) + 3) & ~3);
+    const int STAGE = XS_SZ + (KIND == 0 ? fwd_region(WS_USED, WUNITS, 4) : ((WS_USED + 4 * RS + 3) & ~3));
 
     const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, (short)0, (int)P.in_bytes, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, (short)0, (int)P.w_bytes, 0x00020000);
@@ -913,10 +921,11 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
         const int shift = ((P.col0 % 4) + 4) % 4;
         const int scp4 = (P.SCp + shift + 3) & ~3;
         const size_t cs4 = (size_t)P.TI * P.SR * scp4;
-        const size_t stage4 = 2 * ((size_t)((CK * cs4 + 511) & ~(size_t)255) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3));
+        const int wregion = fwd_region(ntaps * CK * RS, ntaps * CK * (TNW / 4), 4);
+        const size_t stage4 = 2 * ((size_t)fwd_region((int)(CK * cs4), (int)(CK * cs4 / 4), 4) + (size_t)wregion);
         // (not where the wider slab rows push a workgroup over half of the CU's LDS: two forward workgroups of the two graph
         //  branches then no longer share a CU -- measured +0.8 % on the iteration although the kernel alone is 1.6 % faster)
-        const size_t stage1 = 2 * ((size_t)((CK * P.CS + 64) & ~63) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3));
+        const size_t stage1 = 2 * ((size_t)fwd_region(CK * P.CS, CK * P.CS, 1) + (size_t)wregion);
         const bool crosses = stage1 * sizeof(float) <= 80 * 1024 && stage4 * sizeof(float) > 80 * 1024;
         if (stage4 * sizeof(float) <= 160 * 1024 && CK * cs4 / 4 <= (size_t)XE_MAX * 256 && (!crosses || env_int("GGAN_CORR_X4", 1) > 1)) {
             P.xq = 4;
@@ -950,7 +959,7 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     P.out = P.SK > 1 ? (float*)ws : dst;
     P.bias = bias; P.act = act; P.alpha = alpha;
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
-    size_t stage = MODE == 0 ? 2 * ((size_t)(P.xq == 4 ? ((CK * P.CS + 511) & ~255) : ((CK * P.CS + 64) & ~63)) + (size_t)((ntaps * CK * RS + 256 + 3) & ~3))
+    size_t stage = MODE == 0 ? 2 * ((size_t)fwd_region(CK * P.CS, CK * P.CS / P.xq, P.xq) + (size_t)fwd_region(ntaps * CK * RS, ntaps * CK * (TNW / 4), 4))
                              : 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
