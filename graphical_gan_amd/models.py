@@ -525,9 +525,21 @@ class GraphicalGAN(object):
         assert detach or not real_x.requires_grad, 'batched critic with grad_rows: real_x must not require a gradient'
         self.join_side(x_only=True)
         x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
+        fork_h = bool(c.K) and self.fork_nets and self.fork_now and x_cat.is_cuda and not os.environ.get('GGAN_NO_FORK_HYPER')
+        if fork_h:
+            # the mixture critic on (z, k) is a chain of ~12 short launches per direction that reads nothing of the image critic: it
+            # runs on the second stream beside the conv stack (autograd keeps each pass's backward on the stream of its forward)
+            self.join_side()
+            cur = torch.cuda.current_stream(x_cat.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
         d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=self.join_side)
-        if c.K:
+        if fork_h:
+            cur.wait_stream(self._side)
+        elif c.K:
             h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
+        if c.K:
             (hf, hr), (df, dr) = F.SplitRows.apply(h, B), F.SplitRows.apply(d, B)
             return [hf, df], [hr, dr]
         return F.SplitRows.apply(d, B)
