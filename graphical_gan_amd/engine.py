@@ -399,7 +399,8 @@ class Trainer(object):
     def iteration(self, it, batches):
         """batches: iterator of device minibatches (or feed dicts when inject_noise); ignored in ring mode (use_ring)."""
         res = {}
-        if isinstance(self.feed, dict) and self.feed.get('ring') is not None:
+        feed = getattr(self, 'feed', None)
+        if isinstance(feed, dict) and feed.get('ring') is not None:
             kinds = (['gen'] if it > 0 else []) + ['disc'] * self.cfg.critic_iters
             one_graph = (self.graph_enabled and it > 0 and self.world == 1 and not self.split_graph and not self.sync_bn
                          and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))

@@ -138,6 +138,11 @@ def test_loop_step_order():
         t.iteration(1, iter(range(100)))
         assert [x for x in t.log if isinstance(x, str)] == ['gen'] + ['disc'] * ci
         assert [x[1] for x in t.log if not isinstance(x, str)] == list(range(1 + ci))    # fresh minibatch per run
+        # ring mode (Trainer.use_ring): the same step order, nothing copied between the steps; without graphs (or with several
+        # ranks) the iteration stays a sequence of steps
+        t.feed, t.graph_enabled, t.log = {'ring': object()}, False, []
+        t.iteration(2, iter(range(100)))
+        assert t.log == ['gen'] + ['disc'] * ci
 
 
 def test_plot_shim(tmp_path, capsys):
