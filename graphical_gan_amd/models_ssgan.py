@@ -71,6 +71,11 @@ class StateSpaceGAN(object):
 
     def __init__(self, cfg):
         self.cfg = cfg
+        # chains of short launches (the transition operator's scan, the latent critics) go to a second stream beside the conv
+        # stacks while the Trainer builds a single-graph step (fork_now); eager steps keep the reference's op order
+        self._side = None
+        self.fork_nets = not os.environ.get('GGAN_NO_FORK_NETS')
+        self.fork_now = False
 
     # ---- engine hooks: static inputs of one session.run ---------------------------------------------------------------
     def feed_buffers(self, device):
@@ -312,13 +317,33 @@ class StateSpaceGAN(object):
         return gen, lib.params_with_name('Discriminator')
 
     # ---- loss wiring ------------------------------------------------------------------------------------------------------
+    def _fork(self, device):
+        """-> the current stream when a chain of short launches may go to the second stream (a step graph is being captured),
+        with that stream waiting for everything issued so far; else None"""
+        if not (self.fork_nets and self.fork_now) or device.type != 'cuda':
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device)
+        cur = torch.cuda.current_stream(device)
+        self._side.wait_stream(cur)
+        return cur
+
     def forward_nets(self, feed):
         """everything that reads no critic variable (:515-527)"""
         real_y, p_y = feed['real_y'], feed['p_y']
+        # the transition operator's scan is one workgroup per sequence (32 of them) walking LEN-1 steps: it runs on the second
+        # stream beside the Extractor's conv stack over all frames instead of in front of the chip
+        cur = self._fork(feed['p_z_g'].device)
+        if cur is not None:
+            with torch.cuda.stream(self._side):
+                p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
         real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0 / self.cfg.x_div, 0.0, -1.0)      # 2*(x/div-.5)
         q_z_l = self.DynamicExtractor(self.Extractor(real_x, real_y))
         q_z_g = self.G_Extractor(real_x, real_y)
-        p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
+        if cur is not None:
+            cur.wait_stream(self._side)
+        else:
+            p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
         fake_x = self.Generator(feed['p_z_g'], p_z_l, p_y)
         return dict(real_x=real_x, q_z_l=q_z_l, q_z_g=q_z_g, p_z_l=p_z_l, p_z_g=feed['p_z_g'], fake_x=fake_x)
 
@@ -339,13 +364,24 @@ class StateSpaceGAN(object):
                 # data-gradient is needed for the fake frames only
                 nf = c.B * c.LEN
                 assert which == 'disc' or not real_x.requires_grad, 'grad_rows: the real frames must be data'
-                (af, bf), (ar, br) = self._pairs(p_z_l), self._pairs(q_z_l)
-                t = self.DynamicDiscrminator(torch.cat([af, ar], 0), torch.cat([bf, br], 0))
-                zg = self.ZGDiscrminator(torch.cat([p_z_g, q_z_g], 0))
+                # the two latent critics (MLP chains of short launches) run on the second stream beside the frame critic's conv stack
+                cur = self._fork(real_x.device)
+
+                def latent_critics():
+                    (af, bf), (ar, br) = self._pairs(p_z_l), self._pairs(q_z_l)
+                    return (self.DynamicDiscrminator(torch.cat([af, ar], 0), torch.cat([bf, br], 0)),
+                            self.ZGDiscrminator(torch.cat([p_z_g, q_z_g], 0)))
+                if cur is not None:
+                    with torch.cuda.stream(self._side):
+                        t, zg = latent_critics()
+                else:
+                    t, zg = latent_critics()
                 d = self._frame_critic(torch.cat([fake_x.reshape(nf, -1), real_x.reshape(nf, -1)], 0),
                                        torch.cat([self._z_rows(p_z_g, p_z_l, p_y), self._z_rows(q_z_g, q_z_l, real_y)], 0),
                                        torch.cat([self.expand_labels(p_y), self.expand_labels(real_y)], 0),
                                        grad_rows=nf if which == 'gen' else None)
+                if cur is not None:
+                    cur.wait_stream(self._side)
                 (tf_, tr_), (zf, zr), (df, dr) = (F.SplitRows.apply(t, (c.LEN - 1) * c.B), F.SplitRows.apply(zg, c.B),
                                                   F.SplitRows.apply(d, nf))
                 disc_fake, disc_real = [tf_, zf, df], [tr_, zr, dr]
