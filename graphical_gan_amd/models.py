@@ -235,7 +235,7 @@ class GraphicalGAN(object):
             return z, mean, std
         return lib.ops.linear.Linear('Extractor.Output', c.flat, c.dim_latent, out, out=out_slot)
 
-    def Discriminator(self, x, z, grad_rows=None, twice=False, before_z=None):
+    def Discriminator(self, x, z, grad_rows=None, twice=False, before_z=None, z_out=None):
         """grad_rows: only the first grad_rows images of x carry a gradient (generator steps: [fake; real]); twice: the result
         will be differentiated twice (gradient-penalty pass): plain layer composition instead of the fused critic tail"""
         c = self.cfg
@@ -248,7 +248,8 @@ class GraphicalGAN(object):
         out = out.reshape(-1, c.flat)
         if before_z is not None:
             before_z()               # (forward_nets: z's second half may still be in flight on the other stream)
-        z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
+        if z_out is None:            # (else: _critic already ran the z path on the second stream)
+            z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
         if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):
             # Linear on concat([out, z_out], 1) + LeakyReLU + the 512 -> 1 Output layer as one op
             return lib.ops.linear.LinearLReLULinear('Discriminator.zx1', c.flat + 512, 512, 'Discriminator.Output', (out, z_out),
@@ -397,6 +398,9 @@ class GraphicalGAN(object):
             # where their results are first read (join_side): real_x before the critic's first layer, q_z before its z path --
             # a cross-queue dependency that completed long ago costs nothing, one that completes last costs ~11 us of idle chip
             cur = torch.cuda.current_stream(p_z.device)
+            ev_noise = torch.cuda.Event()
+            ev_noise.record(cur)                      # (p_z exists on this stream from here on: the critic's z path reads it there)
+            self._noise_event = ev_noise
             with torch.cuda.stream(self._side):
                 real_x = self.real_x(feed, xs[1])
                 ev_x = torch.cuda.Event()
@@ -525,6 +529,18 @@ class GraphicalGAN(object):
         assert detach or not real_x.requires_grad, 'batched critic with grad_rows: real_x must not require a gradient'
         self.join_side(x_only=True)
         x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
+        z_out = None
+        pj = self._pending_join
+        if pj is not None and not os.environ.get('GGAN_NO_Z_PATH_FORK'):
+            # the Extractor pass is still running on the second stream: the critic's z path (a Linear on [p_z ; q_z]: two short
+            # launches, and two more in the backward pass) follows it THERE, off this stream's chain of conv launches; the join
+            # before the critic's tail then waits for z_out instead of q_z
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._noise_event)
+                z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z_cat, LRELU)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                pj[2] = ev
         fork_h = bool(c.K) and self.fork_nets and self.fork_now and x_cat.is_cuda and not os.environ.get('GGAN_NO_FORK_HYPER')
         if fork_h:
             # the mixture critic on (z, k) is a chain of ~12 short launches per direction that reads nothing of the image critic: it
@@ -534,7 +550,7 @@ class GraphicalGAN(object):
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
-        d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=self.join_side)
+        d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=self.join_side, z_out=z_out)
         if fork_h:
             cur.wait_stream(self._side)
         elif c.K:
