@@ -349,7 +349,7 @@ class GraphicalGAN(object):
         branches and the Extractor pass needs no noise, the second stream is forked here, with nothing in front of it."""
         c = self.cfg
         self._early = False
-        if not (self.fork_nets and self.fork_now) or c.K or c.agg or c.dataset in ('face', 'mnist') or os.environ.get('GGAN_NO_EARLY_FORK'):
+        if not (self.fork_nets and self.fork_now) or c.K or c.agg or c.dataset == 'mnist' or os.environ.get('GGAN_NO_EARLY_FORK'):
             return
         dev = feed['p_z_noise'].device
         if dev.type != 'cuda' or not (c.batch_critic and 'z_pair' in feed):
@@ -402,6 +402,8 @@ class GraphicalGAN(object):
             ev_noise.record(cur)                      # (p_z exists on this stream from here on: the critic's z path reads it there)
             self._noise_event = ev_noise
             with torch.cuda.stream(self._side):
+                if c.dataset == 'face':
+                    self._side.wait_event(ev_noise)       # (the dequantisation noise of the 64x64 scripts comes from the noise launch)
                 real_x = self.real_x(feed, xs[1])
                 ev_x = torch.cuda.Event()
                 ev_x.record(self._side)
@@ -548,9 +550,18 @@ class GraphicalGAN(object):
             self.join_side()
             cur = torch.cuda.current_stream(x_cat.device)
             self._side.wait_stream(cur)
+            ev_z = torch.cuda.Event()
             with torch.cuda.stream(self._side):
+                if z_out is None and not os.environ.get('GGAN_NO_Z_PATH_FORK'):
+                    z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z_cat, LRELU)      # (the image critic's z path too)
+                    ev_z.record(self._side)
+                else:
+                    ev_z = None
                 h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
-        d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=self.join_side, z_out=z_out)
+            before = (lambda: cur.wait_event(ev_z)) if ev_z is not None else self.join_side
+            d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=before, z_out=z_out)
+        else:
+            d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=self.join_side, z_out=z_out)
         if fork_h:
             cur.wait_stream(self._side)
         elif c.K:
