@@ -349,7 +349,7 @@ class GraphicalGAN(object):
         branches and the Extractor pass needs no noise, the second stream is forked here, with nothing in front of it."""
         c = self.cfg
         self._early = False
-        if not (self.fork_nets and self.fork_now) or c.K or c.agg or c.dataset == 'mnist' or os.environ.get('GGAN_NO_EARLY_FORK'):
+        if not (self.fork_nets and self.fork_now) or (c.K and os.environ.get('GGAN_NO_EARLY_FORK_K')) or c.agg or c.dataset == 'mnist' or os.environ.get('GGAN_NO_EARLY_FORK'):
             return
         dev = feed['p_z_noise'].device
         if dev.type != 'cuda' or not (c.batch_critic and 'z_pair' in feed):
@@ -402,17 +402,21 @@ class GraphicalGAN(object):
             ev_noise.record(cur)                      # (p_z exists on this stream from here on: the critic's z path reads it there)
             self._noise_event = ev_noise
             with torch.cuda.stream(self._side):
-                if c.dataset == 'face':
-                    self._side.wait_event(ev_noise)       # (the dequantisation noise of the 64x64 scripts comes from the noise launch)
+                if c.dataset == 'face' or c.K:
+                    self._side.wait_event(ev_noise)       # (dequantisation noise of the 64x64 scripts / Gumbel noise of the mixture scripts)
                 real_x = self.real_x(feed, xs[1])
                 ev_x = torch.cuda.Event()
                 ev_x.record(self._side)
                 q_z = self.Extractor(real_x, zs[1])
+                out = dict(real_x=real_x, q_z=q_z, p_z=p_z)
+                if c.K:
+                    ks = F.RowSlot(feed['k_pair'], B, 2 * B) if (c.batch_critic and 'k_pair' in feed) else None
+                    _, out['q_k'] = self.HyperExtractor(q_z, feed['gumbel_u'], ks)
                 ev_end = torch.cuda.Event()
                 ev_end.record(self._side)
             self._pending_join = [cur, ev_x, ev_end]
-            fake_x = self.Generator(p_z, xs[0])
-            return dict(real_x=real_x, q_z=q_z, p_z=p_z, fake_x=fake_x)
+            out['fake_x'] = self.Generator(p_z, xs[0])
+            return out
         if fork:
             cur = torch.cuda.current_stream(p_z.device)
             if self._side is None:
@@ -547,9 +551,10 @@ class GraphicalGAN(object):
         if fork_h:
             # the mixture critic on (z, k) is a chain of ~12 short launches per direction that reads nothing of the image critic: it
             # runs on the second stream beside the conv stack (autograd keeps each pass's backward on the stream of its forward)
-            self.join_side()
             cur = torch.cuda.current_stream(x_cat.device)
-            self._side.wait_stream(cur)
+            if pj is None:          # (else the second stream still carries the Extractor branch and the z path: the mixture critic follows them)
+                self.join_side()
+                self._side.wait_stream(cur)
             ev_z = torch.cuda.Event()
             with torch.cuda.stream(self._side):
                 if z_out is None and not os.environ.get('GGAN_NO_Z_PATH_FORK'):
