@@ -76,9 +76,10 @@ class GraphicalGAN(object):
         # two-stream Extractor / Generator passes: measured +3 % (ali, face, mnist), -5..7 % with the gradient penalty (more
         # cross-stream edges than overlap), so the joint-critic modes without a penalty ask for it; the Trainer
         # turns it on while it builds a single-graph step (fork_now) -- eager steps are host-bound and gain nothing
-        # (round 2, after the kernels got shorter: +1.5 % with the mixture prior too; still -6.6 % for wali-gp)
+        # (round 2, after the kernels got shorter: +1.5 % with the mixture prior too; wali-gp: -6.6 % with the fork behind the noise
+        #  launch and an immediate join, +1.3 % once the Extractor branch is a root of the graph and carries the critic's z path)
         self.fork_nets = (not os.environ.get('GGAN_NO_FORK_NETS')
-                          and cfg.mode in ('ali', 'alice', 'alice-z', 'alice-x', 'wali', 'local_ep', 'local_epce')) or bool(os.environ.get('GGAN_FORCE_FORK_NETS'))
+                          and cfg.mode in ('ali', 'alice', 'alice-z', 'alice-x', 'wali', 'wali-gp', 'local_ep', 'local_epce')) or bool(os.environ.get('GGAN_FORCE_FORK_NETS'))
         self.fork_now = False
 
     # ---- engine hooks: the static inputs of one session.run (what the reference feeds / samples) -----------------
