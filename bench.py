@@ -376,6 +376,8 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
     del tr, ring, bi
     optim.reset_optimizers()
     lib.delete_all_params()
+    from graphical_gan_amd import functional as _F
+    _F._WS.clear()                     # (per-stream scratch of the streams that just died)
     gc.collect()
     torch.cuda.empty_cache()
     return res

@@ -229,7 +229,7 @@ class Trainer(object):
     def _capture_impl(self, which):
         # warm-up eagerly on a side stream (allocator + lazy init), restoring optimizer state afterwards
         if getattr(self, '_cap_stream', None) is None:
-            self._cap_stream = torch.cuda.Stream(device=self.device)    # warm-up AND capture run on this stream, so the
+            self._cap_stream = F.shared_stream(self.device, 'capture')  # warm-up AND capture run on this stream, so the
         s = self._cap_stream                                            # per-stream scratch buffers exist before capture
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -367,7 +367,7 @@ class Trainer(object):
             self.model.fork_now = True
         try:
             if getattr(self, '_cap_stream', None) is None:
-                self._cap_stream = torch.cuda.Stream(device=self.device)
+                self._cap_stream = F.shared_stream(self.device, 'capture')
             s = self._cap_stream
             s.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(s):

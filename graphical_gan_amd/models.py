@@ -356,7 +356,7 @@ class GraphicalGAN(object):
         if dev.type != 'cuda' or not (c.batch_critic and 'z_pair' in feed):
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(dev)
+            self._side = F.shared_stream(dev, 'side')
         self._side.wait_stream(torch.cuda.current_stream(dev))
         self._early = True
 
@@ -421,7 +421,7 @@ class GraphicalGAN(object):
         if fork:
             cur = torch.cuda.current_stream(p_z.device)
             if self._side is None:
-                self._side = torch.cuda.Stream(p_z.device)
+                self._side = F.shared_stream(p_z.device, 'side')
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 fake_x = self.Generator(p_z, xs[0])

@@ -323,7 +323,7 @@ class StateSpaceGAN(object):
         if not (self.fork_nets and self.fork_now) or device.type != 'cuda':
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(device)
+            self._side = F.shared_stream(device, 'side')
         cur = torch.cuda.current_stream(device)
         self._side.wait_stream(cur)
         return cur
