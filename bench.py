@@ -245,7 +245,7 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
         # counts) instead of through a staging buffer, and one iteration is one graph replay (Trainer.use_ring)
         try:
             tr.use_ring(ring)
-            feed_mode = 'device-resident ring, read in place' + ('; one graph per iteration' if (world == 1 and not args.no_graph) else '')
+            feed_mode = 'device-resident ring, read in place' + ('; one graph per iteration' if ((world == 1 or getattr(tr, 'dp_graph', False)) and not args.no_graph) else '')
         except (ValueError, RuntimeError):
             pass
     for _ in range(max(warmup, 2)):                    # includes graph capture
@@ -422,8 +422,9 @@ def main():
     local_dev = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
-    if world > 1:
+    if world > 1 or os.environ.get('GGAN_FORCE_ALLREDUCE'):     # (forced: a one-rank rehearsal of the RCCL-in-graph path)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:

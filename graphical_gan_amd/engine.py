@@ -11,6 +11,7 @@ device inside the graph.  With data parallelism the graph is split around the gr
 [fwd+bwd+pack] -> RCCL all-reduce of the flat bucket -> [Adam].
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -29,6 +30,18 @@ _CAPTURE_MODE = os.environ.get('GGAN_CAPTURE_MODE', 'thread_local')
 _DP_GRAPH_OK = {}
 
 
+def quiesce_collectives(device):
+    """Call before capturing a graph that contains a collective.  The process group's watchdog thread polls the completion events of
+    eagerly issued collectives; on this stack (PyTorch 2.10 / ROCm 7) a poll of such an event while the communicator's stream is
+    being captured -- it is, as soon as the capture reaches a collective -- raises "operation not permitted on an event last
+    recorded in a capturing stream" in the watchdog thread, which terminates the process (tools/nccl_graph_probe.py: 0 of 5 runs
+    survive a capture issued right after an eager all-reduce).  Once the device is idle the watchdog retires its finished work
+    within one poll interval (100 ms); after that pause nothing is left to poll during the capture (6 of 6 survive)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        torch.cuda.synchronize(device)
+        time.sleep(float(os.environ.get('GGAN_NCCL_QUIESCE_S', '0.6')))
+
+
 def dp_graph_selftest(device):
     """Can this process group's all-reduce be captured in a HIP graph and replayed?  Every rank captures a tiny sum-all-reduce,
     replays it twice and checks the result; the verdicts are combined with an ordinary (eager) MIN all-reduce so that all
@@ -44,7 +57,7 @@ def dp_graph_selftest(device):
         s.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
             dist.all_reduce(t.clone())                    # (communicator warm-up outside the capture)
-            torch.cuda.synchronize(device)
+            quiesce_collectives(device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
                 u = t * 1.0
@@ -226,6 +239,33 @@ class Trainer(object):
             if forkable:
                 self.model.fork_now = False
 
+    def _step_body(self, which):
+        """one whole step as it is captured into a single graph: forward, backward, pack, (gradient exchange), update"""
+        st = None
+        if self.dp_graph and which == 'gen':
+            # two gradient buckets inside the one graph: the Generator's bucket is on the wire (the process group's
+            # stream: a parallel branch of the graph) while the Extractor's backward pass still runs
+            nets = self._nets()
+            cut = self.model.cut_tensors(nets) if hasattr(self.model, 'cut_tensors') else None
+            st = self._bwd_phase1(nets) if (cut and not os.environ.get('GGAN_ONE_BUCKET')) else None
+            if st is not None:
+                opt, cost = st['opt'], st['cost']
+                w1 = opt.all_reduce(async_op=True, lo=0, hi=st['off'])
+                keep = (st['keep'], self._bwd_phase2(st), st, nets)
+                w2 = opt.all_reduce(async_op=True, lo=st['off'], hi=None)
+                for w in (w1, w2):
+                    if w is not None:
+                        w.wait()
+            else:
+                cost, opt, keep = self._fwd_bwd(which, nets)
+                opt.all_reduce()
+        else:
+            cost, opt, keep = self._fwd_bwd(which)
+            if self.dp_graph:
+                opt.all_reduce()
+        opt.update()
+        return cost, opt, keep
+
     def _capture_impl(self, which):
         # warm-up eagerly on a side stream (allocator + lazy init), restoring optimizer state afterwards
         if getattr(self, '_cap_stream', None) is None:
@@ -246,32 +286,12 @@ class Trainer(object):
                 rng.copy_(rng_snap)
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
+        if self.dp_graph:
+            quiesce_collectives(self.device)
         g1 = torch.cuda.CUDAGraph()
         if not self.split_graph:
             with torch.cuda.graph(g1, stream=s, capture_error_mode=_CAPTURE_MODE):
-                st = None
-                if self.dp_graph and which == 'gen':
-                    # two gradient buckets inside the one graph: the Generator's bucket is on the wire (the process group's
-                    # stream: a parallel branch of the graph) while the Extractor's backward pass still runs
-                    nets = self._nets()
-                    cut = self.model.cut_tensors(nets) if hasattr(self.model, 'cut_tensors') else None
-                    st = self._bwd_phase1(nets) if (cut and not os.environ.get('GGAN_ONE_BUCKET')) else None
-                    if st is not None:
-                        opt, cost = st['opt'], st['cost']
-                        w1 = opt.all_reduce(async_op=True, lo=0, hi=st['off'])
-                        keep = (st['keep'], self._bwd_phase2(st), st, nets)
-                        w2 = opt.all_reduce(async_op=True, lo=st['off'], hi=None)
-                        for w in (w1, w2):
-                            if w is not None:
-                                w.wait()
-                    else:
-                        cost, opt, keep = self._fwd_bwd(which, nets)
-                        opt.all_reduce()
-                else:
-                    cost, opt, keep = self._fwd_bwd(which)
-                    if self.dp_graph:
-                        opt.all_reduce()
-                opt.update()
+                cost, opt, keep = self._step_body(which)
             return dict(g0=None, g1=g1, g1b=None, split=None, g2=None, cost=cost, opt=opt, keep=keep)
         # data parallel: [forward + backward + pack] -> all-reduce -> [Adam].  Every step is cut once more, after the
         # Extractor/Generator passes (g0): they read no critic variable, so they run while the previous critic step's gradient
@@ -383,12 +403,13 @@ class Trainer(object):
                     rng.copy_(rng_snap)
             torch.cuda.current_stream(self.device).wait_stream(s)
             torch.cuda.synchronize(self.device)
+            if self.dp_graph:
+                quiesce_collectives(self.device)
             g = torch.cuda.CUDAGraph()
             costs, keeps = {}, []
             with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
                 for k in kinds:
-                    cost, opt, keep = self._fwd_bwd(k)
-                    opt.update()
+                    cost, opt, keep = self._step_body(k)          # (with the in-graph gradient exchange when there are replicas)
                     costs[k + '_cost'] = cost
                     keeps.append((opt, keep))
             return dict(g=g, costs=costs, keep=keeps, kinds=tuple(kinds))
@@ -402,7 +423,7 @@ class Trainer(object):
         feed = getattr(self, 'feed', None)
         if isinstance(feed, dict) and feed.get('ring') is not None:
             kinds = (['gen'] if it > 0 else []) + ['disc'] * self.cfg.critic_iters
-            one_graph = (self.graph_enabled and it > 0 and self.world == 1 and not self.split_graph and not self.sync_bn
+            one_graph = (self.graph_enabled and it > 0 and (self.world == 1 or self.dp_graph) and not self.split_graph and not self.sync_bn
                          and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
             if not one_graph:
                 for k in kinds:

@@ -438,6 +438,25 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert len(d2['variants']) == 1 and d2['variants'][0]['n_gpus'] == 2 and d2['variants'][0]['value'] > 0
 
 
+def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
+    """The driver's N > 1 launch puts the gradient exchange (RCCL all-reduce) INSIDE the captured graphs.  One rank over RCCL is
+    enough to rehearse that on a single-GPU box (GGAN_FORCE_ALLREDUCE): the capture must survive the process group's watchdog
+    thread (engine.quiesce_collectives -- without it the process aborts), replay, and produce finite costs, for the headline
+    workload (one graph per iteration) and one variant."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GGAN_FORCE_ALLREDUCE='1')
+    port = 29400 + (os.getpid() % 200)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '6', '--warmup', '2',
+                        '--variants', 'wali-gp', '--variant-steps', '3', '--no-cpu-baseline', '--repeats', '0'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['value'] > 0 and d['config']['finite_costs'] and 'one graph per iteration' in d['config']['minibatch_feed']
+    assert d['variants'][0]['value'] > 0 and d['variants'][0]['config']['finite_costs']
+
+
 @pytest.mark.parametrize('mode,K', [('ali', 0), ('local_ep', 30)])
 def test_full_size_training_is_bitwise_reproducible(gpu, mode, K):
     """BASELINE-size step (batch 64, HIP-graph replay, two-stream nets pass for ali, on-device noise): two runs from the same
