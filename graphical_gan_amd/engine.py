@@ -259,12 +259,47 @@ class Trainer(object):
             else:
                 cost, opt, keep = self._fwd_bwd(which, nets)
                 opt.all_reduce()
+        elif self.dp_graph and which == 'disc' and hasattr(self.model, 'critic_cut') and not os.environ.get('GGAN_ONE_BUCKET'):
+            cost, opt, keep = self._disc_two_buckets()
         else:
             cost, opt, keep = self._fwd_bwd(which)
             if self.dp_graph:
                 opt.all_reduce()
         opt.update()
         return cost, opt, keep
+
+    def _disc_two_buckets(self):
+        """critic step with two gradient buckets: autograd reaches the critic's tail first, and that is where most of the bytes
+        are (Discriminator.zx1: 2.6 M of the 4.1 M parameters) -- its bucket is exchanged while the conv stack's backward pass
+        (two thirds of the critic's backward time) still runs; the conv stack's bucket follows.  Same sums as one bucket."""
+        out = self.model.forward(self.feed, 'disc', self._nets())
+        op = out['disc_train_op']
+        opt = op.optimizer
+        cutinfo = self.model.critic_cut()
+        sp = None
+        if cutinfo is not None:
+            conv = tuple('Discriminator.%d.' % (i + 1) for i in range(cutinfo[1]))
+            sp = opt.split_at(lambda p: getattr(p, 'param_name', '').startswith(conv))
+        if opt._one is None or opt._one.shape != op.cost.shape:
+            opt._one = F.unit_seed(op.cost)
+        if sp is None:
+            with F.defer_wgrad_reduce(self.single_contrib):
+                keep = opt.pack(opt.compute_gradients(op.cost))
+            opt.all_reduce()
+            return out['disc_cost'].detach(), opt, (keep, out)
+        k, off = sp
+        cut = cutinfo[0]
+        with F.defer_wgrad_reduce(self.single_contrib):
+            g = torch.autograd.grad(op.cost, list(opt.params[k:]) + [cut], grad_outputs=opt._one, allow_unused=True)
+            keep_a = opt.pack_subset(g[:-1], k, len(opt.params), bump=True)
+            w1 = opt.all_reduce(async_op=True, lo=off, hi=None)
+            g2 = torch.autograd.grad([cut], opt.params[:k], grad_outputs=[g[-1]], allow_unused=True)
+            keep_b = opt.pack_subset(g2, 0, k, bump=False)
+            w2 = opt.all_reduce(async_op=True, lo=0, hi=off)
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
+        return out['disc_cost'].detach(), opt, (keep_a, keep_b, g, g2, out)
 
     def _capture_impl(self, which):
         # warm-up eagerly on a side stream (allocator + lazy init), restoring optimizer state afterwards

@@ -97,6 +97,15 @@ class GraphicalGAN(object):
         Generator's gradients while the Extractor's backward pass is still running (engine.Trainer)."""
         return [nets['q_z']] if self.cfg.mode in ('ali', 'local_ep', 'wali', 'wali-gp') else None   # (vegan: G(q_z) re-enters)
 
+    def critic_cut(self):
+        """(tensor, number of conv layers) through which every gradient of the image critic's conv stack flows in the critic step
+        just built, or None (the wali-gp penalty re-enters the stack): lets a data-parallel critic step put the head's large
+        weight gradient (Discriminator.zx1: 10 of the 16 MB) on the wire while the conv stack's backward pass still runs."""
+        t = getattr(self, '_critic_features', None)
+        if t is None or not t.requires_grad or self.cfg.mode not in ('ali', 'local_ep', 'wali') or not self.cfg.batch_critic:
+            return None
+        return t, self.cfg.nl
+
     def feed_buffers(self, device):
         c, B, feed = self.cfg, self.cfg.B, {}
         if c.dataset == 'mnist':
@@ -247,6 +256,7 @@ class GraphicalGAN(object):
             out = self._conv('Discriminator.%d' % (i + 1), ch, cout, out, LRELU, grad_rows)   # dropout == identity
             ch = cout
         out = out.reshape(-1, c.flat)
+        self._critic_features = out      # (Trainer: every gradient of the conv stack's parameters flows through here -- critic_cut)
         if before_z is not None:
             before_z()               # (forward_nets: z's second half may still be in flight on the other stream)
         if z_out is None:            # (else: _critic already ran the z path on the second stream)

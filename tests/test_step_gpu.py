@@ -457,6 +457,25 @@ def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
     assert d['variants'][0]['value'] > 0 and d['variants'][0]['config']['finite_costs']
 
 
+def test_in_graph_exchange_two_buckets_one_rank_bit_identical(gpu):
+    """tools/dp_one_rank_check.py: six one-graph iterations with the gradient exchange inside the graph (one rank over RCCL) --
+    generator step and critic step in two buckets each, the same with GGAN_ONE_BUCKET=1, and no exchange at all -- end in
+    bit-identical weights (the bucket boundaries only decide WHEN a gradient range is summed over the replicas)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for i, extra in enumerate((dict(GGAN_FORCE_ALLREDUCE='1'), dict(GGAN_FORCE_ALLREDUCE='1', GGAN_ONE_BUCKET='1'), dict())):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra)
+        r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                            '127.0.0.1', '--master-port', str(29300 + (os.getpid() % 200) + i), os.path.join(root, 'tools', 'dp_one_rank_check.py'),
+                            'ali', '0'], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        line = [l for l in r.stdout.splitlines() if l.startswith('CHECK')]
+        assert r.returncode == 0 and line, (r.stdout[-500:], r.stderr[-2000:])
+        assert ('dp_graph=True' in line[0]) == bool(extra) and 'one_graph=True' in line[0], line[0]
+        sums.append(line[0].split()[-1])
+    assert sums[0] == sums[1] == sums[2], sums
+
+
 @pytest.mark.parametrize('mode,K', [('ali', 0), ('local_ep', 30)])
 def test_full_size_training_is_bitwise_reproducible(gpu, mode, K):
     """BASELINE-size step (batch 64, HIP-graph replay, two-stream nets pass for ali, on-device noise): two runs from the same
