@@ -9,6 +9,7 @@ Layer names are the reference's, so the registry keys mat
 `fuse=True` folds bias+activation into the producing conv/linear/BN kernel (identical math, fewer HBM passes).
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -101,7 +102,8 @@ class GraphicalGAN(object):
         """(tensor, number of conv layers) through which every gradient of the image critic's conv stack flows in the critic step
         just built, or None (the wali-gp penalty re-enters the stack): lets a data-parallel critic step put the head's large
         weight gradient (Discriminator.zx1: 10 of the 16 MB) on the wire while the conv stack's backward pass still runs."""
-        t = getattr(self, '_critic_features', None)
+        ref = getattr(self, '_critic_features', None)
+        t = ref() if ref is not None else None
         if t is None or not t.requires_grad or self.cfg.mode not in ('ali', 'local_ep', 'wali') or not self.cfg.batch_critic:
             return None
         return t, self.cfg.nl
@@ -256,7 +258,10 @@ class GraphicalGAN(object):
             out = self._conv('Discriminator.%d' % (i + 1), ch, cout, out, LRELU, grad_rows)   # dropout == identity
             ch = cout
         out = out.reshape(-1, c.flat)
-        self._critic_features = out      # (Trainer: every gradient of the conv stack's parameters flows through here -- critic_cut)
+        # (Trainer.critic_cut: every gradient of the conv stack's parameters flows through here.  A WEAK reference: the tape keeps the
+        #  tensor alive until its backward pass; a strong one would carry the previous step's tape into the next graph capture, which
+        #  ROCm answers with a crash in hipStreamEndCapture -- INTEGRATION.md 3d)
+        self._critic_features = weakref.ref(out)
         if before_z is not None:
             before_z()               # (forward_nets: z's second half may still be in flight on the other stream)
         if z_out is None:            # (else: _critic already ran the z path on the second stream)
