@@ -383,6 +383,50 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
     return res
 
 
+def supervise():
+    """N > 1: every rank process that torch.distributed.run starts is only a supervisor; the measurement runs in a child process
+    per rank (same arguments, process group of its own on MASTER_PORT + 1 + attempt).  Attempt 0 captures the gradient exchange
+    inside the step graphs.  Where captured collectives do not work on a stack the failure is not an exception but an ABORT of the
+    rank process (engine.quiesce_collectives), and the other ranks would then sit in a collective until its timeout -- so the
+    supervisors watch a key in the launcher's store: the first child that dies sets it, everybody stops their child, and
+    attempt 1 runs the same benchmark with the exchange issued by the host between cut graphs (GGAN_DP_GRAPH=0).  The JSON line
+    of the attempt that finished is passed through by rank 0."""
+    import datetime
+    import subprocess
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    base_port = int(os.environ.get('MASTER_PORT', '29500'))
+    store = dist.TCPStore(os.environ.get('MASTER_ADDR', '127.0.0.1'), base_port, is_master=False, timeout=datetime.timedelta(seconds=120))
+    modes = ([os.environ['GGAN_DP_GRAPH']] if 'GGAN_DP_GRAPH' in os.environ else ['1']) + ['0']
+    for attempt, dp_graph in enumerate(modes[:2] if modes[0] != '0' else modes[:1]):
+        env = dict(os.environ, GGAN_BENCH_CHILD='1', GGAN_DP_GRAPH=dp_graph, MASTER_PORT=str(base_port + 1 + attempt))
+        env.pop('TORCHELASTIC_USE_AGENT_STORE', None)      # (the children's rank 0 hosts the store of their process group)
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True)
+        fail_key = 'ggan_bench/attempt%d/failed' % attempt
+        t_start, limit = time.time(), float(os.environ.get('GGAN_BENCH_ATTEMPT_TIMEOUT_S', '600'))
+        while p.poll() is None:
+            hung = attempt == 0 and len(modes) > 1 and time.time() - t_start > limit      # (a capture that deadlocks instead of aborting)
+            if hung or store.check([fail_key]):
+                p.kill()
+                break
+            time.sleep(0.5)
+        out = p.communicate()[0]
+        rc = p.returncode
+        if rc != 0:
+            store.set(fail_key, b'1')
+        store.set('ggan_bench/attempt%d/rank%d' % (attempt, rank), str(rc).encode())
+        store.wait(['ggan_bench/attempt%d/rank%d' % (attempt, r) for r in range(world)], datetime.timedelta(seconds=3600))
+        if not store.check([fail_key]):
+            if rank == 0:
+                sys.stdout.write(out)
+                sys.stdout.flush()
+            return 0
+        if rank == 0:
+            sys.stderr.write('[bench] attempt %d (GGAN_DP_GRAPH=%s) did not finish on every rank%s\n' % (
+                attempt, dp_graph, ': retrying with host-issued exchanges between cut graphs' if attempt == 0 and len(modes) > 1 and modes[0] != '0' else ''))
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -407,6 +451,8 @@ def main():
                     help='minibatches start in host memory (pinned double-buffered H->D copies): the PCIe-inclusive rate')
     args = ap.parse_args()
 
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not os.environ.get('GGAN_BENCH_CHILD') and not os.environ.get('GGAN_BENCH_NO_SUPERVISOR'):
+        return supervise()
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -430,6 +476,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if os.environ.get('GGAN_BENCH_ABORT_TEST') == '%s:%s' % (os.environ.get('GGAN_DP_GRAPH', '1'), rank):
+        os.abort()                                         # (tests: a rank that dies the way a failed captured collective kills it)
     import __graft_entry__ as ge
     ge.build()
     env = dict(dev=dev, world=world, rank=rank)
@@ -483,4 +531,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

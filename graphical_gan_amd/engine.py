@@ -39,7 +39,26 @@ def quiesce_collectives(device):
     within one poll interval (100 ms); after that pause nothing is left to poll during the capture (6 of 6 survive)."""
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
         torch.cuda.synchronize(device)
-        time.sleep(float(os.environ.get('GGAN_NCCL_QUIESCE_S', '0.6')))
+        time.sleep(float(os.environ.get('GGAN_NCCL_QUIESCE_S', '1.0')))
+
+
+_GRAPH_GROUP = []
+
+
+def graph_group(device):
+    """A process group of its own for captured collectives (all ranks call this at the same point: Trainer construction).  The
+    hazard described in quiesce_collectives needs eager work on the communicator whose stream is being captured; this group only
+    ever sees one eager all-reduce -- the communicator warm-up below, retired before anything is captured."""
+    if not _GRAPH_GROUP:
+        g = dist.new_group(backend='nccl')
+        t = torch.ones(256, device=device)
+        dist.all_reduce(t, group=g)
+        torch.cuda.synchronize(device)
+        time.sleep(1.0)                                   # (its one eager piece of work retires: see quiesce_collectives)
+        from . import optim
+        optim.set_graph_group(g)
+        _GRAPH_GROUP.append(g)
+    return _GRAPH_GROUP[0]
 
 
 def dp_graph_selftest(device):
@@ -52,6 +71,7 @@ def dp_graph_selftest(device):
     ok = 1.0
     try:
         world = dist.get_world_size()
+        gg = graph_group(device)
         t = torch.ones(256, device=device)
         s = torch.cuda.Stream(device=device)
         s.wait_stream(torch.cuda.current_stream(device))
@@ -61,7 +81,7 @@ def dp_graph_selftest(device):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
                 u = t * 1.0
-                dist.all_reduce(u)
+                dist.all_reduce(u, group=gg)
                 v = u + 1.0
             for _ in range(2):
                 g.replay()

@@ -436,6 +436,15 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     d2 = json.loads(lines[0])
     assert d2['n_gpus'] == 2 and d2['scaling'] == 'weak' and d2['config']['global_batch'] == 128 and d2['value'] > 0
     assert len(d2['variants']) == 1 and d2['variants'][0]['n_gpus'] == 2 and d2['variants'][0]['value'] > 0
+    # a rank that dies in the first attempt the way a failed captured collective kills it (abort): the supervisors stop that
+    # attempt on every rank and the second one -- exchanges issued by the host between cut graphs -- delivers the line
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port + 3), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+                        '--no-variants', '--no-cpu-baseline', '--no-kernel-profile', '--repeats', '0'],
+                       capture_output=True, text=True, timeout=900, env=dict(env2, GGAN_BENCH_ABORT_TEST='1:1'), cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2 and 'retrying with host-issued exchanges' in r.stderr
 
 
 def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
