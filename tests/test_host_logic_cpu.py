@@ -283,3 +283,29 @@ def test_optimizer_returns_contribution_pairs(lib):
     g = Opt([a, b, c]).compute_gradients(cost)
     assert isinstance(g[0], tuple) and float(g[0][0][0]) == 2.0 and float(g[0][1][0]) == 5.0
     assert torch.is_tensor(g[1]) and float(g[1][0]) == 3.0 and g[2] is None
+
+
+def test_fastdiv24_is_exact_for_every_tile_divisor():
+    """csrc/conv.h make_fastdiv24 / fdiv24: floor(n / d) as one 24-bit multiply and a shift, used for the per-thread staging
+    descriptors of the correlation kernels (n <= XE_MAX * 256 = 6144).  The same arithmetic restated with numpy integers: for every
+    divisor a tile can produce, the chosen (mul, shift) keeps both factors below 2^24, the product below 2^32, and is exact for
+    every numerator."""
+    nmax = 24 * 256
+    n = np.arange(nmax + 1, dtype=np.uint64)
+    for d in list(range(1, 1025)) + [1408, 2047, 2048, 3071, 4096, 6143, 6144]:
+        if d <= 1:
+            mul, shift = 1, 0
+        else:
+            mul = shift = None
+            for s in range(31, 0, -1):
+                m = ((1 << s) + d - 1) // d
+                if m >= (1 << 24) or m * nmax >= (1 << 32):
+                    continue
+                err = m * d - (1 << s)
+                assert nmax * err < (1 << s), (d, s)          # make_fastdiv24 returns false here: never for these ranges
+                mul, shift = m, s
+                break
+            assert mul is not None, d
+        assert mul < (1 << 24) and mul * nmax < (1 << 32)
+        q = (n * np.uint64(mul)) >> np.uint64(shift)
+        assert np.array_equal(q, n // np.uint64(d)), d
