@@ -629,14 +629,17 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         if (cn >= P.CNtot) continue;
         const int ca = NC == 4 ? 2 * gsel : gsel, cb = NC == 4 ? 2 * gsel + 1 : gsel;
         float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+        // (all KS partials fetched first, then added in k order: the rolled loop paid one LDS round trip per k)
+        float4 ta[KS], tb[KS];
+#pragma unroll
         for (int k = 0; k < KS; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(red + ((k * NC + ca) * TNW + cnl) * TMW + 4 * p4);
-            va[0] += t.x; va[1] += t.y; va[2] += t.z; va[3] += t.w;
-            if (NC == 4) {
-                const float4 t2 = *reinterpret_cast<const float4*>(red + ((k * NC + cb) * TNW + cnl) * TMW + 4 * p4);
-                vb[0] += t2.x; vb[1] += t2.y; vb[2] += t2.z; vb[3] += t2.w;
-            }
+            ta[k] = *reinterpret_cast<const float4*>(red + ((k * NC + ca) * TNW + cnl) * TMW + 4 * p4);
+            if (NC == 4) tb[k] = *reinterpret_cast<const float4*>(red + ((k * NC + cb) * TNW + cnl) * TMW + 4 * p4);
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            va[0] += ta[k].x; va[1] += ta[k].y; va[2] += ta[k].z; va[3] += ta[k].w;
+            if (NC == 4) { vb[0] += tb[k].x; vb[1] += tb[k].y; vb[2] += tb[k].z; vb[3] += tb[k].w; }
         }
         if (direct) {
             const float bv = P.bias ? P.bias[cn] : 0.f;
