@@ -396,7 +396,14 @@ def supervise():
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     base_port = int(os.environ.get('MASTER_PORT', '29500'))
-    store = dist.TCPStore(os.environ.get('MASTER_ADDR', '127.0.0.1'), base_port, is_master=False, timeout=datetime.timedelta(seconds=120))
+    try:
+        if os.environ.get('TORCHELASTIC_USE_AGENT_STORE', 'True') not in ('True', 'true', '1'):
+            raise RuntimeError('the launcher hosts no store on MASTER_PORT')
+        store = dist.TCPStore(os.environ.get('MASTER_ADDR', '127.0.0.1'), base_port, is_master=False, timeout=datetime.timedelta(seconds=60))
+    except Exception as e:                                # noqa: BLE001
+        if rank == 0:
+            sys.stderr.write('[bench] no launcher store to supervise through (%s): measuring in this process, exchanges between cut graphs\n' % type(e).__name__)
+        return None
     modes = ([os.environ['GGAN_DP_GRAPH']] if 'GGAN_DP_GRAPH' in os.environ else ['1']) + ['0']
     for attempt, dp_graph in enumerate(modes[:2] if modes[0] != '0' else modes[:1]):
         env = dict(os.environ, GGAN_BENCH_CHILD='1', GGAN_DP_GRAPH=dp_graph, MASTER_PORT=str(base_port + 1 + attempt))
@@ -452,7 +459,10 @@ def main():
     args = ap.parse_args()
 
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not os.environ.get('GGAN_BENCH_CHILD') and not os.environ.get('GGAN_BENCH_NO_SUPERVISOR'):
-        return supervise()
+        rc = supervise()
+        if rc is not None:
+            return rc
+        os.environ.setdefault('GGAN_DP_GRAPH', '0')       # (no launcher store to coordinate a retry through: take the path that cannot abort)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
