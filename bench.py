@@ -248,6 +248,13 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
             feed_mode = 'device-resident ring, read in place' + ('; one graph per iteration' if ((world == 1 or getattr(tr, 'dp_graph', False)) and not args.no_graph) else '')
         except (ValueError, RuntimeError):
             pass
+    if args.host_feed and not args.no_ring and not ssgan and cfg.dataset != 'mnist':
+        # host minibatches go straight into the ring's slots on a copy stream, one iteration ahead (Trainer.use_host_ring)
+        try:
+            tr.use_host_ring(lambda: iter(host_ring))
+            feed_mode = 'host -> device ring on a copy stream, one iteration ahead; read in place'
+        except (ValueError, RuntimeError, KeyError):
+            pass
     for _ in range(max(warmup, 2)):                    # includes graph capture
         tr.iteration(it, bi); it += 1
 

@@ -73,3 +73,45 @@ class DevicePrefetcher(object):
         slot['read'].record(torch.cuda.current_stream(self.device))
         dev = slot['dev']
         return dev[0] if len(dev) == 1 else tuple(dev)
+
+
+class RingFeeder(object):
+    """Host minibatches -> the device-resident ring that Trainer.use_ring reads in place (no staging buffer, one graph per
+    iteration).  fill(first, count) copies the next `count` host minibatches into ring slots first .. first+count-1 (mod R) on a
+    COPY stream -- pinned staging buffer -> slot by a copy kernel reading host memory over PCIe, as DevicePrefetcher -- and
+    returns the event the consuming stream waits for; before a slot is overwritten the copy stream waits for the replay that
+    last read it (`done` events handed in by the Trainer).  With R >= 3 iterations' worth of slots the transfer of iteration
+    i+1 runs under the replay of iteration i."""
+
+    def __init__(self, get_epoch, device, ring, dtype=np.int32, pick=None):
+        self.src = DevicePrefetcher(get_epoch, device, pick=pick, dtypes=[dtype])
+        self.device, self.ring = torch.device(device), ring
+        self.R = ring.shape[0]
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.pinned = [torch.empty(ring[0].shape, dtype=ring.dtype).pin_memory() for _ in range(self.R)]
+        self.read_done = [None] * self.R                 # copy kernel that last read pinned[i]
+        self.slot_free = [None] * self.R                 # replay that last read ring[i] (set by the Trainer)
+
+    def fill(self, first, count):
+        from . import functional as F
+        assert count <= self.R
+        with torch.cuda.stream(self.stream):
+            for j in range(count):
+                i = (first + j) % self.R
+                host = self.src._next_host()[0]
+                if self.read_done[i] is not None:
+                    self.read_done[i].synchronize()      # (the host buffer is about to be rewritten)
+                np.copyto(self.pinned[i].numpy(), host.reshape(self.pinned[i].shape))
+                if self.slot_free[i] is not None:
+                    self.stream.wait_event(self.slot_free[i])
+                n = self.pinned[i].numel()
+                F.pack_([self.pinned[i].view(torch.float32).reshape(-1)], [(0, n)], self.ring[i].view(torch.float32).reshape(-1))
+                self.read_done[i] = torch.cuda.Event()
+                self.read_done[i].record(self.stream)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return ev
+
+    def mark_read(self, first, count, event):
+        for j in range(count):
+            self.slot_free[(first + j) % self.R] = event

@@ -159,6 +159,22 @@ class Trainer(object):
     def set_batch(self, batch):
         self.model.set_batch(self.feed, batch)
 
+    def use_host_ring(self, get_epoch, slots=None, pick=None):
+        """use_ring fed from HOST memory: get_epoch() returns an iterator of host minibatches (numpy, the placeholder's shape);
+        a data.RingFeeder copies them into the ring's slots on a copy stream, one iteration ahead of the replay that reads them,
+        so the PCIe transfer runs under the previous iteration instead of in front of every step."""
+        from .data import RingFeeder
+        per_it = 1 + self.cfg.critic_iters
+        R = int(slots) if slots else 4 * per_it
+        assert R >= 3 * per_it, 'the ring must hold three iterations of minibatches'
+        like = self.feed['real_x_int']
+        ring = torch.zeros((R,) + tuple(like.shape), dtype=torch.int32, device=self.device)
+        self.use_ring(list(ring))                         # (stacks a copy: take the Trainer's tensor as the feeder's target)
+        ring = self.feed['ring'][0]
+        self._feeder = RingFeeder(get_epoch, self.device, ring, pick=pick)
+        self._ring_pos = 0                                # steps taken since use_ring == next slot to be read
+        self._ring_ready = self._feeder.fill(0, per_it)   # the first iteration's minibatches
+
     def use_ring(self, batches):
         """batches: equal-shape int32 device minibatches (model.synthetic_ring, or a loader's staging slots).  From here on every
         step reads its minibatch from this ring inside its own launches -- slot (generator steps taken + critic steps taken) mod R,
@@ -474,26 +490,23 @@ class Trainer(object):
 
     def iteration(self, it, batches):
         """batches: iterator of device minibatches (or feed dicts when inject_noise); ignored in ring mode (use_ring)."""
-        res = {}
         feed = getattr(self, 'feed', None)
         if isinstance(feed, dict) and feed.get('ring') is not None:
             kinds = (['gen'] if it > 0 else []) + ['disc'] * self.cfg.critic_iters
-            one_graph = (self.graph_enabled and it > 0 and (self.world == 1 or self.dp_graph) and not self.split_graph and not self.sync_bn
-                         and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
-            if not one_graph:
-                for k in kinds:
-                    res[k + '_cost'] = self.step(k)
-                return res
-            for k in kinds:
-                self._calls[k] += 1
-            if all(self._calls[k] >= 2 for k in set(kinds)):
-                lib.end_build_phase()        # (as step(): every kind has been built once)
-            rec = getattr(self, '_iter_graph', None)
-            if rec is None or rec['kinds'] != tuple(kinds):
-                self.flush()
-                rec = self._iter_graph = self._capture_iteration(kinds)
-            rec['g'].replay()
-            return dict(rec['costs'])
+            feeder = getattr(self, '_feeder', None)
+            if feeder is None:
+                return self._iteration_ring(it, kinds)
+            # host-fed ring: this iteration's slots were filled while the previous one ran; the next iteration's are issued now
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._ring_ready)
+            res = self._iteration_ring(it, kinds)
+            done = torch.cuda.Event()
+            done.record(cur)
+            feeder.mark_read(self._ring_pos, len(kinds), done)
+            self._ring_pos += len(kinds)
+            self._ring_ready = feeder.fill(self._ring_pos, 1 + self.cfg.critic_iters)
+            return res
+        res = {}
 
         def load(b):
             if isinstance(b, dict):
@@ -507,6 +520,23 @@ class Trainer(object):
             load(next(batches))
             res['disc_cost'] = self.step('disc')
         return res
+
+    def _iteration_ring(self, it, kinds):
+        """ring mode: the steps of an iteration with nothing issued between them -- as ONE graph replay where that is possible"""
+        one_graph = (self.graph_enabled and it > 0 and (self.world == 1 or self.dp_graph) and not self.split_graph and not self.sync_bn
+                     and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
+        if not one_graph:
+            return {k + '_cost': self.step(k) for k in kinds}
+        for k in kinds:
+            self._calls[k] += 1
+        if all(self._calls[k] >= 2 for k in set(kinds)):
+            lib.end_build_phase()        # (as step(): every kind has been built once)
+        rec = getattr(self, '_iter_graph', None)
+        if rec is None or rec['kinds'] != tuple(kinds):
+            self.flush()
+            rec = self._iter_graph = self._capture_iteration(kinds)
+        rec['g'].replay()
+        return dict(rec['costs'])
 
     # ---- parameters -------------------------------------------------------------------------------------
     def load_params(self, params):

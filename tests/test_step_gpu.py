@@ -609,7 +609,7 @@ def test_ring_feed_one_graph_per_iteration_matches_staging_buffer(gpu, mode, cri
     from graphical_gan_amd.models import Config
     from graphical_gan_amd.engine import Trainer
     finals = []
-    for use_ring in (False, True):
+    for use_ring in (False, True, 'host'):
         _fresh()
         np.random.seed(0)
         cfg = Config('cifar10', batch_size=16, n_coms=0, mode=mode, dim=16, dim_latent=32)
@@ -621,8 +621,12 @@ def test_ring_feed_one_graph_per_iteration_matches_staging_buffer(gpu, mode, cri
         for it in range(2):                       # eager: parameters + optimizers
             tr.iteration(it, batches)
             taken += (1 if it > 0 else 0) + crit
-        if use_ring:
-            k = taken % len(ring)
+        k = taken % len(ring)
+        if use_ring == 'host':
+            # Trainer.use_host_ring: the same minibatches from HOST memory, copied into the ring's slots one iteration ahead
+            host = [b.cpu().numpy() for b in ring[k:] + ring[:k]]
+            tr.use_host_ring(lambda: iter(host))
+        elif use_ring:
             tr.use_ring(ring[k:] + ring[:k])      # the ring continues where the iterator stands
         for it in range(2, 7):
             res = tr.iteration(it, batches)
@@ -632,6 +636,6 @@ def test_ring_feed_one_graph_per_iteration_matches_staging_buffer(gpu, mode, cri
         torch.cuda.synchronize()
         assert all(np.isfinite(float(v)) for v in res.values())
         finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}))
-    assert finals[0][1] == finals[1][1]
+    assert finals[0][1] == finals[1][1] == finals[2][1]
     for k in finals[0][0]:
-        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
+        assert np.array_equal(finals[0][0][k], finals[1][0][k]) and np.array_equal(finals[0][0][k], finals[2][0][k]), k
