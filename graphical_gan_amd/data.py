@@ -84,7 +84,8 @@ class RingFeeder(object):
     i+1 runs under the replay of iteration i."""
 
     def __init__(self, get_epoch, device, ring, dtype=np.int32, pick=None):
-        self.src = DevicePrefetcher(get_epoch, device, pick=pick, dtypes=[dtype])
+        """get_epoch: callable returning an iterator of host minibatches, or a DevicePrefetcher whose host iterator is continued"""
+        self.src = get_epoch if isinstance(get_epoch, DevicePrefetcher) else DevicePrefetcher(get_epoch, device, pick=pick, dtypes=[dtype])
         self.device, self.ring = torch.device(device), ring
         self.R = ring.shape[0]
         self.stream = torch.cuda.Stream(device=self.device)

@@ -77,6 +77,11 @@ def train(S, cfg, model=None, out_dir=None):
             f.write('data source: %s\n' % source)
     t0 = time.time()
     for it in range(S['ITERS']):
+        if (it == 2 and isinstance(batches, DevicePrefetcher) and S.get('RING_FEED', True) and tr.graph_enabled
+                and isinstance(tr.feed, dict) and 'real_x_int' in tr.feed and tr.world == 1):
+            # int32 image data from a loader: from here on the host minibatches go into a device ring one iteration ahead and an
+            # iteration is one graph replay (Trainer.use_host_ring); the loader's host iterator is continued where it stands
+            tr.use_host_ring(batches)
         res = tr.iteration(it, batches)
         if it % S.get('LOG_EVERY', 100) == 0 or it == S['ITERS'] - 1:
             for k, v in res.items():

@@ -321,6 +321,8 @@ def test_driver_loop_on_loader_data(gpu, tmp_path, monkeypatch):
     tr = run.train(dict(DATASET='cifar10', BATCH_SIZE=8, ITERS=5, LOG_EVERY=2, DATA_DIR=str(tmp_path)),
                    Config('cifar10', batch_size=8, dim=8, dim_latent=16))
     assert tr.feed['real_x_int'].dtype.is_floating_point is False and int(tr.feed['real_x_int'].max()) <= 255
+    # (int32 image data: from the third iteration on the loader feeds the device ring one iteration ahead, one graph per iteration)
+    assert getattr(tr, '_feeder', None) is not None and tr._iter_graph is not None and int(tr.feed['ring'][0].max()) <= 255
     _fresh()
     cfg = SSConfig(batch_size=4, length=3, dim=4, dim_op=16, dim_g=8, dim_l=4)
     tr = run.train(dict(DATASET='moving_mnist', BATCH_SIZE=4, LEN=3, N_C=10, ITERS=4, LOG_EVERY=2), cfg, model=StateSpaceGAN(cfg))
