@@ -237,7 +237,11 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     // (+1 / +4 rows: trash slots that absorb the commit of staging elements beyond the tile, so commits are branch-free)
     // (forward kinds: the slab region is padded to whole 64-float wave-instructions and the filter slice gets a 256-float tail,
     //  so the zero fill of an LDS-DMA instruction's unused lanes lands in padding)
-    constexpr int xq = (KIND == 0 && X4) ? 4 : 1;       // (compile-time: a run-time choice of the DMA size would put branches between the MFMAs)
+    constexpr int xq = X4 ? 4 : 1;       // (compile-time: a run-time choice of the unit size would put branches between the MFMAs)
+    // data-gradient kinds with 16-byte units: the slab goes through registers as whole units (one b128 load + one b128 LDS write
+    // for what took four dword loads and writes); XN units per thread cover the slab with its rows padded to unit multiples
+    constexpr bool XR4 = KIND != 0 && X4;
+    constexpr int XN = XR4 ? (XE + 3) / 4 + 1 : XE;
     const int XS_SZ = KIND == 0 ? fwd_region(CK * P.CS, CK * P.CS / xq, xq) : ((CK * P.CS + 1 + 3) & ~3);
     constexpr int WS_USED = NTT * CK * RS;
     const int STAGE = XS_SZ + (KIND == 0 ? fwd_region(WS_USED, WUNITS, 4) : ((WS_USED + 4 * RS + 3) & ~3));
@@ -252,20 +256,26 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     const bool dma = KIND == 0 && P.dma != 0;        // forward kinds: slab and filter slice by LDS-DMA
     const bool wdma = WD && P.dma != 0;             // data-gradient kinds: filter slice by LDS-DMA, slab through registers
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    unsigned xreg[XE], xref[XE];
+    unsigned xreg[XR4 ? 1 : XE], xref[XR4 ? 1 : XE];
+    u32x4 xreg4[XR4 ? XN : 1], xref4[XR4 ? XN : 1];
+    if constexpr (XR4) {
 #pragma unroll
-    for (int j = 0; j < XE; ++j) xref[j] = 0x3f800000u;      // 1.0f: "positive" reference = identity mask when unmasked
+        for (int j = 0; j < XN; ++j) xref4[j] = u32x4{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+    } else {
+#pragma unroll
+        for (int j = 0; j < XE; ++j) xref[j] = 0x3f800000u;      // 1.0f: "positive" reference = identity mask when unmasked
+    }
 
     // ---- per-thread staging descriptors (fixed across chunks) ---------------------------------------------
     // (the forward DMA path issues the first chunk's loads as soon as each descriptor exists: part of their latency runs under
     //  the rest of the descriptor arithmetic; measured neutral-to-worse for the data-gradient kinds, which keep them together)
-    unsigned xvo[XE];
+    unsigned xvo[XN];
     // (xq == 4: the "elements" are 16-byte units -- 4 consecutive floats of an image row, wholly inside or outside the image --
     //  and the divisors in P are those of the unit grid)
     const int CSu = P.CS / xq, SCpu = P.SCp / xq;
     const int xe_cnt = CK * CSu, srsc = P.SR * SCpu;
 #pragma unroll
-    for (int j = 0; j < XE; ++j) {
+    for (int j = 0; j < XN; ++j) {
         const int e = tid + j * NTHR;
         unsigned off = OOB;
         if (e < xe_cnt) {
@@ -371,6 +381,14 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     auto prefetch = [&](int ck0, bool with_w = true) {
         const int soff_x = ck0 * HWin * 4;
         const int soff_w = ck0 * P.w_sk * 4;
+        if constexpr (XR4) {
+#pragma unroll
+            for (int j = 0; j < XN; ++j) xreg4[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, xvo[j], soff_x, 0);
+            if (masked) {
+#pragma unroll
+                for (int j = 0; j < XN; ++j) xref4[j] = __builtin_amdgcn_raw_buffer_load_b128(rref, xvo[j], soff_x, 0);
+            }
+        } else {
         if (!(P.dbg & 512)) {
 #pragma unroll
         for (int j = 0; j < XE; ++j) xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, xvo[j], soff_x, 0);
@@ -378,6 +396,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         if (masked) {
 #pragma unroll
             for (int j = 0; j < XE; ++j) xref[j] = __builtin_amdgcn_raw_buffer_load_b32(rref, xvo[j], soff_x, 0);
+        }
         }
         if (with_w && !(P.dbg & 256)) {
 #pragma unroll
@@ -392,12 +411,26 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         float* xsb = smem + buf * STAGE;
         float* wsb = xsb + XS_SZ;
         // straight-line: elements beyond the tile (their loads returned 0) land in a trash slot instead of being predicated
+        if constexpr (XR4) {
+#pragma unroll
+            for (int j = 0; j < XN; ++j) {
+                const int e = tid + j * NTHR;
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float a = __uint_as_float(xreg4[j][c]);
+                    v[c] = __uint_as_float(xref4[j][c]) > 0.f ? a : a * mslope;
+                }
+                *reinterpret_cast<f32x4*>(xsb + 4 * min(e, xe_cnt)) = v;      // (unit e = floats [4e, 4e+4): rows are whole units)
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < XE; ++j) {
             const int e = tid + j * NTHR;
             float v = __uint_as_float(xreg[j]);
             if (CAN_MASK) v = __uint_as_float(xref[j]) > 0.f ? v : v * mslope;
             xsb[min(e, xe_cnt)] = v;
+        }
         }
         if (with_w)
 #pragma unroll
@@ -513,7 +546,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
         //  128 cycles of a pair -- more per pair and the waves queue up at the issue port again)
         constexpr int WD_DPS = (WQ + WD_STEPS - 2) / (WD_STEPS - 1);                      // filter blocks per pair
         constexpr int WD_S0 = (WQ + WD_DPS - 1) / WD_DPS < WD_STEPS - 1 ? (WQ + WD_DPS - 1) / WD_DPS : WD_STEPS - 1;   // first slab pair
-        constexpr int WD_SPS = (XE + WD_STEPS - WD_S0 - 1) / (WD_STEPS - WD_S0);          // slab loads per pair
+        constexpr int WD_SPS = (XN + WD_STEPS - WD_S0 - 1) / (WD_STEPS - WD_S0);          // slab loads per pair
         prefetch(ck_begin, false);
         stage_w(ck_begin, 0);
         commit(0, false);
@@ -537,9 +570,14 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
                     if (q < WQ && (q < WQ - 1 || wso[WQ - 1] >= 0)) stage_w1(q, ckn, buf ^ 1);
 #pragma unroll
                 for (int j = (g - WD_S0) * WD_SPS; j < (g - WD_S0 + 1) * WD_SPS; ++j)
-                    if (j >= 0 && j < XE) {
-                        xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
-                        if (masked) xref[j] = __builtin_amdgcn_raw_buffer_load_b32(rref, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
+                    if (j >= 0 && j < XN) {
+                        if constexpr (XR4) {
+                            xreg4[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
+                            if (masked) xref4[j] = __builtin_amdgcn_raw_buffer_load_b128(rref, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
+                        } else {
+                            xreg[j] = __builtin_amdgcn_raw_buffer_load_b32(rin, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
+                            if (masked) xref[j] = __builtin_amdgcn_raw_buffer_load_b32(rref, more2 ? xvo[j] : OOB, ck2 * HWin * 4, 0);
+                        }
                     }
             };
             if constexpr (WD) {
@@ -551,9 +589,9 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
                 if constexpr (NC > 2) mma_taps_wd<CL::th(2), CL::tw(2), DI, PW, TS, S1 + S2>(xs, ws + (NT0 + NT1) * TS, xfrag[2], wfrag_wd, P.CS, P.SCp, acc[2], hook);
                 if constexpr (NC > 3) mma_taps_wd<CL::th(3), CL::tw(3), DI, PW, TS, S1 + S2 + S3>(xs, ws + (NT0 + NT1 + NT2) * TS, xfrag[3], wfrag_wd, P.CS, P.SCp, acc[3], hook);
             }
-            static_assert(2 * XE < 64, "vmcnt field");
-            if (masked) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XE) : "memory");
+            static_assert(2 * XN < 64, "vmcnt field");
+            if (masked) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XN) : "memory");
             __syncthreads();
             if (it_ < 8) stamp(4 + it_);
             ++it_;
@@ -710,11 +748,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void corr_kernel(const CorrParam
     if constexpr (MODE == 0) {
         corr_body<0, 2, 1, WM, WN, KS, PW, X4>(P, split, smem);
     } else if constexpr (MODE == 2) {
-        corr_body<3, 1, -1, WM, WN, KS, PW>(P, split, smem);
+        corr_body<3, 1, -1, WM, WN, KS, PW, X4>(P, split, smem);
     } else if (grp == 0) {
-        corr_body<1, 1, -1, WM, WN, KS, PW>(P, split, smem);
+        corr_body<1, 1, -1, WM, WN, KS, PW, X4>(P, split, smem);
     } else {
-        corr_body<2, 1, -1, WM, WN, KS, PW>(P, split, smem);
+        corr_body<2, 1, -1, WM, WN, KS, PW, X4>(P, split, smem);
     }
 }
 
@@ -805,6 +843,9 @@ void allow_big_lds(K kernel) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+// wave layouts of the data-gradient kinds that have a 16-byte-unit variant (launch_cfg)
+bool dgrad_x4_cfg(int mode, int cfg) { return mode == 1 ? (cfg == 4 || cfg == 5 || cfg == 7) : (cfg == 5 || cfg == 6 || cfg == 7); }
+
 template <int MODE>
 int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_t s, const char* name, double fl) {
     static bool once = false;
@@ -821,6 +862,8 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         allow_big_lds(corr_kernel<0, 4, 1, 2, 2>); allow_big_lds(corr_kernel<2, 4, 1, 2, 2>); allow_big_lds(corr_kernel<1, 1, 1, 8, 2>);
         allow_big_lds(corr_kernel<0, 2, 1, 4, 1, true>); allow_big_lds(corr_kernel<0, 1, 1, 8, 1, true>); allow_big_lds(corr_kernel<0, 2, 2, 2, 1, true>);
         allow_big_lds(corr_kernel<0, 2, 1, 4, 2, true>); allow_big_lds(corr_kernel<0, 4, 1, 2, 2, true>);
+        allow_big_lds(corr_kernel<1, 2, 1, 4, 2, true>); allow_big_lds(corr_kernel<1, 1, 1, 8, 1, true>); allow_big_lds(corr_kernel<1, 1, 1, 8, 2, true>);
+        allow_big_lds(corr_kernel<2, 1, 1, 8, 1, true>); allow_big_lds(corr_kernel<2, 2, 1, 4, 2, true>); allow_big_lds(corr_kernel<2, 2, 2, 2, 1, true>);
         once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
@@ -833,6 +876,26 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
                 case 7: GGAN_LAUNCH("corr_kernel<0, 2, 1, 4, 2, true>", fl, 0, (corr_kernel<0, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
                 case 8: GGAN_LAUNCH("corr_kernel<0, 4, 1, 2, 2, true>", fl, 0, (corr_kernel<0, 4, 1, 2, 2, true>), grid, dim3(512), shmem, s, P); break;
                 default: set_error("%s: no 16-byte-unit variant of wave layout %d", name, cfg); return -3;
+            }
+            return 0;
+        }
+    }
+    if constexpr (MODE == 2) {
+        if (P.xq == 4) {
+            switch (cfg) {
+                case 5: GGAN_LAUNCH("corr_kernel<2, 1, 1, 8, 1, true>", fl, 0, (corr_kernel<2, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 6: GGAN_LAUNCH("corr_kernel<2, 2, 2, 2, 1, true>", fl, 0, (corr_kernel<2, 2, 2, 2, 1, true>), grid, dim3(512), shmem, s, P); break;
+                default: GGAN_LAUNCH("corr_kernel<2, 2, 1, 4, 2, true>", fl, 0, (corr_kernel<2, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
+            }
+            return 0;
+        }
+    }
+    if constexpr (MODE == 1) {
+        if (P.xq == 4) {
+            switch (cfg) {
+                case 4: GGAN_LAUNCH("corr_kernel<1, 2, 1, 4, 2, true>", fl, 0, (corr_kernel<1, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
+                case 5: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 1, true>", fl, 0, (corr_kernel<1, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
+                default: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 2, true>", fl, 0, (corr_kernel<1, 1, 1, 8, 2, true>), grid, dim3(512), shmem, s, P); break;
             }
             return 0;
         }
@@ -931,6 +994,24 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
         const size_t stage1 = 2 * ((size_t)fwd_region(CK * P.CS, CK * P.CS, 1) + (size_t)wregion);
         const bool crosses = stage1 * sizeof(float) <= 80 * 1024 && stage4 * sizeof(float) > 80 * 1024;
         if (stage4 * sizeof(float) <= 160 * 1024 && CK * cs4 / 4 <= (size_t)XE_MAX * 256 && (!crosses || env_int("GGAN_CORR_X4", 1) > 1)) {
+            P.xq = 4;
+            P.col0 -= shift;
+            for (int c = 0; c < 4; ++c) P.cls[c].coff += shift;
+            P.SCp = scp4;
+            P.CS = (int)cs4;
+        }
+    }
+    if (MODE != 0 && dgrad_x4_cfg(MODE, cfg) && (P.Win & 3) == 0 && (((uintptr_t)P.in) & 15) == 0 &&
+        (((uintptr_t)P.in_ref) & 15) == 0 && ((su * P.TC) & 3) == 0 && env_int("GGAN_DGRAD_X4", 1)) {
+        // The same units for the register-staged slab of the data-gradient kinds: a thread fetches and commits 4 floats of an image
+        // row per instruction (the 8-wave layouts staged 3 dwords per thread and chunk, twice that with the activation mask).
+        const int shift = ((P.col0 % 4) + 4) % 4;
+        const int scp4 = (P.SCp + shift + 3) & ~3;
+        const size_t cs4 = (size_t)P.TI * P.SR * scp4;
+        const int nthr = 64 * wc.WM * wc.WN * wc.KS;
+        const int xn = ((XE_MAX / 2) * 256 / nthr + 3) / 4 + 1;           // corr_body: XN
+        const size_t stage4 = 2 * ((size_t)((CK * cs4 + 1 + 3) & ~(size_t)3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
+        if (stage4 * sizeof(float) <= 160 * 1024 && CK * cs4 / 4 <= (size_t)xn * nthr) {
             P.xq = 4;
             P.col0 -= shift;
             for (int c = 0; c < 4; ++c) P.cls[c].coff += shift;
