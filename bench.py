@@ -12,6 +12,7 @@ own ms_per_step, algorithmic GFLOP, roofline (dominant kernel) and cpu_baseline:
   gmgan-cifar10-K30  gmgan_inference_cifar10.py with the script's N_COMS=30;  gmgan-cifar10-K10: BASELINE configs[2] (K=10)
   gan-face           gan_inference_face.py 64x64x3 bs=64 (configs[3])
   ssgan-moving-mnist ssgan_inference_moving_mnist.py 64x64 T=16 bs=32 (configs[4])
+  ssgan-moving-mnist-3dcnn  the same script with MODE='ali', ALI_MODE='3dcnn' (the Conv3D sequence critic, :352-405)
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
@@ -34,6 +35,7 @@ VARIANTS = [
     dict(key='gmgan-cifar10-K10', dataset='cifar10', mode='local_ep', n_coms=10),
     dict(key='gan-face', dataset='face', mode='ali'),
     dict(key='ssgan-moving-mnist', dataset='moving_mnist', ssgan_mode='local_ep'),
+    dict(key='ssgan-moving-mnist-3dcnn', dataset='moving_mnist', ssgan_mode='ali:3dcnn'),
 ]
 
 
@@ -103,9 +105,24 @@ def ssgan_gflop_per_iteration(cfg):
     mlp = lambda n, i: lin(n, i, 512) + 2 * lin(n, 512, 512) + lin(n, 512, 1)
     fDs = mlp((L - 1) * B, 2 * cfg.dim_l) + mlp(B, cfg.dim_g)
     fdyn = (L - 1) * (lin(B, cfg.dim_l + cfg.dim_t, cfg.dim_op) + lin(B, cfg.dim_op, cfg.dim_op) + lin(B, cfg.dim_op, cfg.dim_l))
+    first = F * conv[0]                              # the critic's first layer: no data gradient in the critic step
+    if getattr(cfg, 'seq_critic', False) and cfg.ali_mode == '3dcnn':
+        # MODE ali / alice-z with the Conv3D sequence critic (:352-405): filter 4x4x4, spatial stride 2, the LEN plan of strides
+        # along the sequence; one logit per sequence
+        sls, vox, c3 = ([2, 2, 2, 2] if L == 16 else [2, 1, 2, 1]), L, []
+        for i in range(4):
+            vox = -(-vox // sls[i])
+            c3.append(2.0 * vox * sizes[i] ** 2 * 64 * [1, d, 2 * d, 4 * d][i] * chans[i + 1])
+        fDc, first = B * sum(c3), B * c3[0]
+        fDl = lin(B, cfg.dim_g + cfg.dim_l * L + cfg.n_c, 512) + lin(B, cfg.flat + 512, 512) + lin(B, 512, 1)
+        fDs = 0.0
+        fwd = fE + fEG + fG + fdyn + 2 * (fDc + fDl)
+        gen_bwd = (2 * fE - F * conv[0]) + (2 * fEG - B * convG1) + 2 * fG + 2 * fdyn + fDc + 2 * fDl
+        disc_bwd = 2 * (2 * (fDc + fDl) - first)
+        return ((fwd + gen_bwd) + cfg.critic_iters * (fwd + disc_bwd)) / 1e9
     fwd = fE + fEG + fG + fdyn + 2 * (fDc + fDl + fDs)
     gen_bwd = (2 * fE - F * conv[0]) + (2 * fEG - B * convG1) + 2 * fG + 2 * fdyn + fDc + 2 * fDl + 2 * fDs
-    disc_bwd = 2 * (2 * (fDc + fDl + fDs) - F * conv[0])
+    disc_bwd = 2 * (2 * (fDc + fDl + fDs) - first)
     return ((fwd + gen_bwd) + cfg.critic_iters * (fwd + disc_bwd)) / 1e9
 
 
@@ -136,7 +153,8 @@ def cpu_baseline(spec, cfg, K, np, torch, budget_s=float(os.environ.get('GGAN_BE
     if spec['dataset'] in ('moving_mnist', 'chairs'):
         from oracle import ssgan as OSS
         ob = 2                                         # bounded sample: 2 sequences per minibatch instead of cfg.B
-        ocfg = OSS.Cfg(batch_size=ob, length=cfg.LEN, n_c=cfg.n_c, channels=cfg.C, op_dyn_mode=cfg.op_dyn_mode)
+        ocfg = OSS.Cfg(batch_size=ob, length=cfg.LEN, n_c=cfg.n_c, channels=cfg.C, op_dyn_mode=cfg.op_dyn_mode, mode=cfg.mode,
+                       ali_mode=cfg.ali_mode)
         otr = OSS.Trainer(ocfg, OSS.init_params(ocfg, 0), np.float32)
         feeds = iter([OSS.make_feed(ocfg, np.random.default_rng(i)) for i in range(8)])
         otr.iteration(1, feeds)

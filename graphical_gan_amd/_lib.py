@@ -52,6 +52,10 @@ SIGNATURES = {
     'ggan_conv3d_out_shape': (_I, [_P, _P]),
     'ggan_im2col3d': (_I, [_P, _P, _P, _P]),
     'ggan_col2im3d': (_I, [_P, _P, _P, _P]),
+    'ggan_conv3d_igemm_ok': (_I, [_P, _I]),
+    'ggan_conv3d_fwd': (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
+    'ggan_conv3d_wgrad': (_I, [_P, _P, _P, _P, _P, _Z, _P]),
+    'ggan_conv3d_dgrad': (_I, [_P, _P, _P, _P, _P]),
     'ggan_mix_rbf_mmd2_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'ggan_mix_rbf_mmd2_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'ggan_noise_fill': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),

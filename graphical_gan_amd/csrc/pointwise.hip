@@ -185,12 +185,15 @@ __global__ void chansum_part_k(const float* __restrict__ x, float* __restrict__ 
     if (threadIdx.x == 0) part[(size_t)c * P + p] = s;
 }
 
-__global__ void chansum_final_k(const float* __restrict__ part, float* __restrict__ out, int C, int P) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel: lane l adds partials l, l+64, ... (coalesced), the 64 lane sums are combined by a fixed butterfly --
+// deterministic, and the chain is P/64 long instead of P (one thread per channel took 50-60 us for the ~1000 partials of a tall sum)
+__global__ void __launch_bounds__(256) chansum_final_k(const float* __restrict__ part, float* __restrict__ out, int C, int P) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(size_t)c * P + p];
-    out[c] = s;
+    for (int p = lane; p < P; p += 64) s += part[(size_t)c * P + p];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = s;
 }
 
 // ---- stochastic encoder head (TYPE_Q = 'learn_std', gan_inference_cifar10.py:173-188): std = exp(log_std), z = mean + eps * std ----------
@@ -1008,7 +1011,7 @@ int ggan_colsum_tall(const float* x, float* out, int rows, int cols, void* ws, s
     const int rows_per_slab = cdiv(rows, P);
     float* part = (float*)ws;
     GGAN_LAUNCH("colsum_tall", 0, 4.0 * rows * cols, colsum_part_k, dim3(tiles, P), dim3(256), 0, s, x, part, rows, cols, rows_per_slab, P);
-    GGAN_LAUNCH("chansum_final", 0, 4.0 * cols * P, chansum_final_k, dim3(cdiv(cols, 64)), dim3(64), 0, s, (const float*)part, out, cols, P);
+    GGAN_LAUNCH("chansum_final", 0, 4.0 * cols * P, chansum_final_k, dim3(cdiv(cols, 4)), dim3(256), 0, s, (const float*)part, out, cols, P);
     return 0;
 }
 
@@ -1029,7 +1032,7 @@ int ggan_chansum(const float* x, float* out, int N, int C, int HW, void* ws, siz
     const int threads = HW >= 1024 ? 256 : (HW >= 256 ? 128 : 64);
     float* part = (float*)ws;
     GGAN_LAUNCH("chansum", 0, 4.0 * N * C * HW, chansum_part_k, dim3(C, P), dim3(threads), 0, s, x, part, N, C, HW, P);
-    GGAN_LAUNCH("chansum_final", 0, 4.0 * C * P, chansum_final_k, dim3(cdiv(C, 64)), dim3(64), 0, s, (const float*)part, out, C, P);
+    GGAN_LAUNCH("chansum_final", 0, 4.0 * C * P, chansum_final_k, dim3(cdiv(C, 4)), dim3(256), 0, s, (const float*)part, out, C, P);
     return 0;
 }
 

@@ -242,7 +242,7 @@ class StateSpaceGAN(object):
             out, cin, s24 = x.reshape(n, c.LEN, 64, 64, 1), 1, (2 if c.LEN == 16 else 1)
             for i, (cout, sl) in enumerate(((c.dim, 2), (2 * c.dim, s24), (4 * c.dim, 2), (8 * c.dim, s24))):
                 out = lib.ops.conv3d.Conv3D('Discriminator.%d' % (i + 1), 4, cin, cout, 4, out, stride=2, stride_len=sl,
-                                            activation=LRELU if c.fuse else None)
+                                            activation=LRELU if c.fuse else None, grad_rows=grad_rows)
                 out, cin = (out if c.fuse else lib.ops.act.LeakyReLU(out)), cout
             z = torch.cat([z_g, z_l.reshape(n, c.LEN * c.dim_l), labels], 1)
             z_out = self._lin('Discriminator.z1', c.dim_g + c.dim_l * c.LEN + c.n_c, 512, z, LRELU)

@@ -275,6 +275,19 @@ int ggan_mean_multi_fwd_grad(const float* const* xs, const float* weights, const
 int ggan_conv3d_out_shape(const int* dims10, int* lo_ho_wo);
 int ggan_im2col3d(const int* dims10, const float* x, float* col, ggan_stream_t stream);
 int ggan_col2im3d(const int* dims10, const float* col, float* gx, ggan_stream_t stream);
+/* The same three products as implicit GEMMs (no patch matrix: the gathered operand is addressed in place, csrc/conv3d.hip):
+ *   ggan_conv3d_fwd    y  = act(conv3d(x, w) + bias)                       (tflib/ops/conv3d.py:33-48)
+ *   ggan_conv3d_wgrad  gw = d/dw  for an upstream gradient gy [N,Lo,Ho,Wo,Co] (already multiplied by act'(y))
+ *   ggan_conv3d_dgrad  gx = d/dx  (one product per residue class of the input voxels, all classes in one launch)
+ * ggan_conv3d_igemm_ok(dims10, kind) (kind 0 fwd, 1 filter grad, 2 data grad) returns 1 when the geometry is covered (Co % 4 == 0,
+ * 32-bit sizes; data grad: Ci % 4 == 0, Ci >= 16, strides <= 2); the callers keep ggan_im2col3d / ggan_col2im3d + ggan_gemm for the
+ * rest.  Operands 16-byte aligned; ws as for ggan_gemm (split of the reduction when the tile grid is small). */
+int ggan_conv3d_igemm_ok(const int* dims10, int kind);
+int ggan_conv3d_fwd(const int* dims10, const float* x, const float* w, const float* bias /* may be NULL */, float* y, int act,
+                    float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
+int ggan_conv3d_wgrad(const int* dims10, const float* x, const float* gy, float* gw, void* ws, size_t ws_bytes,
+                      ggan_stream_t stream);
+int ggan_conv3d_dgrad(const int* dims10, const float* gy, const float* w, float* gx, ggan_stream_t stream);
 
 /* Biased MMD^2 with a mixture of RBF kernels between two sets of codes X[m,d], Y[n,d] (MODE vegan-mmd:
  * tflib/objs/mmd.py:20-71 mix_rbf_mmd2(q_z, p_z, sigmas, wts, biased=True)): k(a,b) = sum_s wt_s exp(-||a-b||^2 / (2 sigma_s^2)),

@@ -913,10 +913,18 @@ def test_mix_rbf_mmd2_fused_op(gpu, m, n, d):
     (2, 16, 16, 16, 2, 3, 4, 4, 2, 2),    # LEN 16 plan
     (2, 1, 8, 8, 16, 32, 4, 4, 1, 2),     # Discriminator.4, LEN 4: length 1, three of the four length taps in the padding
     (2, 5, 7, 6, 3, 5, 3, 2, 2, 1),       # ragged: odd sizes, fl != fs, stride 1
-    (1, 3, 4, 4, 2, 2, 1, 1, 1, 1)])
+    (1, 3, 4, 4, 2, 2, 1, 1, 1, 1),
+    # geometries all three implicit-GEMM products cover (Co % 4 == 0, Ci % 4 == 0, Ci >= 16, strides <= 2)
+    (2, 4, 8, 8, 16, 16, 4, 4, 2, 2),     # 8 residue classes, 128x32 tiles
+    (1, 5, 7, 6, 16, 8, 3, 2, 2, 1),      # ragged: classes with different row and tap counts (fl 3 over stride_len 2)
+    (2, 3, 6, 6, 64, 64, 3, 3, 1, 2),     # 64x64 tiles, stride_len 1
+    (3, 2, 5, 5, 32, 12, 1, 1, 2, 2),     # 1x1x1 filter over stride 2: classes without a tap (their voxels get zeros)
+    (1, 8, 16, 16, 20, 36, 4, 4, 2, 2)])  # channel counts that are no multiple of the k step
 def test_conv3d_entry_points(gpu, case):
-    """Conv3D (tflib/ops/conv3d.py:33-48) = ggan_im2col3d + ggan_gemm, gradients through ggan_col2im3d / ggan_gemm, vs the float64
-    oracle (functional.conv3d; bias [1,1,1,1,Co]); the fused LeakyReLU epilogue; im2col / col2im adjointness."""
+    """Conv3D (tflib/ops/conv3d.py:33-48) as implicit GEMMs (ggan_conv3d_fwd / _wgrad / _dgrad) where ggan_conv3d_igemm_ok covers the
+    geometry, else ggan_im2col3d + ggan_gemm with gradients through ggan_col2im3d / ggan_gemm, vs the float64 oracle
+    (functional.conv3d; bias [1,1,1,1,Co]); the fused LeakyReLU epilogue; both routes against each other; im2col / col2im
+    adjointness."""
     import torch
     from graphical_gan_amd import functional as F
     from oracle import ops as O
@@ -943,6 +951,29 @@ def test_conv3d_entry_points(gpu, case):
     assert _rel(y3.detach().cpu().numpy(), np.where(ref > 0, ref, 0.2 * ref)) <= 2e-5
     (gx3,) = torch.autograd.grad(y3, (tx,), _t(gy, gpu))
     assert _rel(gx3.cpu().numpy(), O.conv3d_bwd_data(gy * np.where(ref > 0, 1.0, 0.2), w, x.shape, sl, st)) <= 2e-5
+    # the two routes against each other, and the implicit route under double differentiation
+    import ctypes as C
+    from graphical_gan_amd import _lib
+    dims = (C.c_int * 10)(*case)
+    covered = [bool(_lib.load().ggan_conv3d_igemm_ok(dims, k)) for k in range(3)]
+    if case[4] % 4 == 0 and case[4] >= 16 and case[5] % 4 == 0:
+        assert covered == [True, True, True]
+    yp = F._conv3d_patch(tx, tw, tb, sl, st, F.ACT_LRELU, 0.2)
+    assert _rel(yp.detach().cpu().numpy(), y3.detach().cpu().numpy()) <= 1e-5
+    gxp, gwp, gbp = torch.autograd.grad(yp, (tx, tw, tb), _t(gy, gpu))
+    y3 = F.conv3d(tx, tw, tb, sl, st, F.ACT_LRELU, 0.2)
+    gxi, gwi, gbi = torch.autograd.grad(y3, (tx, tw, tb), _t(gy, gpu), create_graph=True)
+    for a_, b_ in ((gxp, gxi), (gwp, gwi), (gbp, gbi)):
+        assert _rel(a_.detach().cpu().numpy(), b_.detach().cpu().numpy()) <= 1e-5
+    if covered[0]:
+        (hh,) = torch.autograd.grad((gxi * gxi).sum(), (tw,))       # d/dw |dy/dx . gy|^2 through the differentiable backward
+        (hp,) = torch.autograd.grad(gxp_sq(F, tx, tw, tb, sl, st, gy, gpu), (tw,))
+        assert _rel(hh.cpu().numpy(), hp.cpu().numpy()) <= 1e-4
+    # backward pruning hint (the critic on [fake; real] in a generator step): the leading volumes get the same data gradient
+    if covered[0] and N >= 2:
+        y4 = F.conv3d(tx, tw.detach(), tb.detach(), sl, st, F.ACT_LRELU, 0.2, grad_rows=N - 1)
+        (gx4,) = torch.autograd.grad(y4, (tx,), _t(gy, gpu))
+        assert _rel(gx4[:N - 1].cpu().numpy(), gx3[:N - 1].cpu().numpy()) <= 1e-6      # (gx3: the unpruned first-order backward)
     # <im2col(a), c> == <a, col2im(c)>, and the second derivative path (col2im's backward is im2col again)
     col = F.Im2Col3d.apply(tx, fl, fs, sl, st)
     c = torch.randn(col.shape, device=col.device, generator=torch.Generator(device=col.device).manual_seed(sum(case)))
@@ -954,6 +985,14 @@ def test_conv3d_entry_points(gpu, case):
     cg = c.clone().requires_grad_()
     (gc,) = torch.autograd.grad(F.Col2Im3d.apply(cg, tuple(tx.shape), fl, fs, sl, st), (cg,), tx.detach())
     assert torch.equal(gc, col.detach())
+
+
+def gxp_sq(F, tx, tw, tb, sl, st, gy, gpu):
+    """|d conv3d / dx . gy|^2 through the patch-matrix route (the reference for the double-backward check above)"""
+    import torch
+    yp = F._conv3d_patch(tx, tw, tb, sl, st, F.ACT_LRELU, 0.2)
+    (g,) = torch.autograd.grad(yp, (tx,), _t(gy, gpu), create_graph=True)
+    return (g * g).sum()
 
 
 def test_conv3d_layer_registers_reference_parameters(gpu):
