@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'libggan.so')
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PACK_MAX = 64
+PACK_ARRIVE_INTS = 33 * 1024          # include/ggan.h: GGAN_PACK_ARRIVE_INTS (arrival counters of ggan_pack_adam)
 BCE_MAX = 16
 
 
@@ -112,6 +113,8 @@ SIGNATURES = {
     'ggan_pack_parts': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), _I, _P, _P, _P]),
     'ggan_pack_parts2': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), C.POINTER(_P), C.POINTER(_I),
                               C.POINTER(_Z), _I, _P, _P, _P]),
+    'ggan_pack_adam': (_I, [C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_I), C.POINTER(_Z), C.POINTER(_P), C.POINTER(_I),
+                            C.POINTER(_Z), _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
     'ggan_prof_enable': (_I, [_I]),
     'ggan_prof_reset': (_I, []),
     'ggan_prof_report': (_I, [C.POINTER(ProfRec), _I]),

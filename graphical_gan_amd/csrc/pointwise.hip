@@ -595,7 +595,10 @@ struct PackTable {
     int parts2[GGAN_PACK_MAX];
     int count;
     int32_t* bump;                   // optional: counter incremented once per launch (the optimizer's step ordinal)
+    int first[GGAN_PACK_MAX + 1];    // pack_adam_k: first workgroup of tensor k (1-D grid of kPackChunk-float chunks)
 };
+constexpr int kPackChunk = 4096;
+__host__ __device__ inline int pack_chunk(int slabs) { return slabs > 4 ? 1024 : kPackChunk; }
 
 // blockIdx.y = tensor, blockIdx.x grid-strides inside it (16-byte accesses when every side is aligned); a source made of
 // several split-K slabs is summed in slab order on the way
@@ -644,6 +647,104 @@ __global__ void pack_k(PackTable t, float* __restrict__ flat) {
         }
     }
 }
+
+// pack_k and adam_k<true> in one pass (single-replica steps: nothing happens to the packed gradient between the two): a
+// parameter's gradient is summed from its sources exactly as pack_k does, written to the flat gradient buffer (it stays
+// inspectable) and applied at once -- the flat gradient is not read back, and one launch of the step's tail is gone.
+// The update's ordinal is step[0] + 1 for every workgroup; the LAST workgroup to finish advances step[0] (arrival counter, left
+// at zero), so no workgroup can see the advanced value.
+__global__ void pack_adam_k(PackTable t, float* __restrict__ flat, float* __restrict__ theta, float* __restrict__ m,
+                            float* __restrict__ v, int32_t* __restrict__ arrive, float lr, float b1, float b2, float eps,
+                            float gscale) {
+    // 1-D grid: workgroups [first[k], first[k+1]) own 4096-float chunks of tensor k (only workgroups with work exist: every one of
+    // them pays a same-address atomic at the end, and those are served one at a time)
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first[k + 1]) ++k;
+    const float* s = t.src[k];
+    const float* s2 = t.src2[k];
+    const size_t off = t.off[k];
+    float* d = flat + off;
+    float* th = theta + off;
+    float* mp = m + off;
+    float* vp = v + off;
+    const size_t n = t.size[k];
+    const int np = t.parts[k], np2 = s2 ? t.parts2[k] : 0;
+    const size_t ps = t.pstride[k], ps2 = t.pstride2[k];
+    // (a tensor summed from many slabs gets one float4 per thread: its loads are the long chain)
+    const int chunk = pack_chunk(t.parts[k] + (s2 ? t.parts2[k] : 0));
+    const size_t base = (size_t)((int)blockIdx.x - t.first[k]) * chunk;
+    const float tt = (float)(t.bump[0] + 1);
+    const float lr_t = lr * sqrtf(1.f - powf(b2, tt)) / (1.f - powf(b1, tt));
+#define ADAM1(TH, G, M, V)                                     \
+    {                                                          \
+        float gg = (G) * gscale;                               \
+        (M) = b1 * (M) + (1.f - b1) * gg;                      \
+        (V) = b2 * (V) + (1.f - b2) * gg * gg;                 \
+        (TH) = (TH) - lr_t * (M) / (sqrtf(V) + eps);           \
+    }
+    auto one = [&](size_t i) {
+        float a = 0.f;
+        if (s) {
+            a = s[i];
+            for (int p = 1; p < np; ++p) a += s[(size_t)p * ps + i];
+        }
+        for (int p = 0; p < np2; ++p) a += s2[(size_t)p * ps2 + i];
+        d[i] = a;
+        float x = th[i], mm = mp[i], vv = vp[i];
+        ADAM1(x, a, mm, vv)
+        th[i] = x; mp[i] = mm; vp[i] = vv;
+    };
+    if (s && ((((uintptr_t)s) | ((uintptr_t)d) | ((uintptr_t)s2)) & 15) == 0 && (np == 1 || (ps & 3) == 0) && (np2 <= 1 || (ps2 & 3) == 0)) {
+        const size_t n4 = n >> 2;
+#pragma unroll
+        for (int q = 0; q < kPackChunk / 4 / kBlock; ++q) {
+            const size_t i = base / 4 + threadIdx.x + (size_t)q * kBlock;
+            if (i >= n4 || q * kBlock * 4 >= chunk) break;
+            float4 x = reinterpret_cast<const float4*>(th)[i], mm = reinterpret_cast<const float4*>(mp)[i],
+                   vv = reinterpret_cast<const float4*>(vp)[i];
+            float4 a = reinterpret_cast<const float4*>(s)[i];
+#pragma unroll 8
+            for (int p = 1; p < np; ++p) {
+                const float4 b = reinterpret_cast<const float4*>(s + (size_t)p * ps)[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+#pragma unroll 8
+            for (int p = 0; p < np2; ++p) {
+                const float4 b = reinterpret_cast<const float4*>(s2 + (size_t)p * ps2)[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            reinterpret_cast<float4*>(d)[i] = a;
+            ADAM1(x.x, a.x, mm.x, vv.x) ADAM1(x.y, a.y, mm.y, vv.y)
+            ADAM1(x.z, a.z, mm.z, vv.z) ADAM1(x.w, a.w, mm.w, vv.w)
+            reinterpret_cast<float4*>(th)[i] = x; reinterpret_cast<float4*>(mp)[i] = mm; reinterpret_cast<float4*>(vp)[i] = vv;
+        }
+        // (the 1..3 elements behind the last whole float4: the workgroup that owns the end of the tensor)
+        if (base + chunk >= n && (n4 << 2) + threadIdx.x < n) one((n4 << 2) + threadIdx.x);
+    } else {
+        for (int q = 0; q < kPackChunk / kBlock; ++q) {
+            const size_t i = base + threadIdx.x + (size_t)q * kBlock;
+            if (i >= n || q * kBlock >= chunk) break;
+            one(i);
+        }
+    }
+#undef ADAM1
+    // arrival in two levels (same-address atomics are served one at a time, ~13 ns each, and the workgroups of this one-round
+    // launch all finish together): 32 group counters 4 KB apart, the last workgroup of each group reports to counter 0
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int grp = blockIdx.x & 31, members = ((int)gridDim.x - grp + 31) >> 5, groups = gridDim.x < 32 ? (int)gridDim.x : 32;
+        int32_t* c = arrive + (size_t)(1 + grp) * GGAN_PACK_ARRIVE_STRIDE;
+        if (atomicAdd(c, 1) == members - 1) {
+            c[0] = 0;
+            __threadfence();
+            if (atomicAdd(arrive, 1) == groups - 1) {
+                arrive[0] = 0;
+                t.bump[0] += 1;
+            }
+        }
+    }
+}
+
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -1203,6 +1304,40 @@ int ggan_pack_parts2(const float* const* srcs, const size_t* sizes, const size_t
     if (gx < 1) gx = 1;
     if (gx > 512) gx = 512;
     GGAN_LAUNCH("pack", 0, 4.0 * tot + 4.0 * mx, pack_k, dim3(gx, count), dim3(kBlock), 0, (hipStream_t)stream, t, flat);
+    return 0;
+}
+
+int ggan_pack_adam(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts, const size_t* strides,
+                   const float* const* srcs2, const int* parts2, const size_t* strides2, int count, float* flat, float* theta,
+                   float* m, float* v, int32_t* step, int32_t* arrive, float lr, float beta1, float beta2, float eps,
+                   float grad_scale, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(srcs && sizes && offsets && flat && theta && m && v && step && arrive, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_PACK_MAX, "count out of range");
+    PackTable t;
+    size_t mx = 0, tot = 0, all = 0;
+    for (int i = 0; i < count; ++i) {
+        t.src[i] = srcs[i]; t.size[i] = sizes[i]; t.off[i] = offsets[i];
+        t.parts[i] = parts ? parts[i] : 1;
+        t.pstride[i] = strides ? strides[i] : 0;
+        t.src2[i] = srcs2 ? srcs2[i] : nullptr;
+        t.parts2[i] = (srcs2 && parts2) ? parts2[i] : 1;
+        t.pstride2[i] = (srcs2 && strides2) ? strides2[i] : 0;
+        GGAN_CHECK_ARG(t.parts[i] >= 1 && t.parts2[i] >= 1, "parts must be >= 1");
+        if (sizes[i] > mx) mx = sizes[i];
+        tot += sizes[i] * (size_t)(t.parts[i] + (t.src2[i] ? t.parts2[i] : 0));
+        all += sizes[i];
+    }
+    t.count = count;
+    t.bump = step;
+    int nb = 0;
+    for (int i = 0; i < count; ++i) {
+        t.first[i] = nb;
+        nb += (int)cdivz(sizes[i] > 0 ? sizes[i] : 1, (size_t)pack_chunk(t.parts[i] + (t.src2[i] ? t.parts2[i] : 0)));
+    }
+    t.first[count] = nb;
+    (void)mx;
+    GGAN_LAUNCH("pack_adam", 0, 4.0 * tot + 28.0 * all, pack_adam_k, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, t, flat, theta,
+                m, v, arrive, lr, beta1, beta2, eps, grad_scale);
     return 0;
 }
 

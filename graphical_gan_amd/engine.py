@@ -209,14 +209,15 @@ class Trainer(object):
             self._sample_noise()
         return self.model.forward_nets(self.feed)
 
-    def _fwd_bwd(self, which, nets=None):
+    def _fwd_bwd(self, which, nets=None, fuse_update=False):
+        """fuse_update: the caller applies the update next with nothing but a (single-replica: empty) exchange in between"""
         out = self.model.forward(self.feed, which, nets if nets is not None else self._nets())
         op = out[which + '_train_op']
         opt = op.optimizer
         # (the filter-gradient slabs are summed by the pack kernel: legal under the same one-contribution condition)
         with F.defer_wgrad_reduce(self.single_contrib):
             grads = opt.compute_gradients(op.cost)
-            keep = opt.pack(grads)
+            keep = opt.pack(grads, fuse_update=fuse_update)
         return out[which + '_cost'].detach(), opt, keep
 
     def _two_bucket_plan(self, opt, nets):
@@ -254,7 +255,7 @@ class Trainer(object):
 
     def _eager(self, which):
         self.flush()
-        cost, opt, _ = self._fwd_bwd(which)
+        cost, opt, _ = self._fwd_bwd(which, fuse_update=True)
         opt.all_reduce()
         opt.update()
         return cost
@@ -298,7 +299,7 @@ class Trainer(object):
         elif self.dp_graph and which == 'disc' and hasattr(self.model, 'critic_cut') and not os.environ.get('GGAN_ONE_BUCKET'):
             cost, opt, keep = self._disc_two_buckets()
         else:
-            cost, opt, keep = self._fwd_bwd(which)
+            cost, opt, keep = self._fwd_bwd(which, fuse_update=not self.dp_graph)
             if self.dp_graph:
                 opt.all_reduce()
         opt.update()

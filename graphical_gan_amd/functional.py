@@ -1494,12 +1494,15 @@ def noise_fill_(state, specs):
     check(_L().ggan_noise_fill(dsts, sizes, kinds, a, b, widths, n, _p(state), _stream()), 'ggan_noise_fill')
 
 
-def pack_(tensors, offsets, flat, bump=None):
+def pack_(tensors, offsets, flat, bump=None, adam=None):
     """flat[offsets[i] : offsets[i]+n_i] = tensors[i] (None -> zeros); tensors registered by `defer_wgrad_reduce` are
     summed over their split-K slabs on the way.  An entry may be a pair (t, t2): two gradient contributions of one parameter
-    (either may be None), summed here.  bump: int32 device counter incremented once (the Adam step ordinal)."""
+    (either may be None), summed here.  bump: int32 device counter incremented once (the Adam step ordinal).
+    adam = (theta, m, v, step, arrive, lr, beta1, beta2, eps, grad_scale): the Adam update rides in the same launch
+    (ggan_pack_adam; at most PACK_MAX tensors; `step` takes the place of bump)."""
     L = _L()
     reg = _DEFER[0]
+    assert adam is None or len(tensors) <= _lib.PACK_MAX
     for i0 in range(0, len(tensors), _lib.PACK_MAX):
         chunk = [(t if isinstance(t, tuple) else (t, None)) for t in tensors[i0:i0 + _lib.PACK_MAX]]
         chunk = [((b, None) if a is None else (a, b)) for a, b in chunk]        # a lone second contribution is the first
@@ -1515,7 +1518,12 @@ def pack_(tensors, offsets, flat, bump=None):
             strides = (C.c_size_t * n)(*[(e[1] if e else 0) for e in info])
             return srcs, parts, strides
         s1, p1, st1 = table(0)
-        if any(c[1] is not None for c in chunk):
+        if adam is not None:
+            s2, p2, st2 = table(1) if any(c[1] is not None for c in chunk) else (None, None, None)
+            theta, m, v, step, arrive, lr, b1, b2, eps, gscale = adam
+            check(L.ggan_pack_adam(s1, sizes, offs, p1, st1, s2, p2, st2, n, _p(flat), _p(theta), _p(m), _p(v), _p(step), _p(arrive),
+                                   lr, b1, b2, eps, gscale, _stream()), 'ggan_pack_adam')
+        elif any(c[1] is not None for c in chunk):
             s2, p2, st2 = table(1)
             check(L.ggan_pack_parts2(s1, sizes, offs, p1, st1, s2, p2, st2, n, _p(flat), _p(bump if i0 == 0 else None), _stream()),
                   'ggan_pack_parts2')

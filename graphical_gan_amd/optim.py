@@ -97,6 +97,7 @@ class AdamOptimizer(object):
                 p._flat_owner = self
         self.bucket = GradBucket(self.g)
         self._one = None
+        self._arrive, self._updated = None, False
         self.world = self.bucket.world
 
     # -- one optimizer step ---------------------------------------------------------------------------
@@ -118,9 +119,24 @@ class AdamOptimizer(object):
                 out[i] = (out[i], g2)
         return out
 
-    def pack(self, grads):
+    def can_fuse_update(self):
+        """the update may ride in the pack launch: a single replica (nothing happens to the packed gradient before update()),
+        plain Adam, one pack launch"""
+        return (type(self) is AdamOptimizer and self.world == 1 and len(self.params) <= F._lib.PACK_MAX
+                and not _os.environ.get('GGAN_FORCE_ALLREDUCE') and not _os.environ.get('GGAN_NO_PACK_ADAM'))
+
+    def pack(self, grads, fuse_update=False):
+        """fuse_update: the caller goes on to all_reduce() (a no-op on one replica) and update(); where can_fuse_update() allows
+        it, the update is applied by the pack launch and the following update() call does nothing"""
         cc = lambda g: None if g is None else (g if g.is_contiguous() else g.contiguous())
         gs = [(cc(g[0]), cc(g[1])) if isinstance(g, tuple) else cc(g) for g in grads]
+        if fuse_update and self.can_fuse_update():
+            if self._arrive is None:
+                self._arrive = torch.zeros(F._lib.PACK_ARRIVE_INTS, dtype=torch.int32, device=self.theta.device)
+            F.pack_(gs, self.slots, self.g, adam=(self.theta, self.m, self.v, self.step, self._arrive, self.lr, self.beta1, self.beta2,
+                                                  self.eps, self.bucket.scale))
+            self._updated = True
+            return gs
         F.pack_(gs, self.slots, self.g, bump=self.step)     # also advances the step counter (read by update())
         return gs  # keep alive until the kernel ran (stream-ordered)
 
@@ -143,11 +159,14 @@ class AdamOptimizer(object):
         return gs
 
     def update(self):
+        if self._updated:            # applied by the pack launch (pack(fuse_update=True))
+            self._updated = False
+            return
         F.adam_step_(self.theta, self.g, self.m, self.v, self.step, self.lr, self.beta1, self.beta2, self.eps,
                      self.bucket.scale, counted=True)
 
     def apply_gradients(self, grads):
-        keep = self.pack(grads)
+        keep = self.pack(grads, fuse_update=True)
         self.all_reduce()
         self.update()
         return keep

@@ -383,6 +383,18 @@ int ggan_pack_parts(const float* const* srcs, const size_t* sizes, const size_t*
 int ggan_pack_parts2(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts, const size_t* strides,
                      const float* const* srcs2, const int* parts2, const size_t* strides2, int count, float* flat, int32_t* bump,
                      ggan_stream_t stream);
+/* ggan_pack_parts2 followed by ggan_adam_step_counted in ONE launch (single-replica optimizer steps: nothing happens to the packed
+ * gradient between the two; tf.train.AdamOptimizer.minimize = compute_gradients + apply_gradients, gan_inference_cifar10.py:376-380).
+ * The summed gradient is still written to `flat`; theta / m / v are the optimizer's flat buffers with the same offsets.  Every
+ * workgroup uses step[0] + 1 as the update's ordinal and the last one to finish advances step[0]; `arrive` is
+ * GGAN_PACK_ARRIVE_INTS int32 of device memory (arrival counters) that are zero before the call and are left zero.  Same
+ * arithmetic, in the same order, as the two launches. */
+#define GGAN_PACK_ARRIVE_STRIDE 1024
+#define GGAN_PACK_ARRIVE_INTS (33 * GGAN_PACK_ARRIVE_STRIDE)
+int ggan_pack_adam(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts, const size_t* strides,
+                   const float* const* srcs2 /* may be NULL */, const int* parts2, const size_t* strides2, int count, float* flat,
+                   float* theta, float* m, float* v, int32_t* step, int32_t* arrive, float lr, float beta1, float beta2, float eps,
+                   float grad_scale, ggan_stream_t stream);
 
 /* ---- per-kernel timing (bench.py roofline leg) -----------------------------------------------
  * When enabled every launch is bracketed by hipEvents on its own stream.  ggan_prof_report

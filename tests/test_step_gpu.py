@@ -420,7 +420,8 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
     assert 'source' in d['roofline']
     # every BASELINE configuration rides along in the same line, each with its own roofline and CPU baseline
-    assert [v['key'] for v in d['variants']] == ['wali-gp', 'gmgan-cifar10-K30', 'gmgan-cifar10-K10', 'gan-face', 'ssgan-moving-mnist']
+    assert [v['key'] for v in d['variants']] == ['wali-gp', 'gmgan-cifar10-K30', 'gmgan-cifar10-K10', 'gan-face', 'ssgan-moving-mnist',
+                                                 'ssgan-moving-mnist-3dcnn']
     for v in d['variants']:
         assert v['value'] > 0 and v['ms_per_step'] > 0 and v['algorithmic_gflop_per_step'] > 0, v['key']
         assert v['roofline'] is not None and v['roofline']['frac'] > 0 and v['cpu_baseline'] is not None and v['cpu_baseline']['value'] > 0, v['key']
@@ -641,3 +642,40 @@ def test_ring_feed_one_graph_per_iteration_matches_staging_buffer(gpu, mode, cri
     assert finals[0][1] == finals[1][1] == finals[2][1]
     for k in finals[0][0]:
         assert np.array_equal(finals[0][0][k], finals[1][0][k]) and np.array_equal(finals[0][0][k], finals[2][0][k]), k
+
+
+@pytest.mark.parametrize('mode,crit', [('ali', 1), ('wali-gp', 5)])
+def test_update_riding_in_the_pack_launch_is_bit_identical(gpu, monkeypatch, mode, crit):
+    """ggan_pack_adam (gradient pack + Adam update in one launch, single-replica steps) against ggan_pack_parts2 followed by
+    ggan_adam_step_counted: same sums, same update arithmetic, the step counter advanced once per step either way => bit-identical
+    weights, Adam moments and step counts after eager and graph-replayed steps (wali-gp: two gradient contributions per critic
+    parameter, five critic steps per iteration)."""
+    import torch
+    from graphical_gan_amd import optim
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    finals = []
+    for fused in (False, True):
+        if fused:
+            monkeypatch.delenv('GGAN_NO_PACK_ADAM', raising=False)
+        else:
+            monkeypatch.setenv('GGAN_NO_PACK_ADAM', '1')
+        _fresh()
+        np.random.seed(0)
+        cfg = Config('cifar10', batch_size=16, n_coms=0, mode=mode, dim=16, dim_latent=32)
+        tr = Trainer(cfg, device=gpu, graph=True, seed=4321)
+        batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 40)
+        for it in range(6):
+            res = tr.iteration(it, batches)
+        tr.flush()
+        torch.cuda.synchronize()
+        opts = tr._optimizers()
+        assert all(o.can_fuse_update() == fused for o in opts if type(o) is optim.AdamOptimizer)
+        assert all(int(o._arrive.sum()) == 0 for o in opts if o._arrive is not None), 'arrival counters must be left at zero'
+        finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()},
+                       [(o.m.cpu().numpy(), o.v.cpu().numpy(), int(o.step)) for o in opts]))
+    assert finals[0][1] == finals[1][1]
+    for k in finals[0][0]:
+        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
+    for (m0, v0, s0), (m1, v1, s1) in zip(finals[0][2], finals[1][2]):
+        assert s0 == s1 and s0 > 0 and np.array_equal(m0, m1) and np.array_equal(v0, v1)
