@@ -1,33 +1,17 @@
 """Counterpart of the reference's gan_inference_mnist.py for this package's tflib: the same UPPERCASE hyper-parameter block
-(gan_inference_mnist.py:38-60), nets and step order; runs on one MI355X.  `python scripts/gan_inference_mnist.py [ITERS]`."""
+(gan_inference_mnist.py:31-70; `run.reference_block` holds it as data and derives the MODE-dependent constants as the script does), nets and
+step order; runs on one MI355X.  `python scripts/gan_inference_mnist.py [ITERS]`."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphical_gan_amd import run
-from graphical_gan_amd.models import Config
 
-DATASET = 'mnist'
 MODE = 'ali'  # ali, alice, alice-z, alice-x, wali, wali-gp, vegan, vegan-wgan-gp, vegan-mmd, vegan-kl, vegan-ikl, vegan-jsd
-
-if MODE in ('vegan', 'vegan-wgan-gp', 'vegan-kl', 'vegan-jsd', 'vegan-ikl'):   # gan_inference_mnist.py: the code-space objectives
-    BN_FLAG, DIM_LATENT = False, 8
-else:
-    BN_FLAG, DIM_LATENT = True, 128
-Z_SAMPLES = 100  # MC samples of D(q(z) || p(z)) (vegan-kl / -ikl / -jsd)
-BATCH_SIZE = 50
-CRITIC_ITERS = 0 if MODE in ("vegan-mmd", "vegan-kl", "vegan-ikl", "vegan-jsd") else (5 if MODE in ("wali", "wali-gp", "vegan", "vegan-wgan-gp") else 1)
-LR = {"wali-gp": 1e-4, "wali": 5e-5}.get(MODE, 2e-4)  # the wali objectives ignore the scripts' LR (gan_inference.py:4,28)
-BETA1 = .5
-ITERS = 200000  # number of iterations to train
-DATA_DIR = os.environ.get('GGAN_DATA_DIR', '')
-OUT_DIR = os.environ.get('GGAN_OUT_DIR', '')
-SAVE_EVERY = 10000
-LOG_EVERY = 100
-
+SETTINGS = run.reference_block(__file__, MODE=MODE)
+# edit the block here, e.g. SETTINGS['N_COMS'] = 10 -- or pass it to reference_block, which then derives N_VIS etc. from it
+SETTINGS.update(DATA_DIR=os.environ.get('GGAN_DATA_DIR', ''), OUT_DIR=os.environ.get('GGAN_OUT_DIR', ''), SAVE_EVERY=10000, LOG_EVERY=100)
 if len(sys.argv) > 1:
-    ITERS = int(sys.argv[1])
-SETTINGS = {k: v for k, v in dict(globals()).items() if k.isupper() and k != 'SETTINGS'}
-cfg = Config(DATASET, batch_size=BATCH_SIZE, n_coms=0, mode=MODE, dim_latent=DIM_LATENT, lr=LR, bn=BN_FLAG)
-cfg.z_samples = Z_SAMPLES
-run.train(SETTINGS, cfg)
+    SETTINGS['ITERS'] = int(sys.argv[1])
+globals().update(SETTINGS)          # BATCH_SIZE, DIM, DIM_LATENT, CRITIC_ITERS, ... as module constants, as in the reference
+run.train(SETTINGS, run.config(SETTINGS))

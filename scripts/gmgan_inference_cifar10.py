@@ -1,28 +1,17 @@
 """Counterpart of the reference's gmgan_inference_cifar10.py for this package's tflib: the same UPPERCASE hyper-parameter block
-(gmgan_inference_cifar10.py:39-62), nets and step order; runs on one MI355X.  `python scripts/gmgan_inference_cifar10.py [ITERS]`."""
+(gmgan_inference_cifar10.py:39-87; `run.reference_block` holds it as data and derives the MODE-dependent constants as the script does), nets and
+step order; runs on one MI355X.  `python scripts/gmgan_inference_cifar10.py [ITERS]`."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphical_gan_amd import run
-from graphical_gan_amd.models import Config
 
-DATASET = 'cifar10'
 MODE = 'local_ep'  # local_ep, local_epce
-N_COMS = 30  # mixture components of the latent prior
-DIM_LATENT = 128  # latent dimension
-BATCH_SIZE = 64
-CRITIC_ITERS = 1
-LR = 2e-4
-BETA1 = .5
-ITERS = 200000  # number of iterations to train
-DATA_DIR = os.environ.get('GGAN_DATA_DIR', '')
-OUT_DIR = os.environ.get('GGAN_OUT_DIR', '')
-SAVE_EVERY = 10000
-LOG_EVERY = 100
-
+SETTINGS = run.reference_block(__file__, MODE=MODE)
+# edit the block here, e.g. SETTINGS['N_COMS'] = 10 -- or pass it to reference_block, which then derives N_VIS etc. from it
+SETTINGS.update(DATA_DIR=os.environ.get('GGAN_DATA_DIR', ''), OUT_DIR=os.environ.get('GGAN_OUT_DIR', ''), SAVE_EVERY=10000, LOG_EVERY=100)
 if len(sys.argv) > 1:
-    ITERS = int(sys.argv[1])
-SETTINGS = {k: v for k, v in dict(globals()).items() if k.isupper() and k != 'SETTINGS'}
-cfg = Config(DATASET, batch_size=BATCH_SIZE, n_coms=N_COMS, mode=MODE, dim_latent=DIM_LATENT, lr=LR)
-run.train(SETTINGS, cfg)
+    SETTINGS['ITERS'] = int(sys.argv[1])
+globals().update(SETTINGS)          # BATCH_SIZE, DIM, DIM_LATENT, CRITIC_ITERS, ... as module constants, as in the reference
+run.train(SETTINGS, run.config(SETTINGS))

@@ -207,7 +207,7 @@ def test_api_surface_matches_reference_signatures():
         J.vegan_wgan_gp: ['disc_fake', 'disc_real', 'rec_penalty', 'gradient_penalty', 'gen_params', 'disc_params', 'lamb',
                           ('lr', 2e-4), ('beta1', .5)],
         lib.utils.distance.distance: ['x', 'y', 'd_type'],
-        lib.plot.plot: ['name', 'value'], lib.plot.tick: [], lib.plot.flush: [('outf', None), ('logfile', None)],
+        lib.plot.plot: ['name', 'value'], lib.plot.tick: [], lib.plot.flush: ['outf', 'logfile'],
         lib.params_with_name: ['name'], lib.alias_params: ['replace_dict'], lib.print_model_settings: ['locals_'],
         lib.print_model_settings_to_file: ['locals_', 'logfile'], lib.print_model_settings_dict: ['settings'],
         lib.mnist.load: ['batch_size', 'test_batch_size', ('n_labelled', None)],
@@ -309,3 +309,48 @@ def test_fastdiv24_is_exact_for_every_tile_divisor():
         assert mul < (1 << 24) and mul * nmax < (1 << 32)
         q = (n * np.uint64(mul)) >> np.uint64(shift)
         assert np.array_equal(q, n // np.uint64(d)), d
+
+
+def test_reference_hyperparameter_blocks_and_their_mode_rules():
+    """run.reference_block: the UPPERCASE blocks of the ten reference scripts as data, with the MODE-dependent constants derived as
+    the scripts derive them (gan_inference_cifar10.py:39-79, gmgan_inference_cifar10.py:39-87, gmgan_inference_face.py:35-54,
+    ssgan_inference_moving_mnist.py:27-55, ssgan_inference_chairs.py:28-57), and run.config: the model configuration they describe."""
+    import glob
+    import os
+    from graphical_gan_amd import run
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(root, 'scripts', '*.py')))
+    assert len(names) == 10
+    for n in names:
+        S = run.reference_block(n)
+        cfg = run.config(S)
+        assert cfg.B == S['BATCH_SIZE'] and S['OUTPUT_DIM'] == cfg.output_dim and cfg.critic_iters == S['CRITIC_ITERS'], n
+    S = run.reference_block('gan_inference_cifar10.py')
+    assert (S['MODE'], S['TYPE_Q'], S['TYPE_P'], S['STD'], S['CRITIC_ITERS'], S['BATCH_SIZE'], S['LAMBDA'], S['LR'], S['BETA1'], S['ITERS'],
+            S['DIM'], S['OUTPUT_DIM'], S['BN_FLAG'], S['DIM_LATENT'], S['N_VIS'], S['DR_RATE']) == (
+        'ali', 'no_std', 'no_std', .1, 1, 64, 1., 2e-4, .5, 200000, 64, 3072, True, 128, 128, .2)
+    assert 'DISTANCE_X' not in S and 'Z_SAMPLES' not in S and 'N_COMS' not in S
+    S = run.reference_block('/some/where/gan_inference_cifar10.py', MODE='vegan')        # :52-59, :72-74
+    assert (S['DISTANCE_X'], S['CRITIC_ITERS'], S['BN_FLAG'], S['DIM_LATENT']) == ('l2', 5, False, 8)
+    cfg = run.config(S)
+    assert (cfg.bn, cfg.dim_latent, cfg.critic_iters, cfg.latent_critic) == (False, 8, 5, True)
+    S = run.reference_block('gan_inference_cifar10', MODE='vegan-kl')
+    assert (S['TYPE_Q'], S['TYPE_P'], S['Z_SAMPLES'], S['CRITIC_ITERS'], S['DIM_LATENT']) == ('learn_std', 'no_std', 100, 0, 8)
+    assert run.config(S).learn_std
+    S = run.reference_block('gan_inference_mnist', MODE='vegan-mmd')
+    assert (S['CRITIC_ITERS'], S['BN_FLAG'], S['DIM_LATENT'], S['BATCH_SIZE'], S['OUTPUT_DIM']) == (0, True, 128, 50, 784)
+    S = run.reference_block('gmgan_inference_svhn')
+    assert (S['N_COMS'], S['N_VIS'], S['MODE_K'], S['TEMP_INIT'], S['TEMP'], S['BN_FLAG'], S['DR_RATE']) == (50, 500, 'CONCRETE', .1, .1, False, .2)
+    S = run.reference_block('gmgan_inference_face', N_COMS=10)
+    assert (S['N_COMS'], S['N_VIS'], S['DIM_G'], S['DIM_D'], S['BATCH_SIZE'], S['BETA2'], S['DECAY']) == (10, 100, 32, 32, 128, .999, False)
+    cfg = run.config(S)
+    assert (cfg.K, cfg.dim, cfg.B, cfg.temp) == (10, 32, 128, .1)
+    with pytest.raises(NotImplementedError):
+        run.config(run.reference_block('gmgan_inference_cifar10', MODE_K='REINFORCE'))
+    with pytest.raises(NotImplementedError):
+        run.config(run.reference_block('gan_inference_cifar10', MODE='vae'))
+    S = run.reference_block('ssgan_inference_chairs')
+    assert (S['LEN'], S['OUTPUT_SHAPE'], S['OUTPUT_DIM'], S['OP_DYN_MODE'], S['N_C'], S['ITERS'], S['N_VIS'], S['DIM_LATENT_T'], S['BN_FLAG_G']) == (
+        31, [3, 64, 64], 12288, 'res_w', 0, 40000, 50, 8, False)
+    cfg = run.config(run.reference_block('ssgan_inference_moving_mnist', MODE='ali', ALI_MODE='3dcnn'))
+    assert (cfg.seq_critic, cfg.ali_mode, cfg.LEN, cfg.lamb, cfg.lr) == (True, '3dcnn', 16, 0.1, 1e-4)
