@@ -459,9 +459,14 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     if (WD) {
         wd_lane = (unsigned)((lane >> 4) * 4 * P.w_sk + (cn0 + (lane & 15)) * P.w_sn) * 4u;
         wd_cnlim = P.CNtot - cn0 - (lane & 15);
+        // (the block offsets are computed ONCE, lane b for block b, and each wave picks its own by v_readlane: evaluated per
+        //  wave-instruction in a scalar loop the divisions and selects took 3150 cycles of the prologue -- tools/stamps.py)
+        constexpr int BP = (NBLK + 63) / 64;
+        static_assert(BP <= 2, "block offsets: at most two lane passes");
+        int blk[BP];
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const int b = wave_u + q * NWAVE;
+        for (int p = 0; p < BP; ++p) {
+            const int b = lane + 64 * p;
             const int cnb = b % NCB, gh = (b / NCB) % GH;
             int tap = b / (NCB * GH), ci_ = 0;
             if (NC > 1 && tap >= NT0) { tap -= NT0; ci_ = 1; }
@@ -469,7 +474,14 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
             if (NC > 3 && ci_ == 2 && tap >= NT2) { tap -= NT2; ci_ = 3; }
             const int i = tw_of(ci_) == 3 ? tap / 3 : (tw_of(ci_) == 2 ? tap / 2 : tap / 5), j = tap - i * tw_of(ci_);
             const int wb = wbase_of(ci_);
-            wso[q] = __builtin_amdgcn_readfirstlane(b < NBLK ? (wb + i * P.w_si + j * P.w_sj + gh * 16 * P.w_sk + cnb * 16 * P.w_sn) * 4 : -1);
+            blk[p] = b < NBLK ? (wb + i * P.w_si + j * P.w_sj + gh * 16 * P.w_sk + cnb * 16 * P.w_sn) * 4 : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int b = wave_u + q * NWAVE;
+            const int lo = __builtin_amdgcn_readlane(blk[0], b & 63);
+            const int hi = BP > 1 ? __builtin_amdgcn_readlane(blk[BP - 1], b & 63) : -1;
+            wso[q] = b < 64 ? lo : (b < 64 * BP ? hi : -1);
         }
     }
     auto stage_w1 = [&](int q, int ck0, int buf) {                 // one wave-instruction of the filter slice
