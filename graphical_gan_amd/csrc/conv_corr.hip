@@ -674,7 +674,10 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     for (int u = tid; u < UNITS; u += NTHR) {
         const int p4 = u % (TMW / 4);
         const int cnl = (u / (TMW / 4)) % TNW;
-        const int gsel = u / ((TMW / 4) * TNW);
+        // (a group is (TMW / 4) * TNW = a multiple of 64 units: wave-uniform, so the class records below are scalar loads -- indexed by
+        //  a per-lane value they were dependent VECTOR loads from the kernel-argument block)
+        static_assert(((TMW / 4) * TNW) % 64 == 0, "store groups are whole waves");
+        const int gsel = __builtin_amdgcn_readfirstlane(u / ((TMW / 4) * TNW));
         const int cn = cn0 + cnl;
         if (cn >= P.CNtot) continue;
         const int ca = NC == 4 ? 2 * gsel : gsel, cb = NC == 4 ? 2 * gsel + 1 : gsel;
