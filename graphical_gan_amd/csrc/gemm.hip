@@ -643,14 +643,16 @@ int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const fl
 int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const float* a1, const float* a2, const float* w, const float* h,
                          const float* w_out, float alpha, float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b, float* d_wout,
                          float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream) {
-    GGAN_CHECK_ARG(g && a1 && w && h && w_out && gh, "null pointer");
+    GGAN_CHECK_ARG(a1 && w && h && w_out && gh, "null pointer");
     GGAN_CHECK_ARG(M > 0 && K1 > 0 && K2 >= 0 && H > 0 && (a2 || K2 == 0), "bad shape");
     GGAN_CHECK_ARG(!d_a1 || K2 == 0 || d_a2, "d_a2 missing");
     GGAN_CHECK_ARG(!d_b || d_w, "d_b comes out of the weight-gradient product");
     hipStream_t s = (hipStream_t)stream;
     const int K = K1 + K2;
-    GGAN_LAUNCH("head_out_bwd_k", 3.0 * M * H, 8.0 * M * H, head_out_bwd_k, dim3(cdiv(H, 64)), dim3(256), 0, s, g, h, w_out, alpha, gh,
-                d_wout, d_bout, M, H);
+    if (g) {        // (NULL: gh was produced together with the cost, ggan_bce_head_bwd)
+        GGAN_LAUNCH("head_out_bwd_k", 3.0 * M * H, 8.0 * M * H, head_out_bwd_k, dim3(cdiv(H, 64)), dim3(256), 0, s, g, h, w_out, alpha, gh,
+                    d_wout, d_bout, M, H);
+    }
     GemmPlan Gw, Ga;
     int nw = 0, na = 0;
     if (d_w) {      // d_w[K,H] = [a1|a2]^T gh: A stored [M,K] read transposed, sources split the OUTPUT rows; column sums of gh -> d_b

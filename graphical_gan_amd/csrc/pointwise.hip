@@ -429,6 +429,72 @@ __global__ void bce_multi_fwd_k(BceTable t, float* __restrict__ loss) {
     if (threadIdx.x == 0) loss[0] = tot;
 }
 
+// bce_multi_fwd_k with unit-seed gradients AND the row-local part of the critic head's backward (head_out_bwd_k, gemm.hip) in one
+// launch: the logits of a cost are the output of ONE critic head (terms = consecutive row ranges of its logits), the cost's
+// gradient for a unit upstream gradient is row-local, so  gh[r,c] = g[r] * w_out[c] * lrelu'(h[r,c]),  d_wout[c] = sum_r g[r] h[r,c]
+// and d_bout = sum_r g[r]  need nothing but the logits.  Workgroup 0 is bce_multi_fwd_k unchanged (loss, g -- same arithmetic, same
+// order); workgroups 1.. are head_out_bwd_k with g[r] formed on the fly by the same expression.  Saves the head kernel's launch on
+// the critical chain of every BCE step (tail GEMM -> logits -> cost -> head backward -> products).
+__global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restrict__ loss, const float* __restrict__ h,
+                                                      const float* __restrict__ w_out, float alpha, float* __restrict__ gh,
+                                                      float* __restrict__ d_wout, float* __restrict__ d_bout, int M, int H) {
+    __shared__ float sm[32];
+    __shared__ float red[4][64];
+    __shared__ float gs_[GGAN_HEAD_BCE_MAX_ROWS];
+    if (blockIdx.x == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < t.count; ++k) {
+            const float* x = t.x[k];
+            const float z = t.z[k];
+            float s = 0.f;
+            float* gx = t.gx[k];
+            const float g = 1.f * t.w[k] / (float)t.n[k];
+            for (int i = threadIdx.x; i < t.n[k]; i += blockDim.x) {
+                float v = x[i];
+                s += fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)));
+                if (gx) gx[i] = g * (1.f / (1.f + expf(-v)) - z);
+            }
+            s = block_sum(s, sm);
+            const float r = t.w[k] * (s / (float)t.n[k]);
+            tot = k ? tot + r : r;
+        }
+        if (threadIdx.x == 0) loss[0] = tot;
+        return;
+    }
+    // g of every row (the terms are consecutive row ranges of the head's logits, in order)
+    {
+        int r0 = 0;
+        for (int k = 0; k < t.count; ++k) {
+            const float g = 1.f * t.w[k] / (float)t.n[k], z = t.z[k];
+            for (int i = threadIdx.x; i < t.n[k]; i += blockDim.x) gs_[r0 + i] = g * (1.f / (1.f + expf(-t.x[k][i])) - z);
+            r0 += t.n[k];
+        }
+    }
+    __syncthreads();
+    const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
+    const int c = (blockIdx.x - 1) * 64 + cl;
+    float acc = 0.f, gsum = 0.f;
+    if (c < H) {
+        const float w = w_out[c];
+#pragma unroll 4
+        for (int r = rg; r < M; r += 4) {
+            const float gr = gs_[r], hv = h[(size_t)r * H + c];
+            gh[(size_t)r * H + c] = gr * w * (hv > 0.f ? 1.f : alpha);
+            acc = fmaf(gr, hv, acc);
+            gsum += gr;
+        }
+    }
+    red[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < H && d_wout) d_wout[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (blockIdx.x == 1 && d_bout) {
+        __syncthreads();
+        if (cl == 0) red[rg][0] = gsum;
+        __syncthreads();
+        if (tid == 0) d_bout[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    }
+}
+
 __global__ void bce_multi_bwd_k(BceTable t, const float* __restrict__ gloss) {
     const int k = blockIdx.y;
     const int n = t.n[k];
@@ -1180,6 +1246,24 @@ int ggan_bce_logits_multi_fwd_grad(const float* const* xs, const float* labels, 
     int mx;
     GGAN_CHECK_ARG(bce_table(t, xs, gxs, labels, weights, ns, count, &mx) == 0, "bad term");
     GGAN_LAUNCH("bce_logits_fwd_grad", 0, 8.0 * mx * count, bce_multi_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, t, loss);
+    return 0;
+}
+
+int ggan_bce_head_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count, float* loss,
+                      float* const* gxs, int M, int H, const float* h, const float* w_out, float alpha, float* gh, float* d_wout,
+                      float* d_bout, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(xs && labels && weights && ns && loss && gxs && h && w_out && gh, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_BCE_MAX && M > 0 && M <= GGAN_HEAD_BCE_MAX_ROWS && H > 0, "count out of range");
+    BceTable t;
+    int mx, rows = 0;
+    GGAN_CHECK_ARG(bce_table(t, xs, gxs, labels, weights, ns, count, &mx) == 0, "bad term");
+    for (int i = 0; i < count; ++i) {
+        GGAN_CHECK_ARG(xs[i] == xs[0] + rows, "the terms must be consecutive row ranges of one logits vector");
+        rows += ns[i];
+    }
+    GGAN_CHECK_ARG(rows == M, "the terms must cover the head's rows");
+    GGAN_LAUNCH("bce_head_bwd", 3.0 * M * H, 8.0 * M * H, bce_head_bwd_k, dim3(1 + cdiv(H, 64)), dim3(256), 0, (hipStream_t)stream, t, loss,
+                h, w_out, alpha, gh, d_wout, d_bout, M, H);
     return 0;
 }
 

@@ -9,6 +9,7 @@ There is no CPU path: tensors must live on a HIP device and libggan.so must load
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -573,6 +574,15 @@ class CriticHead(Function):
                                         _p(logits), _p(ws), ws.numel(), _stream()), 'ggan_critic_head_fwd')
         ctx.alpha, ctx.has_a2 = float(alpha), a2 is not None
         ctx.save_for_backward(a1, a2, w, w_out, h)
+        # a BCE cost on exactly these logits may take the head kernel of this op's backward into its own launch (BceSum)
+        ctx.rec = None
+        if M <= _lib.HEAD_BCE_MAX_ROWS and any(ctx.needs_input_grad) and not os.environ.get('GGAN_NO_HEAD_BCE'):
+            ctx.rec = dict(ptr=logits.data_ptr(), M=M, H=H, h=weakref.ref(h), w_out=weakref.ref(w_out), alpha=float(alpha),
+                           want_out=ctx.needs_input_grad[4],
+                           want_bout=ctx.needs_input_grad[5], g_ptr=None)
+            if len(HEAD_LOGITS) >= 8:            # (heads whose logits never met a BCE cost: Wasserstein modes)
+                HEAD_LOGITS.clear()
+            HEAD_LOGITS[ctx.rec['ptr']] = ctx.rec
         return logits
 
     @staticmethod
@@ -586,16 +596,19 @@ class CriticHead(Function):
         need = ctx.needs_input_grad
         dev = g.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        gh = new(M, H)
+        rec = ctx.rec
+        fused = rec is not None and rec['g_ptr'] is not None and rec['g_ptr'] == g.data_ptr()
+        gh = rec['gh'] if fused else new(M, H)
         want_a = need[0] or (a2 is not None and need[1])
         d_a1 = new(M, K1) if want_a else None
         d_a2 = new(M, K2) if (want_a and a2 is not None) else None
         d_w = new(K1 + K2, H) if (need[2] or need[3]) else None
         d_b = new(H) if need[3] else None
-        d_wout = new(*w_out.shape) if need[4] else None
-        d_bout = new(1) if need[5] else None
+        d_wout = (rec['d_wout'].view(w_out.shape) if fused else new(*w_out.shape)) if need[4] else None
+        d_bout = (rec['d_bout'] if fused else new(1)) if need[5] else None
         ws = workspace(dev)
-        check(_L().ggan_critic_head_bwd(M, K1, K2, H, _p(g), _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1),
+        # (fused: gh, d_wout, d_bout left with the cost's launch -- ggan_bce_head_bwd; g = NULL launches the products only)
+        check(_L().ggan_critic_head_bwd(M, K1, K2, H, _p(None if fused else g), _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1),
                                         _p(d_a2), _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(ws), ws.numel(), _stream()),
               'ggan_critic_head_bwd')
         return (d_a1 if need[0] else None, d_a2 if (a2 is not None and need[1]) else None, d_w if need[2] else None, d_b, d_wout,
@@ -1283,6 +1296,7 @@ class RowLerp(Function):
 # ---------------------------------------------------------------------------------------------------
 # losses
 # ---------------------------------------------------------------------------------------------------
+HEAD_LOGITS = {}        # logits data pointer -> CriticHead record (CriticHead.forward registers, BceSum.forward consumes)
 UNIT_SEEDS = {}         # data pointer -> the all-ones tensor an optimizer seeds d(cost)/d(cost) with (kept alive here: an address
                         # in this table can never belong to another tensor); emptied by optim.reset_optimizers
 
@@ -1305,6 +1319,21 @@ class BceSum(Function):
         assert n <= _lib.BCE_MAX, 'too many BCE terms for one launch'
         return ((C.c_void_p * n)(*[x.data_ptr() for x in logits]), (C.c_float * n)(*[float(z) for z in labels]),
                 (C.c_float * n)(*[float(w) for w in weights]), (C.c_int * n)(*[x.numel() for x in logits]), n)
+
+    @staticmethod
+    def _head_of(logits):
+        """the CriticHead record whose logits these terms partition into consecutive row ranges (in order), else None"""
+        rec = HEAD_LOGITS.pop(logits[0].data_ptr(), None) if HEAD_LOGITS else None
+        # (weak references: a record that outlives its step -- logits that never met a BCE cost -- must not keep tape tensors alive,
+        #  and an address can come back for another tensor)
+        if rec is None or rec['g_ptr'] is not None or rec['h']() is None or rec['w_out']() is None:
+            return None
+        p, rows = rec['ptr'], 0
+        for x in logits:
+            if x.data_ptr() != p + 4 * rows:
+                return None
+            rows += x.numel()
+        return rec if rows == rec['M'] else None
 
     @staticmethod
     def _grad_buffers(logits, device):
@@ -1330,7 +1359,19 @@ class BceSum(Function):
             # launch; any other upstream gradient takes the backward kernel
             outs = BceSum._grad_buffers(logits, loss.device)
             gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
-            check(_L().ggan_bce_logits_multi_fwd_grad(xs, zs, ws, ns, n, _p(loss), gxs, _stream()), 'ggan_bce_logits_multi_fwd_grad')
+            rec = BceSum._head_of(logits)
+            if rec is not None:
+                # every term is a row range of ONE critic head's logits: the head kernel of that op's backward rides along
+                new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=loss.device)
+                rec['gh'] = new(rec['M'], rec['H'])
+                rec['d_wout'] = new(rec['H']) if rec['want_out'] else None
+                rec['d_bout'] = new(1) if rec['want_bout'] else None
+                check(_L().ggan_bce_head_bwd(xs, zs, ws, ns, n, _p(loss), gxs, rec['M'], rec['H'], _p(rec['h']()), _p(rec['w_out']()),
+                                             rec['alpha'], _p(rec['gh']), _p(rec['d_wout']), _p(rec['d_bout']), _stream()),
+                      'ggan_bce_head_bwd')
+                rec['g_ptr'] = outs[0].data_ptr()
+            else:
+                check(_L().ggan_bce_logits_multi_fwd_grad(xs, zs, ws, ns, n, _p(loss), gxs, _stream()), 'ggan_bce_logits_multi_fwd_grad')
             ctx.unit_grads = outs
         else:
             check(_L().ggan_bce_logits_multi_fwd(xs, zs, ws, ns, n, _p(loss), _stream()), 'ggan_bce_logits_multi_fwd')

@@ -136,7 +136,8 @@ int ggan_dyn_scan_bwd(int B, int T, int dl, int dt, int H, const float* g_zs, co
  *             a1 [M,K1], a2 [M,K2] (NULL when K2 == 0; K1 a multiple of 64 otherwise), w [K1+K2,H], b [H], w_out [H], b_out [1].
  *   backward: from g[M] = d cost / d logits: gh[M,H] = g w_out^T * lrelu'(h) (caller-owned scratch), d_wout[H], d_bout[1],
  *             d_w[K1+K2,H], d_b[H], d_a1[M,K1], d_a2[M,K2]; every output pointer may be NULL (not wanted), d_b needs d_w,
- *             d_a2 goes with d_a1.  Launches: one head kernel + one grouped product launch. */
+ *             d_a2 goes with d_a1.  Launches: one head kernel + one grouped product launch.  g == NULL: gh (and d_wout / d_bout,
+ *             which are then ignored here) were produced by ggan_bce_head_bwd -- only the products are launched. */
 int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* b,
                          const float* w_out, const float* b_out, float alpha, float* h, float* logits, void* ws, size_t ws_bytes,
                          ggan_stream_t stream);
@@ -249,6 +250,15 @@ int ggan_bce_logits_bwd(const float* x, float label, float weight, const float* 
 #define GGAN_BCE_MAX 16
 int ggan_bce_logits_multi_fwd(const float* const* xs, const float* labels, const float* weights, const int* ns,
                               int count, float* loss, ggan_stream_t stream);
+/* ggan_bce_logits_multi_fwd_grad AND the head kernel of ggan_critic_head_bwd in one launch, for a cost whose logits are the output
+ * of ONE critic head (the terms xs[i] are consecutive row ranges of its logits[M], in order): loss and the unit-seed gradients gxs as
+ * above, plus gh[M,H] = g w_out^T * lrelu'(h), d_wout[H] = h^T g, d_bout = sum g (d_wout / d_bout may be NULL) from the head's kept
+ * activation h (gan_inference_cifar10.py:246-254 + tflib/objs/gan_inference.py:104-117).  M <= GGAN_HEAD_BCE_MAX_ROWS.  The products of
+ * the head's backward follow with ggan_critic_head_bwd(g = NULL: gh is given). */
+#define GGAN_HEAD_BCE_MAX_ROWS 2048
+int ggan_bce_head_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count, float* loss,
+                      float* const* gxs, int M, int H, const float* h, const float* w_out, float alpha, float* gh, float* d_wout,
+                      float* d_bout, ggan_stream_t stream);
 int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns,
                               int count, const float* gloss, float* const* gxs, ggan_stream_t stream);
 /* forward AND the gradients for an upstream gradient of exactly 1 in one launch: gxs[i][j] = weights[i]*(sigmoid(x)-z)/n, bit for

@@ -679,3 +679,45 @@ def test_update_riding_in_the_pack_launch_is_bit_identical(gpu, monkeypatch, mod
         assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
     for (m0, v0, s0), (m1, v1, s1) in zip(finals[0][2], finals[1][2]):
         assert s0 == s1 and s0 > 0 and np.array_equal(m0, m1) and np.array_equal(v0, v1)
+
+
+@pytest.mark.parametrize('dataset,mode', [('cifar10', 'ali'), ('face', 'ali'), ('cifar10', 'local_ep')])
+def test_cost_launch_carrying_the_head_backward_is_bit_identical(gpu, monkeypatch, dataset, mode):
+    """ggan_bce_head_bwd (BCE cost + unit-seed gradients + the head kernel of the critic tail's backward in one launch, where the
+    cost's logits are one critic head's output) against ggan_bce_logits_multi_fwd_grad followed by the head kernel of
+    ggan_critic_head_bwd: the same arithmetic in the same order => bit-identical costs and weights after eager and graph-replayed
+    steps.  (The mixture scripts' cost takes logits of two heads: it keeps the separate launches -- same result by construction.)"""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    finals, fused_launches = [], []
+    for fused in (False, True):
+        if fused:
+            monkeypatch.delenv('GGAN_NO_HEAD_BCE', raising=False)
+        else:
+            monkeypatch.setenv('GGAN_NO_HEAD_BCE', '1')
+        _fresh()
+        np.random.seed(0)
+        cfg = Config(dataset, batch_size=16, n_coms=10 if mode == 'local_ep' else 0, mode=mode, dim=16, dim_latent=32)
+        tr = Trainer(cfg, device=gpu, graph=True, seed=4321)
+        batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 40)
+        lib_, calls = _lib.load(), []
+        entry = lib_.ggan_bce_head_bwd
+
+        def counted(*args):
+            calls.append(1)
+            return entry(*args)
+        monkeypatch.setattr(lib_, 'ggan_bce_head_bwd', counted)
+        for it in range(6):
+            res = tr.iteration(it, batches)
+        monkeypatch.setattr(lib_, 'ggan_bce_head_bwd', entry)
+        fused_launches.append(len(calls) > 0)
+        tr.flush()
+        torch.cuda.synchronize()
+        assert not F.HEAD_LOGITS or all(r['h']() is None for r in F.HEAD_LOGITS.values()), 'no record may keep a step alive'
+        finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}))
+    assert fused_launches == [False, mode == 'ali']
+    assert finals[0][1] == finals[1][1]
+    for k in finals[0][0]:
+        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
