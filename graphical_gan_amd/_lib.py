@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libggan.so')
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PACK_MAX = 64
 HEAD_BCE_MAX_ROWS = 2048             # include/ggan.h: GGAN_HEAD_BCE_MAX_ROWS
+BCE_HEADS = 2                        # include/ggan.h: GGAN_BCE_HEADS
 PACK_ARRIVE_INTS = 33 * 1024          # include/ggan.h: GGAN_PACK_ARRIVE_INTS (arrival counters of ggan_pack_adam)
 BCE_MAX = 16
 
@@ -101,6 +102,9 @@ SIGNATURES = {
     'ggan_bce_logits_multi_fwd_grad': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _I, _P, C.POINTER(_P), _P]),
     'ggan_bce_head_bwd': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _I, _P, C.POINTER(_P), _I, _I, _P, _P, _F, _P, _P,
                           _P, _P]),
+    'ggan_bce_heads_bwd': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _I, _P, C.POINTER(_P), _I, C.POINTER(_I),
+                           C.POINTER(_I), C.POINTER(_I), C.POINTER(_P), C.POINTER(_P), C.POINTER(_F), C.POINTER(_P), C.POINTER(_P),
+                           C.POINTER(_P), _P]),
     'ggan_mean_fwd': (_I, [_P, _F, _P, _I, _I, _P]),
     'ggan_mean_bwd': (_I, [_P, _F, _P, _I, _P]),
     'ggan_mean_multi_fwd_grad': (_I, [C.POINTER(_P), C.POINTER(_F), C.POINTER(_I), _I, _P, C.POINTER(_P), _P]),

@@ -435,9 +435,20 @@ __global__ void bce_multi_fwd_k(BceTable t, float* __restrict__ loss) {
 // and d_bout = sum_r g[r]  need nothing but the logits.  Workgroup 0 is bce_multi_fwd_k unchanged (loss, g -- same arithmetic, same
 // order); workgroups 1.. are head_out_bwd_k with g[r] formed on the fly by the same expression.  Saves the head kernel's launch on
 // the critical chain of every BCE step (tail GEMM -> logits -> cost -> head backward -> products).
-__global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restrict__ loss, const float* __restrict__ h,
-                                                      const float* __restrict__ w_out, float alpha, float* __restrict__ gh,
-                                                      float* __restrict__ d_wout, float* __restrict__ d_bout, int M, int H) {
+struct BceHead {
+    const float* h;
+    const float* w_out;
+    float* gh;
+    float* d_wout;
+    float* d_bout;
+    float alpha;
+    int M, H;
+    int k0, k1;             // its terms [k0, k1) of the table: consecutive row ranges of its logits
+    int first;              // its first workgroup
+};
+struct BceHeads { BceHead hd[GGAN_BCE_HEADS]; int count; };
+
+__global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restrict__ loss, const BceHeads hs) {
     __shared__ float sm[32];
     __shared__ float red[4][64];
     __shared__ float gs_[GGAN_HEAD_BCE_MAX_ROWS];
@@ -461,10 +472,19 @@ __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restr
         if (threadIdx.x == 0) loss[0] = tot;
         return;
     }
-    // g of every row (the terms are consecutive row ranges of the head's logits, in order)
+    const int hi = (hs.count > 1 && (int)blockIdx.x >= hs.hd[1].first) ? 1 : 0;
+    const BceHead& hd = hs.hd[hi];
+    const float* __restrict__ h = hd.h;
+    const float* __restrict__ w_out = hd.w_out;
+    float* __restrict__ gh = hd.gh;
+    float* __restrict__ d_wout = hd.d_wout;
+    float* __restrict__ d_bout = hd.d_bout;
+    const float alpha = hd.alpha;
+    const int M = hd.M, H = hd.H;
+    // g of every row (the head's terms are consecutive row ranges of its logits, in order)
     {
         int r0 = 0;
-        for (int k = 0; k < t.count; ++k) {
+        for (int k = hd.k0; k < hd.k1; ++k) {
             const float g = 1.f * t.w[k] / (float)t.n[k], z = t.z[k];
             for (int i = threadIdx.x; i < t.n[k]; i += blockDim.x) gs_[r0 + i] = g * (1.f / (1.f + expf(-t.x[k][i])) - z);
             r0 += t.n[k];
@@ -472,7 +492,7 @@ __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restr
     }
     __syncthreads();
     const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
-    const int c = (blockIdx.x - 1) * 64 + cl;
+    const int c = ((int)blockIdx.x - hd.first) * 64 + cl;
     float acc = 0.f, gsum = 0.f;
     if (c < H) {
         const float w = w_out[c];
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restr
     red[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < H && d_wout) d_wout[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-    if (blockIdx.x == 1 && d_bout) {
+    if ((int)blockIdx.x == hd.first && d_bout) {
         __syncthreads();
         if (cl == 0) red[rg][0] = gsum;
         __syncthreads();
@@ -1249,22 +1269,43 @@ int ggan_bce_logits_multi_fwd_grad(const float* const* xs, const float* labels, 
     return 0;
 }
 
+int ggan_bce_heads_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count, float* loss,
+                       float* const* gxs, int nheads, const int* head_terms, const int* Ms, const int* Hs, const float* const* hs,
+                       const float* const* w_outs, const float* alphas, float* const* ghs, float* const* d_wouts,
+                       float* const* d_bouts, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(xs && labels && weights && ns && loss && gxs && head_terms && Ms && Hs && hs && w_outs && alphas && ghs, "null pointer");
+    GGAN_CHECK_ARG(count > 0 && count <= GGAN_BCE_MAX && nheads >= 1 && nheads <= GGAN_BCE_HEADS, "count out of range");
+    BceTable t;
+    int mx;
+    GGAN_CHECK_ARG(bce_table(t, xs, gxs, labels, weights, ns, count, &mx) == 0, "bad term");
+    BceHeads H;
+    memset(&H, 0, sizeof(H));
+    H.count = nheads;
+    int k = 0, wg = 1;
+    for (int a = 0; a < nheads; ++a) {
+        BceHead& d = H.hd[a];
+        GGAN_CHECK_ARG(hs[a] && w_outs[a] && ghs[a] && Ms[a] > 0 && Ms[a] <= GGAN_HEAD_BCE_MAX_ROWS && Hs[a] > 0 && head_terms[a] > 0 &&
+                       k + head_terms[a] <= count, "bad head");
+        d.h = hs[a]; d.w_out = w_outs[a]; d.gh = ghs[a]; d.d_wout = d_wouts ? d_wouts[a] : nullptr; d.d_bout = d_bouts ? d_bouts[a] : nullptr;
+        d.alpha = alphas[a]; d.M = Ms[a]; d.H = Hs[a]; d.k0 = k; d.k1 = k + head_terms[a]; d.first = wg;
+        int rows = 0;
+        for (int i = d.k0; i < d.k1; ++i) {
+            GGAN_CHECK_ARG(xs[i] == xs[d.k0] + rows, "a head's terms must be consecutive row ranges of one logits vector");
+            rows += ns[i];
+        }
+        GGAN_CHECK_ARG(rows == d.M, "a head's terms must cover its rows");
+        k = d.k1;
+        wg += cdiv(d.H, 64);
+    }
+    GGAN_CHECK_ARG(k == count, "every term belongs to a head");
+    GGAN_LAUNCH("bce_head_bwd", 0, 0, bce_head_bwd_k, dim3(wg), dim3(256), 0, (hipStream_t)stream, t, loss, H);
+    return 0;
+}
+
 int ggan_bce_head_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count, float* loss,
                       float* const* gxs, int M, int H, const float* h, const float* w_out, float alpha, float* gh, float* d_wout,
                       float* d_bout, ggan_stream_t stream) {
-    GGAN_CHECK_ARG(xs && labels && weights && ns && loss && gxs && h && w_out && gh, "null pointer");
-    GGAN_CHECK_ARG(count > 0 && count <= GGAN_BCE_MAX && M > 0 && M <= GGAN_HEAD_BCE_MAX_ROWS && H > 0, "count out of range");
-    BceTable t;
-    int mx, rows = 0;
-    GGAN_CHECK_ARG(bce_table(t, xs, gxs, labels, weights, ns, count, &mx) == 0, "bad term");
-    for (int i = 0; i < count; ++i) {
-        GGAN_CHECK_ARG(xs[i] == xs[0] + rows, "the terms must be consecutive row ranges of one logits vector");
-        rows += ns[i];
-    }
-    GGAN_CHECK_ARG(rows == M, "the terms must cover the head's rows");
-    GGAN_LAUNCH("bce_head_bwd", 3.0 * M * H, 8.0 * M * H, bce_head_bwd_k, dim3(1 + cdiv(H, 64)), dim3(256), 0, (hipStream_t)stream, t, loss,
-                h, w_out, alpha, gh, d_wout, d_bout, M, H);
-    return 0;
+    return ggan_bce_heads_bwd(xs, labels, weights, ns, count, loss, gxs, 1, &count, &M, &H, &h, &w_out, &alpha, &gh, &d_wout, &d_bout, stream);
 }
 
 int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count,

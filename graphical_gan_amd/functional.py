@@ -1321,19 +1321,30 @@ class BceSum(Function):
                 (C.c_float * n)(*[float(w) for w in weights]), (C.c_int * n)(*[x.numel() for x in logits]), n)
 
     @staticmethod
-    def _head_of(logits):
-        """the CriticHead record whose logits these terms partition into consecutive row ranges (in order), else None"""
-        rec = HEAD_LOGITS.pop(logits[0].data_ptr(), None) if HEAD_LOGITS else None
-        # (weak references: a record that outlives its step -- logits that never met a BCE cost -- must not keep tape tensors alive,
-        #  and an address can come back for another tensor)
-        if rec is None or rec['g_ptr'] is not None or rec['h']() is None or rec['w_out']() is None:
+    def _heads_of(logits):
+        """[(CriticHead record, number of terms)] when the terms partition the logits of one or two critic heads into consecutive
+        row ranges (in order), else None"""
+        if not HEAD_LOGITS:
             return None
-        p, rows = rec['ptr'], 0
-        for x in logits:
-            if x.data_ptr() != p + 4 * rows:
+        heads, i = [], 0
+        while i < len(logits):
+            rec = HEAD_LOGITS.get(logits[i].data_ptr())
+            # (weak references: a record that outlives its step -- logits that never met a BCE cost -- must not keep tape tensors
+            #  alive, and an address can come back for another tensor)
+            if (rec is None or rec['g_ptr'] is not None or rec['h']() is None or rec['w_out']() is None or len(heads) == _lib.BCE_HEADS
+                    or any(rec is r for r, _ in heads)):
                 return None
-            rows += x.numel()
-        return rec if rows == rec['M'] else None
+            rows, j = 0, i
+            while j < len(logits) and rows < rec['M'] and logits[j].data_ptr() == rec['ptr'] + 4 * rows:
+                rows += logits[j].numel()
+                j += 1
+            if rows != rec['M']:
+                return None
+            heads.append((rec, j - i))
+            i = j
+        for rec, _ in heads:
+            HEAD_LOGITS.pop(rec['ptr'], None)
+        return heads
 
     @staticmethod
     def _grad_buffers(logits, device):
@@ -1359,17 +1370,26 @@ class BceSum(Function):
             # launch; any other upstream gradient takes the backward kernel
             outs = BceSum._grad_buffers(logits, loss.device)
             gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
-            rec = BceSum._head_of(logits)
-            if rec is not None:
-                # every term is a row range of ONE critic head's logits: the head kernel of that op's backward rides along
+            heads = BceSum._heads_of(logits)
+            if heads is not None:
+                # every term is a row range of a critic head's logits (one head, or the two heads of the mixture scripts): the head
+                # kernels of those ops' backward ride along
                 new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=loss.device)
-                rec['gh'] = new(rec['M'], rec['H'])
-                rec['d_wout'] = new(rec['H']) if rec['want_out'] else None
-                rec['d_bout'] = new(1) if rec['want_bout'] else None
-                check(_L().ggan_bce_head_bwd(xs, zs, ws, ns, n, _p(loss), gxs, rec['M'], rec['H'], _p(rec['h']()), _p(rec['w_out']()),
-                                             rec['alpha'], _p(rec['gh']), _p(rec['d_wout']), _p(rec['d_bout']), _stream()),
-                      'ggan_bce_head_bwd')
-                rec['g_ptr'] = outs[0].data_ptr()
+                k = 0
+                for rec, nt in heads:
+                    rec['gh'] = new(rec['M'], rec['H'])
+                    rec['d_wout'] = new(rec['H']) if rec['want_out'] else None
+                    rec['d_bout'] = new(1) if rec['want_bout'] else None
+                    rec['g_ptr'] = outs[k].data_ptr()
+                    k += nt
+                m = len(heads)
+                arr = lambda ct, vals: (ct * m)(*vals)
+                ptrs = lambda key, call=False: arr(C.c_void_p, [(_t.data_ptr() if _t is not None else 0) for _t in
+                                                                [(r[key]() if call else r[key]) for r, _ in heads]])
+                check(_L().ggan_bce_heads_bwd(xs, zs, ws, ns, n, _p(loss), gxs, m, arr(C.c_int, [nt for _, nt in heads]),
+                                              arr(C.c_int, [r['M'] for r, _ in heads]), arr(C.c_int, [r['H'] for r, _ in heads]),
+                                              ptrs('h', True), ptrs('w_out', True), arr(C.c_float, [r['alpha'] for r, _ in heads]),
+                                              ptrs('gh'), ptrs('d_wout'), ptrs('d_bout'), _stream()), 'ggan_bce_heads_bwd')
             else:
                 check(_L().ggan_bce_logits_multi_fwd_grad(xs, zs, ws, ns, n, _p(loss), gxs, _stream()), 'ggan_bce_logits_multi_fwd_grad')
             ctx.unit_grads = outs

@@ -259,6 +259,13 @@ int ggan_bce_logits_multi_fwd(const float* const* xs, const float* labels, const
 int ggan_bce_head_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count, float* loss,
                       float* const* gxs, int M, int H, const float* h, const float* w_out, float alpha, float* gh, float* d_wout,
                       float* d_bout, ggan_stream_t stream);
+/* the same for a cost over the logits of up to GGAN_BCE_HEADS heads (the mixture scripts: joint critic + mixture critic,
+ * gmgan_inference_cifar10.py:282-301): head a owns the next head_terms[a] terms; all arrays indexed by head (host arrays). */
+#define GGAN_BCE_HEADS 2
+int ggan_bce_heads_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns, int count, float* loss,
+                       float* const* gxs, int nheads, const int* head_terms, const int* Ms, const int* Hs, const float* const* hs,
+                       const float* const* w_outs, const float* alphas, float* const* ghs, float* const* d_wouts /* entries may be NULL */,
+                       float* const* d_bouts /* entries may be NULL */, ggan_stream_t stream);
 int ggan_bce_logits_multi_bwd(const float* const* xs, const float* labels, const float* weights, const int* ns,
                               int count, const float* gloss, float* const* gxs, ggan_stream_t stream);
 /* forward AND the gradients for an upstream gradient of exactly 1 in one launch: gxs[i][j] = weights[i]*(sigmoid(x)-z)/n, bit for

@@ -686,7 +686,7 @@ def test_cost_launch_carrying_the_head_backward_is_bit_identical(gpu, monkeypatc
     """ggan_bce_head_bwd (BCE cost + unit-seed gradients + the head kernel of the critic tail's backward in one launch, where the
     cost's logits are one critic head's output) against ggan_bce_logits_multi_fwd_grad followed by the head kernel of
     ggan_critic_head_bwd: the same arithmetic in the same order => bit-identical costs and weights after eager and graph-replayed
-    steps.  (The mixture scripts' cost takes logits of two heads: it keeps the separate launches -- same result by construction.)"""
+    steps.  The mixture scripts' cost takes the logits of two heads (joint critic, mixture critic): both head kernels ride along."""
     import torch
     from graphical_gan_amd import functional as F, _lib
     from graphical_gan_amd.models import Config
@@ -703,21 +703,21 @@ def test_cost_launch_carrying_the_head_backward_is_bit_identical(gpu, monkeypatc
         tr = Trainer(cfg, device=gpu, graph=True, seed=4321)
         batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 40)
         lib_, calls = _lib.load(), []
-        entry = lib_.ggan_bce_head_bwd
+        entry = lib_.ggan_bce_heads_bwd
 
         def counted(*args):
-            calls.append(1)
+            calls.append(int(args[7]))             # number of heads carried
             return entry(*args)
-        monkeypatch.setattr(lib_, 'ggan_bce_head_bwd', counted)
+        monkeypatch.setattr(lib_, 'ggan_bce_heads_bwd', counted)
         for it in range(6):
             res = tr.iteration(it, batches)
-        monkeypatch.setattr(lib_, 'ggan_bce_head_bwd', entry)
-        fused_launches.append(len(calls) > 0)
+        monkeypatch.setattr(lib_, 'ggan_bce_heads_bwd', entry)
+        fused_launches.append(max(calls) if calls else 0)
         tr.flush()
         torch.cuda.synchronize()
         assert not F.HEAD_LOGITS or all(r['h']() is None for r in F.HEAD_LOGITS.values()), 'no record may keep a step alive'
         finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}))
-    assert fused_launches == [False, mode == 'ali']
+    assert fused_launches == [0, 1 if mode == 'ali' else 2]      # (the mixture scripts: joint critic + mixture critic in one cost)
     assert finals[0][1] == finals[1][1]
     for k in finals[0][0]:
         assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
