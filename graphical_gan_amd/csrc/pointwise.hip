@@ -782,13 +782,26 @@ __global__ void pack_adam_k(PackTable t, float* __restrict__ flat, float* __rest
     };
     if (s && ((((uintptr_t)s) | ((uintptr_t)d) | ((uintptr_t)s2)) & 15) == 0 && (np == 1 || (ps & 3) == 0) && (np2 <= 1 || (ps2 & 3) == 0)) {
         const size_t n4 = n >> 2;
+        // every load of the chunk first (the four float4 groups of a thread, 16 independent loads in flight), then the arithmetic
+        // and the stores: written as "load, update, store" per group the stores of one group ordered the loads of the next behind
+        // them (the buffers may alias as far as the compiler knows) -- four memory round trips per thread instead of one
+        constexpr int NQ = kPackChunk / 4 / kBlock;
+        float4 X[NQ], Mq[NQ], Vq[NQ], Aq[NQ];
+        bool ok[NQ];
 #pragma unroll
-        for (int q = 0; q < kPackChunk / 4 / kBlock; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const size_t i = base / 4 + threadIdx.x + (size_t)q * kBlock;
-            if (i >= n4 || q * kBlock * 4 >= chunk) break;
-            float4 x = reinterpret_cast<const float4*>(th)[i], mm = reinterpret_cast<const float4*>(mp)[i],
-                   vv = reinterpret_cast<const float4*>(vp)[i];
-            float4 a = reinterpret_cast<const float4*>(s)[i];
+            ok[q] = i < n4 && q * kBlock * 4 < chunk;
+            if (ok[q]) {
+                X[q] = reinterpret_cast<const float4*>(th)[i]; Mq[q] = reinterpret_cast<const float4*>(mp)[i];
+                Vq[q] = reinterpret_cast<const float4*>(vp)[i]; Aq[q] = reinterpret_cast<const float4*>(s)[i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (!ok[q]) continue;
+            const size_t i = base / 4 + threadIdx.x + (size_t)q * kBlock;
+            float4 x = X[q], mm = Mq[q], vv = Vq[q], a = Aq[q];
 #pragma unroll 8
             for (int p = 1; p < np; ++p) {
                 const float4 b = reinterpret_cast<const float4*>(s + (size_t)p * ps)[i];
