@@ -30,7 +30,8 @@ constexpr int kRegE = 16;
 __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ offset, float* __restrict__ y,
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                              int N, int C, int HW, float eps, int act, float alpha) {
+                                                              int N, int C, int HW, float eps, int act, float alpha, FastDiv dHW) {
+    // (element index -> (image, pixel) by one v_mul_hi: a division by the run-time HW is ~35 instructions, twice per element)
     __shared__ float sm[32];
     const int c = blockIdx.x;
     const int total = N * HW;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __res
         const int i = threadIdx.x + j * kThreads;
         float t = 0.f;
         if (i < total) {
-            const int n = i / HW, p = i - n * HW;
+            const int n = (int)fdiv((uint32_t)i, dHW), p = i - n * HW;
             t = x[((size_t)n * C + c) * HW + p];
         }
         v[j] = t;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __res
     for (int j = 0; j < kRegE; ++j) {
         const int i = threadIdx.x + j * kThreads;
         if (i < total) {
-            const int n = i / HW, p = i - n * HW;
+            const int n = (int)fdiv((uint32_t)i, dHW), p = i - n * HW;
             y[((size_t)n * C + c) * HW + p] = act_apply(g * ((v[j] - mean) * invstd) + b, act, alpha);
         }
     }
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
                                                               const float* __restrict__ scale, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                               float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ gx_sum, int N,
-                                                              int C, int HW) {
+                                                              int C, int HW, FastDiv dHW) {
     __shared__ float sm[32];
     const int c = blockIdx.x;
     const int total = N * HW;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
         const int i = threadIdx.x + j * kThreads;
         float a = 0.f, b = 0.f;
         if (i < total) {
-            const int n = i / HW, p = i - n * HW;
+            const int n = (int)fdiv((uint32_t)i, dHW), p = i - n * HW;
             const size_t idx = ((size_t)n * C + c) * HW + p;
             b = ld_gy(gy, mk, idx);
             a = (x[idx] - mean) * invstd;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
     for (int j = 0; j < kRegE; ++j) {
         const int i = threadIdx.x + j * kThreads;
         if (i < total) {
-            const int n = i / HW, p = i - n * HW;
+            const int n = (int)fdiv((uint32_t)i, dHW), p = i - n * HW;
             const float o = k * (g[j] - mg - xh[j] * mgx);
             gx[((size_t)n * C + c) * HW + p] = o;
             s3 += o;
@@ -438,7 +439,8 @@ int ggan_bn_fwd_train(const float* x, const float* scale, const float* offset, f
     hipStream_t s = (hipStream_t)stream;
     const double bytes = 12.0 * N * C * HW;
     if (HW > 1 && N * HW <= kRegE * kThreads) {
-        GGAN_LAUNCH("bn_fwd_nchw", 0, 8.0 * N * C * HW, bn_fwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, HW, eps, act, alpha);
+        GGAN_LAUNCH("bn_fwd_nchw", 0, 8.0 * N * C * HW, bn_fwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, HW, eps, act, alpha,
+                    make_fastdiv((uint32_t)HW));
     } else if (HW > 1) {
         GGAN_LAUNCH("bn_fwd_nchw", 0, bytes, bn_fwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, scale, offset, y, save_mean, save_invstd, N, C, HW, eps, act, alpha);
     } else {
@@ -457,7 +459,8 @@ int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, 
     const GyMask mk{y_act != GGAN_ACT_NONE ? y : nullptr, y_act, y_alpha};
     const double bytes = 20.0 * N * C * HW;
     if (HW > 1 && N * HW <= kRegE * kThreads) {
-        GGAN_LAUNCH("bn_bwd_nchw", 0, 12.0 * N * C * HW, bn_bwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, gx_chansum, N, C, HW);
+        GGAN_LAUNCH("bn_bwd_nchw", 0, 12.0 * N * C * HW, bn_bwd_nchw_reg_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, gx_chansum, N, C, HW,
+                    make_fastdiv((uint32_t)HW));
     } else if (HW > 1) {
         GGAN_LAUNCH("bn_bwd_nchw", 0, bytes, bn_bwd_nchw_k, dim3(C), dim3(kThreads), 0, s, x, gy, mk, scale, save_mean, save_invstd, gx, gscale, goffset, gx_chansum, N, C, HW);
     } else {
