@@ -51,6 +51,7 @@ struct ThinDgradParams {
     int mask_act, act;
     float mask_alpha, alpha;
     int dbg;
+    FastDiv d_k4, d_w4, d_W;     // staging / gather index splits (a division by a run-time value is ~35 instructions, ~17 per thread)
 };
 
 template <int NT, bool TWO>
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     if (!(P.dbg & 4)) {
         const int k4 = K >> 2;
         for (int u = tid; u < NT * 16 * k4; u += NTHR) {
-            const int j = u / k4, c4 = u - j * k4;
+            const int j = (int)fdiv((uint32_t)u, P.d_k4), c4 = u - j * k4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < J) v = *reinterpret_cast<const float4*>(P.w + (size_t)j * K + c4 * 4);
             *reinterpret_cast<float4*>(Ws + j * P.KP + c4 * 4) = v;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
         if ((Wo & 3) == 0) {
             const int w4 = Wo >> 2;
             for (int u = tid; u < K * 4 * w4; u += NTHR) {
-                const int c4 = u % w4, t = u / w4, r = t & 3, k = t >> 2;
+                const int t = (int)fdiv((uint32_t)u, P.d_w4), c4 = u - t * w4, r = t & 3, k = t >> 2;
                 const int oh = g0 - 1 + r;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((unsigned)oh < (unsigned)P.Ho) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     // ---- gather: output rows 2*g0 .. 2*g0+3; SAME padding (1, 2): 2*oh + kh - 1 = y ----------------------------
     const int W = P.W, Ci = P.Ci;
     for (int idx = tid; idx < Ci * 4 * W; idx += NTHR) {
-        const int x = idx % W, t = idx / W, yy = t & 3, c = t >> 2;
+        const int t = (int)fdiv((uint32_t)idx, P.d_W), x = idx - t * W, yy = t & 3, c = t >> 2;
         float s = 0.f;
         for (int kh = (P.dbg & 2) ? 5 : ((yy + 1) & 1); kh < 5; kh += 2) {
             const int r = (yy + 1 - kh) / 2 + 1;               // staged row of oh = g0 + (yy+1-kh)/2
@@ -404,7 +405,7 @@ struct ThinFwdParams {
     int GBR, nb, SR, XRS, XCS, WS, PB, MT, J, KS;
     int xunits, act;
     float alpha;
-    FastDiv d_Wo, d_W4, d_SR, d_Ci, d_5;
+    FastDiv d_Wo, d_W4, d_SR, d_Ci, d_5, d_c4;
     unsigned x_bytes;
     int dbg;
 };
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     if (!(P.dbg & 2)) {
         const int c4 = P.Co >> 2, rows = P.KS * 4;
         for (int u = tid; u < rows * c4; u += NTHR) {
-            const int j = u / c4, f = u - j * c4;
+            const int j = (int)fdiv((uint32_t)u, P.d_c4), f = u - j * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < P.J) v = *reinterpret_cast<const float4*>(P.w + (size_t)j * P.Co + f * 4);
             *reinterpret_cast<float4*>(wsm + j * P.WS + f * 4) = v;
@@ -557,6 +558,7 @@ int conv_dgrad_thin(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     while ((P.PS & 31) != 16) P.PS += 16;      // == 16 (mod 32): the four k-rows of an A fragment hit disjoint bank halves
     P.KP = g.Co + 4;                            // == 4 (mod 32) for K = 32, 64, 96, 128: conflict-free B fragments
     P.TS = NT * 16 + 4;
+    P.d_k4 = make_fastdiv((uint32_t)(g.Co / 4)); P.d_w4 = make_fastdiv((uint32_t)(g.Wo / 4 > 0 ? g.Wo / 4 : 1)); P.d_W = make_fastdiv((uint32_t)g.W);
     const size_t tile = (size_t)g.Co * P.PS, tt = (size_t)P.MT * 16 * P.TS;
     const size_t shmem = ((size_t)NT * 16 * P.KP + (tile > tt ? tile : tt)) * sizeof(float);
     if (shmem > 64 * 1024) return 1;
@@ -687,6 +689,7 @@ int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const
     P.x = x; P.w = w; P.bias = bias; P.y = y; P.act = act; P.alpha = alpha; P.x_bytes = (unsigned)xb;
     { const char* d = getenv("GGAN_THIN_DBG"); P.dbg = d ? atoi(d) : 0; }
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo; P.pad_t = g.pad_t; P.pad_l = g.pad_l;
+    P.d_c4 = make_fastdiv((uint32_t)(g.Co / 4 > 0 ? g.Co / 4 : 1));
     // band of output rows: whole 16-pixel tiles, at most 8 of them; the smallest band that still gives every wave a tile
     // (more workgroups to spread over the chip), one that divides the image if possible
     P.GBR = 0;

@@ -2,6 +2,7 @@
 // interpolation, BCE / Wasserstein / gradient-penalty losses, Adam, gradient packing.
 // All are grid-stride, float4-vectorised where the layout allows, wave-shuffle reductions.
 #include "common.h"
+#include "conv.h"
 using namespace ggan;
 
 namespace {
@@ -131,6 +132,15 @@ __global__ void row_lerp_k(const float* __restrict__ x, const float* __restrict_
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t j = i; j < total; j += stride) {
         float a = alpha[j / (size_t)cols];
+        out[j] = x[j] + a * (y[j] - x[j]);
+    }
+}
+// (32-bit indices and the row by one v_mul_hi: the 64-bit division above is ~100 instructions per element)
+__global__ void row_lerp32_k(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ alpha,
+                             float* __restrict__ out, unsigned total, int cols, FastDiv dc) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const float a = alpha[fdiv(j, dc)];
         out[j] = x[j] + a * (y[j] - x[j]);
     }
 }
@@ -1190,6 +1200,11 @@ int ggan_axpby(const float* x, const float* y, float* out, size_t n, float a, fl
 int ggan_row_lerp(const float* x, const float* y, const float* alpha, float* out, int rows, int cols, ggan_stream_t stream) {
     GGAN_CHECK_ARG(x && y && alpha && out && rows > 0 && cols > 0, "bad argument");
     size_t n = (size_t)rows * cols;
+    if ((double)n * cols < 4.0e9) {
+        GGAN_LAUNCH("row_lerp", 0, 12.0 * n, row_lerp32_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, alpha, out, (unsigned)n, cols,
+                    make_fastdiv((uint32_t)cols));
+        return 0;
+    }
     GGAN_LAUNCH("row_lerp", 0, 12.0 * n, row_lerp_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, alpha, out, rows, cols);
     return 0;
 }
