@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __res
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                               int N, int C, int HW, float eps, int act, float alpha, FastDiv dHW) {
     // (element index -> (image, pixel) by one v_mul_hi: a division by the run-time HW is ~35 instructions, twice per element)
-    __shared__ float sm[32];
+    __shared__ float sm[32], sm2[32];      // (one buffer per reduction: no barrier in front of the second one)
     const int c = blockIdx.x;
     const int total = N * HW;
     const float inv_cnt = 1.f / (float)total;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __res
         v[j] = t;
         s += t;
     }
-    const float mean = block_sum(s, sm) * inv_cnt;
+    const float mean = block_sum_fresh(s, sm) * inv_cnt;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < kRegE; ++j) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_nchw_reg_k(const float* __res
         const float d = v[j] - mean;
         if (i < total) q += d * d;
     }
-    const float var = block_sum(q, sm) * inv_cnt;
+    const float var = block_sum_fresh(q, sm2) * inv_cnt;
     const float invstd = 1.f / sqrtf(var + eps);
     const float g = scale[c], b = offset[c];
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
                                                               const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                               float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ gx_sum, int N,
                                                               int C, int HW, FastDiv dHW) {
-    __shared__ float sm[32];
+    __shared__ float sm[32], sm2[32];      // (the two sums in one pass; the third reduction has its own buffer)
     const int c = blockIdx.x;
     const int total = N * HW;
     const float mean = save_mean[c], invstd = save_invstd[c];
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
         s1 += b;
         s2 += b * a;
     }
-    const float sum_g = block_sum(s1, sm);
-    const float sum_gx = block_sum(s2, sm);
+    block_sum2_fresh(s1, s2, sm);
+    const float sum_g = s1, sum_gx = s2;
     const float inv_cnt = 1.f / (float)total;
     const float k = scale[c] * invstd, mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
     float s3 = 0.f;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_nchw_reg_k(const float* __res
         }
     }
     if (gx_sum) {   // channel sum of the result: the bias gradient of the layer below (mathematically 0, kept for parity)
-        const float t = block_sum(s3, sm);
+        const float t = block_sum_fresh(s3, sm2);
         if (threadIdx.x == 0) gx_sum[c] = t;
     }
     if (threadIdx.x == 0) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_nchw_reg4_k(const float* __restrict
                                                          const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                          float* __restrict__ gscale, float* __restrict__ goffset,
                                                          float* __restrict__ gx_sum, int N, int C, int HW, FastDiv dHW) {
-    __shared__ float sm[32];
+    __shared__ float sm[32], sm2[32];      // (the two sums in one pass; the third reduction has its own buffer)
     const int c = blockIdx.x;
     const int total = N * HW, units = total >> 2;
     const float mean = save_mean[c], invstd = save_invstd[c];
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_nchw_reg4_k(const float* __restrict
             s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
         }
     }
-    const float sum_g = block_sum(s1, sm);
-    const float sum_gx = block_sum(s2, sm);
+    block_sum2_fresh(s1, s2, sm);
+    const float sum_g = s1, sum_gx = s2;
     const float inv_cnt = 1.f / (float)total;
     const float k = scale[c] * invstd, mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
     float s3 = 0.f;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_nchw_reg4_k(const float* __restrict
         }
     }
     if (gx_sum) {
-        const float t = block_sum(s3, sm);
+        const float t = block_sum_fresh(s3, sm2);
         if (threadIdx.x == 0) gx_sum[c] = t;
     }
     if (threadIdx.x == 0) {

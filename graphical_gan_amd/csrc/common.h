@@ -110,6 +110,28 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats 
     return t;
 }
 
+// block_sum into a buffer no earlier reduction of the kernel used: no leading barrier (the reads of an earlier reduction cannot be
+// overtaken).  block_sum2_fresh: two values in one pass (one barrier instead of four).
+__device__ __forceinline__ float block_sum_fresh(float v, float* smem /* >= 16 floats, not yet used */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += smem[i];
+    return t;
+}
+__device__ __forceinline__ void block_sum2_fresh(float& a, float& b, float* smem /* >= 32 floats, not yet used */) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) { smem[wid] = a; smem[16 + wid] = b; }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+    for (int i = 0; i < nw; ++i) { ta += smem[i]; tb += smem[16 + i]; }
+    a = ta; b = tb;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
