@@ -460,7 +460,7 @@ struct BceHeads { BceHead hd[GGAN_BCE_HEADS]; int count; };
 
 __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restrict__ loss, const BceHeads hs) {
     __shared__ float sm[32];
-    __shared__ float red[4][64];
+    __shared__ float red[8][32];
     __shared__ float gs_[GGAN_HEAD_BCE_MAX_ROWS];
     if (blockIdx.x == 0) {
         float tot = 0.f;
@@ -501,13 +501,13 @@ __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restr
         }
     }
     __syncthreads();
-    const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
-    const int c = ((int)blockIdx.x - hd.first) * 64 + cl;
+    const int tid = threadIdx.x, cl = tid & 31, rg = tid >> 5;          // (the loop of head_out_bwd_k, gemm.hip)
+    const int c = ((int)blockIdx.x - hd.first) * 32 + cl;
     float acc = 0.f, gsum = 0.f;
     if (c < H) {
         const float w = w_out[c];
-#pragma unroll 4
-        for (int r = rg; r < M; r += 4) {
+#pragma unroll 8
+        for (int r = rg; r < M; r += 8) {
             const float gr = gs_[r], hv = h[(size_t)r * H + c];
             gh[(size_t)r * H + c] = gr * w * (hv > 0.f ? 1.f : alpha);
             acc = fmaf(gr, hv, acc);
@@ -516,12 +516,13 @@ __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restr
     }
     red[rg][cl] = acc;
     __syncthreads();
-    if (rg == 0 && c < H && d_wout) d_wout[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (rg == 0 && c < H && d_wout)
+        d_wout[c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
     if ((int)blockIdx.x == hd.first && d_bout) {
         __syncthreads();
         if (cl == 0) red[rg][0] = gsum;
         __syncthreads();
-        if (tid == 0) d_bout[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        if (tid == 0) d_bout[0] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) + ((red[4][0] + red[5][0]) + (red[6][0] + red[7][0]));
     }
 }
 
@@ -1323,7 +1324,7 @@ int ggan_bce_heads_bwd(const float* const* xs, const float* labels, const float*
         }
         GGAN_CHECK_ARG(rows == d.M, "a head's terms must cover its rows");
         k = d.k1;
-        wg += cdiv(d.H, 64);
+        wg += cdiv(d.H, 32);
     }
     GGAN_CHECK_ARG(k == count, "every term belongs to a head");
     GGAN_LAUNCH("bce_head_bwd", 0, 0, bce_head_bwd_k, dim3(wg), dim3(256), 0, (hipStream_t)stream, t, loss, H);
