@@ -436,20 +436,21 @@ __global__ __launch_bounds__(256) void head_out_fwd_k(const float* __restrict__ 
 }
 
 // backward head: gh[r,c] = g[r] * w_out[c] * lrelu'(h[r,c]);  d_wout[c] = sum_r g[r] h[r,c];  d_bout = sum_r g[r].
-// One workgroup per 32 columns (twice the workgroups of a 64-column split: the launch is a chain of L2 round trips per thread, not
-// bandwidth); 8 row groups, combined in a fixed order (deterministic).  bce_head_bwd_k (pointwise.hip) is the same loop with g
+// One workgroup per 16 columns, 16 row groups (measured against 64 x 4 and 32 x 8: the launch is a chain of L2 round trips per
+// thread, not bandwidth -- 8 rows per thread at 128 rows, all of their loads in flight at once); the row groups are combined in a
+// fixed order (deterministic).  bce_head_bwd_k (pointwise.hip) is the same loop with g
 // formed from the logits.
 __global__ __launch_bounds__(256) void head_out_bwd_k(const float* __restrict__ g, const float* __restrict__ h,
                                                       const float* __restrict__ w_out, float alpha, float* __restrict__ gh,
                                                       float* __restrict__ d_wout, float* __restrict__ d_bout, int M, int H) {
-    __shared__ float red[8][32];
-    const int tid = threadIdx.x, cl = tid & 31, rg = tid >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ float red[16][16];
+    const int tid = threadIdx.x, cl = tid & 15, rg = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float acc = 0.f, gs = 0.f;
     if (c < H) {
         const float w = w_out[c];
 #pragma unroll 8
-        for (int r = rg; r < M; r += 8) {
+        for (int r = rg; r < M; r += 16) {
             const float gr = g[r], hv = h[(size_t)r * H + c];
             gh[(size_t)r * H + c] = gr * w * (hv > 0.f ? 1.f : alpha);
             acc = fmaf(gr, hv, acc);
@@ -459,12 +460,14 @@ __global__ __launch_bounds__(256) void head_out_bwd_k(const float* __restrict__ 
     red[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < H && d_wout)
-        d_wout[c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+        d_wout[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) +
+                    (((red[8][cl] + red[9][cl]) + (red[10][cl] + red[11][cl])) + ((red[12][cl] + red[13][cl]) + (red[14][cl] + red[15][cl])));
     if (blockIdx.x == 0 && d_bout) {
         __syncthreads();
         if (cl == 0) red[rg][0] = gs;
         __syncthreads();
-        if (tid == 0) d_bout[0] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) + ((red[4][0] + red[5][0]) + (red[6][0] + red[7][0]));
+        if (tid == 0) d_bout[0] = (((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) + ((red[4][0] + red[5][0]) + (red[6][0] + red[7][0]))) +
+                                (((red[8][0] + red[9][0]) + (red[10][0] + red[11][0])) + ((red[12][0] + red[13][0]) + (red[14][0] + red[15][0])));
     }
 }
 
@@ -656,7 +659,7 @@ int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const flo
     hipStream_t s = (hipStream_t)stream;
     const int K = K1 + K2;
     if (g) {        // (NULL: gh was produced together with the cost, ggan_bce_head_bwd)
-        GGAN_LAUNCH("head_out_bwd_k", 3.0 * M * H, 8.0 * M * H, head_out_bwd_k, dim3(cdiv(H, 32)), dim3(256), 0, s, g, h, w_out, alpha, gh,
+        GGAN_LAUNCH("head_out_bwd_k", 3.0 * M * H, 8.0 * M * H, head_out_bwd_k, dim3(cdiv(H, 16)), dim3(256), 0, s, g, h, w_out, alpha, gh,
                     d_wout, d_bout, M, H);
     }
     GemmPlan Gw, Ga;

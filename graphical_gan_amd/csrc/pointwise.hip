@@ -460,7 +460,7 @@ struct BceHeads { BceHead hd[GGAN_BCE_HEADS]; int count; };
 
 __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restrict__ loss, const BceHeads hs) {
     __shared__ float sm[32];
-    __shared__ float red[8][32];
+    __shared__ float red[16][16];
     __shared__ float gs_[GGAN_HEAD_BCE_MAX_ROWS];
     if (blockIdx.x == 0) {
         float tot = 0.f;
@@ -501,13 +501,13 @@ __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restr
         }
     }
     __syncthreads();
-    const int tid = threadIdx.x, cl = tid & 31, rg = tid >> 5;          // (the loop of head_out_bwd_k, gemm.hip)
-    const int c = ((int)blockIdx.x - hd.first) * 32 + cl;
+    const int tid = threadIdx.x, cl = tid & 15, rg = tid >> 4;          // (the loop of head_out_bwd_k, gemm.hip)
+    const int c = ((int)blockIdx.x - hd.first) * 16 + cl;
     float acc = 0.f, gsum = 0.f;
     if (c < H) {
         const float w = w_out[c];
 #pragma unroll 8
-        for (int r = rg; r < M; r += 8) {
+        for (int r = rg; r < M; r += 16) {
             const float gr = gs_[r], hv = h[(size_t)r * H + c];
             gh[(size_t)r * H + c] = gr * w * (hv > 0.f ? 1.f : alpha);
             acc = fmaf(gr, hv, acc);
@@ -517,12 +517,14 @@ __global__ __launch_bounds__(256) void bce_head_bwd_k(BceTable t, float* __restr
     red[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < H && d_wout)
-        d_wout[c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+        d_wout[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) +
+                    (((red[8][cl] + red[9][cl]) + (red[10][cl] + red[11][cl])) + ((red[12][cl] + red[13][cl]) + (red[14][cl] + red[15][cl])));
     if ((int)blockIdx.x == hd.first && d_bout) {
         __syncthreads();
         if (cl == 0) red[rg][0] = gsum;
         __syncthreads();
-        if (tid == 0) d_bout[0] = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) + ((red[4][0] + red[5][0]) + (red[6][0] + red[7][0]));
+        if (tid == 0) d_bout[0] = (((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) + ((red[4][0] + red[5][0]) + (red[6][0] + red[7][0]))) +
+                                (((red[8][0] + red[9][0]) + (red[10][0] + red[11][0])) + ((red[12][0] + red[13][0]) + (red[14][0] + red[15][0])));
     }
 }
 
@@ -1324,7 +1326,7 @@ int ggan_bce_heads_bwd(const float* const* xs, const float* labels, const float*
         }
         GGAN_CHECK_ARG(rows == d.M, "a head's terms must cover its rows");
         k = d.k1;
-        wg += cdiv(d.H, 32);
+        wg += cdiv(d.H, 16);
     }
     GGAN_CHECK_ARG(k == count, "every term belongs to a head");
     GGAN_LAUNCH("bce_head_bwd", 0, 0, bce_head_bwd_k, dim3(wg), dim3(256), 0, (hipStream_t)stream, t, loss, H);
