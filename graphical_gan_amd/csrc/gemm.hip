@@ -496,6 +496,8 @@ size_t ggan_gemm_workspace(int M, int N, int K) {
 
 // Fill the parameter block of one product (operand views, float4 legality, split-K choice, FAST path); no launch.
 // mode 0: normal (split-K result reduced by the caller)   1: no split-K (grouped launches, fused column sums)
+int g_split_target = 256;      // workgroups a split-K product aims at (the critic head's forward may ask for more)
+
 struct GemmPlan {
     GemmParams P;
     int gx, gy;
@@ -544,10 +546,10 @@ static int gemm_plan(GemmPlan& G, int mode, int ta, int tb, int M, int N, int K,
             // (long reductions -- the Conv3D patch-matrix filter gradients, K = 10^4..10^6 rows: four workgroups per CU and up to
             // 256 slabs, so each workgroup's serial chain stays ~10^3 rows)
             const bool tall = K >= 16384;
-            sk = (tall ? 1024 : 256) / base;
+            sk = (tall ? 1024 : g_split_target) / base;
             const int max_sk = K / BK;
             if (sk > max_sk) sk = max_sk;
-            if (sk > (tall ? 256 : 64)) sk = tall ? 256 : 64;
+            if (sk > (tall ? 256 : g_split_target / 4)) sk = tall ? 256 : g_split_target / 4;
             // short reductions over a grid that already covers a good part of the chip (the weight gradients of the batch-64
             // layers): the extra reduce launch costs more than it spreads (5.4 vs 8.4 us measured at 512x512x64)
             if (K <= 128 && base >= 32) sk = 1;
@@ -632,8 +634,12 @@ int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const fl
     GGAN_CHECK_ARG(al16(b) && al16(w_out) && al16(h), "b, w_out, h must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     GemmPlan G;
+    // (twice the workgroups of the other split products: the tail kernel below sums the slabs anyway, and this product sits alone on
+    //  the step's critical chain -- 9 serial k-steps per workgroup at 256, 5 at 512: 1.127 -> 1.122 ms; 1024: slower again)
+    { const char* e = getenv("GGAN_HEAD_WGS"); g_split_target = e ? atoi(e) : 512; }
     int rc = gemm_plan(G, 0, 0, 0, M, H, K1 + K2, a1, w, nullptr, h, nullptr, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
                        K2 ? a2 : nullptr, K2 ? K1 : 0);
+    g_split_target = 256;
     if (rc) return rc;
     rc = gemm_launch_planned(G, 0, 0, s);
     if (rc) return rc;
