@@ -560,7 +560,9 @@ static int gemm_plan(GemmPlan& G, int mode, int ta, int tb, int M, int N, int K,
         if (colsum && !(gx * gy < 64 && K >= 512)) sk = 1;
         while (sk > 1 && (size_t)sk * (P.out_elems + (colsum ? N : 0)) * sizeof(float) > ws_bytes) sk /= 2;
     }
-    P.kps = cdiv(cdiv(K, sk), BK) * BK;
+    // (a two-source operand is switched per k-STEP: every split must start on the step grid, or a step would straddle a_split)
+    const int kq = (A2 && !ta) ? KSTEP : BK;
+    P.kps = cdiv(cdiv(K, sk), kq) * kq;
     P.SK = cdiv(K, P.kps);
     P.slab_stride = P.out_elems + ((colsum && P.SK > 1) ? (size_t)N : 0);
     if (P.SK > 1) {
