@@ -130,6 +130,7 @@ class AdamOptimizer(object):
         it, the update is applied by the pack launch and the following update() call does nothing"""
         cc = lambda g: None if g is None else (g if g.is_contiguous() else g.contiguous())
         gs = [(cc(g[0]), cc(g[1])) if isinstance(g, tuple) else cc(g) for g in grads]
+        self._updated = False            # (a fused pack whose update() call never came must not swallow the next one)
         if fuse_update and self.can_fuse_update():
             if self._arrive is None:
                 self._arrive = torch.zeros(F._lib.PACK_ARRIVE_INTS, dtype=torch.int32, device=self.theta.device)
@@ -154,6 +155,7 @@ class AdamOptimizer(object):
         return k, self.slots[k][0]
 
     def pack_subset(self, grads, lo, hi, bump):
+        self._updated = False
         gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
         F.pack_(gs, self.slots[lo:hi], self.g, bump=self.step if bump else None)
         return gs
