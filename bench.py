@@ -141,7 +141,7 @@ def _pmc_table(workload_key):
     return {}, tag
 
 
-def cpu_baseline(spec, cfg, K, np, torch, budget_s=float(os.environ.get('GGAN_BENCH_CPU_BUDGET_S', '10'))):
+def cpu_baseline(spec, cfg, K, np, torch, budget_s=float(os.environ.get('GGAN_BENCH_CPU_BUDGET_S', '3'))):
     """The same step on the host cores (oracle/, test infrastructure; the reference itself is Python 2 + TF1 and cannot run):
     PyTorch-CPU restatement (oneDNN convolutions, every granted core) for the image scripts, the numpy restatement on a
     bounded sample for the state-space script."""
@@ -347,17 +347,25 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
             tab, tag = _pmc_table(spec.get('key', 'headline'))
             pmc = tab.get(dom['name'])
+            avg_us = 1e3 * dom['total_ms'] / dom['launches']
+            fpl = dom['flops'] / dom['launches']
+            ig_us = (pmc or {}).get('avg_us_in_graph')          # rocprofv3 --kernel-trace of the graph-replayed step, same workload
             roofline = dict(bound='mfma', kernel=dom['name'], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
                             unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                            source='HIP-event bracket around every launch of this kernel on the launch stream, eager replay of '
-                                   'the same step in this process (%d iterations); the timed region above replays HIP graphs, '
-                                   'whose per-kernel durations are in profiles/ (rocprofv3 --kernel-trace)' % n_prof,
+                            frac_eager=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                            frac_in_graph=round(fpl / (ig_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if ig_us else None,
+                            avg_launch_us=round(avg_us, 2), avg_launch_us_in_graph=ig_us,
+                            flop_per_launch=fpl,
                             traffic=pmc['traffic_bytes'] if pmc else None,
-                            traffic_source=('static: profiles/pmc_traffic.json @%s (separate rocprofv3 --pmc passes of this '
-                                            'workload, bytes/launch, FETCH_SIZE x2 per the gfx950 note)' % tag) if pmc else None,
+                            algorithmic_bytes=round(dom['bytes'] / dom['launches']) if dom.get('bytes') else None,
+                            mfma_util_pct=(pmc or {}).get('mfma_util_pct'),
+                            static_tag=tag if pmc else None,
+                            source='achieved / frac / frac_eager: HIP-event bracket around every launch of this kernel on the launch '
+                                   'stream, eager replay of the same step in this process (%d iterations); frac_in_graph, traffic, '
+                                   'mfma_util_pct: static, profiles/pmc_traffic.json @%s (rocprofv3 --kernel-trace of the graph-replayed '
+                                   'step and separate --pmc passes of this workload, per launch; FETCH_SIZE corrected per staging '
+                                   'path, tools/pmc_summary.py)' % (n_prof, tag),
                             pmc=pmc,
-                            avg_launch_us=round(1e3 * dom['total_ms'] / dom['launches'], 2),
-                            flop_per_launch=dom['flops'] / dom['launches'],
                             whole_step_tflops=round(step_tflops, 2),
                             whole_step_frac=round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                             libggan_launches_per_step=launches_per_iter)
@@ -459,6 +467,73 @@ def supervise():
     return 1
 
 
+LINE_LIMIT = 4096      # the driver keeps the tail of stdout: the LAST line must be one parseable JSON object well under that
+
+
+def _short_cpu(c):
+    return None if not c else dict(value=c['value'], unit=c['unit'], cores=c['cores'], kind=c['kind'], sample=c['sample'][:120])
+
+
+def _short_roofline(r):
+    if not r:
+        return None
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_eager', 'frac_in_graph', 'avg_launch_us',
+            'avg_launch_us_in_graph', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'static_tag')
+    d = {k: r.get(k) for k in keep}
+    d['source'] = 'frac=frac_eager: live HIP-event bracket (eager replay); frac_in_graph/traffic/mfma_util_pct: profiles/pmc_traffic.json'
+    return d
+
+
+def compact_line(full):
+    """The contract line: headline keys + roofline + cpu_baseline + one short record per variant; everything else
+    (kernel tables, prose, per-variant configs) lives in the full record (bench_full.json)."""
+    line = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                 'vs_baseline', 'dtype', 'data')}
+    c = full['config']
+    line['config'] = {k: c[k] for k in ('workload', 'parallelism', 'global_batch', 'hip_graph', 'minibatches_per_step',
+                                         'algorithmic_gflop_per_step', 'finite_costs') if k in c}
+    line['whole_step_frac'] = full.get('whole_step_frac')
+    if full.get('roofline'):
+        line['launches_per_step'] = full['roofline'].get('libggan_launches_per_step')
+    line['roofline'] = _short_roofline(full.get('roofline'))
+    line['cpu_baseline'] = _short_cpu(full.get('cpu_baseline'))
+    if full.get('data_parallel'):
+        line['data_parallel'] = full['data_parallel']
+    vs = []
+    for v in full.get('variants') or []:
+        r = v.get('roofline') or {}
+        vs.append(dict(key=v['key'], value=v['value'], unit=v['unit'], ms_per_step=v['ms_per_step'],
+                       whole_step_frac=v.get('whole_step_frac'), kernel=r.get('kernel'), frac=r.get('frac'),
+                       frac_in_graph=r.get('frac_in_graph'), cpu=(v.get('cpu_baseline') or {}).get('value'),
+                       finite=(v.get('config') or {}).get('finite_costs')))
+    line['variants'] = vs
+    line['full_record'] = full.get('_full_path')
+    txt = json.dumps(line, separators=(',', ':'))
+    if len(txt) >= LINE_LIMIT:                          # never let the line outgrow the driver's window: drop detail, keep the contract
+        for v in vs:
+            v.pop('kernel', None)
+        line['roofline'].pop('source', None)
+        txt = json.dumps(line, separators=(',', ':'))
+    assert len(txt) < LINE_LIMIT, len(txt)
+    return txt
+
+
+def emit(full):
+    """Full record -> gpurun_out/bench_full.json (GGAN_BENCH_FULL overrides; merged back from the GPU box), compact line -> the
+    last line of stdout."""
+    path = os.environ.get('GGAN_BENCH_FULL') or os.path.join(ROOT, 'gpurun_out', 'bench_full.json')
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(full, f, indent=1)
+        full['_full_path'] = os.path.relpath(path, ROOT)
+    except OSError:
+        full['_full_path'] = None
+    sys.stdout.flush()
+    print(compact_line(full))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -557,10 +632,8 @@ def main():
         if dp_extra is not None:
             out['data_parallel'] = dict(dp_extra, exchange='captured in the step graph' if os.environ.get('GGAN_DP_GRAPH', '1') != '0'
                                         else 'host-issued between cut graphs', weak_scaling_per_gpu_batch=64)
-        if variants or not args.no_variants:
-            out['metric'] = out['metric'] + ('; variants: G+D+GP (wali-gp), gmgan K=30/K=10, face 64x64, ssgan T=16' if variants else '')
-            out['variants'] = variants
-        print(json.dumps(out))
+        out['variants'] = variants
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

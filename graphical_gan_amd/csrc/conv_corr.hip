@@ -863,6 +863,8 @@ bool dgrad_x4_cfg(int mode, int cfg) { return mode == 1 ? (cfg == 4 || cfg == 5 
 
 template <int MODE>
 int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_t s, const char* name, double fl) {
+    // algorithmic bytes of the launch: input + filter + output, one pass each (SURVEY.md App. B "bytes")
+    const double ab = (double)P.in_bytes + (double)P.w_bytes + 4.0 * (double)P.out_elems;
     static bool once = false;
     if (!once) {   // double-buffered staging can exceed the 64 KiB default dynamic-LDS limit
         allow_big_lds(corr_kernel<0, 2, 2, 1, 2>); allow_big_lds(corr_kernel<0, 2, 1, 2, 2>); allow_big_lds(corr_kernel<0, 1, 1, 4, 1>);
@@ -885,11 +887,11 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
     if constexpr (MODE == 0) {
         if (P.xq == 4) {       // slab staged in 16-byte units (the 8-wave layouts only: plan_and_launch)
             switch (cfg) {
-                case 4: GGAN_LAUNCH("corr_kernel<0, 2, 1, 4, 1, true>", fl, 0, (corr_kernel<0, 2, 1, 4, 1, true>), grid, dim3(512), shmem, s, P); break;
-                case 5: GGAN_LAUNCH("corr_kernel<0, 1, 1, 8, 1, true>", fl, 0, (corr_kernel<0, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
-                case 6: GGAN_LAUNCH("corr_kernel<0, 2, 2, 2, 1, true>", fl, 0, (corr_kernel<0, 2, 2, 2, 1, true>), grid, dim3(512), shmem, s, P); break;
-                case 7: GGAN_LAUNCH("corr_kernel<0, 2, 1, 4, 2, true>", fl, 0, (corr_kernel<0, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
-                case 8: GGAN_LAUNCH("corr_kernel<0, 4, 1, 2, 2, true>", fl, 0, (corr_kernel<0, 4, 1, 2, 2, true>), grid, dim3(512), shmem, s, P); break;
+                case 4: GGAN_LAUNCH("corr_kernel<0, 2, 1, 4, 1, true>", fl, ab, (corr_kernel<0, 2, 1, 4, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 5: GGAN_LAUNCH("corr_kernel<0, 1, 1, 8, 1, true>", fl, ab, (corr_kernel<0, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 6: GGAN_LAUNCH("corr_kernel<0, 2, 2, 2, 1, true>", fl, ab, (corr_kernel<0, 2, 2, 2, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 7: GGAN_LAUNCH("corr_kernel<0, 2, 1, 4, 2, true>", fl, ab, (corr_kernel<0, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
+                case 8: GGAN_LAUNCH("corr_kernel<0, 4, 1, 2, 2, true>", fl, ab, (corr_kernel<0, 4, 1, 2, 2, true>), grid, dim3(512), shmem, s, P); break;
                 default: set_error("%s: no 16-byte-unit variant of wave layout %d", name, cfg); return -3;
             }
             return 0;
@@ -898,9 +900,9 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
     if constexpr (MODE == 2) {
         if (P.xq == 4) {
             switch (cfg) {
-                case 5: GGAN_LAUNCH("corr_kernel<2, 1, 1, 8, 1, true>", fl, 0, (corr_kernel<2, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
-                case 6: GGAN_LAUNCH("corr_kernel<2, 2, 2, 2, 1, true>", fl, 0, (corr_kernel<2, 2, 2, 2, 1, true>), grid, dim3(512), shmem, s, P); break;
-                default: GGAN_LAUNCH("corr_kernel<2, 2, 1, 4, 2, true>", fl, 0, (corr_kernel<2, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
+                case 5: GGAN_LAUNCH("corr_kernel<2, 1, 1, 8, 1, true>", fl, ab, (corr_kernel<2, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
+                case 6: GGAN_LAUNCH("corr_kernel<2, 2, 2, 2, 1, true>", fl, ab, (corr_kernel<2, 2, 2, 2, 1, true>), grid, dim3(512), shmem, s, P); break;
+                default: GGAN_LAUNCH("corr_kernel<2, 2, 1, 4, 2, true>", fl, ab, (corr_kernel<2, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
             }
             return 0;
         }
@@ -908,35 +910,35 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
     if constexpr (MODE == 1) {
         if (P.xq == 4) {
             switch (cfg) {
-                case 4: GGAN_LAUNCH("corr_kernel<1, 2, 1, 4, 2, true>", fl, 0, (corr_kernel<1, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
-                case 5: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 1, true>", fl, 0, (corr_kernel<1, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
-                default: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 2, true>", fl, 0, (corr_kernel<1, 1, 1, 8, 2, true>), grid, dim3(512), shmem, s, P); break;
+                case 4: GGAN_LAUNCH("corr_kernel<1, 2, 1, 4, 2, true>", fl, ab, (corr_kernel<1, 2, 1, 4, 2, true>), grid, dim3(512), shmem, s, P); break;
+                case 5: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 1, true>", fl, ab, (corr_kernel<1, 1, 1, 8, 1, true>), grid, dim3(512), shmem, s, P); break;
+                default: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 2, true>", fl, ab, (corr_kernel<1, 1, 1, 8, 2, true>), grid, dim3(512), shmem, s, P); break;
             }
             return 0;
         }
     }
     if constexpr (MODE == 0 || MODE == 2) {
         switch (cfg) {
-            case 0: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 1, 2, false>" : "corr_kernel<2, 2, 2, 1, 2, false>"), fl, 0, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
-            case 1: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 2, 2, false>" : "corr_kernel<2, 2, 1, 2, 2, false>"), fl, 0, (corr_kernel<MODE, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
-            case 2: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 4, 1, false>" : "corr_kernel<2, 1, 1, 4, 1, false>"), fl, 0, (corr_kernel<MODE, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
-            case 3: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 4, 2, false>" : "corr_kernel<2, 1, 1, 4, 2, false>"), fl, 0, (corr_kernel<MODE, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
-            case 4: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 1, false>" : "corr_kernel<2, 2, 1, 4, 1, false>"), fl, 0, (corr_kernel<MODE, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
-            case 5: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 8, 1, false>" : "corr_kernel<2, 1, 1, 8, 1, false>"), fl, 0, (corr_kernel<MODE, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
-            case 6: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 2, 1, false>" : "corr_kernel<2, 2, 2, 2, 1, false>"), fl, 0, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
-            case 7: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 2, false>" : "corr_kernel<2, 2, 1, 4, 2, false>"), fl, 0, (corr_kernel<MODE, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 4, 1, 2, 2, false>" : "corr_kernel<2, 4, 1, 2, 2, false>"), fl, 0, (corr_kernel<MODE, 4, 1, 2, 2>), grid, dim3(512), shmem, s, P); break;
+            case 0: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 1, 2, false>" : "corr_kernel<2, 2, 2, 1, 2, false>"), fl, ab, (corr_kernel<MODE, 2, 2, 1, 2>), grid, dim3(256), shmem, s, P); break;
+            case 1: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 2, 2, false>" : "corr_kernel<2, 2, 1, 2, 2, false>"), fl, ab, (corr_kernel<MODE, 2, 1, 2, 2>), grid, dim3(256), shmem, s, P); break;
+            case 2: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 4, 1, false>" : "corr_kernel<2, 1, 1, 4, 1, false>"), fl, ab, (corr_kernel<MODE, 1, 1, 4, 1>), grid, dim3(256), shmem, s, P); break;
+            case 3: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 4, 2, false>" : "corr_kernel<2, 1, 1, 4, 2, false>"), fl, ab, (corr_kernel<MODE, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 4: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 1, false>" : "corr_kernel<2, 2, 1, 4, 1, false>"), fl, ab, (corr_kernel<MODE, 2, 1, 4, 1>), grid, dim3(512), shmem, s, P); break;
+            case 5: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 1, 1, 8, 1, false>" : "corr_kernel<2, 1, 1, 8, 1, false>"), fl, ab, (corr_kernel<MODE, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
+            case 6: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 2, 2, 1, false>" : "corr_kernel<2, 2, 2, 2, 1, false>"), fl, ab, (corr_kernel<MODE, 2, 2, 2, 1>), grid, dim3(512), shmem, s, P); break;
+            case 7: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 2, 1, 4, 2, false>" : "corr_kernel<2, 2, 1, 4, 2, false>"), fl, ab, (corr_kernel<MODE, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH((MODE == 0 ? "corr_kernel<0, 4, 1, 2, 2, false>" : "corr_kernel<2, 4, 1, 2, 2, false>"), fl, ab, (corr_kernel<MODE, 4, 1, 2, 2>), grid, dim3(512), shmem, s, P); break;
         }
     } else {
         switch (cfg) {
-            case 0: GGAN_LAUNCH("corr_kernel<1, 2, 2, 1, 4, false>", fl, 0, (corr_kernel<1, 2, 2, 1, 4>), grid, dim3(256), shmem, s, P); break;
-            case 1: GGAN_LAUNCH("corr_kernel<1, 2, 1, 2, 4, false>", fl, 0, (corr_kernel<1, 2, 1, 2, 4>), grid, dim3(256), shmem, s, P); break;
-            case 2: GGAN_LAUNCH("corr_kernel<1, 1, 1, 4, 2, false>", fl, 0, (corr_kernel<1, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
-            case 3: GGAN_LAUNCH("corr_kernel<1, 1, 1, 4, 4, false>", fl, 0, (corr_kernel<1, 1, 1, 4, 4>), grid, dim3(256), shmem, s, P); break;
-            case 4: GGAN_LAUNCH("corr_kernel<1, 2, 1, 4, 2, false>", fl, 0, (corr_kernel<1, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
-            case 5: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 1, false>", fl, 0, (corr_kernel<1, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
-            case 6: GGAN_LAUNCH("corr_kernel<1, 2, 2, 2, 2, false>", fl, 0, (corr_kernel<1, 2, 2, 2, 2>), grid, dim3(512), shmem, s, P); break;
-            default: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 2, false>", fl, 0, (corr_kernel<1, 1, 1, 8, 2>), grid, dim3(512), shmem, s, P); break;
+            case 0: GGAN_LAUNCH("corr_kernel<1, 2, 2, 1, 4, false>", fl, ab, (corr_kernel<1, 2, 2, 1, 4>), grid, dim3(256), shmem, s, P); break;
+            case 1: GGAN_LAUNCH("corr_kernel<1, 2, 1, 2, 4, false>", fl, ab, (corr_kernel<1, 2, 1, 2, 4>), grid, dim3(256), shmem, s, P); break;
+            case 2: GGAN_LAUNCH("corr_kernel<1, 1, 1, 4, 2, false>", fl, ab, (corr_kernel<1, 1, 1, 4, 2>), grid, dim3(256), shmem, s, P); break;
+            case 3: GGAN_LAUNCH("corr_kernel<1, 1, 1, 4, 4, false>", fl, ab, (corr_kernel<1, 1, 1, 4, 4>), grid, dim3(256), shmem, s, P); break;
+            case 4: GGAN_LAUNCH("corr_kernel<1, 2, 1, 4, 2, false>", fl, ab, (corr_kernel<1, 2, 1, 4, 2>), grid, dim3(512), shmem, s, P); break;
+            case 5: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 1, false>", fl, ab, (corr_kernel<1, 1, 1, 8, 1>), grid, dim3(512), shmem, s, P); break;
+            case 6: GGAN_LAUNCH("corr_kernel<1, 2, 2, 2, 2, false>", fl, ab, (corr_kernel<1, 2, 2, 2, 2>), grid, dim3(512), shmem, s, P); break;
+            default: GGAN_LAUNCH("corr_kernel<1, 1, 1, 8, 2, false>", fl, ab, (corr_kernel<1, 1, 1, 8, 2>), grid, dim3(512), shmem, s, P); break;
         }
     }
     return 0;

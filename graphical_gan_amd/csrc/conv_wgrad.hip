@@ -459,11 +459,12 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     }
     const int nit = env_int("GGAN_WGRAD_DEAL", 1) ? (P.PC == 128 ? 2 : (P.PC == 64 ? 1 : 0)) : 0;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
+    const double ab = 4.0 * ((double)g.N * g.Ci * g.H * g.W + (double)g.N * g.Co * g.Ho * g.Wo + 25.0 * g.Ci * g.Co);
     if (parts && ws_bytes < P.slab_stride * sizeof(float)) { set_error("conv_wgrad: partial-slab buffer too small"); return -1; }
     if (want_stamps && !parts && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
-    if (nit == 2) { GGAN_LAUNCH("wgrad_kernel<2>", fl, 0, wgrad_kernel<2>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
-    else if (nit == 1) { GGAN_LAUNCH("wgrad_kernel<1>", fl, 0, wgrad_kernel<1>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
-    else { GGAN_LAUNCH("wgrad_kernel<0>", fl, 0, wgrad_kernel<0>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
+    if (nit == 2) { GGAN_LAUNCH("wgrad_kernel<2>", fl, ab, wgrad_kernel<2>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
+    else if (nit == 1) { GGAN_LAUNCH("wgrad_kernel<1>", fl, ab, wgrad_kernel<1>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
+    else { GGAN_LAUNCH("wgrad_kernel<0>", fl, ab, wgrad_kernel<0>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
     if (parts) {
         parts->n = P.SK;
         parts->stride = P.slab_stride;

@@ -408,25 +408,30 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '2', '--variant-steps', '4'],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    # the driver keeps the tail of stdout: the LAST line must parse on its own and stay well under 4 KB
+    last = r.stdout.rstrip('\n').splitlines()[-1]
+    assert len(last) < 4096, len(last)
+    d = json.loads(last)
+    assert len([l for l in r.stdout.splitlines() if l.startswith('{')]) == 1
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 2 and d['dtype'] == 'f32' and d['value'] > 0
-    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_eager', 'frac_in_graph', 'algorithmic_bytes')) <= set(d['roofline'])
     assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-3
+    assert d['roofline']['algorithmic_bytes'] > 0
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
-    assert 'source' in d['roofline']
-    # every BASELINE configuration rides along in the same line, each with its own roofline and CPU baseline
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    # every BASELINE configuration rides along as a SHORT record; the long form is the full record next to it
     assert [v['key'] for v in d['variants']] == ['wali-gp', 'gmgan-cifar10-K30', 'gmgan-cifar10-K10', 'gan-face', 'ssgan-moving-mnist',
                                                  'ssgan-moving-mnist-3dcnn']
     for v in d['variants']:
-        assert v['value'] > 0 and v['ms_per_step'] > 0 and v['algorithmic_gflop_per_step'] > 0, v['key']
-        assert v['roofline'] is not None and v['roofline']['frac'] > 0 and v['cpu_baseline'] is not None and v['cpu_baseline']['value'] > 0, v['key']
-        assert v['config']['finite_costs'], v['key']
-    assert 'G+D+GP' in d['variants'][0]['metric'] and 'N_COMS=10' in d['variants'][2]['config']['workload']
+        assert v['value'] > 0 and v['ms_per_step'] > 0 and v['frac'] > 0 and v['cpu'] > 0 and v['finite'], v['key']
+    full = json.load(open(os.path.join(root, d['full_record'])))
+    assert full['value'] == d['value'] and len(full['variants']) == 6
+    for v in full['variants']:
+        assert v['algorithmic_gflop_per_step'] > 0 and v['roofline']['frac'] > 0 and v['cpu_baseline']['value'] > 0, v['key']
+    assert 'G+D+GP' in full['variants'][0]['metric'] and 'N_COMS=10' in full['variants'][2]['config']['workload']
     port = 29700 + (os.getpid() % 200)
     env2 = dict(env, GGAN_DIST_BACKEND='gloo')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
@@ -435,8 +440,8 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
                        capture_output=True, text=True, timeout=900, env=env2, cwd=root)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1                                  # rank 0 only
-    d2 = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4096         # rank 0 only
+    d2 = json.loads(r.stdout.rstrip('\n').splitlines()[-1])
     assert d2['n_gpus'] == 2 and d2['scaling'] == 'weak' and d2['config']['global_batch'] == 128 and d2['value'] > 0
     assert len(d2['variants']) == 1 and d2['variants'][0]['n_gpus'] == 2 and d2['variants'][0]['value'] > 0
     # a rank that dies in the first attempt the way a failed captured collective kills it (abort): the supervisors stop that

@@ -71,7 +71,8 @@ def main(dirs):
             corr = 2.0 if k.startswith(wide) else 1.0
             tab[k] = dict(fetch_bytes_raw=round(f), write_bytes=round(w), fetch_correction=corr,
                           traffic_bytes=round(f * corr + w),
-                          mfma_util_pct=round(c['~MFMA_util_%'][0], 2) if c['~MFMA_util_%'][1] else None)
+                          mfma_util_pct=round(c['~MFMA_util_%'][0], 2) if c['~MFMA_util_%'][1] else None,
+                          avg_us_in_graph=round(dur[k][0] / dur[k][1] / 1e3, 2) if dur[k][1] else None)
         json.dump(tab, open(jout, 'w'), indent=1, sort_keys=True)
 
 
