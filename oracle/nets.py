@@ -16,7 +16,7 @@ from . import tape as tp
 
 class Cfg(object):
     def __init__(self, dataset='cifar10', batch_size=64, n_coms=0, dim=None, dim_latent=128,
-                 bn=None, mode_k='CONCRETE', temp=0.1, latent_critic=False, learn_std=False, z_samples=100):
+                 bn=None, mode_k='CONCRETE', temp=0.1, latent_critic=False, learn_std=False, z_samples=100, script=None, critic=True):
         self.dataset = dataset
         self.B = batch_size
         self.K = n_coms                      # 0 => plain gan_inference_* (no GMM prior)
@@ -39,6 +39,11 @@ class Cfg(object):
             self.dim = dim
         if bn is not None:
             self.bn = bn
+        self.critic = critic                   # False: MODE vegan-mmd / vegan-kl / -ikl / -jsd define no Discriminator (gan_inference_cifar10.py:224-225)
+        # gan_inference_mnist.py:215-250: the joint critic of THAT script has BatchNorm after conv 2 / 3 (BN_FLAG) and a second
+        # Linear on the z path ('Discriminator.2', sharing its prefix with the conv layer) and on the joint path ('Discriminator.zx2');
+        # gmgan_inference_mnist.py's critic is the plain one
+        self.critic_deep = dataset == 'mnist' and not n_coms and not latent_critic
         self.top = self.dim * 2 ** (self.nl - 1)      # channels at the 4x4 stage
         self.flat = 16 * self.top
         self.output_dim = self.C * self.S * self.S
@@ -119,11 +124,20 @@ def init_params(cfg, seed=0):
                 bn('Discriminator.BN%d' % (i + 1), nout, fused=False)
         lin('Discriminator.Output', 256, 1)
         return P
+    if not getattr(cfg, 'critic', True):
+        return P
+    deep = getattr(cfg, 'critic_deep', False)
     for i in range(nl):
         P['Discriminator.%d.Filters' % (i + 1)] = conv_init(rng, chans[i], chans[i + 1])
         P['Discriminator.%d.Biases' % (i + 1)] = np.zeros(chans[i + 1], 'float32')
+        if deep and cfg.bn and i > 0:
+            bn('Discriminator.BN%d' % (i + 1), chans[i + 1])
     lin('Discriminator.z1', cfg.dim_latent, 512)
+    if deep:
+        lin('Discriminator.2', 512, 512)
     lin('Discriminator.zx1', cfg.flat + 512, 512)
+    if deep:
+        lin('Discriminator.zx2', 512, 512)
     lin('Discriminator.Output', 512, 1)
     if cfg.K:
         lin('Discriminator.HyperInput', cfg.dim_latent + cfg.K, 512)
@@ -201,13 +215,23 @@ def Extractor(cfg, P, x, eps=None):
 
 
 def Discriminator(cfg, P, x, z):
+    """gan_inference_cifar10.py:226-255 / gmgan_inference_cifar10.py:270-301 (plain); gan_inference_mnist.py:215-250 (cfg.critic_deep:
+    BatchNorm after conv 2 / 3 under BN_FLAG, 'Discriminator.2' Linear 512->512 on the z path, 'Discriminator.zx2' on the joint path)."""
+    deep = getattr(cfg, 'critic_deep', False)
     out = tp.reshape(x, (-1, cfg.C, cfg.S, cfg.S))
     for i in range(cfg.nl):
-        out = tp.leaky_relu(Conv2D(P, 'Discriminator.%d' % (i + 1), out))
+        out = Conv2D(P, 'Discriminator.%d' % (i + 1), out)
+        if deep and cfg.bn and i > 0:
+            out = Batchnorm(P, 'Discriminator.BN%d' % (i + 1), [0, 2, 3], out)
+        out = tp.leaky_relu(out)
     out = tp.reshape(out, (-1, cfg.flat))
     zo = tp.leaky_relu(Linear(P, 'Discriminator.z1', z))
+    if deep:
+        zo = tp.leaky_relu(Linear(P, 'Discriminator.2', zo))
     out = tp.concat([out, zo], 1)
     out = tp.leaky_relu(Linear(P, 'Discriminator.zx1', out))
+    if deep:
+        out = tp.leaky_relu(Linear(P, 'Discriminator.zx2', out))
     return tp.reshape(Linear(P, 'Discriminator.Output', out), (-1,))
 
 

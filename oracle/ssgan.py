@@ -85,7 +85,7 @@ def init_params(cfg, seed=0):
         lin('Discriminator.z1', cfg.dim_g + cfg.dim_l * cfg.LEN + cfg.n_c, 512)
         lin('Discriminator.zx1', cfg.flat + 512, 512)
         lin('Discriminator.Output', 512, 1)
-        return P
+        return _only_created(cfg, P)
     conv('Discriminator.1', cfg.C * cfg.LEN if seq_x else cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
     conv('Discriminator.4', 4 * d, 8 * d)
     if seq_z:
@@ -102,7 +102,15 @@ def init_params(cfg, seed=0):
     lin('Discriminator.Output', 512, 1)
     for nm, nin in (('Discriminator.Dynamic', 2 * cfg.dim_l), ('Discriminator.ZG', cfg.dim_g)):
         lin(nm + '.Input', nin, 512); lin(nm + '.2', 512, 512); lin(nm + '.3', 512, 512); lin(nm + '.Output', 512, 1)
-    return P
+    return _only_created(cfg, P)
+
+
+def _only_created(cfg, P):
+    """The script only creates (lib.param) what its configuration reaches: no '.ZW' under OP_DYN_MODE 'res', no dynamic
+    extractor under POS_MODE 'naive_mean_field', no factor critics next to a sequence critic (tests/golden/param_manifest.json).
+    Dropped AFTER drawing, so the initial values of the rest do not depend on the configuration."""
+    skip = used_names(cfg)
+    return {k: v for k, v in P.items() if not any(s in k for s in skip)}
 
 
 def used_names(cfg):
