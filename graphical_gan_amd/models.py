@@ -4,6 +4,7 @@ One parametrised definition covers the six image scripts (the reference repeats 
   gan_inference_cifar10.py:133-255,261-366      Generator / Extractor / Discriminator, MODE ali | alice* | wali | wali-gp | vegan | vegan-wgan-gp
   gmgan_inference_cifar10.py:114-301,341-398    + HyperGenerator / HyperExtractor / HyperDiscriminator, MODE local_ep
   gmgan_inference_mnist.py:166-300              28x28x1, crop [:,:,:7,:7], sigmoid output, float input
+  gan_inference_mnist.py:122-250                the same nets, but a critic of its own (BatchNorm, two more Linear layers: Config.critic_deep)
   gmgan_inference_face.py:82-274                64x64x3, four conv stages, DIM 32, no BatchNorm, dequantisation
 Layer names are the reference's, so the registry keys match.
 `fuse=True` folds bias+activation into the producing conv/linear/BN kernel (identical math, fewer HBM passes).
@@ -64,6 +65,12 @@ class Config(object):
         # rows are independent and the result is identical); generator steps keep the two branches separate because
         # only the fake branch needs the conv data-gradients
         self.batch_critic = batch_critic
+        # gan_inference_mnist.py:215-250: the joint critic of THAT script has BatchNorm after conv 2 / 3 (BN_FLAG) and a second Linear
+        # on the z path ('Discriminator.2': the prefix is shared with the conv layer, the keys are distinct) and on the joint path
+        # ('Discriminator.zx2').  BatchNorm makes the critic's rows dependent: the fake and the real pair are two evaluations.
+        self.critic_deep = dataset == 'mnist' and not n_coms and not self.latent_critic and not self.no_critic
+        if self.critic_deep and self.bn:
+            self.batch_critic = False
 
 
 class GraphicalGAN(object):
@@ -255,7 +262,12 @@ class GraphicalGAN(object):
         ch = c.C
         for i in range(c.nl):
             cout = c.dim * 2 ** i
-            out = self._conv('Discriminator.%d' % (i + 1), ch, cout, out, LRELU, grad_rows)   # dropout == identity
+            name = 'Discriminator.%d' % (i + 1)
+            if c.critic_deep and c.bn and i > 0:              # gan_inference_mnist.py:223-230
+                out = lib.ops.conv2d.Conv2D(name, ch, cout, 5, out, stride=2, grad_rows=grad_rows)
+                out = self._bn('Discriminator.BN%d' % (i + 1), [0, 2, 3], out, LRELU)
+            else:
+                out = self._conv(name, ch, cout, out, LRELU, grad_rows)   # dropout == identity
             ch = cout
         out = out.reshape(-1, c.flat)
         # (Trainer.critic_cut: every gradient of the conv stack's parameters flows through here.  A WEAK reference: the tape keeps the
@@ -266,6 +278,13 @@ class GraphicalGAN(object):
             before_z()               # (forward_nets: z's second half may still be in flight on the other stream)
         if z_out is None:            # (else: _critic already ran the z path on the second stream)
             z_out = self._lin('Discriminator.z1', c.dim_latent, 512, z, LRELU)
+        if c.critic_deep:            # gan_inference_mnist.py:236-248: z1 -> '2' | concat -> zx1 -> zx2 -> Output
+            z_out = self._lin('Discriminator.2', 512, 512, z_out, LRELU)
+            out = self._lin('Discriminator.zx1', c.flat + 512, 512, (out, z_out), LRELU)
+            if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):
+                return lib.ops.linear.LinearLReLULinear('Discriminator.zx2', 512, 512, 'Discriminator.Output', out, differentiable=twice)
+            out = self._lin('Discriminator.zx2', 512, 512, out, LRELU)
+            return lib.ops.linear.Linear('Discriminator.Output', 512, 1, out).reshape(-1)
         if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):
             # Linear on concat([out, z_out], 1) + LeakyReLU + the 512 -> 1 Output layer as one op
             return lib.ops.linear.LinearLReLULinear('Discriminator.zx1', c.flat + 512, 512, 'Discriminator.Output', (out, z_out),

@@ -42,8 +42,9 @@ class Cfg(object):
         return r * 1.0 / (len(r) + self.LEN - 1)
 
 
-def init_params(cfg, seed=0):
-    """Reference initialisers in creation order of the script's graph build (Extractor, G_Extractor, [Dynamic extractor],
+def init_params(cfg, seed=0, keep_unused=False):
+    """keep_unused: also the parameters of the POS_MODE / OP_DYN_MODE branches this configuration never creates (fixture generators that
+    perturb the dictionary in order).  Reference initialisers in creation order of the script's graph build (Extractor, G_Extractor, [Dynamic extractor],
     Generator, Dynamic generator, critics)."""
     rng = np.random.RandomState(seed)
     P = {}
@@ -85,7 +86,7 @@ def init_params(cfg, seed=0):
         lin('Discriminator.z1', cfg.dim_g + cfg.dim_l * cfg.LEN + cfg.n_c, 512)
         lin('Discriminator.zx1', cfg.flat + 512, 512)
         lin('Discriminator.Output', 512, 1)
-        return _only_created(cfg, P)
+        return P if keep_unused else _only_created(cfg, P)
     conv('Discriminator.1', cfg.C * cfg.LEN if seq_x else cfg.C, d); conv('Discriminator.2', d, 2 * d); conv('Discriminator.3', 2 * d, 4 * d)
     conv('Discriminator.4', 4 * d, 8 * d)
     if seq_z:
@@ -102,7 +103,7 @@ def init_params(cfg, seed=0):
     lin('Discriminator.Output', 512, 1)
     for nm, nin in (('Discriminator.Dynamic', 2 * cfg.dim_l), ('Discriminator.ZG', cfg.dim_g)):
         lin(nm + '.Input', nin, 512); lin(nm + '.2', 512, 512); lin(nm + '.3', 512, 512); lin(nm + '.Output', 512, 1)
-    return _only_created(cfg, P)
+    return P if keep_unused else _only_created(cfg, P)
 
 
 def _only_created(cfg, P):

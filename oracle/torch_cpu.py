@@ -30,7 +30,7 @@ class Step(object):
         self.T = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=not k.endswith(('moving_mean', 'moving_variance')))
                   for k, v in params.items()}
         self.gen_names = [n for n in self.T if ('Generator' in n or 'Extractor' in n) and self.T[n].requires_grad]
-        self.disc_names = [n for n in self.T if 'Discriminator' in n]
+        self.disc_names = [n for n in self.T if 'Discriminator' in n and self.T[n].requires_grad]
         self.adam = {r: dict(t=0, m={}, v={}) for r in ('gen', 'disc')}
         self.critic_iters = 5 if mode == 'wali-gp' else 1
         # tflib/objs/gan_inference.py:34-43 (wali_gp: 1e-4, .5, .9) vs the scripts' LR / BETA1 with the default beta2
@@ -104,11 +104,19 @@ class Step(object):
     def Discriminator(self, x, z):
         c = self.cfg
         o = x.reshape(-1, c.C, c.S, c.S)
+        deep = getattr(c, 'critic_deep', False)          # gan_inference_mnist.py:215-250 (oracle/nets.py Discriminator)
         for i in range(c.nl):
-            o = self.lrelu(self.conv(o, 'Discriminator.%d' % (i + 1)))
+            o = self.conv(o, 'Discriminator.%d' % (i + 1))
+            if deep and c.bn and i > 0:
+                o = self.bn(o, 'Discriminator.BN%d' % (i + 1), (0, 2, 3))
+            o = self.lrelu(o)
         zo = self.lrelu(self.lin(z, 'Discriminator.z1'))
+        if deep:
+            zo = self.lrelu(self.lin(zo, 'Discriminator.2'))
         o = torch.cat([o.reshape(-1, c.flat), zo], 1)
         o = self.lrelu(self.lin(o, 'Discriminator.zx1'))
+        if deep:
+            o = self.lrelu(self.lin(o, 'Discriminator.zx2'))
         return self.lin(o, 'Discriminator.Output').view(-1)
 
     def HyperDiscriminator(self, z, k):

@@ -34,6 +34,8 @@ FULL = {   # name -> (dataset, B, K, mode)
     'full_cifar_gmgan_k10': ('cifar10', 64, 10, 'local_ep'),     # BASELINE configs[2]
     'full_face_ali': ('face', 64, 0, 'ali'),                     # configs[3]
     'full_face_gmgan_k100': ('face', 64, 100, 'local_ep'),
+    'full_mnist_ali': ('mnist', 64, 0, 'ali'),                   # BASELINE configs[0]: gan_inference_mnist.py (critic with BatchNorm)
+    'full_mnist_gmgan': ('mnist', 50, 30, 'local_ep'),           # gmgan_inference_mnist.py at the script's BATCH_SIZE / N_COMS
 }
 SSGAN = {'full_ssgan_b32_t16': dict(batch_size=32, length=16)}   # configs[4]
 
@@ -52,12 +54,12 @@ def perturbed_params(cfg, seed=0):
 
 def ssgan_params(ocfg):
     from oracle import ssgan as O
-    P0 = O.init_params(ocfg, seed=0)
+    P0 = O.init_params(ocfg, seed=0, keep_unused=True)     # (the perturbation below walks the full dictionary in order)
     rng = np.random.default_rng(5)
     for k in P0:
         if k.endswith('.b') or k.endswith('.Biases'):
             P0[k] = (0.1 * rng.standard_normal(P0[k].shape)).astype(np.float32)
-    return P0
+    return O._only_created(ocfg, P0)
 
 
 def feed_checksum(feed):

@@ -36,7 +36,7 @@ def _check_grads(z, which, names, grads, tol):
 
 
 @pytest.mark.parametrize('name', ['full_cifar_ali', 'full_cifar_wali_gp', 'full_cifar_gmgan_k30', 'full_cifar_gmgan_k10',
-                                  'full_face_ali', 'full_face_gmgan_k100'])
+                                  'full_face_ali', 'full_face_gmgan_k100', 'full_mnist_ali', 'full_mnist_gmgan'])
 def test_full_size_first_step_vs_fixture(gpu, name):
     import torch
     import make_golden_full as MG

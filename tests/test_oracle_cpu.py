@@ -116,7 +116,8 @@ def test_full_step_vs_torch_autograd():
 
 
 @pytest.mark.parametrize('dataset,mode,K', [('cifar10', 'wali-gp', 0), ('cifar10', 'local_ep', 5), ('face', 'ali', 0),
-                                            ('face', 'local_ep', 4), ('mnist', 'local_ep', 3), ('svhn', 'ali', 0)])
+                                            ('face', 'local_ep', 4), ('mnist', 'local_ep', 3), ('svhn', 'ali', 0),
+                                            ('mnist', 'ali', 0), ('mnist', 'wali-gp', 0)])   # (gan_inference_mnist.py: critic with BatchNorm)
 def test_torch_restatement_matches_numpy_tape(dataset, mode, K):
     """oracle/torch_cpu.py generates the full-size golden fixtures (tests/golden/make_golden.py): every configuration it is used
     for agrees with the numpy tape in float64 at small sizes -- costs, critic logits, every gradient, two iterations of Adam."""

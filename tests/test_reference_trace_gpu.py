@@ -1,0 +1,139 @@
+"""-m gpu: the HIP path against what the REFERENCE'S OWN scripts did (tests/golden/param_manifest.json, reference_trace.json;
+recorded by tests/golden/make_reference_trace.py, see tests/test_reference_trace_cpu.py for what those fixtures pin).
+
+  * the product's parameter registry after building each script's graph == the reference's lib.param names / shapes at the
+    scripts' own sizes, for every (script, MODE) of the manifest;
+  * the reference's train loop replayed through engine.Trainer on the trace's weights, minibatches and noise: the cost of every
+    session.run, the first critic step's gradients, the weights after the last run.
+"""
+import numpy as np
+import pytest
+
+import test_reference_trace_cpu as RC
+from oracle import reftrace as RT
+
+pytestmark = pytest.mark.gpu
+CODE_MODES = RC.CODE_MODES
+
+
+def _fresh():
+    from graphical_gan_amd import tflib as lib, optim
+    optim.reset_optimizers()
+    lib.delete_all_params()
+
+
+def _image_config(key, consts, fuse=True):
+    from graphical_gan_amd.models import Config
+    script, mode = key.split(':')
+    ds = script.split('_')[-1]
+    kw = dict(batch_size=consts['BATCH_SIZE'], n_coms=consts.get('N_COMS', 0) if script.startswith('gmgan') else 0,
+              dim=consts.get('DIM', consts.get('DIM_G')), mode=mode, fuse=fuse)
+    if mode in CODE_MODES and ds != 'face':
+        kw.update(dim_latent=8, bn=False)
+    cfg = Config(ds, **kw)
+    if 'Z_SAMPLES' in consts:
+        cfg.z_samples = consts['Z_SAMPLES']
+    return cfg
+
+
+@pytest.mark.parametrize('key', sorted(RC.MANIFEST))
+def test_product_registry_matches_the_reference_manifest(gpu, key):
+    """Build the step graphs of the script at its own width (small minibatch) and compare the registry with the reference's."""
+    from graphical_gan_amd import tflib as lib
+    from graphical_gan_amd.engine import Trainer
+    m = RC.MANIFEST[key]
+    script, mode = key.split(':')
+    _fresh()
+    if script.startswith('ssgan'):
+        from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
+        c = m['constants']
+        chairs = 'chairs' in script
+        cfg = SSConfig(batch_size=2, length=c['LEN'], n_c=c.get('N_C', 0), channels=3 if chairs else 1,
+                       op_dyn_mode='res_w' if chairs else 'res', dataset='chairs' if chairs else 'moving_mnist', mode=mode)
+        tr = Trainer(cfg, device=gpu, graph=False, inject_noise=True, model=StateSpaceGAN(cfg))
+    else:
+        cfg = _image_config(key, dict(m['constants'], BATCH_SIZE=4))
+        tr = Trainer(cfg, device=gpu, graph=False, inject_noise=True)
+    for which in ('gen', 'disc'):
+        if which == 'disc' and not m['critic_iters']:
+            continue
+        tr.model.forward(tr.feed, which)
+    ours = {n: list(p.shape) for n, p in lib.named_params().items()}
+    assert ours == m['params'], (sorted(set(ours) ^ set(m['params'])), [k for k in ours if k in m['params'] and ours[k] != m['params'][k]])
+    # the optimizers own what the reference's minimize(var_list=...) owns (trainable variables; the moving statistics get no gradient)
+    from graphical_gan_amd import optim
+    roles = {key_[0]: opt for key_, opt in optim._optimizers.items()}
+    for role, ro in zip(('gen', 'disc'), m['optimizers']):
+        ref = sorted(n for n in ro['var_list'] if not n.endswith(('moving_mean', 'moving_variance')))
+        opt = roles[role]
+        assert sorted(p.param_name for p in opt.params if p.requires_grad) == ref, (key, role)
+        hp = ro['hp']
+        if ro['kind'] == 'adam':
+            assert (opt.lr, opt.beta1, opt.beta2, opt.eps) == (hp['lr'], hp['beta1'], hp['beta2'], hp['eps']), (key, role)
+    _fresh()
+
+
+REPLAY = ['gan_inference_mnist:ali', 'gan_inference_mnist:wali-gp', 'gan_inference_mnist:alice', 'gan_inference_cifar10:ali',
+          'gan_inference_cifar10:wali-gp', 'gan_inference_svhn:ali', 'gan_inference_face:ali', 'gmgan_inference_cifar10:local_ep',
+          'gmgan_inference_mnist:local_ep', 'gmgan_inference_face:local_ep', 'gan_inference_cifar10:vegan-wgan-gp',
+          'gan_inference_cifar10:vegan-jsd']
+
+
+@pytest.mark.parametrize('key', REPLAY)
+def test_hip_path_replays_the_reference_run(gpu, key):
+    import torch
+    from graphical_gan_amd.engine import Trainer
+    t = RC.TRACE[key]
+    consts = dict(t['constants'], **t.get('script_constants', {}))
+    ocfg, mode = RC.image_cfg(key, consts)
+    roles, missing = RC.roles_for(ocfg, mode, t['random_nodes'])
+    assert not missing
+    _fresh()
+    cfg = _image_config(key, consts)
+    tr = Trainer(cfg, device=gpu, graph=False, inject_noise=True)
+    tr.load_params({n: RT.det_weight(n, shp, np.float32) for n, shp in t['params'].items()})
+    runs = [r for r in t['runs'] if r['train']]
+    feeds = [RC.make_feed(ocfg, mode, t, r, roles)[0] for r in runs]
+    # (a) the first session.run of the reference's loop (a critic step, or the generator step of the critic-free modes) on the
+    #     initial weights: cost and every gradient digest
+    tr.set_feed(feeds[0])
+    first = runs[0]['train'][0]
+    which = 'disc' if (len(t['optimizers']) > 1 and first['optimizer'] == 1) else 'gen'
+    out = tr.model.forward(tr.feed, which)
+    c = float(out[which + '_cost'].detach())
+    assert abs(c - first['cost']) <= 2e-5 * max(1.0, abs(first['cost'])), (key, c, first['cost'])
+    opt = out[which + '_train_op'].optimizer
+    grads = [(g[0] + g[1]) if isinstance(g, tuple) else g for g in opt.compute_gradients(out[which + '_cost'])]
+    gmax = max(d[1] for d in first['grads'].values() if d is not None)
+    tol = 2e-3 if mode in ('wali-gp', 'vegan-wgan-gp') else 3e-4
+    for p, g in zip(opt.params, grads):
+        ref = first['grads'].get(p.param_name)
+        if ref is None:
+            assert g is None or float(g.abs().max()) == 0.0, p.param_name
+            continue
+        mine = RT.digest(p.param_name, g.detach().cpu().numpy())
+        scale = max(ref[1], 1e-2 * gmax)
+        assert np.abs(np.asarray(mine[2:]) - np.asarray(ref[2:])).max() <= tol * scale, (key, p.param_name, mine[:2], ref[:2])
+        assert abs(mine[0] - ref[0]) <= tol * max(ref[0], scale), (key, p.param_name, 'l2', mine[0], ref[0])
+    del out, grads
+    # (b) the loop itself through engine.Trainer: iteration 0 = critic step(s) only, then generator step + critic step(s), each
+    #     on the next minibatch and fresh noise; every fetched cost against the reference's
+    tr.load_params({n: RT.det_weight(n, shp, np.float32) for n, shp in t['params'].items()})
+    it_feeds, j, it = iter(feeds), 0, 0
+    while j < len(runs):
+        res = tr.iteration(it, it_feeds)
+        order = (['gen_cost'] if it > 0 else []) + (['disc_cost'] * cfg.critic_iters)
+        # (Trainer.iteration reports the LAST critic cost of the iteration)
+        for name in order:
+            rec = runs[j]['train'][0]
+            if name == 'gen_cost' or j == len(runs) - 1 or runs[j + 1]['train'][0]['optimizer'] == 0:
+                v = float(res[name])
+                assert abs(v - rec['cost']) <= 2e-3 * max(1.0, abs(rec['cost'])), (key, 'run', runs[j]['run'], name, v, rec['cost'])
+            j += 1
+        it += 1
+    P = tr.get_params()
+    for n, dg in t['final'].items():
+        mine = RT.digest(n, P[n])
+        # weights moved by at most lr per Adam step; fp32 noise in tiny gradients can flip an entry's step: compare the norm
+        assert abs(mine[0] - dg[0]) <= 1e-4 * max(dg[0], 1e-3) + 1e-6, (key, n, mine[0], dg[0])
+    _fresh()
