@@ -132,7 +132,15 @@ def test_hip_path_replays_the_reference_run(gpu, key):
             j += 1
         it += 1
     P = tr.get_params()
+    gscale = {}
+    for r in runs:                                       # largest gradient any run of the trace saw, per tensor and overall
+        for n, dg in r['train'][0]['grads'].items():
+            if dg is not None:
+                gscale[n] = max(gscale.get(n, 0.0), dg[1])
+    gall = max(gscale.values())
     for n, dg in t['final'].items():
+        if n in gscale and gscale[n] < 1e-9 * gall:
+            continue                                     # mathematically zero gradient (a bias in front of a BatchNorm): Adam random-walks it on rounding noise
         mine = RT.digest(n, P[n])
         # weights moved by at most lr per Adam step; fp32 noise in tiny gradients can flip an entry's step: compare the norm
         assert abs(mine[0] - dg[0]) <= 1e-4 * max(dg[0], 1e-3) + 1e-6, (key, n, mine[0], dg[0])
