@@ -490,7 +490,7 @@ def compact_line(full):
     line = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                                  'vs_baseline', 'dtype', 'data')}
     c = full['config']
-    line['config'] = {k: c[k] for k in ('workload', 'parallelism', 'global_batch', 'hip_graph', 'minibatches_per_step',
+    line['config'] = {k: c[k] for k in ('workload', 'parallelism', 'global_batch', 'hip_graph', 'minibatch_feed', 'minibatches_per_step',
                                          'algorithmic_gflop_per_step', 'finite_costs') if k in c}
     line['whole_step_frac'] = full.get('whole_step_frac')
     if full.get('roofline'):

@@ -29,10 +29,14 @@ struct ProfScope {
     int idx_;
 };
 int check_launch(const char* name);
+// Timing experiments only (tools/criticality.sh): kernels whose name contains one of the comma-separated substrings of
+// GGAN_SKIP_KERNELS are not launched at all.  Results are garbage; what the step then gains is that kernel's share of the critical path.
+bool launch_skipped(const char* name);
 
 // LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, args...)
 #define GGAN_LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, ...)          \
     do {                                                                                    \
+        if (ggan::launch_skipped(name)) break;                                              \
         ggan::ProfScope _ps(name, stream, (double)(flops), (double)(bytes));              \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
     } while (0);                                                                            \

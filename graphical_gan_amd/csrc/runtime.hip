@@ -25,6 +25,25 @@ int check_launch(const char* name) {
     return 0;
 }
 
+bool launch_skipped(const char* name) {
+    static const char* list = getenv("GGAN_SKIP_KERNELS");
+    if (!list || !*list) return false;
+    const char* p = list;
+    while (*p) {
+        const char* q = strchr(p, ',');
+        const size_t n = q ? (size_t)(q - p) : strlen(p);
+        if (n && n < 96) {
+            char buf[96];
+            memcpy(buf, p, n);
+            buf[n] = 0;
+            if (strstr(name, buf)) return true;
+        }
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+
 // ---- profiling --------------------------------------------------------------------------------
 struct ProfEntry {
     const char* name;

@@ -41,7 +41,7 @@ def _mk(dataset, B, K, mode, dim, dl, fuse, graph, gpu, z_samples=None, bn=None)
     return ocfg, P0, cfg, tr
 
 
-UPDATE_REL_TOL = 0.15      # deviation of the post-step weights from the oracle's, relative to the norm of the oracle's total update
+UPDATE_REL_TOL = 0.02      # deviation of the post-step weights from the oracle's, relative to the norm of the oracle's total update
 
 CASES = [  # dataset, B, K, mode, dim, dim_latent
     ('cifar10', 8, 0, 'ali', 8, 16),
@@ -492,7 +492,7 @@ def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert d['value'] > 0 and d['config']['finite_costs'] and 'one graph per iteration' in d['config']['minibatch_feed']
-    assert d['variants'][0]['value'] > 0 and d['variants'][0]['config']['finite_costs']
+    assert d['variants'][0]['value'] > 0 and d['variants'][0]['finite']
 
 
 def test_in_graph_exchange_two_buckets_one_rank_bit_identical(gpu):
