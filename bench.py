@@ -420,7 +420,7 @@ def supervise():
     """N > 1: every rank process that torch.distributed.run starts is only a supervisor; the measurement runs in a child process
     per rank (same arguments, process group of its own on MASTER_PORT + 1 + attempt).  Attempt 0 captures the gradient exchange
     inside the step graphs.  Where captured collectives do not work on a stack the failure is not an exception but an ABORT of the
-    rank process (engine.quiesce_collectives), and the other ranks would then sit in a collective until its timeout -- so the
+    rank process, and the other ranks would then sit in a collective until its timeout -- so the
     supervisors watch a key in the launcher's store: the first child that dies sets it, everybody stops their child, and
     attempt 1 runs the same benchmark with the exchange issued by the host between cut graphs (GGAN_DP_GRAPH=0).  The JSON line
     of the attempt that finished is passed through by rank 0."""

@@ -11,7 +11,6 @@ device inside the graph.  With data parallelism the graph is split around the gr
 [fwd+bwd+pack] -> RCCL all-reduce of the flat bucket -> [Adam].
 """
 import os
-import time
 
 import numpy as np
 import torch
@@ -30,72 +29,52 @@ _CAPTURE_MODE = os.environ.get('GGAN_CAPTURE_MODE', 'thread_local')
 _DP_GRAPH_OK = {}
 
 
-def quiesce_collectives(device):
-    """Call before capturing a graph that contains a collective.  The process group's watchdog thread polls the completion events of
-    eagerly issued collectives; on this stack (PyTorch 2.10 / ROCm 7) a poll of such an event while the communicator's stream is
-    being captured -- it is, as soon as the capture reaches a collective -- raises "operation not permitted on an event last
-    recorded in a capturing stream" in the watchdog thread, which terminates the process (tools/nccl_graph_probe.py: 0 of 5 runs
-    survive a capture issued right after an eager all-reduce).  Once the device is idle the watchdog retires its finished work
-    within one poll interval (100 ms); after that pause nothing is left to poll during the capture (6 of 6 survive)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
-        torch.cuda.synchronize(device)
-        time.sleep(float(os.environ.get('GGAN_NCCL_QUIESCE_S', '1.0')))
-
-
-_GRAPH_GROUP = []
-
-
-def graph_group(device):
-    """A process group of its own for captured collectives (all ranks call this at the same point: Trainer construction).  The
-    hazard described in quiesce_collectives needs eager work on the communicator whose stream is being captured; this group only
-    ever sees one eager all-reduce -- the communicator warm-up below, retired before anything is captured."""
-    if not _GRAPH_GROUP:
-        g = dist.new_group(backend='nccl')
-        t = torch.ones(256, device=device)
-        dist.all_reduce(t, group=g)
-        torch.cuda.synchronize(device)
-        time.sleep(1.0)                                   # (its one eager piece of work retires: see quiesce_collectives)
-        from . import optim
-        optim.set_graph_group(g)
-        _GRAPH_GROUP.append(g)
-    return _GRAPH_GROUP[0]
-
-
-def dp_graph_selftest(device):
-    """Can this process group's all-reduce be captured in a HIP graph and replayed?  Every rank captures a tiny sum-all-reduce,
-    replays it twice and checks the result; the verdicts are combined with an ordinary (eager) MIN all-reduce so that all
-    replicas take the same path.  Cached per device."""
+def dp_graph_selftest(device, comm):
+    """Can an all-reduce on the directly bound RCCL communicator (rccl.py) be captured in a HIP graph and replayed here?  Two rounds,
+    each closed by an ordinary (eager, torch.distributed) MIN all-reduce so that every replica takes the same path and no rank ever
+    waits in a captured collective another rank never joins: (1) every rank CAPTURES a tiny sum-all-reduce; only if all of them could,
+    (2) every rank replays it twice and checks the sum.  Cached per device."""
     key = str(device)
     if key in _DP_GRAPH_OK:
         return _DP_GRAPH_OK[key]
-    ok = 1.0
+
+    def agree(ok):
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(float(flag[0]) > 0.5)
+    world = dist.get_world_size()
+    t = torch.ones(256, device=device)
+    s = torch.cuda.Stream(device=device)
+    g, v, ok = None, None, True
     try:
-        world = dist.get_world_size()
-        gg = graph_group(device)
-        t = torch.ones(256, device=device)
-        s = torch.cuda.Stream(device=device)
         s.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
-            dist.all_reduce(t.clone())                    # (communicator warm-up outside the capture)
-            quiesce_collectives(device)
+            comm.all_reduce_(t.clone())                   # (communicator warm-up outside the capture)
+            torch.cuda.synchronize(device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
                 u = t * 1.0
-                dist.all_reduce(u, group=gg)
+                comm.all_reduce_(u)
                 v = u + 1.0
-            for _ in range(2):
-                g.replay()
-            torch.cuda.synchronize(device)
-            if abs(float(v[0]) - (world + 1.0)) > 1e-6:
-                ok = 0.0
         torch.cuda.current_stream(device).wait_stream(s)
     except Exception as e:                                # noqa: BLE001 (any capture failure selects the cut graphs)
         print('[engine] all-reduce capture self-test failed (%s): falling back to cut graphs' % (str(e).splitlines()[0] if str(e) else type(e).__name__))
-        ok = 0.0
-    flag = torch.tensor([ok], device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    _DP_GRAPH_OK[key] = bool(float(flag[0]) > 0.5)
-    return _DP_GRAPH_OK[key]
+        ok = False
+    if agree(ok):
+        try:
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    g.replay()
+            torch.cuda.synchronize(device)
+            ok = abs(float(v[0]) - (world + 1.0)) <= 1e-6
+        except Exception as e:                            # noqa: BLE001
+            print('[engine] replay of the captured all-reduce failed (%s): falling back to cut graphs' % type(e).__name__)
+            ok = False
+        ok = agree(ok)
+    else:
+        ok = False
+    _DP_GRAPH_OK[key] = ok
+    return ok
 
 
 class Trainer(object):
@@ -127,15 +106,20 @@ class Trainer(object):
         # single-GPU step plus the exposed part of the exchange.  GGAN_DP_GRAPH=0 restores the cut graphs
         # ([nets] [critic+backward+pack] -> host-issued all-reduce -> [update]) with the exchange overlapped across steps.
         dp = self.world > 1 or bool(os.environ.get('GGAN_FORCE_ALLREDUCE')) and dist.is_available() and dist.is_initialized()
-        self.dp_graph = (dp and os.environ.get('GGAN_DP_GRAPH', '1') != '0' and not os.environ.get('GGAN_FORCE_SPLIT_GRAPH')
-                         and dist.get_backend() == 'nccl')      # (gloo stages device tensors through the host: not capturable)
-        if self.dp_graph and graph and not dp_graph_selftest(self.device):
+        # the exchange itself goes through a communicator of our own (rccl.py: no process-group watchdog polls its stream, so it can be
+        # captured); on other backends (gloo stages device tensors through the host) it stays a host-issued collective between cut graphs
+        from . import rccl
+        self.comm = rccl.get(self.device) if dp else None
+        self.dp_graph = (dp and self.comm is not None and os.environ.get('GGAN_DP_GRAPH', '1') != '0'
+                         and not os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
+        if self.dp_graph and graph and not dp_graph_selftest(self.device, self.comm):
             self.dp_graph = False
         self.split_graph = (self.world > 1 and not self.dp_graph) or bool(os.environ.get('GGAN_FORCE_SPLIT_GRAPH'))
-        self.sync_bn = bool(sync_bn) and self.world > 1
+        self.sync_bn = bool(sync_bn) and (self.world > 1 or dp)       # (dp at world 1: the one-rank RCCL rehearsal)
         if self.sync_bn:
             lib.ops.batchnorm.set_sync_group(True)
-            self.graph_enabled = False
+            if self.comm is None:       # the statistics exchange is a host-issued collective inside the passes: eager steps.  With the
+                self.graph_enabled = False   # direct communicator it is an enqueue on the step's stream and is captured like a kernel
             if hasattr(self.model, 'fork_nets'):
                 self.model.fork_nets = False      # keep the statistics exchanges of the two passes in one stream order
         # the pack kernel may sum the filter-gradient slabs only if every parameter receives ONE gradient contribution per
@@ -358,8 +342,6 @@ class Trainer(object):
                 rng.copy_(rng_snap)
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
-        if self.dp_graph:
-            quiesce_collectives(self.device)
         g1 = torch.cuda.CUDAGraph()
         if not self.split_graph:
             with torch.cuda.graph(g1, stream=s, capture_error_mode=_CAPTURE_MODE):
@@ -475,8 +457,6 @@ class Trainer(object):
                     rng.copy_(rng_snap)
             torch.cuda.current_stream(self.device).wait_stream(s)
             torch.cuda.synchronize(self.device)
-            if self.dp_graph:
-                quiesce_collectives(self.device)
             g = torch.cuda.CUDAGraph()
             costs, keeps = {}, []
             with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
@@ -524,7 +504,7 @@ class Trainer(object):
 
     def _iteration_ring(self, it, kinds):
         """ring mode: the steps of an iteration with nothing issued between them -- as ONE graph replay where that is possible"""
-        one_graph = (self.graph_enabled and it > 0 and (self.world == 1 or self.dp_graph) and not self.split_graph and not self.sync_bn
+        one_graph = (self.graph_enabled and it > 0 and (self.world == 1 or self.dp_graph) and not self.split_graph
                      and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
         if not one_graph:
             return {k + '_cost': self.step(k) for k in kinds}

@@ -830,6 +830,10 @@ def _all_gather_rows(t, group):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    from . import rccl
+    comm = rccl.get(create=False) if (t.is_cuda and (group is None or group is dist.group.WORLD)) else None
+    if comm is not None:             # an enqueue on the current stream (capturable: cross-replica BatchNorm inside a step graph)
+        return comm.all_gather(out, t.contiguous())
     try:
         dist.all_gather_into_tensor(out, t, group=group)
     except (RuntimeError, NotImplementedError):

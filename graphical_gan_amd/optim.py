@@ -27,15 +27,6 @@ def layout_slots(sizes, align=_ALIGN):
     return slots, off
 
 
-_graph_group = [None]
-
-
-def set_graph_group(group):
-    """process group used for the exchanges that are CAPTURED into step graphs (engine.graph_group): its watchdog thread never
-    holds eagerly issued work, so it never polls an event on a stream that is being captured"""
-    _graph_group[0] = group
-
-
 class GradBucket(object):
     """The data-parallel exchange step: ONE sum-all-reduce of a flat gradient buffer per optimizer step
     (SURVEY.md 8e).  Every replica holds the full model and an equal-size local minibatch, so
@@ -57,10 +48,16 @@ class GradBucket(object):
             return None
         if self.world > 1 or (_os.environ.get('GGAN_FORCE_ALLREDUCE') and dist.is_available() and dist.is_initialized()):
             buf = self.flat if (lo == 0 and hi is None) else self.flat[lo:hi]
-            group = self.group
-            if _graph_group[0] is not None and buf.is_cuda and torch.cuda.is_current_stream_capturing():
-                group = _graph_group[0]
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            from . import rccl
+            comm = rccl.get(create=False) if buf.is_cuda else None
+            if comm is not None:
+                # RCCL bound directly: an enqueue on the communicator's own stream (a parallel branch of the step graph while one is
+                # being captured), no process-group watchdog behind it (rccl.py)
+                return comm.all_reduce_(buf, async_op=async_op)
+            if buf.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('a torch.distributed collective cannot be captured into a step graph (engine.Trainer only captures '
+                                   'exchanges issued through rccl.Communicator)')
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             return work if async_op else None
         return None
 

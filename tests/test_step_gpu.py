@@ -478,9 +478,9 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
 
 def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
     """The driver's N > 1 launch puts the gradient exchange (RCCL all-reduce) INSIDE the captured graphs.  One rank over RCCL is
-    enough to rehearse that on a single-GPU box (GGAN_FORCE_ALLREDUCE): the capture must survive the process group's watchdog
-    thread (engine.quiesce_collectives -- without it the process aborts), replay, and produce finite costs, for the headline
-    workload (one graph per iteration) and one variant."""
+    enough to rehearse that on a single-GPU box (GGAN_FORCE_ALLREDUCE): the exchange goes through the directly bound communicator
+    (graphical_gan_amd/rccl.py: no process-group watchdog polls a captured stream, nothing to wait out before a capture), is
+    captured, replayed, and the costs stay finite, for the headline workload (one graph per iteration) and one variant."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GGAN_FORCE_ALLREDUCE='1')
@@ -512,6 +512,65 @@ def test_in_graph_exchange_two_buckets_one_rank_bit_identical(gpu):
         assert ('dp_graph=True' in line[0]) == bool(extra) and 'one_graph=True' in line[0], line[0]
         sums.append(line[0].split()[-1])
     assert sums[0] == sums[1] == sums[2], sums
+
+
+def test_direct_rccl_communicator_eager_and_captured(gpu):
+    """graphical_gan_amd/rccl.py at one rank: all-reduce and all-gather issued eagerly and from a replayed HIP graph, on the
+    communicator's stream and on a caller's stream, right after an eager torch.distributed collective -- the situation in which a
+    captured process-group collective used to kill the process (no pauses anywhere here)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        from graphical_gan_amd import rccl
+        comm = rccl.get(dev)
+        t = torch.arange(1 << 16, dtype=torch.float32, device=dev)
+        dist.all_reduce(t.clone())                                   # eager process-group work just before the captures
+        ref = t.clone()
+        comm.all_reduce_(t); torch.cuda.synchronize(); assert torch.equal(t, ref)
+        s = torch.cuda.Stream(device=dev); s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                u = t * 2.0
+                w = comm.all_reduce_(u, async_op=True)              # parallel branch on the communicator's stream
+                v = t + 1.0
+                w.wait()
+                out = torch.empty((1, 16), dtype=torch.float32, device=dev)
+                comm.all_gather(out, u[:16].contiguous())            # on the capturing stream itself
+                z = u + v
+            for _ in range(3):
+                g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(z, 3 * ref + 1) and torch.equal(out[0], 2 * ref[:16])
+        import time; time.sleep(1.5)                                 # (a watchdog poll interval: nothing dies afterwards either)
+        print('RCCL_DIRECT_OK')
+        dist.destroy_process_group()
+    ''' % root)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29250 + os.getpid() % 200))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and 'RCCL_DIRECT_OK' in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_cross_replica_batchnorm_inside_the_step_graph_one_rank_rehearsal(gpu):
+    """Trainer(sync_bn=True) with the directly bound communicator: the statistics exchange (ncclAllGather) is an enqueue on the
+    step's stream, so the steps run from HIP graphs (one graph per iteration) -- same weights, bit for bit, as the eager steps."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for i, extra in enumerate((dict(), dict(CHECK_EAGER='1'))):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GGAN_FORCE_ALLREDUCE='1', CHECK_SYNC_BN='1', **extra)
+        r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                            '127.0.0.1', '--master-port', str(29100 + (os.getpid() % 200) + i), os.path.join(root, 'tools', 'dp_one_rank_check.py'),
+                            'ali', '0'], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        line = [l for l in r.stdout.splitlines() if l.startswith('CHECK')]
+        assert r.returncode == 0 and line, (r.stdout[-500:], r.stderr[-2000:])
+        assert 'sync_bn=True' in line[0] and ('one_graph=True' in line[0]) == (not extra), line[0]
+        sums.append(line[0].split()[-1])
+    assert sums[0] == sums[1], sums
 
 
 @pytest.mark.parametrize('mode,K', [('ali', 0), ('local_ep', 30)])

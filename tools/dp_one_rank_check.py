@@ -13,7 +13,7 @@ from graphical_gan_amd.models import Config
 from graphical_gan_amd.engine import Trainer
 np.random.seed(0)
 cfg = Config('cifar10', batch_size=16, n_coms=K, mode=mode, dim=16, dim_latent=32)
-tr = Trainer(cfg, device=dev, graph=True, seed=4321)
+tr = Trainer(cfg, device=dev, graph=not os.environ.get('CHECK_EAGER'), seed=4321, sync_bn=bool(os.environ.get('CHECK_SYNC_BN')))
 ring = tr.model.synthetic_ring(dev, n=5, seed=99)
 b = iter(ring * 40)
 for it in range(2):
@@ -25,6 +25,6 @@ tr.flush(); torch.cuda.synchronize()
 h = hashlib.sha256()
 for k, v in sorted(tr.get_params().items()):
     h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
-print('CHECK dp_graph=%s one_graph=%s %s' % (tr.dp_graph, tr._iter_graph is not None, h.hexdigest()))
+print('CHECK dp_graph=%s one_graph=%s sync_bn=%s %s' % (tr.dp_graph, getattr(tr, '_iter_graph', None) is not None, tr.sync_bn, h.hexdigest()))
 if dist.is_initialized():
     dist.destroy_process_group()

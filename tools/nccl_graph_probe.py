@@ -11,7 +11,8 @@ dist.init_process_group('nccl', rank=0, world_size=1, **({} if os.environ.get('P
 if mode == 'selftest':
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from graphical_gan_amd.engine import dp_graph_selftest
-    print('selftest ->', dp_graph_selftest(dev)); time.sleep(3); print('alive after 3 s'); sys.exit(0)
+    from graphical_gan_amd import rccl
+    print('selftest ->', dp_graph_selftest(dev, rccl.get(dev))); time.sleep(3); print('alive after 3 s'); sys.exit(0)
 t = torch.ones(1 << 20, device=dev)
 s = torch.cuda.Stream(device=dev)
 s.wait_stream(torch.cuda.current_stream(dev))
