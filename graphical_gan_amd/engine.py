@@ -178,6 +178,8 @@ class Trainer(object):
         self.flush()
         torch.cuda.synchronize(self.device)
         taken = sum(int(t.item()) for t in ctr.values())
+        from . import optim as _optim
+        self._ring_epoch = _optim.STATE_EPOCH[0]
         self.feed['ring'] = (ring, ctr['gen'], ctr.get('disc'), -taken)
         self._graphs = {}                      # (captured steps read the staging buffer)
         self._iter_graph = None
@@ -187,6 +189,7 @@ class Trainer(object):
 
     # ---- one session.run ------------------------------------------------------------------------------
     def _nets(self):
+        self._sl0 = lib.second_leaf_count()          # (see _no_second_leaves)
         if hasattr(self.model, 'begin_nets'):
             self.model.begin_nets(self.feed)
         if not self.inject_noise:
@@ -222,6 +225,7 @@ class Trainer(object):
         if plan is None:
             return None
         k, off, cut = plan
+        self._no_second_leaves(opt)
         if opt._one is None or opt._one.shape != op.cost.shape:
             opt._one = F.unit_seed(op.cost)
         with F.defer_wgrad_reduce(self.single_contrib):
@@ -236,6 +240,13 @@ class Trainer(object):
         with F.defer_wgrad_reduce(self.single_contrib):
             g = torch.autograd.grad([t for t, _ in pairs], opt.params[k:], grad_outputs=[gg for _, gg in pairs], allow_unused=True)
             return opt.pack_subset(g, k, len(opt.params), bump=False)
+
+    def _no_second_leaves(self, opt):
+        """the two-bucket paths ask the tape for opt.params directly (not through AdamOptimizer.compute_gradients): a contribution that
+        arrives through a second leaf (tflib.second_leaf: a weight two passes of the step reach) would be dropped without a word"""
+        if lib.second_leaf_count() != getattr(self, '_sl0', lib.second_leaf_count()):
+            raise NotImplementedError('two-bucket gradient exchange in a step that handed out second leaves (a weight reached by two '
+                                      'passes): its second contribution would be lost -- use one bucket (GGAN_ONE_BUCKET=1)')
 
     def _eager(self, which):
         self.flush()
@@ -310,6 +321,7 @@ class Trainer(object):
             return out['disc_cost'].detach(), opt, (keep, out)
         k, off = sp
         cut = cutinfo[0]
+        self._no_second_leaves(opt)
         with F.defer_wgrad_reduce(self.single_contrib):
             g = torch.autograd.grad(op.cost, list(opt.params[k:]) + [cut], grad_outputs=opt._one, allow_unused=True)
             keep_a = opt.pack_subset(g[:-1], k, len(opt.params), bump=True)
@@ -473,6 +485,13 @@ class Trainer(object):
         """batches: iterator of device minibatches (or feed dicts when inject_noise); ignored in ring mode (use_ring)."""
         feed = getattr(self, 'feed', None)
         if isinstance(feed, dict) and feed.get('ring') is not None:
+            from . import optim as _optim
+            if _optim.STATE_EPOCH[0] != getattr(self, '_ring_epoch', _optim.STATE_EPOCH[0]):
+                # the optimizers' step counters were overwritten (checkpoint.restore / load_adam_state) since the ring was anchored:
+                # the device-side slot index (counters + offset) would jump; anchor it again at the slot the host-side feeder is at
+                if getattr(self, '_feeder', None) is not None:
+                    raise RuntimeError('optimizer state was restored while a host-fed ring is active: call use_host_ring() again')
+                self.use_ring(list(feed['ring'][0]))
             kinds = (['gen'] if it > 0 else []) + ['disc'] * self.cfg.critic_iters
             feeder = getattr(self, '_feeder', None)
             if feeder is None:

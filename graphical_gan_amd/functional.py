@@ -66,8 +66,15 @@ _DEFER = [None]
 _DATA_ONLY = [False]
 
 
+def _is_param(t):
+    """a registry parameter or one of its second leaves (tflib.param tags both): the operands data_grad_only may skip.  A weight slot
+    fed with a data-dependent tensor (a product of two activations, say) keeps its gradient."""
+    return t is not None and getattr(t, 'param_name', None) is not None
+
+
 class data_grad_only(object):
-    """with data_grad_only(): torch.autograd.grad(out, [x], create_graph=True) -- layer backwards skip parameter gradients"""
+    """with data_grad_only(): torch.autograd.grad(out, [x], create_graph=True) -- layer backwards skip the gradients of PARAMETER
+    operands (weights / biases handed out by tflib.param); any other operand in a weight slot is differentiated as usual"""
 
     def __enter__(self):
         self.prev, _DATA_ONLY[0] = _DATA_ONLY[0], True
@@ -224,6 +231,7 @@ class ConvFwd(Function):
         check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
                                    act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
+        ctx.w_param, ctx.b_param = _is_param(w), _is_param(bias)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
@@ -239,10 +247,9 @@ class ConvFwd(Function):
         if ctx.act != ACT_NONE:
             gy = ActBwd.apply(gy, y, ctx.act, ctx.alpha)       # lrelu/relu: sign(y) == sign(pre-activation)
         gx = gw = gb = None
-        params = not _DATA_ONLY[0]
-        if ctx.needs_input_grad[1] and params:
+        if ctx.needs_input_grad[1] and not (_DATA_ONLY[0] and ctx.w_param):
             gw = ConvWgrad.apply(x, gy, ctx.geom)
-        if ctx.has_bias and ctx.needs_input_grad[2] and params:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not (_DATA_ONLY[0] and ctx.b_param):
             gb = ChanSum.apply(gy)
         if ctx.needs_input_grad[0]:
             gx = ConvDgrad.apply(gy, w, None, ctx.geom, ACT_NONE, 0.0)
@@ -433,6 +440,7 @@ class Gemm(Function):
         check(_L().ggan_gemm(int(ta), int(tb), M, N, K, _p(a), _p(b), _p(_c(bias)) if bias is not None else _p(None),
                              _p(out), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm')
         ctx.ta, ctx.tb, ctx.act, ctx.alpha, ctx.has_bias = ta, tb, act, alpha, bias is not None
+        ctx.b_param, ctx.bias_param = _is_param(b), _is_param(bias)
         ctx.save_for_backward(a, b, out if act != ACT_NONE else None)
         return out
 
@@ -448,8 +456,15 @@ class Gemm(Function):
         if ctx.act != ACT_NONE:
             g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
         da = db = dbias = None
-        if _DATA_ONLY[0]:
-            pass                                                               # (parameter gradients not wanted by this grad call)
+        skip_b = _DATA_ONLY[0] and ctx.b_param                                 # (parameter gradients not wanted by this grad call)
+        skip_bias = _DATA_ONLY[0] and ctx.bias_param
+        if skip_b and (skip_bias or not (ctx.has_bias and ctx.needs_input_grad[2])):
+            pass
+        elif skip_b or skip_bias:
+            if ctx.needs_input_grad[1] and not skip_b:
+                db = Gemm.apply(a, g, None, not ta, False, ACT_NONE, 0.0) if not tb else Gemm.apply(g, a, None, True, ta, ACT_NONE, 0.0)
+            if ctx.has_bias and ctx.needs_input_grad[2] and not skip_bias:
+                dbias = ColSum.apply(g)
         elif (ctx.needs_input_grad[1] and not tb and ctx.has_bias and ctx.needs_input_grad[2]
                 and not torch.is_grad_enabled() and g.shape[0] < TALL_ROWS):
             db, dbias = gemm_colsum_(a, g, not ta)                             # dW and db in ONE launch
@@ -513,6 +528,7 @@ class Gemm2(Function):
         check(_L().ggan_gemm_split(0, 0, M, N, K, _p(a1), _p(a2), K1, _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(out),
                                    _p(None), 0, _p(None), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
         ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
+        ctx.w_param, ctx.bias_param = _is_param(w), _is_param(bias)
         ctx.save_for_backward(a1, a2, w, out if act != ACT_NONE else None)
         return out
 
@@ -523,10 +539,10 @@ class Gemm2(Function):
         if torch.is_grad_enabled():          # differentiable composition (second derivatives: wali-gp)
             if ctx.act != ACT_NONE:
                 g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
-            params = not _DATA_ONLY[0]
             da = Gemm.apply(g, w, None, False, True, ACT_NONE, 0.0) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
-            dw = Gemm.apply(torch.cat([a1, a2], 1), g, None, True, False, ACT_NONE, 0.0) if (ctx.needs_input_grad[2] and params) else None
-            db = ColSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[3] and params) else None
+            dw = (Gemm.apply(torch.cat([a1, a2], 1), g, None, True, False, ACT_NONE, 0.0)
+                  if (ctx.needs_input_grad[2] and not (_DATA_ONLY[0] and ctx.w_param)) else None)
+            db = ColSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[3] and not (_DATA_ONLY[0] and ctx.bias_param)) else None
             return (da[:, :K1] if da is not None else None, da[:, K1:] if da is not None else None, dw, db, None, None)
         g = _c(g)
         if ctx.act != ACT_NONE:
@@ -597,7 +613,9 @@ class CriticHead(Function):
         dev = g.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         rec = ctx.rec
-        fused = rec is not None and rec['g_ptr'] is not None and rec['g_ptr'] == g.data_ptr()
+        # (address AND content version of the gradient buffer the cost launch wrote: a gradient autograd accumulated in place into a buffer
+        #  at that address carries another version and takes the backward kernel)
+        fused = rec is not None and rec['g_ptr'] is not None and rec['g_ptr'] == g.data_ptr() and rec.get('g_version') == g._version
         gh = rec['gh'] if fused else new(M, H)
         want_a = need[0] or (a2 is not None and need[1])
         d_a1 = new(M, K1) if want_a else None
@@ -1313,6 +1331,13 @@ def unit_seed(like):
     return one
 
 
+def is_unit_seed(g):
+    """g IS a registered unit seed: same storage address AND still the tensor registered there, unmodified (a gradient that autograd
+    accumulated in place into a buffer at that address has another shape / version and takes the backward kernel)"""
+    one = UNIT_SEEDS.get(g.data_ptr())
+    return one is not None and g.shape == one.shape and g._version == one._version and (g is one or g._base is one or g.untyped_storage().data_ptr() == one.untyped_storage().data_ptr())
+
+
 class BceSum(Function):
     """sum_i weight_i * mean(sigmoid_cross_entropy_with_logits(x_i, label_i)) -> 0-dim tensor; one launch forward and one
     backward for all terms."""
@@ -1384,7 +1409,7 @@ class BceSum(Function):
                     rec['gh'] = new(rec['M'], rec['H'])
                     rec['d_wout'] = new(rec['H']) if rec['want_out'] else None
                     rec['d_bout'] = new(1) if rec['want_bout'] else None
-                    rec['g_ptr'] = outs[k].data_ptr()
+                    rec['g_ptr'], rec['g_version'] = outs[k].data_ptr(), outs[k]._version
                     k += nt
                 m = len(heads)
                 arr = lambda ct, vals: (ct * m)(*vals)
@@ -1405,7 +1430,7 @@ class BceSum(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        if ctx.unit_grads is not None and g.data_ptr() in UNIT_SEEDS:
+        if ctx.unit_grads is not None and is_unit_seed(g):
             return (None, None) + tuple(ctx.unit_grads)
         g = _c(g.reshape(1))
         logits = ctx.saved_tensors
@@ -1474,7 +1499,7 @@ class MeanSum(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        if ctx.unit_grads is not None and g.data_ptr() in UNIT_SEEDS:
+        if ctx.unit_grads is not None and is_unit_seed(g):
             return (None,) + tuple(ctx.unit_grads)
         g = _c(g.reshape(1))
         outs = []

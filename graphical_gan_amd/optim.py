@@ -222,8 +222,12 @@ def get_optimizer(role, params, **hp):
 _pending_state = {}
 
 
+STATE_EPOCH = [0]       # bumped whenever an optimizer's step counter is overwritten from outside (engine.Trainer re-anchors its ring feed)
+
+
 def load_adam_state(opt, state):
     """state: {'step': int32[1], '<param name>/m': array, '<param name>/v': array} (checkpoint.py)"""
+    STATE_EPOCH[0] += 1
     with torch.no_grad():
         opt.step.copy_(torch.as_tensor(state['step']).to(opt.step.device).reshape(opt.step.shape))
         for p, (o, n) in zip(opt.params, opt.slots):

@@ -67,7 +67,16 @@ class second_leaf(object):
         _second[0] = self.prev
 
 
+_second_count = [0]
+
+
+def second_leaf_count():
+    """how many times a second leaf has been handed out so far (engine.Trainer: did THIS step use any?)"""
+    return _second_count[0]
+
+
 def _second_leaf_of(name, p):
+    _second_count[0] += 1
     t = _second_leaves.get(name)
     if t is None or t.data_ptr() != p.data_ptr() or t.shape != p.shape:       # (re-homed into an optimizer's flat buffer since)
         t = p.detach().requires_grad_(True)

@@ -21,6 +21,7 @@ def main(dirs):
         i = dirs.index('--json'); jout = dirs[i + 1]; dirs = dirs[:i] + dirs[i + 2:]
     ctr = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))     # kernel -> counter -> [sum, dispatches]
     dur = defaultdict(lambda: [0.0, 0])
+    util = defaultdict(list)
     for d in dirs:
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             per = defaultdict(float)                               # (dispatch, kernel, counter) -> summed over dimensions
@@ -34,6 +35,12 @@ def main(dirs):
                 a = ctr[k][c]; a[0] += v; a[1] += 1
             for (_, k), v in span.items():
                 a = ctr[k]['_dur_ns_under_pmc']; a[0] += v; a[1] += 1
+            # MFMA utilisation per DISPATCH (busy cycles / that dispatch's own duration); the table reports the median, so that one
+            # dispatch stretched by something outside the kernel (r02o_face: a 118 us outlier of a 22 us kernel read as 9 %) cannot
+            # drag the figure
+            for (disp, k, c), v in per.items():
+                if c == 'SQ_VALU_MFMA_BUSY_CYCLES' and span.get((disp, k)):
+                    util[k].append(100.0 * v / (span[(disp, k)] * 2.4 * 1024))
         for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
                 a = dur[short(r['Kernel_Name'])]
@@ -41,10 +48,9 @@ def main(dirs):
     # derived columns (MI355X: 256 CUs x 4 SIMDs, 2.4 GHz; FETCH_SIZE / WRITE_SIZE are KiB)
     for k in ctr:
         c = ctr[k]
-        if c['SQ_VALU_MFMA_BUSY_CYCLES'][1] and c['_dur_ns_under_pmc'][1]:
-            busy = c['SQ_VALU_MFMA_BUSY_CYCLES'][0] / c['SQ_VALU_MFMA_BUSY_CYCLES'][1]
-            ns = c['_dur_ns_under_pmc'][0] / c['_dur_ns_under_pmc'][1]
-            c['~MFMA_util_%'] = [100.0 * busy / (ns * 2.4 * 1024), 1]
+        if util[k]:
+            u = sorted(util[k])
+            c['~MFMA_util_%'] = [u[len(u) // 2], 1]
     names = sorted(set(c for k in ctr for c in ctr[k] if ctr[k][c][1]))
     print('| kernel | dispatches | avg us (trace) | ' + ' | '.join(names) + ' |')
     print('|---|---|---|' + '---|' * len(names))
@@ -56,11 +62,11 @@ def main(dirs):
             ('%.4g' % (ctr[k][c][0] / ctr[k][c][1]) if ctr[k][c][1] else '') for c in names) + ' |')
     if jout:
         import json
-        # FETCH_SIZE under-reports 16 B/lane streaming reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section); the
-        # wgrad and pointwise kernels load float4, the GEMM kernels and the scan backward too;
-        # the corr kernels load dwords (slab) and float4 (filter): uncalibrated -> raw value kept
-        wide = ('wgrad_kernel', 'adam_k', 'pack_k', 'act_bwd_k', 'splitk_reduce_k', 'gemm_kernel', 'gemm_group_kernel', 'head_out_fwd_k',
-                'dyn_scan_bwd_k')
+        # FETCH_SIZE on gfx950 counts 64 B per 128-B fabric request: tools/fetch_calib.hip reads a known GiB through each access path
+        # the kernels here stage their operands with and the counter reports exactly half of it on ALL of them -- coalesced dword
+        # loads, 16-byte loads, LDS-DMA (buffer_load ... lds) in its dword and its 16-byte form (profiles/r03_fetch_calib.json:
+        # 2.0000 / 2.0000 / 1.9999 / 1.9999 bytes per counted byte); WRITE_SIZE reports a GiB fill as a GiB.  One factor for every kernel.
+        FETCH_CORRECTION = 2.0
         tab = {}
         for k in ctr:
             c = ctr[k]
@@ -68,7 +74,7 @@ def main(dirs):
                 continue
             f = 1024.0 * c['FETCH_SIZE'][0] / c['FETCH_SIZE'][1]
             w = 1024.0 * c['WRITE_SIZE'][0] / c['WRITE_SIZE'][1]
-            corr = 2.0 if k.startswith(wide) else 1.0
+            corr = FETCH_CORRECTION
             tab[k] = dict(fetch_bytes_raw=round(f), write_bytes=round(w), fetch_correction=corr,
                           traffic_bytes=round(f * corr + w),
                           mfma_util_pct=round(c['~MFMA_util_%'][0], 2) if c['~MFMA_util_%'][1] else None,
