@@ -29,7 +29,7 @@ struct ProfScope {
     int idx_;
 };
 int check_launch(const char* name);
-// Timing experiments only (tools/criticality.sh): kernels whose name contains one of the comma-separated substrings of
+// Timing experiments only (tools/criticality.sh): kernels whose name contains one of the ';'-separated substrings of
 // GGAN_SKIP_KERNELS are not launched at all.  Results are garbage; what the step then gains is that kernel's share of the critical path.
 bool launch_skipped(const char* name);
 

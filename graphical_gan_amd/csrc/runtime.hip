@@ -26,22 +26,36 @@ int check_launch(const char* name) {
 }
 
 bool launch_skipped(const char* name) {
+    // GGAN_SKIP_KERNELS = ';'-separated entries (kernel names contain commas) "substr" (every launch whose name contains it) or "substr@k/n" (of the launches
+    // matching substr, those whose ordinal is k modulo n: one launch SITE of an iteration that issues n of them)
     static const char* list = getenv("GGAN_SKIP_KERNELS");
     if (!list || !*list) return false;
+    static std::mutex mu;
+    static std::vector<long> counts;
+    std::lock_guard<std::mutex> lk(mu);
     const char* p = list;
-    while (*p) {
-        const char* q = strchr(p, ',');
+    bool skip = false;
+    for (size_t idx = 0; *p; ++idx) {
+        const char* q = strchr(p, ';');
         const size_t n = q ? (size_t)(q - p) : strlen(p);
+        if (counts.size() <= idx) counts.push_back(0);
         if (n && n < 96) {
             char buf[96];
             memcpy(buf, p, n);
             buf[n] = 0;
-            if (strstr(name, buf)) return true;
+            long k = -1, m = 1;
+            if (char* at = strrchr(buf, '@')) {
+                if (sscanf(at + 1, "%ld/%ld", &k, &m) == 2 && m > 0) *at = 0; else k = -1;
+            }
+            if (strstr(name, buf)) {
+                const long ord = counts[idx]++;
+                if (k < 0 || ord % m == k) skip = true;
+            }
         }
         if (!q) break;
         p = q + 1;
     }
-    return false;
+    return skip;
 }
 
 // ---- profiling --------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ echo "baseline $base $base2" | tee gpurun_out/criticality.txt
 for k in "noise_fill_k" "cast_scale" "gemm_kernel<false, false" "gemm_kernel<true, false" "gemm_kernel<false, true" "gemm_group_kernel" \
          "thin_fwd_kernel" "thin_dgrad_kernel" "thin_wgrad_kernel" "bn_fwd_rows_k" "bn_fwd_nchw" "bn_bwd_nchw" "bn_bwd_rows_k" \
          "splitk_reduce" "head_out_fwd_k" "bce_head_bwd_k" "act_bwd_chansum_k" "pack_adam_k" "wgrad_kernel" "corr_kernel<0" \
-         "corr_kernel<1" "corr_kernel<2" "gemm_,splitk_,head_out,bce_head" "bn_" "thin_"; do
+         "corr_kernel<1" "corr_kernel<2" "gemm_;splitk_;head_out;bce_head" "bn_" "thin_"; do
   v=$(ms "$k")
   python - "$k" "$base" "$v" <<'P' | tee -a gpurun_out/criticality.txt
 import sys
