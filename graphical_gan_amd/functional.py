@@ -843,6 +843,58 @@ class BatchNormBwd(Function):
         return gx2, ggy, None, gsc.view(sc.shape), None, None, None, None, None
 
 
+class LinearBatchNormRows(Function):
+    """y = act(BN_rows(x @ W + b)) in ONE launch (ggan_linear_bn_rows_fwd): Linear 'Generator.Input' + Batchnorm 'Generator.BN1' over the
+    batch axis + relu (gan_inference_cifar10.py:134-138).  The backward is the composition's: ggan_bn_bwd_act on the kept Linear
+    output, then the Linear layer's gradients (dW and db in one launch, the data gradient when the input needs one)."""
+
+    @staticmethod
+    def usable(x, w):
+        M, K = x.shape
+        N = w.shape[1]
+        return (x.dim() == 2 and M <= 128 and M % 16 == 0 and K <= 256 and K % 4 == 0 and N % 32 == 0 and x.is_contiguous()
+                and not _os.environ.get('GGAN_NO_LINEAR_BN'))
+
+    @staticmethod
+    def forward(ctx, x, w, b, scale, offset, eps, act, alpha):
+        x, w = _c(x), _c(w)
+        M, K = x.shape
+        N = w.shape[1]
+        h = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(h)
+        mean = torch.empty((N,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        sc, of = _c(scale).reshape(-1), _c(offset).reshape(-1)
+        check(_L().ggan_linear_bn_rows_fwd(_p(x), _p(w), _p(_c(b)) if b is not None else _p(None), _p(sc), _p(of), _p(h), _p(y), _p(mean),
+                                           _p(invstd), M, K, N, eps, act, alpha, _stream()), 'ggan_linear_bn_rows_fwd')
+        ctx.act, ctx.alpha, ctx.has_bias, ctx.pshape = act, alpha, b is not None, tuple(scale.shape)
+        ctx.save_for_backward(x, w, h, sc, mean, invstd, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w, h, sc, mean, invstd, y = ctx.saved_tensors
+        M, N = h.shape
+        gy = _c(gy)
+        gh = torch.empty_like(h)
+        gs = torch.empty((N,), dtype=torch.float32, device=h.device)
+        go = torch.empty_like(gs)
+        check(_L().ggan_bn_bwd_act(_p(h), _p(gy), _p(y) if ctx.act != ACT_NONE else _p(None), ctx.act, ctx.alpha, _p(sc), _p(mean),
+                                   _p(invstd), _p(gh), _p(gs), _p(go), _p(None), M, N, 1, _stream()), 'ggan_bn_bwd_act')
+        dx = dw = db = None
+        need = ctx.needs_input_grad
+        if need[1] or (ctx.has_bias and need[2]):
+            dw, db = gemm_colsum_(x, gh, True)                         # dW = x^T gh and db = column sums of gh in one launch
+            if not need[1]:
+                dw = None
+            if not (ctx.has_bias and need[2]):
+                db = None
+        if need[0]:
+            dx = Gemm.apply(gh, w, None, False, True, ACT_NONE, 0.0)    # gh W^T
+        return (dx, dw, db, gs.view(ctx.pshape) if need[3] else None, go.view(ctx.pshape) if need[4] else None, None, None, None)
+
+
 def _all_gather_rows(t, group):
     """[world, *t.shape]: every replica's `t`, in rank order"""
     import torch.distributed as dist

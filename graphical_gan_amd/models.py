@@ -201,7 +201,9 @@ class GraphicalGAN(object):
     def Generator(self, noise, out_slot=None):
         """out_slot: optional functional.RowSlot for the generated images (only honoured with fused epilogues)"""
         c = self.cfg
-        if c.bn:
+        if c.bn and c.fuse:
+            out = lib.ops.linear.LinearBatchnormRows('Generator.Input', c.dim_latent, c.flat, noise, 'Generator.BN1', activation=RELU)
+        elif c.bn:
             out = lib.ops.linear.Linear('Generator.Input', c.dim_latent, c.flat, noise)
             out = self._bn('Generator.BN1', [0], out, RELU)
         else:

@@ -120,3 +120,22 @@ def linear_params(name, input_dim, output_dim):
     w = _param(name + '.W', _initial(None, input_dim, output_dim) if _draw(name + '.W') else None)
     b = _param(name + '.b', np.zeros((output_dim,), dtype='float32'))
     return w, b
+
+
+def LinearBatchnormRows(name, input_dim, output_dim, inputs, bn_name, activation=None, alpha=0.2):
+    """Extension: Linear(name, input_dim, output_dim, inputs) followed by Batchnorm(bn_name, [0], .) and an activation -- the head
+    of every Generator of the image scripts (gan_inference_cifar10.py:134-138) -- as ONE op (functional.LinearBatchNormRows) where
+    the shapes allow (whole minibatch in one workgroup: at most 128 rows, a multiple of 16); otherwise the two calls.  Same registry
+    keys, shapes and initial-value draws, in the same order, as the two calls."""
+    from . import batchnorm
+    w = _param(name + '.W', _initial(None, input_dim, output_dim) if _draw(name + '.W') else None)
+    b = _param(name + '.b', np.zeros((output_dim,), dtype='float32'))
+    x = inputs if inputs.dim() == 2 else inputs.reshape(-1, input_dim)
+    act = F.ACT_NONE if activation is None else activation
+    if batchnorm._SYNC_GROUP in (None, False) and F.LinearBatchNormRows.usable(x, w):
+        shape = [1, output_dim]
+        offset = _param(bn_name + '.offset', np.zeros(shape, dtype='float32'))
+        scale = _param(bn_name + '.scale', np.ones(shape, dtype='float32'))
+        return F.LinearBatchNormRows.apply(x, w, b, scale, offset, 1e-5, act, float(alpha))
+    out = F.Gemm.apply(x, w, b, False, False, F.ACT_NONE, 0.0, None)
+    return batchnorm.Batchnorm(bn_name, [0], out, activation=activation, alpha=alpha)

@@ -181,6 +181,17 @@ int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, 
                     const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset,
                     float* gx_chansum, int N, int C, int HW, ggan_stream_t stream);
 
+/* Linear + Batchnorm([0]) + activation in one launch: the head of every Generator of the image scripts
+ * (gan_inference_cifar10.py:134-138: Linear 'Generator.Input' -> Batchnorm 'Generator.BN1' over the batch axis -> relu).
+ * x [M,K], w [K,N], b [N] (may be NULL); h [M,N] = x @ w + b (BatchNorm's input, kept for its backward), y [M,N] =
+ * act(scale * (h - mean) * invstd + offset) with the batch statistics of the M rows, save_mean / save_invstd [N] as
+ * ggan_bn_fwd_train leaves them (the backward is ggan_bn_bwd_act followed by the Linear layer's gradients).  Returns 1 when the
+ * shape is not covered (M > 128 or not a multiple of 16, K > 256 or not a multiple of 4, N not a multiple of 32): nothing
+ * written, use ggan_gemm + ggan_bn_fwd_train. */
+int ggan_linear_bn_rows_fwd(const float* x, const float* w, const float* b, const float* scale, const float* offset, float* h,
+                            float* y, float* save_mean, float* save_invstd, int M, int K, int N, float eps, int act,
+                            float alpha, ggan_stream_t stream);
+
 /* Second derivative of ggan_bn_bwd_act w.r.t. its inputs, for objectives that differentiate a network containing BatchNorm twice
  * (MODE vegan-wgan-gp: the gradient penalty on the latent critic, gan_inference_cifar10.py:305-317 with BN_FLAG = True).  h =
  * dL/d(gx).  Outputs: ggy = dL/d(gy), gx2 = dL/d(x) (all of it: through the batch statistics too), gscale2 = dL/d(scale).  The

@@ -1176,3 +1176,43 @@ def test_dyn_scan(gpu, B, T, dl, dt, res_w):
     g = torch.autograd.grad(out, dev, grad_outputs=_t(gz, gpu))
     for n, a, b in zip(names, g, gref):
         assert _rel(a.cpu().numpy(), b.numpy()) < 5e-5, n
+
+
+@pytest.mark.parametrize('M,K,N', [(64, 128, 4096), (128, 128, 4096), (16, 16, 64), (32, 128, 512), (48, 256, 96)])
+@pytest.mark.parametrize('act', ['relu', 'none'])
+def test_linear_batchnorm_rows_fused_op(gpu, M, K, N, act):
+    """ggan_linear_bn_rows_fwd (Linear 'Generator.Input' + Batchnorm([0]) + relu in one launch) and its backward against the
+    float64 oracle tape: output, and the gradients of the input, the weight, the bias (mathematically zero: it feeds a BatchNorm),
+    scale and offset; and against the two-op composition it replaces."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import tape as tp
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    sc = (1 + 0.2 * rng.standard_normal((1, N))).astype(np.float32)
+    of = (0.2 * rng.standard_normal((1, N))).astype(np.float32)
+    gy = rng.standard_normal((M, N)).astype(np.float32)
+    T = lambda a: tp.T(a.astype(np.float64))
+    tx, tw, tb, ts, to = T(x), T(w), T(b), T(sc), T(of)
+    h = tp.add(tp.matmul(tx, tw), tb)
+    y = tp.batchnorm_train(h, ts, to, [0], 1e-5)
+    if act == 'relu':
+        y = tp.relu(y)
+    ref = tp.grad(tp.reduce_sum(tp.mul(y, T(gy))), [tx, tw, tb, ts, to])
+    dev = lambda a: torch.as_tensor(a).to(gpu).requires_grad_(True)
+    a = F.ACT_RELU if act == 'relu' else F.ACT_NONE
+    dx, dw, db_, ds, do = dev(x), dev(w), dev(b), dev(sc), dev(of)
+    assert F.LinearBatchNormRows.usable(dx, dw)
+    out = F.LinearBatchNormRows.apply(dx, dw, db_, ds, do, 1e-5, a, 0.0)
+    g = torch.autograd.grad(out, [dx, dw, db_, ds, do], grad_outputs=torch.as_tensor(gy).to(gpu))
+    assert np.abs(out.detach().cpu().numpy() - y.v).max() <= 2e-5 * max(1.0, np.abs(y.v).max())
+    gmax = max(np.abs(r.v).max() for r in ref)
+    for name, mine, r in zip(('x', 'w', 'b', 'scale', 'offset'), g, ref):
+        err = np.abs(mine.cpu().numpy().reshape(r.v.shape) - r.v).max()
+        assert err <= 1e-4 * max(np.abs(r.v).max(), 1e-2 * gmax), (name, err, np.abs(r.v).max())
+    # the composition it replaces (MFMA GEMM, then the BatchNorm kernel): same numbers to fp32 summation order
+    ex, ew, eb, es, eo = dev(x), dev(w), dev(b), dev(sc), dev(of)
+    out2 = F.BatchNormTrain.apply(F.Gemm.apply(ex, ew, eb, False, False, F.ACT_NONE, 0.0), es, eo, 1e-5, a, 0.0)
+    assert np.abs((out - out2).detach().cpu().numpy()).max() <= 2e-5 * max(1.0, float(out2.abs().max()))
