@@ -161,9 +161,12 @@ def cpu_baseline(spec, cfg, K, np, torch, budget_s=float(os.environ.get('GGAN_BE
         t1 = time.perf_counter()
         otr.iteration(2, feeds)
         cdt = time.perf_counter() - t1
+        # (the work of an iteration is linear in the number of sequences -- every layer is per frame or per sequence -- except the
+        #  two Adam updates; the sample runs `ob` of the GPU workload's cfg.B sequences per minibatch)
         return dict(value=round(ob / cdt, 3), unit='sequences/sec', cores=host_cores(), kind='port',
-                    sample='1 iteration (gen step + critic step) at %d sequences x %d frames per minibatch, numpy fp32 '
-                    'oracle with multi-threaded BLAS' % (ob, cfg.LEN))
+                    sample='1 iteration (gen step + critic step) of the same script at %d of the %d sequences per minibatch x %d frames '
+                           '(1/%d of the GPU iteration: per-sequence work is batch-independent), numpy fp32 oracle, multi-threaded BLAS'
+                           % (ob, cfg.B, cfg.LEN, cfg.B // ob))
     mode = spec['mode']
     if mode not in ('ali', 'wali-gp', 'local_ep'):
         from oracle import nets as ON, step as OS

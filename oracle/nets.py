@@ -1,6 +1,6 @@
 """Net definitions of the reference's driver scripts, restated on the oracle tape.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE (see oracle/__init__.py: composition pinned by tests/golden/reference_trace.json, TF primitives unpinned).
 
 Follows
   gan_inference_cifar10.py:133-255      (Generator / Extractor / Discriminator, 32x32x3)

@@ -1,6 +1,6 @@
 """Objectives of tflib/objs/gan_inference.py restated on the oracle tape.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE (see oracle/__init__.py: composition pinned by tests/golden/reference_trace.json, TF primitives unpinned).
 """
 import numpy as np
 from . import tape as tp

@@ -1,7 +1,7 @@
 """State-space GAN (ssgan_inference_moving_mnist.py) restated on the oracle tape.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED: the reference is Python 2 + TensorFlow 1.x and cannot
-run here; this file follows its net definitions and loss wiring line by line so the product model
+TEST INFRASTRUCTURE (see oracle/__init__.py).  TF primitives UNPINNED (the reference is Python 2 + TensorFlow 1.x); the composition
+below is pinned by running the two ssgan scripts under oracle/tf1_shim.py (tests/golden/reference_trace.json, MODE local_ep); this file follows its net definitions and loss wiring line by line so the product model
 (graphical_gan_amd/models_ssgan.py, which batches the per-time-step factors) can be checked against it.
 
 Covered: MODE='local_ep' (the script default) with weighted_local_epce; POS_MODE 'naive_mean_field' (default),

@@ -1,6 +1,6 @@
 """The training iteration of the reference's driver scripts, restated on the oracle.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE (see oracle/__init__.py: composition pinned by tests/golden/reference_trace.json, TF primitives unpinned).
 
 Wiring follows gan_inference_cifar10.py:261-366 (MODE 'ali' / 'wali-gp') and
 gmgan_inference_cifar10.py:341-398 (MODE 'local_ep'); the loop follows
