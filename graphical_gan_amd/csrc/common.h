@@ -32,11 +32,14 @@ int check_launch(const char* name);
 // Timing experiments only (tools/criticality.sh): kernels whose name contains one of the ';'-separated substrings of
 // GGAN_SKIP_KERNELS are not launched at all.  Results are garbage; what the step then gains is that kernel's share of the critical path.
 bool launch_skipped(const char* name);
+// debugging aid: GGAN_TRACE_LAUNCHES=1 prints one stderr line per launch (name, grid, block, dynamic LDS, flops)
+void trace_launch(const char* name, dim3 grid, dim3 block, size_t shmem, double flops);
 
 // LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, args...)
 #define GGAN_LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, ...)          \
     do {                                                                                    \
         if (ggan::launch_skipped(name)) break;                                              \
+        ggan::trace_launch(name, grid, block, shmem, (double)(flops));                      \
         ggan::ProfScope _ps(name, stream, (double)(flops), (double)(bytes));              \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
     } while (0);                                                                            \

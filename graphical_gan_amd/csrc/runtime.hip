@@ -25,6 +25,13 @@ int check_launch(const char* name) {
     return 0;
 }
 
+void trace_launch(const char* name, dim3 grid, dim3 block, size_t shmem, double flops) {
+    static const bool on = getenv("GGAN_TRACE_LAUNCHES") != nullptr;
+    if (on)
+        fprintf(stderr, "[ggan launch] %-44s grid %5u x %3u x %3u  block %4u  lds %6zu  MFLOP %10.2f\n", name, grid.x, grid.y, grid.z, block.x, shmem,
+                flops * 1e-6);
+}
+
 bool launch_skipped(const char* name) {
     // GGAN_SKIP_KERNELS = ';'-separated entries (kernel names contain commas) "substr" (every launch whose name contains it) or "substr@k/n" (of the launches
     // matching substr, those whose ordinal is k modulo n: one launch SITE of an iteration that issues n of them)

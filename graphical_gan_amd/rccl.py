@@ -134,16 +134,35 @@ class Communicator(object):
 
 
 _COMM = [None]
+_FAILED = [False]      # creation was tried and refused: do not retry (every retry is a collective)
 
 
 def get(device=None, create=True):
     """The process's communicator for captured (and eager) exchanges: created on first use when torch.distributed runs on the nccl
     backend (a collective call: every rank reaches it at Trainer construction); None on other backends -- gloo stages device
     tensors through the host and the exchange stays a host-issued torch.distributed collective between cut graphs."""
-    if _COMM[0] is None and create and dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' \
-            and not os.environ.get('GGAN_NO_DIRECT_RCCL'):
+    if _COMM[0] is None and create and not _FAILED[0] and dist.is_available() and dist.is_initialized() \
+            and dist.get_backend() == 'nccl' and not os.environ.get('GGAN_NO_DIRECT_RCCL'):
         dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
-        _COMM[0] = Communicator(dist.get_rank(), dist.get_world_size(), dev)
+        comm, err = None, None
+        try:
+            comm = Communicator(dist.get_rank(), dist.get_world_size(), dev)
+        except (RcclError, OSError, AttributeError) as e:       # library missing / symbol missing / init refused on this rank
+            err = e
+        # every replica takes the same path: one rank without a communicator sends all of them to the process-group exchange
+        # (host-issued between cut graphs, engine.Trainer.split_graph) instead of leaving the others in a collective it never joins
+        flag = torch.tensor([0.0 if comm is None else 1.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag[0]) < 0.5:
+            if comm is not None:
+                comm.destroy()
+            if dist.get_rank() == 0 or err is not None:
+                import sys
+                sys.stderr.write('[rccl] rank %d: no direct communicator (%s): the gradient exchange goes through torch.distributed '
+                                 'between cut graphs\n' % (dist.get_rank(), err if err is not None else 'another rank failed'))
+            _FAILED[0] = True
+            return None
+        _COMM[0] = comm
     return _COMM[0]
 
 
@@ -151,3 +170,4 @@ def reset():
     if _COMM[0] is not None:
         _COMM[0].destroy()
         _COMM[0] = None
+    _FAILED[0] = False

@@ -185,21 +185,16 @@ def test_restatement_reproduces_the_reference_run(key):
         assert close(RT.digest(n, tr.P[n]), dg, 1e-8, 1e-10), (key, 'final', n)
 
 
-@pytest.mark.parametrize('key', SS_KEYS)
-def test_state_space_restatement_reproduces_the_reference_run(key):
-    """ssgan_inference_moving_mnist.py / ssgan_inference_chairs.py (MODE local_ep) at reduced width: the per-time-step factors,
-    the weighted objective, the two Adam instances and the loop, against oracle/ssgan.py."""
+def ss_case(key):
+    """(oracle cfg, constructor keywords, runs with a train op, feeds of those runs) of a state-space trace: the minibatch stream,
+    the binarised labels (ssgan_inference_moving_mnist.py:81-85) and every random node's draw, by its role"""
     from oracle import ssgan as OSS
     t = TRACE[key]
     c = dict(t['script_constants'], **t['constants'])
     chairs = 'chairs' in key
-    cfg = OSS.Cfg(batch_size=c['BATCH_SIZE'], length=c['LEN'], dim=c['DIM'], dim_op=c['DIM_OP'], dim_g=c['DIM_LATENT_G'], dim_l=c['DIM_LATENT_L'],
-                  n_c=c.get('N_C', 0), channels=3 if chairs else 1, op_dyn_mode='res_w' if chairs else 'res', mode=c['MODE'])
-    assert {k: list(v.shape) for k, v in OSS.init_params(cfg, 0).items()} == t['params']
-    tr = OSS.Trainer(cfg, {n: RT.det_weight(n, shp) for n, shp in t['params'].items()}, np.float64)
-    for opt, ro in zip((tr.gen_opt, tr.disc_opt), t['optimizers']):
-        assert sorted(opt.names) == sorted(ro['var_list']) and ro['kind'] == 'adam'
-        assert (opt.lr, opt.b1, opt.b2, opt.eps) == (ro['hp']['lr'], ro['hp']['beta1'], ro['hp']['beta2'], ro['hp']['eps'])
+    kw = dict(batch_size=c['BATCH_SIZE'], length=c['LEN'], dim=c['DIM'], dim_op=c['DIM_OP'], dim_g=c['DIM_LATENT_G'], dim_l=c['DIM_LATENT_L'],
+              n_c=c.get('N_C', 0), channels=3 if chairs else 1, op_dyn_mode='res_w' if chairs else 'res', mode=c['MODE'])
+    cfg = OSS.Cfg(**kw)
     B = cfg.B
     order = {('normal', (B, cfg.dim_l)): ['p_z_l_0', 'epsilon'], ('normal', (B, cfg.dim_g)): ['p_z_g'], ('categorical', (B,)): ['p_y_idx']}
     roles, seen = {}, {}
@@ -210,14 +205,14 @@ def test_state_space_restatement_reproduces_the_reference_run(key):
         if sig in order and i < len(order[sig]):
             roles[nid] = (order[sig][i], kind, tuple(shape))
     runs = [r for r in t['runs'] if r['train']]
-    assert [r['train'][0]['optimizer'] for r in runs] == [1, 0, 1][:len(runs)]          # iteration 0: critic only
+    feeds = []
     for j, r in enumerate(runs):
         d = [x for x in r['feeds'] if x['stream']][0]
         assert d['index'] == j
         x = RT.det_batch(d['stream'], d['index'], (d['spec'][0], tuple(d['spec'][1])))
         feed = {'real_x_unit': x.astype(np.float64)}
         y = np.zeros((B, cfg.n_c), np.float32)
-        if cfg.n_c:                                  # the script binarises the loader's labels (:81-85)
+        if cfg.n_c:
             y[np.arange(B), RT.det_batch(d['stream'] + '/y', d['index'], ('label', B, cfg.n_c))] = 1
         feed['real_y'] = y
         feed['p_y'] = np.zeros((B, cfg.n_c), np.float32)
@@ -228,6 +223,24 @@ def test_state_space_restatement_reproduces_the_reference_run(key):
                 feed['p_y'][np.arange(B), v] = 1
             else:
                 feed[name] = v
+        feeds.append(feed)
+    return cfg, kw, runs, feeds
+
+
+@pytest.mark.parametrize('key', SS_KEYS)
+def test_state_space_restatement_reproduces_the_reference_run(key):
+    """ssgan_inference_moving_mnist.py / ssgan_inference_chairs.py (MODE local_ep) at reduced width: the per-time-step factors,
+    the weighted objective, the two Adam instances and the loop, against oracle/ssgan.py."""
+    from oracle import ssgan as OSS
+    t = TRACE[key]
+    cfg, _, runs, feeds = ss_case(key)
+    assert {k: list(v.shape) for k, v in OSS.init_params(cfg, 0).items()} == t['params']
+    tr = OSS.Trainer(cfg, {n: RT.det_weight(n, shp) for n, shp in t['params'].items()}, np.float64)
+    for opt, ro in zip((tr.gen_opt, tr.disc_opt), t['optimizers']):
+        assert sorted(opt.names) == sorted(ro['var_list']) and ro['kind'] == 'adam'
+        assert (opt.lr, opt.b1, opt.b2, opt.eps) == (ro['hp']['lr'], ro['hp']['beta1'], ro['hp']['beta2'], ro['hp']['eps'])
+    assert [r['train'][0]['optimizer'] for r in runs] == [1, 0, 1][:len(runs)]          # iteration 0: critic only
+    for r, feed in zip(runs, feeds):
         rec = r['train'][0]
         which = 'gen' if rec['optimizer'] == 0 else 'disc'
         cost, grads, out = tr._run(feed, which)

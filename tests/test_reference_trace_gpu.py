@@ -73,10 +73,7 @@ def test_product_registry_matches_the_reference_manifest(gpu, key):
     _fresh()
 
 
-REPLAY = ['gan_inference_mnist:ali', 'gan_inference_mnist:wali-gp', 'gan_inference_mnist:alice', 'gan_inference_cifar10:ali',
-          'gan_inference_cifar10:wali-gp', 'gan_inference_svhn:ali', 'gan_inference_face:ali', 'gmgan_inference_cifar10:local_ep',
-          'gmgan_inference_mnist:local_ep', 'gmgan_inference_face:local_ep', 'gan_inference_cifar10:vegan-wgan-gp',
-          'gan_inference_cifar10:vegan-jsd']
+REPLAY = RC.IMG_KEYS        # every (script, MODE) the trace holds
 
 
 @pytest.mark.parametrize('key', REPLAY)
@@ -143,5 +140,64 @@ def test_hip_path_replays_the_reference_run(gpu, key):
             continue                                     # mathematically zero gradient (a bias in front of a BatchNorm): Adam random-walks it on rounding noise
         mine = RT.digest(n, P[n])
         # weights moved by at most lr per Adam step; fp32 noise in tiny gradients can flip an entry's step: compare the norm
+        assert abs(mine[0] - dg[0]) <= 1e-4 * max(dg[0], 1e-3) + 1e-6, (key, n, mine[0], dg[0])
+    _fresh()
+
+
+@pytest.mark.parametrize('key', RC.SS_KEYS)
+def test_hip_path_replays_the_state_space_reference_run(gpu, key):
+    """ssgan_inference_moving_mnist.py / ssgan_inference_chairs.py: the reference's loop (critic step; generator step, critic step)
+    through engine.Trainer on the trace's weights, sequences, labels and noise -- the first run's gradients, every cost, the weights
+    after the last run."""
+    import torch
+    from graphical_gan_amd.engine import Trainer
+    from graphical_gan_amd.models_ssgan import SSConfig, StateSpaceGAN
+    t = RC.TRACE[key]
+    ocfg, kw, runs, feeds = RC.ss_case(key)
+    _fresh()
+    cfg = SSConfig(dataset='chairs' if 'chairs' in key else 'moving_mnist', **kw)
+    tr = Trainer(cfg, device=gpu, graph=False, inject_noise=True, model=StateSpaceGAN(cfg))
+    W0 = {n: RT.det_weight(n, shp, np.float32) for n, shp in t['params'].items()}
+    tr.load_params(W0)
+    tr.set_feed(feeds[0])
+    first = runs[0]['train'][0]
+    which = 'disc' if first['optimizer'] == 1 else 'gen'
+    out = tr.model.forward(tr.feed, which)
+    c = float(out[which + '_cost'].detach())
+    assert abs(c - first['cost']) <= 2e-5 * max(1.0, abs(first['cost'])), (key, c, first['cost'])
+    opt = out[which + '_train_op'].optimizer
+    grads = torch.autograd.grad(out[which + '_cost'], opt.params, allow_unused=True)
+    gmax = max(d[1] for d in first['grads'].values() if d is not None)
+    for p, g in zip(opt.params, grads):
+        ref = first['grads'].get(p.param_name)
+        if ref is None:
+            assert g is None or float(g.abs().max()) == 0.0, p.param_name
+            continue
+        mine = RT.digest(p.param_name, g.detach().cpu().numpy())
+        scale = max(ref[1], 1e-2 * gmax)
+        assert np.abs(np.asarray(mine[2:]) - np.asarray(ref[2:])).max() <= 3e-4 * scale, (key, p.param_name, mine[:2], ref[:2])
+        assert abs(mine[0] - ref[0]) <= 3e-4 * max(ref[0], scale), (key, p.param_name, 'l2', mine[0], ref[0])
+    del out, grads
+    tr.load_params(W0)
+    it_feeds, j, it = iter(feeds), 0, 0
+    while j < len(runs):
+        res = tr.iteration(it, it_feeds)
+        for name in (['gen_cost'] if it > 0 else []) + ['disc_cost']:
+            rec = runs[j]['train'][0]
+            v = float(res[name])
+            assert abs(v - rec['cost']) <= 2e-3 * max(1.0, abs(rec['cost'])), (key, 'run', runs[j]['run'], name, v, rec['cost'])
+            j += 1
+        it += 1
+    P = tr.get_params()
+    gscale = {}
+    for r in runs:
+        for n, dg in r['train'][0]['grads'].items():
+            if dg is not None:
+                gscale[n] = max(gscale.get(n, 0.0), dg[1])
+    gall = max(gscale.values())
+    for n, dg in t['final'].items():
+        if n in gscale and gscale[n] < 1e-9 * gall:
+            continue
+        mine = RT.digest(n, P[n])
         assert abs(mine[0] - dg[0]) <= 1e-4 * max(dg[0], 1e-3) + 1e-6, (key, n, mine[0], dg[0])
     _fresh()
