@@ -443,10 +443,14 @@ def supervise():
     modes = ([os.environ['GGAN_DP_GRAPH']] if 'GGAN_DP_GRAPH' in os.environ else ['1']) + ['0']
     for attempt, dp_graph in enumerate(modes[:2] if modes[0] != '0' else modes[:1]):
         env = dict(os.environ, GGAN_BENCH_CHILD='1', GGAN_DP_GRAPH=dp_graph, MASTER_PORT=str(base_port + 1 + attempt))
+        if attempt > 0:
+            # the retry takes the most conservative exchange there is: torch.distributed's own process group issuing the all-reduce from
+            # the host between cut graphs -- not the directly bound communicator, whose first attempt just failed or hung
+            env['GGAN_NO_DIRECT_RCCL'] = '1'
         env.pop('TORCHELASTIC_USE_AGENT_STORE', None)      # (the children's rank 0 hosts the store of their process group)
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True)
         fail_key = 'ggan_bench/attempt%d/failed' % attempt
-        t_start, limit = time.time(), float(os.environ.get('GGAN_BENCH_ATTEMPT_TIMEOUT_S', '600'))
+        t_start, limit = time.time(), float(os.environ.get('GGAN_BENCH_ATTEMPT_TIMEOUT_S', '420'))
         while p.poll() is None:
             hung = attempt == 0 and len(modes) > 1 and time.time() - t_start > limit      # (a capture that deadlocks instead of aborting)
             if hung or store.check([fail_key]):
