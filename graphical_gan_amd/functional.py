@@ -539,11 +539,13 @@ class Gemm2(Function):
         if torch.is_grad_enabled():          # differentiable composition (second derivatives: wali-gp)
             if ctx.act != ACT_NONE:
                 g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
-            da = Gemm.apply(g, w, None, False, True, ACT_NONE, 0.0) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+            # (the two halves leave in two buffers here too: column slices of one product were views that the conv stack then copied,
+            #  and their backward a zero-filled [M, K] buffer plus a copy per critic step)
+            da1, da2 = Gemm2Dgrad.apply(g, w, K1) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else (None, None)
             dw = (Gemm.apply(torch.cat([a1, a2], 1), g, None, True, False, ACT_NONE, 0.0)
                   if (ctx.needs_input_grad[2] and not (_DATA_ONLY[0] and ctx.w_param)) else None)
             db = ColSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[3] and not (_DATA_ONLY[0] and ctx.bias_param)) else None
-            return (da[:, :K1] if da is not None else None, da[:, K1:] if da is not None else None, dw, db, None, None)
+            return (da1, da2, dw, db, None, None)
         g = _c(g)
         if ctx.act != ACT_NONE:
             g = ActBwd.apply(g, out, ctx.act, ctx.alpha)
@@ -566,6 +568,64 @@ class Gemm2(Function):
             check(L.ggan_gemm_split(0, 1, M, K, N, _p(g), _p(None), 0, _p(w), _p(None), _p(da1), _p(da2), K1, _p(None), ACT_NONE, 0.0,
                                     _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
         return da1, da2, dw, db if (ctx.has_bias and ctx.needs_input_grad[3]) else None, None, None
+
+
+_CONSTS = {}
+
+
+def cached_const(value, shape, device):
+    """a persistent constant tensor (never written): unit seeds of inner gradient calls, zero operands -- no fill launch per step"""
+    device = torch.device(device)
+    key = (float(value), tuple(shape), device.type, device.index)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full(tuple(shape), float(value), dtype=torch.float32, device=device)
+    return t
+
+
+class Gemm2Dgrad(Function):
+    """(da1[M,K1], da2[M,K-K1]) = the column halves of g[M,N] @ w[K,N]^T -- Gemm2's data gradient as an op of its own, so that the
+    gradient-penalty pass can differentiate through it: its backward is Gemm2's forward ([h1 | h2] @ w) and Gemm2's weight-gradient
+    form ([h1 | h2]^T g), both reading the two halves in place (ggan_gemm_split).  An undefined half is a zero operand."""
+
+    @staticmethod
+    def forward(ctx, g, w, K1):
+        g, w = _c(g), _c(w)
+        M, N = g.shape
+        K = w.shape[0]
+        da1 = torch.empty((M, K1), dtype=torch.float32, device=g.device)
+        da2 = torch.empty((M, K - K1), dtype=torch.float32, device=g.device)
+        ws = workspace(g.device)
+        check(_L().ggan_gemm_split(0, 1, M, K, N, _p(g), _p(None), 0, _p(w), _p(None), _p(da1), _p(da2), K1, _p(None), ACT_NONE, 0.0,
+                                   _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
+        ctx.K1 = K1
+        ctx.w_param = _is_param(w)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(g, w)
+        return da1, da2
+
+    @staticmethod
+    def backward(ctx, h1, h2):
+        if h1 is None and h2 is None:
+            return None, None, None
+        g, w = ctx.saved_tensors
+        K1 = ctx.K1
+        M, N = g.shape
+        K = w.shape[0]
+        h1 = _c(h1) if h1 is not None else cached_const(0.0, (M, K1), g.device)
+        h2 = _c(h2) if h2 is not None else cached_const(0.0, (M, K - K1), g.device)
+        dg = dw = None
+        if ctx.needs_input_grad[0]:
+            dg = Gemm2.apply(h1, h2, w, None, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1] and not (_DATA_ONLY[0] and ctx.w_param):
+            if torch.is_grad_enabled():            # (a third derivative: plain composition)
+                dw = Gemm.apply(torch.cat([h1, h2], 1), g, None, True, False, ACT_NONE, 0.0)
+            else:
+                dw = torch.empty((K, N), dtype=torch.float32, device=g.device)
+                ws = workspace(g.device)
+                check(_L().ggan_gemm_split(1, 0, K, N, M, _p(h1), _p(h2), K1, _p(g), _p(None), _p(dw), _p(None), 0, _p(None), ACT_NONE,
+                                           0.0, _p(ws), ws.numel(), _stream()), 'ggan_gemm_split')
+        return dg, dw, None
 
 
 @_skip_undefined

@@ -328,7 +328,7 @@ class GraphicalGAN(object):
                     z_hat.requires_grad_(True)
                 d_hat = self.LatentDiscriminator(z_hat, noise('h'))
                 with F.data_grad_only():
-                    (g,) = torch.autograd.grad(d_hat, [z_hat], grad_outputs=torch.ones_like(d_hat), create_graph=True)
+                    (g,) = torch.autograd.grad(d_hat, [z_hat], grad_outputs=F.cached_const(1.0, d_hat.shape, d_hat.device), create_graph=True)
                 gp = F.GradPenalty.apply(g, 10.0)
         rec = 1. * lib.utils.distance.distance(real_x, self.Generator(q_z), 'l2') if which != 'disc' else None
         gen_params, disc_params = self._var_lists()

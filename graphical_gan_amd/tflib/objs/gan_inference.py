@@ -152,7 +152,7 @@ def gradient_penalty(critic, real_x, fake_x, q_z, p_z, alpha, lam=10.):
     if not x_hat.requires_grad:
         x_hat.requires_grad_(True)
     d_hat = critic(x_hat, z_hat)
-    ones = torch.ones_like(d_hat)
+    ones = F.cached_const(1.0, d_hat.shape, d_hat.device)      # (persistent: no fill launch per critic step)
     with F.data_grad_only():             # only d/d x_hat is asked for: the layers skip their parameter gradients
         (g,) = torch.autograd.grad(d_hat, [x_hat], grad_outputs=ones, create_graph=True)
     return F.GradPenalty.apply(g.reshape(g.shape[0], -1), float(lam))
