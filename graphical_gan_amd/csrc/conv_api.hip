@@ -173,6 +173,24 @@ int ggan_conv2d_bwd_filter_parts(const ggan_conv_geom* g, const float* x, const 
     return r;
 }
 
+// y = conv(x, w) masked by the derivative of the activation that produced yref (see ggan.h)
+int ggan_conv2d_fwd_masked(const ggan_conv_geom* g, const float* x, const float* w, float* y, const float* yref, int ref_act,
+                           float ref_alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    GGAN_CHECK_ARG(x && w && y && yref, "null pointer");
+    if (g_force_naive || getenv("GGAN_NAIVE_FWD") || getenv("GGAN_NO_FWD_MASK")) return 1;
+    if ((((uintptr_t)yref) & 15) != 0) return 1;
+    // (thin first layers too: the padded-channel MFMA launch with the mask measured 1 % of a wali-gp iteration shorter than
+    //  conv_thin.hip + act_bwd; GGAN_NO_FWD_MASK_THIN selects that pair)
+    if (g->Ci <= 4 && getenv("GGAN_NO_FWD_MASK_THIN")) return 1;
+    OutMask M{yref, ref_act, ref_alpha, false};
+    g_out_mask = &M;
+    const int rc = conv_fwd_mfma(*g, x, w, nullptr, y, GGAN_ACT_NONE, 0.f, ws, ws ? ws_bytes : 0, (hipStream_t)stream);
+    g_out_mask = nullptr;
+    if (rc == 0 && !M.applied) { set_error("conv2d_fwd_masked: launch without the mask"); return -3; }
+    return rc;
+}
+
 // Deconv2D = the adjoint family with the same filter bytes (see ggan.h)
 int ggan_deconv2d_fwd(const ggan_conv_geom* g, const float* x_small, const float* w, const float* bias, float* y_big,
                       int act, float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {

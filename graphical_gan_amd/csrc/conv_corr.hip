@@ -68,6 +68,9 @@ struct CorrParams {
     int dma;                      // forward kinds: stage the slab and the filter slice by LDS-DMA (buffer_load ... lds)
     int xq;                       // 4: the slab is staged in 16-byte units of image rows (forward DMA path, see plan_and_launch), else 1
     unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
+    const float* out_ref;    // optional (forward kind, SK == 1): the stored value is act_grad(v, out_ref[same index]) -- the double backward of
+    int out_act;             // a masked data gradient (functional.ConvDgradMasked) without an act_bwd launch behind the conv
+    float out_alpha;
     const float* in_ref;     // optional: slab values are in[i] * act'(in_ref[i]) (fused activation backward)
     int in_act;
     float in_alpha;
@@ -717,6 +720,11 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
             if (NC != 4 && P.ocs == 1 && (A.Wv & 3) == 0 && (u0 + ur) < A.Hu && (v0 + vc + 3) < A.Wv) {
                 const int off = (A.or0 + P.ors * (u0 + ur)) * P.Wout + A.oc0 + v0 + vc;
                 if ((off & 3) == 0) {
+                    if (KIND == 0 && P.out_ref) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(P.out_ref + cbase + off);
+                        va[0] = act_grad(va[0], r4.x, P.out_act, P.out_alpha); va[1] = act_grad(va[1], r4.y, P.out_act, P.out_alpha);
+                        va[2] = act_grad(va[2], r4.z, P.out_act, P.out_alpha); va[3] = act_grad(va[3], r4.w, P.out_act, P.out_alpha);
+                    }
                     *reinterpret_cast<float4*>(outp + cbase + off) = make_float4(va[0], va[1], va[2], va[3]);
                     done = true;
                 }
@@ -744,8 +752,10 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
                 const int vcj = rm - urj * P.TC;
                 if (!(im < P.TI && (n0 + im) < P.N)) continue;
                 const size_t cb2 = ((size_t)(n0 + im) * P.CNtot + cn) * chw;
-                if ((u0 + urj) < A.Hu && (v0 + vcj) < A.Wv)
-                    outp[cb2 + (A.or0 + P.ors * (u0 + urj)) * P.Wout + A.oc0 + P.ocs * (v0 + vcj)] = va[j];
+                if ((u0 + urj) < A.Hu && (v0 + vcj) < A.Wv) {
+                    const size_t oi = cb2 + (A.or0 + P.ors * (u0 + urj)) * P.Wout + A.oc0 + P.ocs * (v0 + vcj);
+                    outp[oi] = (KIND == 0 && P.out_ref) ? act_grad(va[j], P.out_ref[oi], P.out_act, P.out_alpha) : va[j];
+                }
                 if (NC == 4 && (u0 + urj) < B.Hu && (v0 + vcj) < B.Wv)
                     outp[cb2 + (B.or0 + P.ors * (u0 + urj)) * P.Wout + B.oc0 + P.ocs * (v0 + vcj)] = vb[j];
             }
@@ -1059,6 +1069,12 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     }
     P.out = P.SK > 1 ? (float*)ws : dst;
     P.bias = bias; P.act = act; P.alpha = alpha;
+    if (g_out_mask) {
+        // the stored values masked by a reference tensor (conv.h: OutMask): only where the epilogue writes the final values
+        if (MODE != 0 || P.SK != 1) return 1;
+        P.out_ref = g_out_mask->ref; P.out_act = g_out_mask->act; P.out_alpha = g_out_mask->alpha;
+        g_out_mask->applied = true;
+    }
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     size_t stage = MODE == 0 ? 2 * ((size_t)fwd_region(CK * P.CS, CK * P.CS / P.xq, P.xq) + (size_t)fwd_region(ntaps * CK * RS, ntaps * CK * (TNW / 4), 4))
                              : 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
@@ -1074,6 +1090,8 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
 }  // namespace
 
 namespace ggan {
+
+thread_local OutMask* g_out_mask = nullptr;
 
 int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,
                          float alpha, hipStream_t s, size_t slab_stride, float* tail_out, size_t tail) {

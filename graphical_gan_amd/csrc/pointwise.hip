@@ -624,6 +624,42 @@ __global__ void gp_pen_k(const float* __restrict__ slopes, float* __restrict__ p
     if (threadIdx.x == 0) pen[0] = lam * (s / (float)B);
 }
 
+// gp_slopes_k + gp_pen_k + gp_bwd_k for a unit upstream gradient in ONE launch: a workgroup per row computes its norm, writes the
+// row of d(pen)/dg, and the LAST workgroup to arrive (counter in `arrive`, left zero) forms the penalty from all slopes with the same
+// fixed-order block sum as gp_pen_k -- deterministic.
+__global__ void gp_fwd_grad_k(const float* __restrict__ g, float* __restrict__ slopes, float* __restrict__ pen, float* __restrict__ gg,
+                              int32_t* __restrict__ arrive, int B, int D, float lam) {
+    __shared__ float sm[32];
+    __shared__ int last;
+    const int b = blockIdx.x;
+    const float* row = g + (size_t)b * D;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) s += row[i] * row[i];
+    s = block_sum(s, sm);
+    const float sl = sqrtf(s);
+    const float coef = lam * 2.f * (sl - 1.f) / ((float)B * sl);
+    float* orow = gg + (size_t)b * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) orow[i] = coef * row[i];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(slopes + b, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(arrive, 1) == B - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float d = __hip_atomic_load(slopes + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1.f;
+        t += d * d;
+    }
+    t = block_sum(t, sm);
+    if (threadIdx.x == 0) {
+        pen[0] = lam * (t / (float)B);
+        arrive[0] = 0;
+    }
+}
+
 __global__ void gp_bwd_k(const float* __restrict__ g, const float* __restrict__ slopes, const float* __restrict__ gpen,
                          float* __restrict__ gg, int B, int D, float lam) {
     const int b = blockIdx.x;
@@ -1393,6 +1429,14 @@ int ggan_gp_penalty_fwd(const float* g, float* slopes, float* pen, int B, int D,
     hipStream_t s = (hipStream_t)stream;
     GGAN_LAUNCH("gp_slopes", 0, 4.0 * B * D, gp_slopes_k, dim3(B), dim3(256), 0, s, g, slopes, D);
     GGAN_LAUNCH("gp_penalty", 0, 4.0 * B, gp_pen_k, dim3(1), dim3(256), 0, s, slopes, pen, B, lam);
+    return 0;
+}
+
+int ggan_gp_penalty_fwd_grad(const float* g, float* slopes, float* pen, float* gg_unit, int32_t* arrive, int B, int D, float lam,
+                             ggan_stream_t stream) {
+    GGAN_CHECK_ARG(g && slopes && pen && gg_unit && arrive && B > 0 && D > 0, "bad argument");
+    GGAN_LAUNCH("gp_fwd_grad", 0, 8.0 * B * D, gp_fwd_grad_k, dim3(B), dim3(256), 0, (hipStream_t)stream, g, slopes, pen, gg_unit, arrive, B, D,
+                lam);
     return 0;
 }
 

@@ -244,6 +244,13 @@ class ConvFwd(Function):
             r = _fused_conv_backward(ctx, gy, x, w, y)
             if r is not None:
                 return r + (None,)
+        want_w = ctx.needs_input_grad[1] and not (_DATA_ONLY[0] and ctx.w_param)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not (_DATA_ONLY[0] and ctx.b_param)
+        if (ctx.act in (ACT_LRELU, ACT_RELU) and torch.is_grad_enabled() and ctx.needs_input_grad[0] and not want_w and not want_b
+                and not ctx.grad_rows and not _os.environ.get('GGAN_NO_DGRAD_MASKED')):
+            # a double backward is being recorded and only the data gradient is asked for (the gradient-penalty pass): the activation
+            # derivative rides in the data-gradient launch, and in its backward's launches (ConvDgradMasked)
+            return ConvDgradMasked.apply(gy, y, w, ctx.geom, ctx.act, ctx.alpha), None, None, None, None, None, None
         if ctx.act != ACT_NONE:
             gy = ActBwd.apply(gy, y, ctx.act, ctx.alpha)       # lrelu/relu: sign(y) == sign(pre-activation)
         gx = gw = gb = None
@@ -342,6 +349,68 @@ class ConvDgrad(Function):
         if ctx.needs_input_grad[0]:
             d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
         return (d_gy, d_w, d_b) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+@_skip_undefined
+class ConvDgradMasked(Function):
+    """gx = conv^T(gy * act'(yref), w): ActBwd + ConvDgrad as one differentiable op (ggan_conv2d_bwd_data_act stages gy through the
+    mask).  Backward, for the gradient h arriving at gx: d_gy = conv(h, w) * act'(yref) (ggan_conv2d_fwd_masked: the mask in the
+    epilogue; conv + act_bwd where that geometry has no such kernel), d_w = the filter gradient of (h, gy * act'(yref)) with the mask
+    applied while gy is staged (ggan_conv2d_bwd_filter_act).  yref gets no gradient (lrelu / relu: zero almost everywhere)."""
+
+    @staticmethod
+    def forward(ctx, gy, yref, w, geom, act, alpha):
+        gy, yref, w = _c(gy), _c(yref), _c(w)
+        N, Ci, H, W, Co, Ho, Wo = geom[:7]
+        assert tuple(gy.shape) == (N, Co, Ho, Wo) == tuple(yref.shape), (gy.shape, yref.shape, geom)
+        gx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gy.device)
+        ws = workspace(gy.device)
+        g = _geom(geom)
+        check(_L().ggan_conv2d_bwd_data_act(C.byref(g), _p(gy), _p(yref), act, alpha, _p(w), _p(gx), _p(ws), ws.numel(), _stream()),
+              'ggan_conv2d_bwd_data_act')
+        ctx.geom, ctx.act, ctx.alpha = geom, act, alpha
+        ctx.w_param = _is_param(w)
+        ctx.save_for_backward(gy, yref, w)
+        return gx
+
+    @staticmethod
+    def backward(ctx, h):
+        gy, yref, w = ctx.saved_tensors
+        geom = ctx.geom
+        d_gy = d_w = None
+        if torch.is_grad_enabled():              # (a third derivative: plain composition)
+            gm = ActBwd.apply(gy, yref, ctx.act, ctx.alpha)
+            if ctx.needs_input_grad[0]:
+                d_gy = ActBwd.apply(ConvFwd.apply(h, w, None, geom, ACT_NONE, 0.0), yref, ctx.act, ctx.alpha)
+            if ctx.needs_input_grad[2] and not (_DATA_ONLY[0] and ctx.w_param):
+                d_w = ConvWgrad.apply(h, gm, geom)
+            return d_gy, None, d_w, None, None, None
+        h = _c(h)
+        N, Ci, H, W, Co, Ho, Wo, k = geom[:8]
+        g = _geom(geom)
+        L, ws = _L(), workspace(h.device)
+        if ctx.needs_input_grad[0]:
+            d_gy = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=h.device)
+            rc = L.ggan_conv2d_fwd_masked(C.byref(g), _p(h), _p(w), _p(d_gy), _p(yref), ctx.act, ctx.alpha, _p(ws), ws.numel(), _stream())
+            if rc == 1:                          # no kernel fuses the mask for this geometry: the two launches
+                check(L.ggan_conv2d_fwd(C.byref(g), _p(h), _p(w), _p(None), _p(d_gy), ACT_NONE, 0.0, _p(ws), ws.numel(), _stream()),
+                      'ggan_conv2d_fwd')
+                d_gy = ActBwd.apply(d_gy, yref, ctx.act, ctx.alpha)
+            else:
+                check(rc, 'ggan_conv2d_fwd_masked')
+        if ctx.needs_input_grad[2] and not (_DATA_ONLY[0] and ctx.w_param):
+            parts = _wgrad_parts(h, gy, yref, ctx.act, ctx.alpha, geom, False)
+            if parts is not None:
+                d_w = parts[0]
+            else:
+                d_w = torch.empty((k, k, Ci, Co), dtype=torch.float32, device=h.device)
+                rc = L.ggan_conv2d_bwd_filter_act(C.byref(g), _p(h), _p(gy), _p(yref), ctx.act, ctx.alpha, _p(d_w), _p(None), _p(ws),
+                                                  ws.numel(), _stream())
+                if rc == 1:
+                    d_w = ConvWgrad.apply(h, ActBwd.apply(gy, yref, ctx.act, ctx.alpha), geom)
+                else:
+                    check(rc, 'ggan_conv2d_bwd_filter_act')
+        return d_gy, None, d_w, None, None, None
 
 
 @_skip_undefined
@@ -1586,6 +1655,7 @@ class MeanSum(Function):
 
     @staticmethod
     def forward(ctx, weights, *xs):
+        ctx.shapes = [x.shape for x in xs]
         xs = [_c(x).reshape(-1) for x in xs]
         loss = torch.empty((1,), dtype=torch.float32, device=xs[0].device)
         ctx.weights = weights
@@ -1612,18 +1682,25 @@ class MeanSum(Function):
     @once_differentiable
     def backward(ctx, g):
         if ctx.unit_grads is not None and is_unit_seed(g):
-            return (None,) + tuple(ctx.unit_grads)
+            # (a one-element term of weight 1 -- the gradient penalty riding in the cost launch -- receives the seed itself, so that its
+            #  producer recognises it in turn)
+            return (None,) + tuple((g if (n == 1 and float(w) == 1.0 and shp == g.shape) else u.reshape(shp))
+                                   for u, n, w, shp in zip(ctx.unit_grads, ctx.sizes, ctx.weights, ctx.shapes))
         g = _c(g.reshape(1))
         outs = []
-        for n, w in zip(ctx.sizes, ctx.weights):
+        for n, w, shp in zip(ctx.sizes, ctx.weights, ctx.shapes):
             gx = torch.empty((n,), dtype=torch.float32, device=ctx.dev)
             check(_L().ggan_mean_bwd(_p(g), float(w), _p(gx), n, _stream()), 'ggan_mean_bwd')
-            outs.append(gx)
+            outs.append(gx.reshape(shp))
         return (None,) + tuple(outs)
 
 
 class GradPenalty(Function):
-    """lam * mean_b((||g[b,:]||_2 - 1)^2)  (gan_inference_cifar10.py:363-364)."""
+    """lam * mean_b((||g[b,:]||_2 - 1)^2)  (gan_inference_cifar10.py:363-364).  The forward launch also leaves d(pen)/dg for a unit
+    upstream gradient (the penalty enters the critic cost with weight 1): backward hands that out when the train op's unit seed
+    comes back (as BceSum / MeanSum do), and runs the backward kernel otherwise."""
+
+    _ARRIVE = {}
 
     @staticmethod
     def forward(ctx, g, lam):
@@ -1631,7 +1708,18 @@ class GradPenalty(Function):
         B, D = g.shape
         slopes = torch.empty((B,), dtype=torch.float32, device=g.device)
         pen = torch.empty((1,), dtype=torch.float32, device=g.device)
-        check(_L().ggan_gp_penalty_fwd(_p(g), _p(slopes), _p(pen), B, D, lam, _stream()), 'ggan_gp_penalty_fwd')
+        ctx.unit_grad = None
+        if ctx.needs_input_grad[0] and not os.environ.get('GGAN_NO_BCE_FWD_GRAD'):
+            key = (g.device.type, g.device.index)
+            arrive = GradPenalty._ARRIVE.get(key)
+            if arrive is None:
+                arrive = GradPenalty._ARRIVE[key] = torch.zeros((1,), dtype=torch.int32, device=g.device)
+            gg = torch.empty_like(g)
+            check(_L().ggan_gp_penalty_fwd_grad(_p(g), _p(slopes), _p(pen), _p(gg), _p(arrive), B, D, lam, _stream()),
+                  'ggan_gp_penalty_fwd_grad')
+            ctx.unit_grad = gg
+        else:
+            check(_L().ggan_gp_penalty_fwd(_p(g), _p(slopes), _p(pen), B, D, lam, _stream()), 'ggan_gp_penalty_fwd')
         ctx.lam = lam
         ctx.save_for_backward(g, slopes)
         return pen.reshape(())
@@ -1639,6 +1727,8 @@ class GradPenalty(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gpen):
+        if ctx.unit_grad is not None and is_unit_seed(gpen):
+            return ctx.unit_grad, None
         g, slopes = ctx.saved_tensors
         B, D = g.shape
         gg = torch.empty_like(g)

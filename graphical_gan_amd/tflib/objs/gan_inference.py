@@ -98,7 +98,10 @@ def vegan_wgan_gp(disc_fake, disc_real, rec_penalty, gradient_penalty, gen_param
     if ONLY[0] != 'disc':
         gen_cost = _plus(F.MeanSum.apply((-float(lamb), float(lamb)), disc_fake, disc_real), rec_penalty)
     if ONLY[0] != 'gen':
-        disc_cost = _plus(F.MeanSum.apply((float(lamb), -float(lamb)), disc_fake, disc_real), gradient_penalty)
+        if gradient_penalty is not None:
+            disc_cost = F.MeanSum.apply((float(lamb), -float(lamb), 1.0), disc_fake, disc_real, gradient_penalty)
+        else:
+            disc_cost = F.MeanSum.apply((float(lamb), -float(lamb)), disc_fake, disc_real)
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
@@ -134,9 +137,10 @@ def wali_gp(disc_fake, disc_real, gradient_penalty, gen_params, disc_params, lr=
     gen_cost = F.MeanSum.apply((-1.0, 1.0), disc_fake, disc_real) if ONLY[0] != 'disc' else None
     disc_cost = None
     if ONLY[0] != 'gen':
-        disc_cost = F.MeanSum.apply((1.0, -1.0), disc_fake, disc_real)
-        if gradient_penalty is not None:
-            disc_cost = disc_cost + gradient_penalty
+        if gradient_penalty is not None:     # (the penalty is a one-element term of weight 1 of the same cost launch: no addition launch)
+            disc_cost = F.MeanSum.apply((1.0, -1.0, 1.0), disc_fake, disc_real, gradient_penalty)
+        else:
+            disc_cost = F.MeanSum.apply((1.0, -1.0), disc_fake, disc_real)
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=0.5, beta2=0.9)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=0.5, beta2=0.9)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)

@@ -181,6 +181,14 @@ int ggan_bn_bwd_act(const float* x, const float* gy, const float* y, int y_act, 
                     const float* save_mean, const float* save_invstd, float* gx, float* gscale, float* goffset,
                     float* gx_chansum, int N, int C, int HW, ggan_stream_t stream);
 
+/* y = conv2d(x, w) * act'(yref), act' the derivative of the activation (ref_act, ref_alpha) that produced yref, taken at yref (as
+ * ggan_act_bwd does): ggan_conv2d_fwd followed by ggan_act_bwd in one launch.  This is the backward of ggan_conv2d_bwd_data_act with
+ * respect to its gy operand -- what the gradient-penalty pass of MODE wali-gp differentiates through (gan_inference_cifar10.py:353-364:
+ * tf.gradients of a cost that contains tf.gradients(disc_hat, [x_hat])).  Returns 1, having launched nothing, where no kernel fuses
+ * the mask for this geometry (filters other than 5x5 stride 2, split-K launches): the caller composes the two calls. */
+int ggan_conv2d_fwd_masked(const ggan_conv_geom* g, const float* x, const float* w, float* y, const float* yref, int ref_act,
+                           float ref_alpha, void* ws, size_t ws_bytes, ggan_stream_t stream);
+
 /* Linear + Batchnorm([0]) + activation in one launch: the head of every Generator of the image scripts
  * (gan_inference_cifar10.py:134-138: Linear 'Generator.Input' -> Batchnorm 'Generator.BN1' over the batch axis -> relu).
  * x [M,K], w [K,N], b [N] (may be NULL); h [M,N] = x @ w + b (BatchNorm's input, kept for its backward), y [M,N] =
@@ -377,6 +385,11 @@ int ggan_gp_penalty_fwd(const float* g, float* slopes, float* pen, int B, int D,
                         ggan_stream_t stream);
 int ggan_gp_penalty_bwd(const float* g, const float* slopes, const float* gpen, float* gg, int B, int D,
                         float lam, ggan_stream_t stream);
+/* ggan_gp_penalty_fwd together with ggan_gp_penalty_bwd for a unit upstream gradient (gg_unit = d pen / d g) in one launch -- the
+ * penalty enters the critic cost with weight 1 (gan_inference_cifar10.py:365), so that IS its upstream gradient.  arrive: one int32,
+ * zero before the first call, left zero (the last workgroup forms the penalty: fixed order, deterministic). */
+int ggan_gp_penalty_fwd_grad(const float* g, float* slopes, float* pen, float* gg_unit, int32_t* arrive, int B, int D, float lam,
+                             ggan_stream_t stream);
 
 /* ---- optimiser --------------------------------------------------------------------------------
  * tf.train.AdamOptimizer step over a flat parameter buffer (tflib/objs/gan_inference.py:108-117;

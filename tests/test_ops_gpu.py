@@ -1216,3 +1216,100 @@ def test_linear_batchnorm_rows_fused_op(gpu, M, K, N, act):
     ex, ew, eb, es, eo = dev(x), dev(w), dev(b), dev(sc), dev(of)
     out2 = F.BatchNormTrain.apply(F.Gemm.apply(ex, ew, eb, False, False, F.ACT_NONE, 0.0), es, eo, 1e-5, a, 0.0)
     assert np.abs((out - out2).detach().cpu().numpy()).max() <= 2e-5 * max(1.0, float(out2.abs().max()))
+
+
+@pytest.mark.parametrize('case', [(4, 8, 16, 64), (64, 64, 16, 128), (64, 128, 8, 256), (64, 3, 32, 64), (5, 24, 12, 40), (6, 1, 28, 64)])
+@pytest.mark.parametrize('act', ['lrelu', 'relu'])
+def test_masked_data_gradient_and_its_backward(gpu, case, act):
+    """functional.ConvDgradMasked = ActBwd + ConvDgrad as one differentiable op (the gradient-penalty pass of MODE wali-gp,
+    gan_inference_cifar10.py:353-364, differentiates through the critic's data gradient): forward against the oracle
+    (conv2d_bwd_data of the masked gy), backward -- ggan_conv2d_fwd_masked (mask in the MFMA epilogue; conv + act_bwd for the thin
+    first layer) and the mask-while-staging filter gradient -- against the oracle's conv2d / conv2d_bwd_filter on the same operands,
+    and against the two-op composition it replaces."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from oracle import ops as O
+    N, Ci, H, Co = case
+    rng = np.random.default_rng(sum(case))
+    a, alpha = (F.ACT_LRELU, 0.2) if act == 'lrelu' else (F.ACT_RELU, 0.0)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2, 'SAME')
+    Ho = geom[5]
+    w = (rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci)).astype(np.float32)
+    gy = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    yref = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    if act == 'relu':
+        yref = np.maximum(yref, 0.0)                   # (a relu output: zeros where the unit is off)
+    h = rng.standard_normal((N, Ci, H, H)).astype(np.float32)
+    slope = np.where(yref > 0, 1.0, alpha)
+    gm64, w64, h64 = gy.astype(np.float64) * slope, w.astype(np.float64), h.astype(np.float64)
+    tg, tw = _t(gy, gpu).requires_grad_(True), _t(w, gpu).requires_grad_(True)
+    gx = F.ConvDgradMasked.apply(tg, _t(yref, gpu), tw, geom, a, alpha)
+    ref = O.conv2d_bwd_data(gm64, w64, (H, H), 2, 'SAME')
+    assert _rel(gx.detach().cpu().numpy(), ref) < 2e-5
+    d_gy, d_w = torch.autograd.grad(gx, [tg, tw], grad_outputs=_t(h, gpu))
+    ref_gy = O.conv2d(h64, w64, 2, 'SAME') * slope
+    ref_w = O.conv2d_bwd_filter(h64, gm64, 5, 2, 'SAME')
+    assert _rel(d_gy.cpu().numpy(), ref_gy) < 2e-5, _rel(d_gy.cpu().numpy(), ref_gy)
+    assert _rel(d_w.cpu().numpy(), ref_w) < 2e-5, _rel(d_w.cpu().numpy(), ref_w)
+    # the composition it replaces
+    ug, uw = _t(gy, gpu).requires_grad_(True), _t(w, gpu).requires_grad_(True)
+    gx2 = F.ConvDgrad.apply(F.ActBwd.apply(ug, _t(yref, gpu), a, alpha), uw, None, geom, F.ACT_NONE, 0.0)
+    e_gy, e_w = torch.autograd.grad(gx2, [ug, uw], grad_outputs=_t(h, gpu))
+    assert _rel(gx.detach().cpu().numpy(), gx2.detach().cpu().numpy()) < 1e-5
+    assert _rel(d_gy.cpu().numpy(), e_gy.cpu().numpy()) < 1e-5 and _rel(d_w.cpu().numpy(), e_w.cpu().numpy()) < 1e-5
+
+
+def test_masked_forward_entry_reports_what_it_cannot_fuse(gpu):
+    """ggan_conv2d_fwd_masked returns 1 and writes nothing where no MFMA launch with final values in its epilogue exists for the
+    geometry (other filter sizes / strides): the caller composes conv + act_bwd."""
+    import ctypes as C
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    L = _lib.load()
+    for (N, Ci, H, Co), expect in (((64, 3, 32, 64), 0), ((64, 64, 16, 128), 0), ((3, 8, 9, 12), 1)):
+        k, st = (5, 2) if (N, Ci) != (3, 8) else (3, 1)
+        geom = F.conv_geom(N, Ci, H, H, Co, k, st, 'SAME')
+        x = torch.randn(N, Ci, H, H, device=gpu)
+        w = torch.randn(k, k, Ci, Co, device=gpu)
+        y = torch.full((N, Co, geom[5], geom[6]), 7.0, device=gpu)
+        ref = torch.randn_like(y)
+        ws = F.workspace(gpu)
+        g = F._geom(geom)
+        rc = L.ggan_conv2d_fwd_masked(C.byref(g), F._p(x), F._p(w), F._p(y), F._p(ref), F.ACT_LRELU, 0.2, F._p(ws), ws.numel(), F._stream())
+        torch.cuda.synchronize()
+        assert rc == expect, ((N, Ci, H, Co), rc)
+        if expect == 1:
+            assert float((y - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('B,D', [(64, 3072), (7, 130), (128, 8), (1, 5)])
+def test_gradient_penalty_one_launch_forward_and_unit_gradient(gpu, B, D):
+    """ggan_gp_penalty_fwd_grad (penalty + d pen / d g for a unit upstream gradient in one launch, the last workgroup to arrive forms the
+    penalty) against the float64 formula of gan_inference_cifar10.py:363-364 and against the two entry points it replaces; called
+    repeatedly (the arrival counter goes back to zero); and through functional.GradPenalty as a one-element term of the cost launch
+    (tflib.objs.gan_inference.wali_gp), where the registered unit seed must come back to it."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(B + D)
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    g64 = g.astype(np.float64)
+    sl = np.sqrt((g64 ** 2).sum(1))
+    pen_ref = 10.0 * np.mean((sl - 1.0) ** 2)
+    gg_ref = (10.0 * 2.0 * (sl - 1.0) / (B * sl))[:, None] * g64
+    tg = _t(g, gpu).requires_grad_(True)
+    for rep in range(3):
+        pen = F.GradPenalty.apply(tg, 10.0)
+        d_fake, d_real = _t(rng.standard_normal(B), gpu).requires_grad_(True), _t(rng.standard_normal(B), gpu).requires_grad_(True)
+        cost = F.MeanSum.apply((1.0, -1.0, 1.0), d_fake, d_real, pen)
+        seed = F.unit_seed(cost)
+        gg, gf, gr = torch.autograd.grad(cost, [tg, d_fake, d_real], grad_outputs=seed)
+        assert abs(float(pen) - pen_ref) <= 2e-5 * max(1.0, pen_ref), (rep, float(pen), pen_ref)
+        ref_cost = float(d_fake.mean() - d_real.mean()) + pen_ref
+        assert abs(float(cost) - ref_cost) <= 2e-5 * max(1.0, abs(ref_cost))
+        assert _rel(gg.cpu().numpy(), gg_ref) < 2e-5
+        assert np.allclose(gf.cpu().numpy(), 1.0 / B) and np.allclose(gr.cpu().numpy(), -1.0 / B)
+    # the generic path (an upstream gradient that is not the unit seed) and the two-launch entry points
+    pen = F.GradPenalty.apply(tg, 10.0)
+    (gg2,) = torch.autograd.grad(pen, [tg], grad_outputs=torch.full((), 0.5, device=gpu))
+    assert _rel(gg2.cpu().numpy(), 0.5 * gg_ref) < 2e-5
+    assert int(F.GradPenalty._ARRIVE[(gpu.type, gpu.index)][0]) == 0
