@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One eager iteration with GGAN_TRACE_LAUNCHES=1: every launch with its grid, block, dynamic LDS and flops (stderr).
-usage: python tools/launch_list.py [dataset] [mode] [batch]     (default: cifar10 ali 64 = the headline)"""
+usage: python tools/launch_list.py [dataset] [mode] [batch] [n_coms]     (default: cifar10 ali 64 0 = the headline)"""
 import os
 import sys
 
@@ -16,9 +16,10 @@ def main():
     dataset = sys.argv[1] if len(sys.argv) > 1 else 'cifar10'
     mode = sys.argv[2] if len(sys.argv) > 2 else 'ali'
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    n_coms = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     dev = torch.device('cuda:0')
     np.random.seed(0)
-    cfg = Config(dataset, batch_size=batch, n_coms=0, mode=mode)
+    cfg = Config(dataset, batch_size=batch, n_coms=n_coms, mode=mode)
     tr = Trainer(cfg, device=dev, graph=False, seed=1234)
     ring = tr.model.synthetic_ring(dev, n=4, seed=1234)
 
