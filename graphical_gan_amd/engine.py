@@ -94,7 +94,7 @@ class Trainer(object):
         self.gen.manual_seed(seed)
         # static input buffers (what the reference feeds / samples per session.run)
         self.feed = self.model.feed_buffers(self.device)
-        if hasattr(self.model, 'cfg') and isinstance(self.feed, dict) and 'p_z_noise' in self.feed:
+        if hasattr(self.model, 'cfg') and isinstance(self.feed, dict) and ('p_z_noise' in self.feed or 'p_z_g' in self.feed):
             self.feed['rng_state'] = F.noise_state(self.device, seed)      # functional.noise_fill_: all noise of a step in one launch
         self._graphs = {}
         self._calls = {'gen': 0, 'disc': 0}

@@ -81,17 +81,22 @@ class StateSpaceGAN(object):
     def feed_buffers(self, device):
         c = self.cfg
         z = lambda *s: torch.zeros(*s, device=device)
+        # x_pair: [fake frames ; real frames], each half written in place by its producer (the frame generator's last layer, the input
+        # scaling), so that the critics' [fake; real] batch is an alias instead of a 33 MB copy per step (functional.RowSlot / JoinRows)
         return dict(real_x_unit=z(c.B, c.LEN, c.output_dim), real_y=z(c.B, c.n_c), p_z_l_0=z(c.B, c.dim_l),
-                    epsilon=z(c.B, c.dim_t), p_z_g=z(c.B, c.dim_g), p_y=z(c.B, c.n_c))
+                    epsilon=z(c.B, c.dim_t), p_z_g=z(c.B, c.dim_g), p_y=z(c.B, c.n_c), x_pair=z(2 * c.B * c.LEN, c.output_dim))
 
     def sample_noise(self, feed):
+        """Fresh noise of one session.run in ONE launch (functional.noise_fill_: the draw number lives on the device, so a captured
+        step draws anew on every replay): p_z_l_0, epsilon, p_z_g ~ N(0,1), p_y one-hot rows with a uniform class
+        (ssgan_inference_moving_mnist.py:98-101, :510-519)."""
         c = self.cfg
-        feed['p_z_l_0'].normal_()
-        feed['epsilon'].normal_()
-        feed['p_z_g'].normal_()
+        if 'rng_state' not in feed:
+            feed['rng_state'] = F.noise_state(feed['p_z_g'].device)
+        specs = [(feed['p_z_l_0'], F.NOISE_NORMAL, 0., 1.), (feed['epsilon'], F.NOISE_NORMAL, 0., 1.), (feed['p_z_g'], F.NOISE_NORMAL, 0., 1.)]
         if c.n_c:
-            idx = torch.randint(0, c.n_c, (c.B, 1), device=feed['p_y'].device)
-            feed['p_y'].zero_().scatter_(1, idx, 1.0)
+            specs.append((feed['p_y'], F.NOISE_ONEHOT, 0., 0.))
+        F.noise_fill_(feed['rng_state'], specs)
 
     def set_batch(self, feed, batch):
         x, y = batch if isinstance(batch, (tuple, list)) else (batch, None)
@@ -122,9 +127,9 @@ class StateSpaceGAN(object):
             return lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, activation=LRELU, grad_rows=grad_rows)
         return F.ActFwd.apply(lib.ops.conv2d.Conv2D(name, cin, cout, 5, x, stride=2, grad_rows=grad_rows), LRELU, 0.2)
 
-    def _deconv(self, name, cin, cout, x, act):
+    def _deconv(self, name, cin, cout, x, act, out=None):
         if self.cfg.fuse:
-            return lib.ops.deconv2d.Deconv2D(name, cin, cout, 5, x, activation=act)
+            return lib.ops.deconv2d.Deconv2D(name, cin, cout, 5, x, activation=act, out=out)
         return F.ActFwd.apply(lib.ops.deconv2d.Deconv2D(name, cin, cout, 5, x), act, 0.0)
 
     def expand_labels(self, y):
@@ -192,14 +197,14 @@ class StateSpaceGAN(object):
                 zs.append(self.ConcatOperator(zs[-1], tmp[i + 1], 'Extractor.Dynamic.Forward'))
         return torch.stack(zs, 1)
 
-    def Generator(self, z_g, z_l, labels):
+    def Generator(self, z_g, z_l, labels, out_slot=None):
         c, d = self.cfg, self.cfg.dim
         out = self._lin('Generator.Input', c.dim_g + c.dim_l + c.n_c, c.flat, self._z_rows(z_g, z_l, labels), RELU)
         out = out.reshape(c.B * c.LEN, 8 * d, 4, 4)
         out = self._deconv('Generator.2', 8 * d, 4 * d, out, RELU)
         out = self._deconv('Generator.3', 4 * d, 2 * d, out, RELU)
         out = self._deconv('Generator.4', 2 * d, d, out, RELU)
-        out = self._deconv('Generator.5', d, c.C, out, TANH)
+        out = self._deconv('Generator.5', d, c.C, out, TANH, out=out_slot)
         return out.reshape(c.B, c.LEN, c.output_dim)
 
     def _conv_stack(self, pre, x, cin, grad_rows=None):
@@ -274,7 +279,7 @@ class StateSpaceGAN(object):
         with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
             if which in ('gen', 'disc'):
                 assert which == 'disc' or not real_x.requires_grad, 'grad_rows: the real sequences must be data'
-                d = self.SequenceDiscriminator(torch.cat([fake_x, real_x], 0), torch.cat([p_z_g, q_z_g], 0), torch.cat([p_z_l, q_z_l], 0),
+                d = self.SequenceDiscriminator(F.JoinRows.apply(fake_x, real_x), torch.cat([p_z_g, q_z_g], 0), torch.cat([p_z_l, q_z_l], 0),
                                                torch.cat([p_y, real_y], 0), grad_rows=c.B if which == 'gen' else None)
                 d_fake, d_real = F.SplitRows.apply(d, c.B)
             else:
@@ -337,14 +342,17 @@ class StateSpaceGAN(object):
         if cur is not None:
             with torch.cuda.stream(self._side):
                 p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
-        real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0 / self.cfg.x_div, 0.0, -1.0)      # 2*(x/div-.5)
+        nf = self.cfg.B * self.cfg.LEN
+        pair = feed.get('x_pair') if self.cfg.fuse else None
+        slots = (F.RowSlot(pair, 0, nf), F.RowSlot(pair, nf, 2 * nf)) if pair is not None else (None, None)
+        real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0 / self.cfg.x_div, 0.0, -1.0, slots[1])      # 2*(x/div-.5)
         q_z_l = self.DynamicExtractor(self.Extractor(real_x, real_y))
         q_z_g = self.G_Extractor(real_x, real_y)
         if cur is not None:
             cur.wait_stream(self._side)
         else:
             p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
-        fake_x = self.Generator(feed['p_z_g'], p_z_l, p_y)
+        fake_x = self.Generator(feed['p_z_g'], p_z_l, p_y, out_slot=slots[0])
         return dict(real_x=real_x, q_z_l=q_z_l, q_z_g=q_z_g, p_z_l=p_z_l, p_z_g=feed['p_z_g'], fake_x=fake_x)
 
     def forward(self, feed, which=None, nets=None):
@@ -376,7 +384,7 @@ class StateSpaceGAN(object):
                         t, zg = latent_critics()
                 else:
                     t, zg = latent_critics()
-                d = self._frame_critic(torch.cat([fake_x.reshape(nf, -1), real_x.reshape(nf, -1)], 0),
+                d = self._frame_critic(F.JoinRows.apply(fake_x.reshape(nf, -1), real_x.reshape(nf, -1)),
                                        torch.cat([self._z_rows(p_z_g, p_z_l, p_y), self._z_rows(q_z_g, q_z_l, real_y)], 0),
                                        torch.cat([self.expand_labels(p_y), self.expand_labels(real_y)], 0),
                                        grad_rows=nf if which == 'gen' else None)
