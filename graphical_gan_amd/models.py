@@ -9,6 +9,7 @@ One parametrised definition covers the six image scripts (the reference repeats 
 Layer names are the reference's, so the registry keys match.
 `fuse=True` folds bias+activation into the producing conv/linear/BN kernel (identical math, fewer HBM passes).
 """
+import contextlib
 import os
 import weakref
 
@@ -81,6 +82,7 @@ class GraphicalGAN(object):
         self._side = None                                     # second stream of forward_nets
         self._early = False                                   # begin_nets() forked it before the noise launch
         self._pending_join = None                             # [stream, event after real_x, event at the branch's end]
+        self._gp_stream = None                                # third stream: the gradient-penalty pass of a wali-gp critic step
         # two-stream Extractor / Generator passes: measured +3 % (ali, face, mnist), -5..7 % with the gradient penalty (more
         # cross-stream edges than overlap), so the joint-critic modes without a penalty ask for it; the Trainer
         # turns it on while it builds a single-graph step (fork_now) -- eager steps are host-bound and gain nothing
@@ -513,9 +515,26 @@ class GraphicalGAN(object):
         J.ONLY[0] = which            # TF prunes the cost a session.run does not fetch; so do we
         batched = c.batch_critic and which in ('gen', 'disc')
         # a generator step owns only Generator/Extractor variables: hand the critic its weights without gradient edges
+        # wali-gp critic steps: the penalty pass (third critic pass on the interpolates, its data gradient, later their second
+        # derivatives: a chain of ~45 launches that shares nothing but weights with the [fake; real] pass) goes to a stream of its own
+        # while a step graph is built -- issued first, so that it runs beside the main pass in both directions (autograd keeps every
+        # backward node on the stream of its forward)
+        gp_early = None
+        if (c.mode == 'wali-gp' and which == 'disc' and batched and self.fork_nets and self.fork_now and real_x.is_cuda
+                and not os.environ.get('GGAN_NO_FORK_GP')):
+            cur = torch.cuda.current_stream(real_x.device)
+            if self._gp_stream is None:
+                self._gp_stream = F.shared_stream(real_x.device, 'penalty')
+            self._gp_stream.wait_stream(cur)                          # fake_x, p_z (Generator branch)
+            if self._pending_join is not None:
+                self._gp_stream.wait_event(self._pending_join[2])     # real_x, q_z (Extractor branch, still on the second stream)
+            with torch.cuda.stream(self._gp_stream):
+                gp_early = self._penalty(J, batched, real_x, fake_x, q_z, p_z, feed)
         with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
             d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None,
                                           detach=which == 'disc')
+        if gp_early is not None:
+            torch.cuda.current_stream(real_x.device).wait_stream(self._gp_stream)
         gen_params, disc_params = self._var_lists()
         rec_penalty = None
         if which != 'disc' and c.mode in ('alice', 'alice-z', 'alice-x', 'local_epce'):
@@ -541,9 +560,7 @@ class GraphicalGAN(object):
             else:
                 # (the penalty pass reaches the critic's weights through second autograd leaves: the optimizer sums the two
                 #  gradient contributions of every weight where it packs the bucket, not with an addition launch per weight)
-                with (lib.second_leaf() if (batched and not os.environ.get('GGAN_NO_SECOND_LEAF')) else lib.frozen()):
-                    gp = J.gradient_penalty(lambda xx, zz: self.Discriminator(xx, zz, twice=True), real_x, fake_x.detach() if batched else fake_x,
-                                            q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
+                gp = gp_early if gp_early is not None else self._penalty(J, batched, real_x, fake_x, q_z, p_z, feed)
             res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
             out['gradient_penalty'] = gp
         else:
@@ -552,6 +569,13 @@ class GraphicalGAN(object):
         out.update(disc_fake=d_fake, disc_real=d_real, gen_cost=res[0], disc_cost=res[1],
                    gen_train_op=res[2], disc_train_op=res[3])
         return out
+
+    def _penalty(self, J, batched, real_x, fake_x, q_z, p_z, feed):
+        # (the penalty pass reaches the critic's weights through second autograd leaves: the optimizer sums the two
+        #  gradient contributions of every weight where it packs the bucket, not with an addition launch per weight)
+        with (lib.second_leaf() if (batched and not os.environ.get('GGAN_NO_SECOND_LEAF')) else lib.frozen()):
+            return J.gradient_penalty(lambda xx, zz: self.Discriminator(xx, zz, twice=True), real_x, fake_x.detach() if batched else fake_x,
+                                      q_z.detach() if batched else q_z, p_z.detach() if batched else p_z, feed['alpha'])
 
     def _critic(self, batched, real_x, q_z, p_z, fake_x, onehot, q_k, detach=True):
         """critic logits of the fake and the real pair.  batched: the critic is evaluated ONCE on [fake; real] (its rows
