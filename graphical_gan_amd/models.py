@@ -82,7 +82,7 @@ class GraphicalGAN(object):
         self._side = None                                     # second stream of forward_nets
         self._early = False                                   # begin_nets() forked it before the noise launch
         self._pending_join = None                             # [stream, event after real_x, event at the branch's end]
-        self._gp_stream = None                                # third stream: the gradient-penalty pass of a wali-gp critic step
+        self._gp_stream = None                                # the stream the gradient-penalty pass of a wali-gp critic step was issued on
         # two-stream Extractor / Generator passes: measured +3 % (ali, face, mnist), -5..7 % with the gradient penalty (more
         # cross-stream edges than overlap), so the joint-critic modes without a penalty ask for it; the Trainer
         # turns it on while it builds a single-graph step (fork_now) -- eager steps are host-bound and gain nothing
@@ -522,12 +522,14 @@ class GraphicalGAN(object):
         gp_early = None
         if (c.mode == 'wali-gp' and which == 'disc' and batched and self.fork_nets and self.fork_now and real_x.is_cuda
                 and not os.environ.get('GGAN_NO_FORK_GP')):
+            # (the SECOND stream, behind the Extractor branch whose q_z it reads -- not a third one: every further stream of the process
+            #  shifts how the graphs' branches map onto the hardware queues, and the workload run next in the same process measured
+            #  2.6 % slower.  The critic's short z path, which otherwise rides on that stream, stays on the main one in these steps.)
             cur = torch.cuda.current_stream(real_x.device)
-            if self._gp_stream is None:
-                self._gp_stream = F.shared_stream(real_x.device, 'penalty')
+            if self._side is None:
+                self._side = F.shared_stream(real_x.device, 'side')
+            self._gp_stream = self._side
             self._gp_stream.wait_stream(cur)                          # fake_x, p_z (Generator branch)
-            if self._pending_join is not None:
-                self._gp_stream.wait_event(self._pending_join[2])     # real_x, q_z (Extractor branch, still on the second stream)
             with torch.cuda.stream(self._gp_stream):
                 gp_early = self._penalty(J, batched, real_x, fake_x, q_z, p_z, feed)
         with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
@@ -598,7 +600,8 @@ class GraphicalGAN(object):
         x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
         z_out = None
         pj = self._pending_join
-        if pj is not None and not os.environ.get('GGAN_NO_Z_PATH_FORK'):
+        gp_on_side = self._gp_stream is not None and self.cfg.mode == 'wali-gp' and detach and self.fork_now
+        if pj is not None and not os.environ.get('GGAN_NO_Z_PATH_FORK') and not gp_on_side:
             # the Extractor pass is still running on the second stream: the critic's z path (a Linear on [p_z ; q_z]: two short
             # launches, and two more in the backward pass) follows it THERE, off this stream's chain of conv launches; the join
             # before the critic's tail then waits for z_out instead of q_z
