@@ -134,6 +134,8 @@ def _pmc_table(workload_key):
     except (OSError, ValueError):
         return {}, None
     tag = tab.get('_tag')
+    if workload_key == 'gmgan-cifar10-K30' and workload_key not in tab:      # (profiled at K = 10: the same kernels and launch shapes but the mixture size)
+        workload_key = 'gmgan-cifar10-K10'
     if workload_key in tab and isinstance(tab[workload_key], dict) and 'traffic_bytes' not in tab[workload_key]:
         return tab[workload_key], tag
     if workload_key == 'headline' and '_tag' not in tab:      # round-1 layout: kernel -> record of the headline workload
@@ -372,6 +374,16 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
                             whole_step_tflops=round(step_tflops, 2),
                             whole_step_frac=round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                             libggan_launches_per_step=launches_per_iter)
+            # the conv stack as a whole (north star: "MFMA utilisation on the Conv2D / Deconv2D stack"): counter MFMA utilisation of every
+            # MFMA conv kernel (static table, median per dispatch) weighted by the kernel time measured here
+            cw = ca = 0.0
+            for r in recs:
+                if r['name'].startswith(('corr_kernel', 'wgrad_kernel', 'conv3d_igemm')) and (tab.get(r['name']) or {}).get('mfma_util_pct') is not None:
+                    cw += r['total_ms']
+                    ca += r['total_ms'] * tab[r['name']]['mfma_util_pct']
+            if cw > 0:
+                roofline['conv_stack_mfma_util_pct'] = round(ca / cw, 1)
+                roofline['conv_stack_share_of_kernel_time'] = round(cw / sum(r['total_ms'] for r in recs), 3)
     if world > 1:
         dist.barrier()
 
@@ -485,9 +497,9 @@ def _short_roofline(r):
     if not r:
         return None
     keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_eager', 'frac_in_graph', 'avg_launch_us',
-            'avg_launch_us_in_graph', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'static_tag')
+            'avg_launch_us_in_graph', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'conv_stack_mfma_util_pct', 'static_tag')
     d = {k: r.get(k) for k in keep}
-    d['source'] = 'frac=frac_eager: live HIP-event bracket (eager replay); frac_in_graph/traffic/mfma_util_pct: profiles/pmc_traffic.json'
+    d['source'] = 'frac=frac_eager: live HIP-event bracket (eager replay); frac_in_graph/traffic/mfma_util_pct/conv_stack_mfma_util_pct (all MFMA conv kernels, time-weighted): profiles/pmc_traffic.json'
     return d
 
 
@@ -511,7 +523,7 @@ def compact_line(full):
         r = v.get('roofline') or {}
         vs.append(dict(key=v['key'], value=v['value'], unit=v['unit'], ms_per_step=v['ms_per_step'],
                        whole_step_frac=v.get('whole_step_frac'), kernel=r.get('kernel'), frac=r.get('frac'),
-                       frac_in_graph=r.get('frac_in_graph'), cpu=(v.get('cpu_baseline') or {}).get('value'),
+                       frac_in_graph=r.get('frac_in_graph'), conv_mfma_util=r.get('conv_stack_mfma_util_pct'), cpu=(v.get('cpu_baseline') or {}).get('value'),
                        finite=(v.get('config') or {}).get('finite_costs')))
     line['variants'] = vs
     line['full_record'] = full.get('_full_path')
