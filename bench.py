@@ -526,6 +526,9 @@ def compact_line(full):
                        frac_in_graph=r.get('frac_in_graph'), conv_mfma_util=r.get('conv_stack_mfma_util_pct'), cpu=(v.get('cpu_baseline') or {}).get('value'),
                        finite=(v.get('config') or {}).get('finite_costs')))
     line['variants'] = vs
+    gp = next((v for v in vs if v['key'] == 'wali-gp'), None)
+    if gp is not None:          # BASELINE.json's metric string names the "G+D+GP step": the same script with MODE wali-gp (CRITIC_ITERS 5)
+        line['g_d_gp_step'] = dict(value=gp['value'], unit=gp['unit'], ms_per_step=gp['ms_per_step'], whole_step_frac=gp['whole_step_frac'])
     line['full_record'] = full.get('_full_path')
     txt = json.dumps(line, separators=(',', ':'))
     if len(txt) >= LINE_LIMIT:                          # never let the line outgrow the driver's window: drop detail, keep the contract
