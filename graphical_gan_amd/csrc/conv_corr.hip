@@ -959,7 +959,7 @@ template <int MODE>
 int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c, int ntaps, int groups, float* dst,
                     const float* bias, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s, const char* name,
                     double fl, const char* sk_env, const char* cfg_env) {
-    const int target = env_int("GGAN_TARGET_WGS", 200);
+    const int target = g_target_wgs > 0 ? g_target_wgs : env_int("GGAN_TARGET_WGS", 200);
     const WaveCfg* kCfgs = MODE == 1 ? kCfgsDgrad : kCfgsFwd;
     int cfg = env_int(cfg_env, -1);
     if (cfg < 0 || cfg > (MODE == 1 ? 7 : 8)) {
@@ -1197,7 +1197,7 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     // otherwise balanced class pairs (twice the workgroups)
     const long wgs_all = (long)cdiv(g.N * Hu * Wv, 32) * cdiv(g.Ci, 32);
     int mode = env_int("GGAN_DGRAD_MODE", 0);
-    if (mode == 0) mode = wgs_all >= env_int("GGAN_TARGET_WGS", 200) ? 2 : 1;
+    if (mode == 0) mode = wgs_all >= (g_target_wgs > 0 ? g_target_wgs : env_int("GGAN_TARGET_WGS", 200)) ? 2 : 1;
     if (mode == 2)
         return plan_and_launch<2>(P, Hu, Wv, 1, hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, 25, 1, gx, bias, act, alpha, ws, ws_bytes,
                                   s, "conv_dgrad_mfma", fl, "GGAN_DGRAD_SK", "GGAN_DGRAD_CFG");

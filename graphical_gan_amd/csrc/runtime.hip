@@ -8,6 +8,7 @@ namespace ggan {
 
 static thread_local char t_err[512] = "";
 bool g_force_naive = false;
+int g_target_wgs = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -105,6 +106,12 @@ const char* ggan_last_error(void) { return t_err; }
 int ggan_set_naive(int on) {
     g_force_naive = on != 0;
     return 0;
+}
+
+int ggan_set_target_workgroups(int n) {
+    const int prev = g_target_wgs;
+    g_target_wgs = n > 0 ? n : 0;
+    return prev;
 }
 
 int ggan_prof_enable(int on) {

@@ -10,6 +10,7 @@ buffers (a device-resident ring of pre-staged minibatches feeds them with one d2
 device inside the graph.  With data parallelism the graph is split around the gradient all-reduce:
 [fwd+bwd+pack] -> RCCL all-reduce of the flat bucket -> [Adam].
 """
+import contextlib
 import os
 
 import numpy as np
@@ -250,7 +251,8 @@ class Trainer(object):
 
     def _eager(self, which):
         self.flush()
-        cost, opt, _ = self._fwd_bwd(which, fuse_update=True)
+        with self._launch_hint(which):       # (the warm-up steps of a capture launch what the capture will launch)
+            cost, opt, _ = self._fwd_bwd(which, fuse_update=True)
         opt.all_reduce()
         opt.update()
         return cost
@@ -273,6 +275,25 @@ class Trainer(object):
 
     def _step_body(self, which):
         """one whole step as it is captured into a single graph: forward, backward, pack, (gradient exchange), update"""
+        with self._launch_hint(which):
+            return self._step_body_impl(which)
+
+    @contextlib.contextmanager
+    def _launch_hint(self, which):
+        """a step whose conv launches run as TWO chains side by side (models.launch_hint: the wali-gp critic step with the penalty pass on
+        the second stream) plans each launch for fewer workgroups, so that the chains share the chip by CUs instead of time-slicing it"""
+        hint = self.model.launch_hint(which) if hasattr(self.model, 'launch_hint') else 0
+        if not hint:
+            yield
+            return
+        L = F._lib.load()
+        prev = L.ggan_set_target_workgroups(int(hint))
+        try:
+            yield
+        finally:
+            L.ggan_set_target_workgroups(prev)
+
+    def _step_body_impl(self, which):
         st = None
         if self.dp_graph and which == 'gen':
             # two gradient buckets inside the one graph: the Generator's bucket is on the wire (the process group's

@@ -101,6 +101,17 @@ class GraphicalGAN(object):
         return bool(self.cfg.batch_critic) and (self.cfg.mode in ('ali', 'local_ep', 'wali') or
                                                 (self.cfg.mode == 'wali-gp' and not os.environ.get('GGAN_NO_SECOND_LEAF')))
 
+    def launch_hint(self, which):
+        """workgroups per conv launch the step should plan for (engine.Trainer._step_body -> ggan_set_target_workgroups), 0 = default:
+        128 in wali-gp critic steps while a step graph is built -- there the penalty pass runs beside the [fake; real] pass, and launches
+        of ~128 workgroups let the two chains run on different CUs (measured -1 % of the iteration even with the generator step, which
+        wants the default, planned the same way; GGAN_NO_LAUNCH_HINT)"""
+        c = self.cfg
+        if (c.mode == 'wali-gp' and which == 'disc' and c.batch_critic and self.fork_nets and self.fork_now
+                and not os.environ.get('GGAN_NO_FORK_GP') and not os.environ.get('GGAN_NO_LAUNCH_HINT')):
+            return int(os.environ.get('GGAN_GP_TARGET_WGS', '128'))
+        return 0
+
     def cut_tensors(self, nets):
         """tensors through which EVERY gradient of the Extractor's parameters flows (None if there is no such cut: the
         reconstruction modes apply the Extractor a second time) -- lets a data-parallel generator step exchange the

@@ -38,6 +38,11 @@ int ggan_version(void);
 const char* ggan_last_error(void);
 /* 0: MFMA kernels (default); 1: force the plain one-thread-per-output HIP kernels (debug cross-check). */
 int ggan_set_naive(int on);
+/* How many workgroups a conv launch plans for (tile size / split-K choice of the MFMA kernels): default 200, about one per CU, which is
+ * what a launch running alone wants.  A caller that runs TWO chains of conv launches side by side on two streams (the wali-gp critic
+ * step: gradient-penalty pass beside the [fake; real] pass) asks for ~128, so that each launch leaves CUs to the other chain.
+ * n <= 0 restores the default; returns the previous setting.  Process-wide, read when a launch is planned. */
+int ggan_set_target_workgroups(int n);
 
 /* ---- convolution geometry ------------------------------------------------------------------
  * A strided cross-correlation y[N,Co,Ho,Wo] = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) with explicit

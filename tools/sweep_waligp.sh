@@ -1,0 +1,3 @@
+run() { env "$@" python bench.py --gpus 1 --steps 40 --warmup 6 --mode wali-gp --no-variants --no-cpu-baseline --no-kernel-profile --repeats 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])" 2>/dev/null || echo FAIL; }
+echo "default $(run A=1)"
+for kv in "$@"; do echo "$kv $(run $kv)   default $(run A=1)"; done
