@@ -41,6 +41,7 @@ SIGNATURES = {
     'ggan_last_error': (C.c_char_p, []),
     'ggan_set_naive': (_I, [_I]),
     'ggan_set_target_workgroups': (_I, [_I]),
+    'ggan_set_target_workgroups_filter_grad': (_I, [_I]),
     'ggan_conv2d_workspace': (_Z, [_G]),
     'ggan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),

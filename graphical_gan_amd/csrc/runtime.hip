@@ -9,6 +9,7 @@ namespace ggan {
 static thread_local char t_err[512] = "";
 bool g_force_naive = false;
 int g_target_wgs = 0;
+int g_target_wgs_wgrad = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -111,6 +112,12 @@ int ggan_set_naive(int on) {
 int ggan_set_target_workgroups(int n) {
     const int prev = g_target_wgs;
     g_target_wgs = n > 0 ? n : 0;
+    return prev;
+}
+
+int ggan_set_target_workgroups_filter_grad(int n) {
+    const int prev = g_target_wgs_wgrad;
+    g_target_wgs_wgrad = n > 0 ? n : 0;
     return prev;
 }
 

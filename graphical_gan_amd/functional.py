@@ -185,6 +185,37 @@ def workspace(device):
 # ---------------------------------------------------------------------------------------------------
 # geometry (TF padding arithmetic)
 # ---------------------------------------------------------------------------------------------------
+_TARGET = [0]
+
+
+class target_workgroups(object):
+    """with target_workgroups(n): the conv ops recorded inside plan their launches -- forward AND, later, backward -- for n workgroups
+    (ggan_set_target_workgroups) instead of about one per CU: for layers of two chains that run side by side on two streams"""
+
+    def __init__(self, n):
+        self.n = int(n or 0)
+
+    def __enter__(self):
+        self.prev, _TARGET[0] = _TARGET[0], self.n
+
+    def __exit__(self, *a):
+        _TARGET[0] = self.prev
+
+
+class _planned_for(object):
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        if self.n:
+            self.prev = (_L().ggan_set_target_workgroups(self.n), _L().ggan_set_target_workgroups_filter_grad(self.n))
+
+    def __exit__(self, *a):
+        if self.n:
+            _L().ggan_set_target_workgroups(self.prev[0])
+            _L().ggan_set_target_workgroups_filter_grad(self.prev[1])
+
+
 def same_geometry(size, k, stride, padding='SAME'):
     if padding == 'SAME':
         out = -(-size // stride)
@@ -228,8 +259,10 @@ class ConvFwd(Function):
         y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         ws = workspace(x.device)
         g = _geom(geom)
-        check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
-                                   act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
+        ctx.target = _TARGET[0]
+        with _planned_for(ctx.target):
+            check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
+                                       act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
         ctx.w_param, ctx.b_param = _is_param(w), _is_param(bias)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -241,7 +274,8 @@ class ConvFwd(Function):
         if not torch.is_grad_enabled() and FUSED_CONV_BWD:
             # plain backward: two launches -- the activation derivative is applied while gy is staged and the bias
             # gradient comes out of the filter-gradient kernel (no act_bwd / chansum passes, no intermediate tensor)
-            r = _fused_conv_backward(ctx, gy, x, w, y)
+            with _planned_for(getattr(ctx, 'target', 0)):
+                r = _fused_conv_backward(ctx, gy, x, w, y)
             if r is not None:
                 return r + (None,)
         want_w = ctx.needs_input_grad[1] and not (_DATA_ONLY[0] and ctx.w_param)
@@ -311,8 +345,10 @@ class ConvDgrad(Function):
         gx = _new_out(slot, (N, Ci, H, W), gy.device)
         ws = workspace(gy.device)
         g = _geom(geom)
-        check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
-                                        _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
+        ctx.target = _TARGET[0]
+        with _planned_for(ctx.target):
+            check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
+                                            _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
         ctx.save_for_backward(gy, w, gx if act != ACT_NONE else None)
         return gx
@@ -340,14 +376,17 @@ class ConvDgrad(Function):
                 reg[d_b.data_ptr()] = (n.value, Cc, part)
         elif ctx.act != ACT_NONE:
             h = ActBwd.apply(h, out, ctx.act, ctx.alpha)
+        tgt = getattr(ctx, 'target', 0)
         if ctx.needs_input_grad[1]:
-            parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None
-            d_w = parts[0] if parts is not None else ConvWgrad.apply(h, gy, ctx.geom)
+            with _planned_for(tgt):
+                parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None
+                d_w = parts[0] if parts is not None else ConvWgrad.apply(h, gy, ctx.geom)
         if ctx.has_bias and ctx.needs_input_grad[2] and d_b is None:
             pre = getattr(h, '_ggan_chansum', None) if not torch.is_grad_enabled() else None
             d_b = pre if (pre is not None and pre.numel() == h.shape[1]) else ChanSum.apply(h)
         if ctx.needs_input_grad[0]:
-            d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
+            with target_workgroups(tgt):
+                d_gy = ConvFwd.apply(h, w, None, ctx.geom, ACT_NONE, 0.0)
         return (d_gy, d_w, d_b) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 

@@ -441,6 +441,17 @@ class GraphicalGAN(object):
         # chains of a generator step overlap the same way.  (Requested by the Trainer for single-graph steps only.)
         p_z = self.HyperGenerator(feed['k_onehot'], feed['p_z_noise'], zs[0]) if c.K else feed['p_z_noise']
         fork = self.fork_nets and self.fork_now and p_z.is_cuda
+        nets_target = int(os.environ.get('GGAN_NETS_TARGET_WGS', '128'))
+        if fork and nets_target > 0:
+            # The two passes run side by side on two streams, and in a generator step so do their backward passes.  A conv launch planned
+            # for ~one workgroup per CU (the default, right for a launch that has the chip to itself) makes two such chains time-slice every
+            # CU; planned for 128 workgroups each (forward, data and filter gradients: functional.target_workgroups is remembered by the
+            # layer for its backward) they run on different CUs: 1.125 -> 1.09 ms per CIFAR iteration.  GGAN_NETS_TARGET_WGS=0: default plan.
+            with F.target_workgroups(nets_target):
+                return self._forward_nets(feed, c, B, xs, zs, p_z, fork)
+        return self._forward_nets(feed, c, B, xs, zs, p_z, fork)
+
+    def _forward_nets(self, feed, c, B, xs, zs, p_z, fork):
         early, self._early = self._early, False
         if fork and early:
             # begin_nets() forked before the noise launch: the Extractor pass (which reads no noise) is a ROOT branch of the step

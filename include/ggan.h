@@ -43,6 +43,10 @@ int ggan_set_naive(int on);
  * step: gradient-penalty pass beside the [fake; real] pass) asks for ~128, so that each launch leaves CUs to the other chain.
  * n <= 0 restores the default; returns the previous setting.  Process-wide, read when a launch is planned. */
 int ggan_set_target_workgroups(int n);
+/* the same for the filter-gradient kernels (default 256 split-K workgroups): a separate setting, because the optimum differs -- the
+ * generator / extractor passes of a step (64 images, two chains side by side) want 128 for both, the wali-gp critic step (128-image
+ * filter gradients of the main pass beside the penalty pass) wants the default here. */
+int ggan_set_target_workgroups_filter_grad(int n);
 
 /* ---- convolution geometry ------------------------------------------------------------------
  * A strided cross-correlation y[N,Co,Ho,Wo] = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) with explicit
