@@ -1313,3 +1313,42 @@ def test_gradient_penalty_one_launch_forward_and_unit_gradient(gpu, B, D):
     (gg2,) = torch.autograd.grad(pen, [tg], grad_outputs=torch.full((), 0.5, device=gpu))
     assert _rel(gg2.cpu().numpy(), 0.5 * gg_ref) < 2e-5
     assert int(F.GradPenalty._ARRIVE[(gpu.type, gpu.index)][0]) == 0
+
+
+@pytest.mark.parametrize('case', [(64, 64, 16, 128), (64, 128, 8, 256), (64, 32, 32, 64), (128, 64, 16, 128), (64, 3, 32, 64)])
+@pytest.mark.parametrize('target', [128, 100])
+def test_conv_family_planned_for_fewer_workgroups(gpu, case, target):
+    """functional.target_workgroups / ggan_set_target_workgroups[_filter_grad]: the tile and split-K choices a layer makes when it is
+    one of two conv chains running side by side (Generator / Extractor passes, wali-gp critic steps) -- other template instances and
+    splits than the default plan at the same shapes, so: forward, data gradient (also as Deconv2D forward) and filter gradient against
+    the float64 oracle again, through the autograd path that remembers the setting for the backward launches."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from oracle import ops as O
+    N, Ci, H, Co = case
+    rng = np.random.default_rng(sum(case) + target)
+    x = rng.standard_normal((N, Ci, H, H)).astype(np.float32)
+    w = (rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci)).astype(np.float32)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2, 'SAME')
+    Ho = geom[5]
+    gy = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    x64, w64, gy64 = x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64)
+    tx, tw = _t(x, gpu).requires_grad_(True), _t(w, gpu).requires_grad_(True)
+    with F.target_workgroups(target):
+        y = F.ConvFwd.apply(tx, tw, None, geom, F.ACT_NONE, 0.0)
+        tg = _t(gy, gpu).requires_grad_(True)
+        tw2 = _t(w, gpu).requires_grad_(True)
+        dx = F.ConvDgrad.apply(tg, tw2, None, geom, F.ACT_NONE, 0.0)          # Deconv2D forward
+    L = _lib.load()
+    assert L.ggan_set_target_workgroups(0) == 0 and L.ggan_set_target_workgroups_filter_grad(0) == 0      # nothing left set
+    assert _rel(y.detach().cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < 2e-5
+    assert _rel(dx.detach().cpu().numpy(), O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME')) < 2e-5
+    with torch.no_grad():
+        pass
+    gx, gw = torch.autograd.grad(y, [tx, tw], grad_outputs=_t(gy, gpu))        # backward launches: the remembered plan
+    assert _rel(gx.cpu().numpy(), O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME')) < 2e-5
+    assert _rel(gw.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < 2e-5
+    dg, dw2 = torch.autograd.grad(dx, [tg, tw2], grad_outputs=_t(x, gpu))      # Deconv2D backward: forward conv + filter gradient
+    assert _rel(dg.cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < 2e-5
+    assert _rel(dw2.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < 2e-5
+    assert L.ggan_set_target_workgroups(0) == 0 and L.ggan_set_target_workgroups_filter_grad(0) == 0
