@@ -477,7 +477,11 @@ def supervise():
         store.wait(['ggan_bench/attempt%d/rank%d' % (attempt, r) for r in range(world)], datetime.timedelta(seconds=3600))
         if not store.check([fail_key]):
             if rank == 0:
-                sys.stdout.write(out)
+                lines = out.splitlines()
+                js = [l for l in lines if l.startswith('{"metric"')]
+                sys.stdout.write(''.join(l + '\n' for l in lines if not l.startswith('{"metric"')))
+                if js:
+                    sys.stdout.write(js[-1] + '\n')      # (whatever else a library wrote to the child's stdout: the contract line stays last)
                 sys.stdout.flush()
             return 0
         if rank == 0:
@@ -540,6 +544,14 @@ def compact_line(full):
     return txt
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                      # noqa: BLE001
+        pass
+
+
 def emit(full):
     """Full record -> gpurun_out/bench_full.json (GGAN_BENCH_FULL overrides; merged back from the GPU box), compact line -> the
     last line of stdout."""
@@ -552,6 +564,7 @@ def emit(full):
     except OSError:
         full['_full_path'] = None
     sys.stdout.flush()
+    _flush_c_stdio()
     print(compact_line(full))
     sys.stdout.flush()
 
@@ -650,14 +663,23 @@ def main():
             if rank == 0:
                 dp_extra['strong_scaling'] = {'global_batch': 64, 'per_gpu_batch': 64 // world, 'images_per_sec': r1['value'],
                                               'ms_per_step': r1['ms_per_step']}
+    # the contract line must be the LAST thing on stdout: librccl writes its version banner to stdout through C stdio (block-buffered on a
+    # pipe, so it would surface at exit, behind the line) -- tear the process groups down first, flush C stdio, then print
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        try:
+            from graphical_gan_amd import rccl
+            rccl.reset()
+        except Exception:                                  # noqa: BLE001
+            pass
+        dist.destroy_process_group()
+    _flush_c_stdio()
     if rank == 0:
         if dp_extra is not None:
             out['data_parallel'] = dict(dp_extra, exchange='captured in the step graph' if os.environ.get('GGAN_DP_GRAPH', '1') != '0'
                                         else 'host-issued between cut graphs', weak_scaling_per_gpu_batch=64)
         out['variants'] = variants
         emit(out)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -229,7 +229,7 @@ class Trainer(object):
         self._no_second_leaves(opt)
         if opt._one is None or opt._one.shape != op.cost.shape:
             opt._one = F.unit_seed(op.cost)
-        with F.defer_wgrad_reduce(self.single_contrib):
+        with F.defer_wgrad_reduce(self.single_contrib), F.serial_backward():      # (Generator half, then Extractor half: one chain at a time)
             g = torch.autograd.grad(op.cost, list(opt.params[:k]) + cut, grad_outputs=opt._one, allow_unused=True)
             keep = opt.pack_subset(g[:k], 0, k, bump=True)
         return dict(cost=out['gen_cost'].detach(), opt=opt, k=k, off=off, cut=cut, g_cut=g[k:], keep=keep)
@@ -238,7 +238,7 @@ class Trainer(object):
         """the Extractor's backward from the gradients at the cut; its gradients packed behind the Generator's"""
         opt, k = st['opt'], st['k']
         pairs = [(t, g) for t, g in zip(st['cut'], st['g_cut']) if g is not None]
-        with F.defer_wgrad_reduce(self.single_contrib):
+        with F.defer_wgrad_reduce(self.single_contrib), F.serial_backward():
             g = torch.autograd.grad([t for t, _ in pairs], opt.params[k:], grad_outputs=[gg for _, gg in pairs], allow_unused=True)
             return opt.pack_subset(g, k, len(opt.params), bump=False)
 
@@ -300,7 +300,12 @@ class Trainer(object):
             # stream: a parallel branch of the graph) while the Extractor's backward pass still runs
             nets = self._nets()
             cut = self.model.cut_tensors(nets) if hasattr(self.model, 'cut_tensors') else None
-            st = self._bwd_phase1(nets) if (cut and not os.environ.get('GGAN_ONE_BUCKET')) else None
+            # (two buckets in the generator step mean two autograd passes, Generator half then Extractor half -- and those two backward
+            #  chains otherwise run SIDE BY SIDE on two streams, planned for half the chip each: one rank, forced exchange, 1.20 ms with
+            #  the split against 1.09 without.  The overlap the split buys is at most the Generator bucket's time on the wire during the
+            #  Extractor's ~100 us of backward, so the default is one bucket here; GGAN_GEN_TWO_BUCKETS=1 restores the split.  The
+            #  critic step keeps its two buckets: one chain, and the large tail bucket travels during the conv stack's backward.)
+            st = self._bwd_phase1(nets) if (cut and os.environ.get('GGAN_GEN_TWO_BUCKETS') and not os.environ.get('GGAN_ONE_BUCKET')) else None
             if st is not None:
                 opt, cost = st['opt'], st['cost']
                 w1 = opt.all_reduce(async_op=True, lo=0, hi=st['off'])

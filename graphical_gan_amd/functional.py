@@ -186,6 +186,23 @@ def workspace(device):
 # geometry (TF padding arithmetic)
 # ---------------------------------------------------------------------------------------------------
 _TARGET = [0]
+_SERIAL_BWD = [False]
+
+
+class serial_backward(object):
+    """with serial_backward(): the backward launches of layers recorded under target_workgroups take the DEFAULT plan -- for a backward
+    pass whose two chains are NOT going to run side by side (the data-parallel generator step differentiates the Generator's and the
+    Extractor's halves one after the other, so that the first gradient bucket can go on the wire early: engine._bwd_phase1 / 2)"""
+
+    def __enter__(self):
+        self.prev, _SERIAL_BWD[0] = _SERIAL_BWD[0], True
+
+    def __exit__(self, *a):
+        _SERIAL_BWD[0] = self.prev
+
+
+def _bwd_target(ctx):
+    return 0 if _SERIAL_BWD[0] else getattr(ctx, 'target', 0)
 
 
 class target_workgroups(object):
@@ -274,7 +291,7 @@ class ConvFwd(Function):
         if not torch.is_grad_enabled() and FUSED_CONV_BWD:
             # plain backward: two launches -- the activation derivative is applied while gy is staged and the bias
             # gradient comes out of the filter-gradient kernel (no act_bwd / chansum passes, no intermediate tensor)
-            with _planned_for(getattr(ctx, 'target', 0)):
+            with _planned_for(_bwd_target(ctx)):
                 r = _fused_conv_backward(ctx, gy, x, w, y)
             if r is not None:
                 return r + (None,)
@@ -376,7 +393,7 @@ class ConvDgrad(Function):
                 reg[d_b.data_ptr()] = (n.value, Cc, part)
         elif ctx.act != ACT_NONE:
             h = ActBwd.apply(h, out, ctx.act, ctx.alpha)
-        tgt = getattr(ctx, 'target', 0)
+        tgt = _bwd_target(ctx)
         if ctx.needs_input_grad[1]:
             with _planned_for(tgt):
                 parts = _wgrad_parts(_c(h), gy, None, ACT_NONE, 0.0, ctx.geom, False) if not torch.is_grad_enabled() else None

@@ -476,6 +476,23 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2 and 'retrying with host-issued exchanges' in r.stderr
 
 
+def test_bench_line_stays_last_when_rccl_writes_to_stdout(gpu):
+    """librccl prints its version banner to STDOUT through C stdio (block-buffered on a pipe: it would surface at exit, behind the
+    JSON line, and the driver reads the LAST line).  One rank over RCCL (the forced-exchange rehearsal) initialises the library in the
+    bench process: the contract line must still be the last line, and the only JSON one."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GGAN_FORCE_ALLREDUCE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(29900 + (os.getpid() % 90)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-variants',
+                        '--no-cpu-baseline', '--no-kernel-profile', '--repeats', '0'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.rstrip('\n').splitlines()
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and len([l for l in lines if l.startswith('{')]) == 1
+
+
 def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
     """The driver's N > 1 launch puts the gradient exchange (RCCL all-reduce) INSIDE the captured graphs.  One rank over RCCL is
     enough to rehearse that on a single-GPU box (GGAN_FORCE_ALLREDUCE): the exchange goes through the directly bound communicator
