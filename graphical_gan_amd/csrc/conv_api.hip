@@ -54,6 +54,8 @@ static int bwd_data(const ggan_conv_geom* g, const float* gy, GyMask m, const fl
     if (!g_force_naive && !getenv("GGAN_NAIVE_DGRAD")) {
         int r = conv_dgrad_thin(*g, gy, m, w, bias, gx, act, alpha, s);
         if (r <= 0) return r;
+        r = conv_dgrad_dg16(*g, gy, m, w, bias, gx, act, alpha, g_target_wgs, ws, ws ? ws_bytes : 0, s);
+        if (r <= 0) return r;
         r = conv_dgrad_mfma(*g, gy, m, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
     }

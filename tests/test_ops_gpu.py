@@ -1352,3 +1352,77 @@ def test_conv_family_planned_for_fewer_workgroups(gpu, case, target):
     assert _rel(dg.cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < 2e-5
     assert _rel(dw2.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < 2e-5
     assert L.ggan_set_target_workgroups(0) == 0 and L.ggan_set_target_workgroups_filter_grad(0) == 0
+
+
+DG16_CASES = [  # (N, Ci, H, Co): data gradient gy [N, Co, H/2, H/2] -> gx [N, Ci, H, H]
+    (6, 32, 32, 64),      # 16x16 class grid: 4-row x 16-column tiles, four tile positions per image
+    (3, 16, 64, 32),      # 32x32 class grid: two tile columns (left unit of the second one inside the image)
+    (5, 32, 8, 16),       # 4x4 class grid: four images per tile, the last image group ragged
+    (2, 16, 8, 32),
+    (3, 32, 16, 48),      # 8x8 class grid, reduction channels not a multiple of 32
+]
+
+
+@pytest.mark.parametrize('case', DG16_CASES)
+@pytest.mark.parametrize('kq', [4, 2])
+@pytest.mark.parametrize('variant', ['plain', 'masked', 'bias_relu'])
+def test_dg16_data_gradient(gpu, case, kq, variant, monkeypatch):
+    """conv_dg16.hip (round 4: 64 class pixels x 16 / 32 channels on v_mfma_f32_16x16x4_f32, plan-time slab table, three-stage LDS-DMA
+    ring) against the float64 oracle: Conv2DBackpropInput of tflib/ops/conv2d.py:106 = the Deconv2D forward of deconv2d.py:101-107,
+    with the fused bias + activation epilogue and with the LeakyReLU derivative applied while the operand is staged.  The kernel is
+    forced (GGAN_DG16_FORCE) at sizes the planner would leave to the older kernels, both tile widths, and the launch is checked to be
+    the new kernel's."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from oracle import ops as O
+    N, Ci, H, Co = case
+    if kq == 2 and Ci % 32:
+        pytest.skip('32-channel tiles need Ci % 32 == 0')
+    monkeypatch.setenv('GGAN_DG16', '1')
+    monkeypatch.setenv('GGAN_DG16_FORCE', '1')
+    monkeypatch.setenv('GGAN_DG16_KQ', str(kq))
+    rng = np.random.default_rng(sum(case) + kq)
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2, 'SAME')
+    Ho = geom[5]
+    gy = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    w = (rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci)).astype(np.float32)
+    b = rng.standard_normal(Ci).astype(np.float32)
+    yref = rng.standard_normal((N, Co, Ho, Ho)).astype(np.float32)
+    L = _lib.load()
+    L.ggan_prof_reset(); L.ggan_prof_enable(1)
+    if variant == 'masked':
+        gx = F.ConvDgradMasked.apply(_t(gy, gpu), _t(yref, gpu), _t(w, gpu), geom, F.ACT_LRELU, 0.2)
+        ref = O.conv2d_bwd_data(gy.astype(np.float64) * np.where(yref > 0, 1.0, 0.2), w.astype(np.float64), (H, H), 2, 'SAME')
+    elif variant == 'bias_relu':
+        gx = F.ConvDgrad.apply(_t(gy, gpu), _t(w, gpu), _t(b, gpu), geom, F.ACT_RELU, 0.0)
+        ref = np.maximum(O.conv2d_bwd_data(gy.astype(np.float64), w.astype(np.float64), (H, H), 2, 'SAME') + b.reshape(1, -1, 1, 1), 0.0)
+    else:
+        gx = F.ConvDgrad.apply(_t(gy, gpu), _t(w, gpu), None, geom, F.ACT_NONE, 0.0)
+        ref = O.conv2d_bwd_data(gy.astype(np.float64), w.astype(np.float64), (H, H), 2, 'SAME')
+    torch.cuda.synchronize()
+    L.ggan_prof_enable(0)
+    names = [r['name'] for r in _lib.prof_report()]
+    L.ggan_prof_reset()
+    assert any(n.startswith('dg16_kernel<') for n in names), names
+    assert _rel(gx.cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.parametrize('case', [(64, 64, 16, 128), (128, 64, 16, 128), (128, 128, 8, 256), (64, 256, 8, 256), (64, 32, 32, 64)])
+def test_dg16_agrees_with_the_class_kernels_at_full_size(gpu, case, monkeypatch):
+    """At BASELINE sizes (where the numpy oracle takes minutes): the new data-gradient kernel against the parity-class kernels of
+    conv_corr.hip it replaces, which the oracle checks at these shapes through test_conv_family -- as planned by default, plain and masked."""
+    import torch
+    from graphical_gan_amd import functional as F
+    N, Ci, H, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    geom = F.conv_geom(N, Ci, H, H, Co, 5, 2, 'SAME')
+    Ho = geom[5]
+    gy = torch.randn(N, Co, Ho, Ho, generator=g).to(gpu)
+    w = (torch.randn(5, 5, Ci, Co, generator=g) / (25 * Ci) ** .5).to(gpu)
+    yref = torch.randn(N, Co, Ho, Ho, generator=g).to(gpu)
+    out = {}
+    for on in ('1', '0'):
+        monkeypatch.setenv('GGAN_DG16', on)
+        out[on] = (F.ConvDgrad.apply(gy, w, None, geom, F.ACT_NONE, 0.0), F.ConvDgradMasked.apply(gy, yref, w, geom, F.ACT_LRELU, 0.2))
+    for a, b2 in zip(out['1'], out['0']):
+        assert float((a - b2).abs().max() / b2.abs().max()) < 5e-6
