@@ -324,21 +324,21 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
         # EVERY rank runs these eager iterations (they contain the gradient all-reduce: a collective issued by rank 0 alone
         # would hang the job); only rank 0 records and reports
         tr.flush()
-        tr_graph = tr.graph_enabled
-        tr.graph_enabled = False
         L = _lib.load()
-        for _ in range(2):
-            tr.iteration(it, bi); it += 1
-        torch.cuda.synchronize(dev)
-        L.ggan_prof_reset(); L.ggan_prof_enable(1 if rank == 0 else 0)
-        n_prof = 5 if not ssgan else 3
-        for _ in range(n_prof):
-            tr.iteration(it, bi); it += 1
-        torch.cuda.synchronize(dev)
-        L.ggan_prof_enable(0)
+        # (eager replay on the launch plan of the timed graph: the two-stream nets pass and its 128-workgroup plans are otherwise switched
+        #  on for captures only, and the table would describe another kernel mix than `value` was timed on -- round-3 review)
+        with tr.eager_as_captured():
+            for _ in range(2):
+                tr.iteration(it, bi); it += 1
+            torch.cuda.synchronize(dev)
+            L.ggan_prof_reset(); L.ggan_prof_enable(1 if rank == 0 else 0)
+            n_prof = 5 if not ssgan else 3
+            for _ in range(n_prof):
+                tr.iteration(it, bi); it += 1
+            torch.cuda.synchronize(dev)
+            L.ggan_prof_enable(0)
         recs = _lib.prof_report() if rank == 0 else []
         L.ggan_prof_reset()
-        tr.graph_enabled = tr_graph
     if rank == 0 and not args.no_kernel_profile:
         recs.sort(key=lambda r: -r['total_ms'])
         kernels = [dict(name=r['name'], launches_per_iter=r['launches'] / n_prof,
@@ -365,8 +365,9 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
                             algorithmic_bytes=round(dom['bytes'] / dom['launches']) if dom.get('bytes') else None,
                             mfma_util_pct=(pmc or {}).get('mfma_util_pct'),
                             static_tag=tag if pmc else None,
-                            source='achieved / frac / frac_eager: HIP-event bracket around every launch of this kernel on the launch '
-                                   'stream, eager replay of the same step in this process (%d iterations); frac_in_graph, traffic, '
+                            source='achieved / frac / frac_eager: HIP-event bracket around every launch of this kernel on the stream it is launched '
+                                   'on, eager replay of the same step ON THE LAUNCH PLAN OF THE TIMED GRAPH (two-stream nets pass, 128-workgroup '
+                                   'plans of side-by-side chains) in this process (%d iterations); frac_in_graph, traffic, '
                                    'mfma_util_pct: static, profiles/pmc_traffic.json @%s (rocprofv3 --kernel-trace of the graph-replayed '
                                    'step and separate --pmc passes of this workload, per launch; FETCH_SIZE corrected per staging '
                                    'path, tools/pmc_summary.py)' % (n_prof, tag),
@@ -490,6 +491,40 @@ def supervise():
     return 1
 
 
+DIAG_ENV = ('GGAN_SKIP_KERNELS', 'GGAN_SKIP_ALLREDUCE', 'GGAN_TARGET_WGS', 'GGAN_WGRAD_WGS', 'GGAN_DBG', 'GGAN_DG16', 'GGAN_DG16_KQ',
+            'GGAN_DG16_FORCE', 'GGAN_FWD_CFG', 'GGAN_DGRAD_CFG', 'GGAN_FWD_SK', 'GGAN_DGRAD_SK', 'GGAN_WGRAD_SK', 'GGAN_DGRAD_MODE')
+
+
+def diag_env():
+    """diagnostic switches of libggan / the engine that change what is launched: a line measured with any of them set says so"""
+    return sorted(k for k in DIAG_ENV if os.environ.get(k) not in (None, ''))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the form the driver uses for its 1-GPU run): start the N ranks
+    here -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N on 127.0.0.1 and a free port, this script, the same
+    arguments -- pass their output through and keep the contract line the last line of stdout."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    port = max(20000, min(port, 60000))                  # (bench children use MASTER_PORT + 1 + attempt)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), GGAN_BENCH_SELF_LAUNCHED='1')
+    sys.stderr.write('[bench] --gpus %d without a launcher: starting the ranks with %s\n' % (args.gpus, ' '.join(cmd[1:9])))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    out = p.communicate()[0]
+    lines = out.splitlines()
+    js = [l for l in lines if l.startswith('{"metric"')]
+    sys.stdout.write(''.join(l + '\n' for l in lines if not l.startswith('{"metric"')))
+    if js:
+        sys.stdout.write(js[-1] + '\n')
+    sys.stdout.flush()
+    return p.returncode if (p.returncode != 0 or js) else 1
+
+
 LINE_LIMIT = 4096      # the driver keeps the tail of stdout: the LAST line must be one parseable JSON object well under that
 
 
@@ -503,16 +538,16 @@ def _short_roofline(r):
     keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_eager', 'frac_in_graph', 'avg_launch_us',
             'avg_launch_us_in_graph', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'conv_stack_mfma_util_pct', 'static_tag')
     d = {k: r.get(k) for k in keep}
-    d['source'] = 'frac=frac_eager: live HIP-event bracket (eager replay); frac_in_graph/traffic/mfma_util_pct/conv_stack_mfma_util_pct (all MFMA conv kernels, time-weighted): profiles/pmc_traffic.json'
+    d['source'] = 'frac=frac_eager: live HIP-event bracket, eager replay on the timed graph\'s launch plan; frac_in_graph/traffic/mfma_util_pct/conv_stack_mfma_util_pct (all MFMA conv kernels, time-weighted): profiles/pmc_traffic.json'
     return d
 
 
 def compact_line(full):
     """The contract line: headline keys + roofline + cpu_baseline + one short record per variant; everything else
     (kernel tables, prose, per-variant configs) lives in the full record (bench_full.json)."""
-    line = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-                                 'vs_baseline', 'dtype', 'data')}
-    c = full['config']
+    line = {k: full.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                     'vs_baseline', 'dtype', 'data')}
+    c = full.get('config') or {}
     line['config'] = {k: c[k] for k in ('workload', 'parallelism', 'global_batch', 'hip_graph', 'minibatch_feed', 'minibatches_per_step',
                                          'algorithmic_gflop_per_step', 'finite_costs') if k in c}
     line['whole_step_frac'] = full.get('whole_step_frac')
@@ -534,13 +569,28 @@ def compact_line(full):
     if gp is not None:          # BASELINE.json's metric string names the "G+D+GP step": the same script with MODE wali-gp (CRITIC_ITERS 5)
         line['g_d_gp_step'] = dict(value=gp['value'], unit=gp['unit'], ms_per_step=gp['ms_per_step'], whole_step_frac=gp['whole_step_frac'])
     line['full_record'] = full.get('_full_path')
+    if full.get('diag_env'):
+        line['diag_env'] = full['diag_env']
     txt = json.dumps(line, separators=(',', ':'))
-    if len(txt) >= LINE_LIMIT:                          # never let the line outgrow the driver's window: drop detail, keep the contract
+    # never let the line outgrow the driver's window: drop detail step by step, keep the contract keys
+    if len(txt) >= LINE_LIMIT:
         for v in vs:
             v.pop('kernel', None)
-        line['roofline'].pop('source', None)
+        if line.get('roofline'):
+            line['roofline'].pop('source', None)
         txt = json.dumps(line, separators=(',', ':'))
-    assert len(txt) < LINE_LIMIT, len(txt)
+    for drop in ('variants', 'data_parallel', 'g_d_gp_step', 'cpu_baseline', 'roofline', 'config'):
+        if len(txt) < LINE_LIMIT:
+            break
+        if drop == 'cpu_baseline' and line.get(drop):
+            line[drop] = {k: line[drop].get(k) for k in ('value', 'unit', 'cores', 'kind')}
+        elif drop == 'roofline' and line.get(drop):
+            line[drop] = {k: line[drop].get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
+        elif drop == 'config':
+            line[drop] = {'workload': str((line.get(drop) or {}).get('workload'))[:200]}
+        else:
+            line.pop(drop, None)
+        txt = json.dumps(line, separators=(',', ':'))
     return txt
 
 
@@ -592,7 +642,10 @@ def main():
     ap.add_argument('--host-feed', action='store_true',
                     help='minibatches start in host memory (pinned double-buffered H->D copies): the PCIe-inclusive rate')
     args = ap.parse_args()
+    diag0 = diag_env()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ and not os.environ.get('GGAN_BENCH_CHILD'):
+        return self_launch(args)
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not os.environ.get('GGAN_BENCH_CHILD') and not os.environ.get('GGAN_BENCH_NO_SUPERVISOR'):
         rc = supervise()
         if rc is not None:
@@ -649,6 +702,14 @@ def main():
     # N > 1: the same headline step (a) without its gradient exchange -> what the exchange costs a step once overlap is
     # accounted for, (b) strong scaling: the reference's global batch of 64 split over the replicas
     dp_extra = None
+    rccl_ranks = None
+    if world > 1:
+        try:
+            from graphical_gan_amd import rccl as _rccl
+            c = _rccl.get(create=False)
+            rccl_ranks = c.count() if c is not None else None
+        except Exception:                                  # noqa: BLE001
+            rccl_ranks = None
     if world > 1 and default_head and not args.no_variants:
         os.environ['GGAN_SKIP_ALLREDUCE'] = '1'
         r0 = run_workload(head_spec, args, env, min(args.steps, 100), min(args.warmup, 5), top_kernels=1)
@@ -675,8 +736,13 @@ def main():
         dist.destroy_process_group()
     _flush_c_stdio()
     if rank == 0:
-        if dp_extra is not None:
-            out['data_parallel'] = dict(dp_extra, exchange='captured in the step graph' if os.environ.get('GGAN_DP_GRAPH', '1') != '0'
+        if diag0:
+            out['diag_env'] = diag0
+            sys.stderr.write('[bench] diagnostic switches set: %s -- this line does not describe the product configuration\n' % ', '.join(diag0))
+        if world > 1:
+            out['data_parallel'] = dict(dp_extra or {}, ranks=world, rccl_ranks=rccl_ranks, backend=os.environ.get('GGAN_DIST_BACKEND', 'nccl'),
+                                        launched_by='bench.py itself' if os.environ.get('GGAN_BENCH_SELF_LAUNCHED') else 'external launcher',
+                                        exchange='captured in the step graph' if os.environ.get('GGAN_DP_GRAPH', '1') != '0'
                                         else 'host-issued between cut graphs', weak_scaling_per_gpu_batch=64)
         out['variants'] = variants
         emit(out)

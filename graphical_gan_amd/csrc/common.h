@@ -39,9 +39,16 @@ bool launch_skipped(const char* name);
 void trace_launch(const char* name, dim3 grid, dim3 block, size_t shmem, double flops);
 
 // LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, args...)
+// (GGAN_SKIP_KERNELS is compiled in only with -DGGAN_DIAG -- tools/variant_lib.sh builds such a library for tools/criticality*.sh; the
+//  product library has no switch that silently drops launches)
+#ifdef GGAN_DIAG
+#define GGAN_LAUNCH_SKIPPED(name) ggan::launch_skipped(name)
+#else
+#define GGAN_LAUNCH_SKIPPED(name) false
+#endif
 #define GGAN_LAUNCH(name, flops, bytes, kernel, grid, block, shmem, stream, ...)          \
     do {                                                                                    \
-        if (ggan::launch_skipped(name)) break;                                              \
+        if (GGAN_LAUNCH_SKIPPED(name)) break;                                               \
         ggan::trace_launch(name, grid, block, shmem, (double)(flops));                      \
         ggan::ProfScope _ps(name, stream, (double)(flops), (double)(bytes));              \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \

@@ -119,6 +119,8 @@ class Trainer(object):
         self.sync_bn = bool(sync_bn) and (self.world > 1 or dp)       # (dp at world 1: the one-rank RCCL rehearsal)
         if self.sync_bn:
             lib.ops.batchnorm.set_sync_group(True)
+            if self.comm is not None:
+                rccl.get_stats(self.device)   # (collective: the statistics exchange's own communicator, functional._all_gather_rows)
             if self.comm is None:       # the statistics exchange is a host-issued collective inside the passes: eager steps.  With the
                 self.graph_enabled = False   # direct communicator it is an enqueue on the step's stream and is captured like a kernel
             if hasattr(self.model, 'fork_nets'):
@@ -270,6 +272,22 @@ class Trainer(object):
         try:
             return self._capture_impl(which)
         finally:
+            if forkable:
+                self.model.fork_now = False
+
+    @contextlib.contextmanager
+    def eager_as_captured(self):
+        """eager steps that launch what the captured graphs launch: the two-stream nets pass (and with it the launch plan of side-by-side
+        conv chains, models.launch_hint / functional.target_workgroups) is otherwise switched on for captures only.  bench.py brackets
+        the kernels of such steps with HIP events, so that its per-kernel table is the timed graph's kernel mix."""
+        forkable = hasattr(self.model, 'fork_now') and not self.split_graph and not self.sync_bn
+        prev_graph, self.graph_enabled = self.graph_enabled, False
+        if forkable:
+            self.model.fork_now = True
+        try:
+            yield
+        finally:
+            self.graph_enabled = prev_graph
             if forkable:
                 self.model.fork_now = False
 

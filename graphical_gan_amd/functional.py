@@ -1086,7 +1086,9 @@ def _all_gather_rows(t, group):
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     from . import rccl
-    comm = rccl.get(create=False) if (t.is_cuda and (group is None or group is dist.group.WORLD)) else None
+    # (the statistics travel on a communicator of their own, created by Trainer(sync_bn=True): the gradient buckets may be in flight on
+    #  the first one's stream at the same time, and one communicator's operations must stay on one stream)
+    comm = rccl._STATS[0] if (t.is_cuda and (group is None or group is dist.group.WORLD)) else None
     if comm is not None:             # an enqueue on the current stream (capturable: cross-replica BatchNorm inside a step graph)
         return comm.all_gather(out, t.contiguous())
     try:

@@ -50,6 +50,7 @@ def _lib():
         L.ncclGetUniqueId.argtypes = [C.POINTER(ncclUniqueId)]
         L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, ncclUniqueId, C.c_int]
         L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         _LIB[0] = L
@@ -78,15 +79,22 @@ class Communicator(object):
         self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
         L = _lib()
         uid = ncclUniqueId()
+        rc0 = 0
         if self.rank == 0:
-            _check(L.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+            rc0 = L.ncclGetUniqueId(C.byref(uid))
         if self.world > 1:
+            # the id travels with a success flag: a rank 0 that could not create it must not leave the others sitting in the broadcast
+            # (and then walk into the next collective alone) -- every rank abandons the creation together
             on_dev = dist.get_backend(group) == 'nccl'
-            t = torch.tensor(list(bytes(uid.internal) if self.rank == 0 else bytes(NCCL_UNIQUE_ID_BYTES)), dtype=torch.uint8,
-                             device=self.device if on_dev else 'cpu')
+            payload = (list(bytes(uid.internal)) + [1 if rc0 == 0 else 0]) if self.rank == 0 else [0] * (NCCL_UNIQUE_ID_BYTES + 1)
+            t = torch.tensor(payload, dtype=torch.uint8, device=self.device if on_dev else 'cpu')
             dist.broadcast(t, src=0, group=group)
             raw = bytes(t.cpu().tolist())
-            C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+            if raw[NCCL_UNIQUE_ID_BYTES] != 1:
+                raise RcclError('ncclGetUniqueId failed on rank 0' + (': %s' % L.ncclGetErrorString(rc0).decode() if self.rank == 0 else ''))
+            C.memmove(C.byref(uid), raw[:NCCL_UNIQUE_ID_BYTES], NCCL_UNIQUE_ID_BYTES)
+        else:
+            _check(rc0, 'ncclGetUniqueId')
         self._comm = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(L.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), 'ncclCommInitRank')
@@ -105,11 +113,12 @@ class Communicator(object):
         L = _lib()
         cur = torch.cuda.current_stream(self.device)
         s = stream if stream is not None else self.stream
-        if s is not cur:
+        same = s.cuda_stream == cur.cuda_stream           # (current_stream() returns a fresh object each call: compare the handles)
+        if not same:
             s.wait_stream(cur)
         self._enqueue(lambda st: L.ncclAllReduce(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(), ncclFloat32, ncclSum,
                                                  self._comm, st), s)
-        if s is cur:
+        if same:
             return None
         w = Work(s, self.device)
         if async_op:
@@ -127,6 +136,12 @@ class Communicator(object):
                                                  self._comm, st), s)
         return out
 
+    def count(self):
+        """the number of ranks as RCCL itself reports it (ncclCommCount)"""
+        n = C.c_int(0)
+        _check(_lib().ncclCommCount(self._comm, C.byref(n)), 'ncclCommCount')
+        return int(n.value)
+
     def destroy(self):
         if self._comm:
             _lib().ncclCommDestroy(self._comm)
@@ -134,7 +149,31 @@ class Communicator(object):
 
 
 _COMM = [None]
+_STATS = [None]
 _FAILED = [False]      # creation was tried and refused: do not retry (every retry is a collective)
+
+
+def get_stats(device=None):
+    """A SECOND communicator for the cross-replica BatchNorm statistics (all-gathers on the step's own stream): the gradient buckets
+    travel on the first one's stream at the same time (two-bucket steps), and operations of ONE communicator must not be in flight from
+    two streams.  Created on first use (a collective call: every rank enables sync_bn at the same point); None where get() is None."""
+    base = get(device)
+    if base is None:
+        return None
+    if _STATS[0] is None:
+        comm, err = None, None
+        try:
+            comm = Communicator(base.rank, base.world, base.device)
+        except (RcclError, OSError, AttributeError) as e:
+            err = e
+        flag = torch.tensor([0.0 if comm is None else 1.0], device=base.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag[0]) < 0.5:
+            if comm is not None:
+                comm.destroy()
+            raise RcclError('no second communicator for the BatchNorm statistics (%s)' % (err if err is not None else 'another rank failed'))
+        _STATS[0] = comm
+    return _STATS[0]
 
 
 def get(device=None, create=True):
@@ -167,7 +206,8 @@ def get(device=None, create=True):
 
 
 def reset():
-    if _COMM[0] is not None:
-        _COMM[0].destroy()
-        _COMM[0] = None
+    for slot in (_STATS, _COMM):
+        if slot[0] is not None:
+            slot[0].destroy()
+            slot[0] = None
     _FAILED[0] = False

@@ -455,8 +455,9 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert 'G+D+GP' in full['variants'][0]['metric'] and 'N_COMS=10' in full['variants'][2]['config']['workload']
     port = 29700 + (os.getpid() % 200)
     env2 = dict(env, GGAN_DIST_BACKEND='gloo')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+    # exactly as the driver invokes it: no launcher around it -- bench.py starts its own ranks (round-3 review: this form used to exit)
+    env2 = {k: v for k, v in env2.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
                         '--variants', 'gmgan-cifar10-K10', '--variant-steps', '4'],
                        capture_output=True, text=True, timeout=900, env=env2, cwd=root)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
@@ -464,6 +465,8 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert len(lines) == 1 and len(lines[0]) < 4096         # rank 0 only
     d2 = json.loads(r.stdout.rstrip('\n').splitlines()[-1])
     assert d2['n_gpus'] == 2 and d2['scaling'] == 'weak' and d2['config']['global_batch'] == 128 and d2['value'] > 0
+    assert d2['config']['parallelism'] == 'dp2' and d2['data_parallel']['ranks'] == 2 and d2['data_parallel']['launched_by'] == 'bench.py itself'
+    assert 'diag_env' not in d2
     assert len(d2['variants']) == 1 and d2['variants'][0]['key'] == 'gmgan-cifar10-K10' and d2['variants'][0]['value'] > 0
     # a rank that dies in the first attempt the way a failed captured collective kills it (abort): the supervisors stop that
     # attempt on every rank and the second one -- exchanges issued by the host between cut graphs -- delivers the line

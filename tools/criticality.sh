@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a diagnostic build of the library: GGAN_BUILD_DIAG=1 python graphical_gan_amd/build.py --force (the product build has no GGAN_SKIP_KERNELS)
 # What does each kernel family contribute to the CRITICAL PATH of an iteration?  Re-measure the step with that family not launched
 # at all (GGAN_SKIP_KERNELS: results are garbage, the timing is not) and report the difference to the full step.
 # usage (GPU box): bash tools/criticality.sh [bench args]   -> gpurun_out/criticality.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a diagnostic build of the library: GGAN_BUILD_DIAG=1 python graphical_gan_amd/build.py --force (the product build has no GGAN_SKIP_KERNELS)
 # Per launch SITE: the step re-measured with the k-th of the n launches of a kernel family per iteration left out (GGAN_SKIP_KERNELS
 # "name@k/n").  usage (GPU box): bash tools/criticality_sites.sh  -> gpurun_out/criticality_sites.txt
 R=${GRAFT_REPO_ROOT:-.}
