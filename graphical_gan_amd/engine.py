@@ -129,6 +129,7 @@ class Trainer(object):
         # backward pass (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
         self.single_contrib = bool(self.model.single_contribution)
         self._opts = None
+        self.keep_outputs, self.last_out = False, {}
         self._pending = None         # (work handle, Adam graph) of a critic-step exchange still in flight (see step())
 
     # ---- inputs ---------------------------------------------------------------------------------------
@@ -202,6 +203,9 @@ class Trainer(object):
     def _fwd_bwd(self, which, nets=None, fuse_update=False):
         """fuse_update: the caller applies the update next with nothing but a (single-replica: empty) exchange in between"""
         out = self.model.forward(self.feed, which, nets if nets is not None else self._nets())
+        if self.keep_outputs:        # (tests: the critic logits of a captured step -- static graph memory, valid after every replay)
+            det = lambda v: [t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()    # (no tape kept alive across steps)
+            self.last_out[which] = {k: det(v) for k, v in out.items() if k in ('disc_fake', 'disc_real')}
         op = out[which + '_train_op']
         opt = op.optimizer
         # (the filter-gradient slabs are summed by the pack kernel: legal under the same one-contribution condition)
