@@ -22,6 +22,9 @@
 #include "common.h"
 #include "conv.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <vector>
 using namespace ggan;
 
 namespace {
@@ -67,6 +70,8 @@ struct CorrParams {
     int dbg;
     int dma;                      // forward kinds: stage the slab and the filter slice by LDS-DMA (buffer_load ... lds)
     int xq;                       // 4: the slab is staged in 16-byte units of image rows (forward DMA path, see plan_and_launch), else 1
+    int nstg;                     // forward DMA path: LDS staging buffers (3: ring fetched two chunks ahead, round 4; 2: the round-2 scheme)
+    const unsigned* xtab;         // forward DMA path: plan-time slab offsets [tile position][XE][NTHR] (relative to the tile's first image), or NULL
     unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
     const float* out_ref;    // optional (forward kind, SK == 1): the stored value is act_grad(v, out_ref[same index]) -- the double backward of
     int out_act;             // a masked data gradient (functional.ConvDgradMasked) without an act_bwd launch behind the conv
@@ -174,6 +179,33 @@ __device__ __forceinline__ void mma_taps_wd(const float* __restrict__ xs, const 
     }
 }
 
+__device__ __forceinline__ void wait_vm_n(int n) {      // s_waitcnt vmcnt(n) for a wave-uniform run-time n
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 // Class lists.  KIND 0: forward, one 5x5 class.  KIND 1 / 2: data-gradient class pairs {0,3} / {1,2} (13 / 12 taps).
 // KIND 3: all four parity classes in one workgroup (25 taps): each lane then owns the 2x2 output block of its class pixel
 // and the epilogue writes FULL output rows as float2 (the pair kinds leave every 128-B line half-written by two different
@@ -277,6 +309,16 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     //  and the divisors in P are those of the unit grid)
     const int CSu = P.CS / xq, SCpu = P.SCp / xq;
     const int xe_cnt = CK * CSu, srsc = P.SR * SCpu;
+    // Round 4: the forward DMA path reads its slab offsets from a table built ONCE per geometry on the host (they depend on the tile
+    // position and the geometry only): one coalesced load per staging instruction instead of ~24 instructions of index arithmetic
+    // each (4300 of the 5400 cycles this kernel spent before its first barrier), and the filter slice -- whose offsets are cheap --
+    // goes out while the table is on its way.
+    const bool tabled = KIND == 0 && dma && P.xtab != nullptr;
+    if (tabled) {
+        const unsigned* tab = P.xtab + (size_t)tt * (XN * NTHR) + tid;
+#pragma unroll
+        for (int j = 0; j < XN; ++j) xvo[j] = (wave_u * 64 + j * NTHR < xe_cnt) ? tab[j * NTHR] : OOB;
+    } else {
 #pragma unroll
     for (int j = 0; j < XN; ++j) {
         const int e = tid + j * NTHR;
@@ -303,6 +345,7 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 4, off, so, 0, 0);
             }
         }
+    }
     }
     stamp(2);
     // (filter base of each class of the list, fetched with STATIC kernel-argument offsets: indexing P.cls by a run-time class
@@ -349,6 +392,22 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     }
     }
 
+    if (tabled) {
+        // (the image part joins the per-lane offset, so that images beyond N fall out of the buffer's range; the chunk part is scalar)
+        const unsigned img_base = (unsigned)n0 * (unsigned)P.CKtot * (unsigned)HWin * 4u;
+#pragma unroll
+        for (int j = 0; j < XN; ++j) {
+            const unsigned t = xvo[j];
+            xvo[j] = t >= OOB ? OOB : t + img_base;
+            const int e0 = wave_u * 64 + j * NTHR;
+            if (e0 < xe_cnt) {
+                float* dst = smem + e0 * xq;
+                const int so = ck_begin * HWin * 4;
+                if (xq == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 16, xvo[j], so, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)dst, 4, xvo[j], so, 0, 0);
+            }
+        }
+    }
     stamp(15);
     // ---- per-lane MFMA fragment bases ----------------------------------------------------------------------
     int xfrag[NC];
@@ -525,7 +584,50 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
     stamp(1);
     int buf = 0;
     int it_ = 0;
-    if (dma) {
+    if (dma && P.nstg == 3) {
+        // Round 4: a ring of THREE staging buffers, fetched TWO chunks ahead.  The wait at the end of chunk c retires the loads of chunk
+        // c+1, issued during chunk c-1 -- they landed long ago, so the end of a chunk costs the skew of the waves at the barrier and
+        // not a memory round trip (with two buffers the loads retired there had been issued in the same chunk, the last of them two
+        // MFMA pairs earlier).  WAR: the buffer chunk c+2 lands in was last read in chunk c-1, and every wave is past that barrier.
+        int ndma = 0;                                   // staging instructions of this wave per chunk
+#pragma unroll
+        for (int j = 0; j < XE; ++j) ndma += (wave_u * 64 + j * NTHR < xe_cnt) ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < WE; ++q) ndma += (wave_u * 64 + q * NTHR < WUNITS) ? 1 : 0;
+        if (ck_begin + CK < ck_end) {
+#pragma unroll
+            for (int q = 0; q < WE; ++q) dma_w1(q, ck_begin + CK, 1);
+#pragma unroll
+            for (int j = 0; j < XE; ++j) dma_x1(j, ck_begin + CK, 1);
+            wait_vm_n(ndma);                            // (chunk 0 was issued with the descriptors)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        stamp(3);
+        constexpr int NSTEP = (NT0 * PW + 1) / 2, NITEM = XE + WE;
+        constexpr int IPS = (NITEM + NSTEP - 3) / (NSTEP - 2);
+        for (int ck0 = ck_begin; ck0 < ck_end; ck0 += CK, buf = buf == 2 ? 0 : buf + 1) {
+            const int ck2 = ck0 + 2 * CK;
+            const bool more2 = ck2 < ck_end;
+            const int b2 = buf == 0 ? 2 : buf - 1;      // (buf + 2) % 3
+            auto hook = [&](int g) {
+#pragma unroll
+                for (int it = g * IPS; it < (g + 1) * IPS; ++it) {
+                    if (more2 && it < XE) dma_x1(it, ck2, b2);
+                    if (more2 && it >= XE && it < NITEM) dma_w1(it - XE, ck2, b2);
+                }
+            };
+            const float* xs = smem + buf * STAGE;
+            const float* ws = xs + XS_SZ;
+            mma_taps<CL::th(0), CL::tw(0), DI, PW, CK, RS, 0>(xs, ws, xfrag[0], wfrag, P.CS, P.SCp, acc[0], hook);
+            if (more2) wait_vm_n(ndma);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (it_ < 8) stamp(4 + it_);
+            ++it_;
+        }
+    } else if (dma) {
         // chunk c+1 is in flight into the other buffer while chunk c is multiplied: the wait + barrier at the end of the chunk
         // retires it for every wave (RAW), and every wave's fragment reads of that buffer were retired one barrier earlier (WAR)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (chunk 0 was issued with the descriptors)
@@ -954,6 +1056,49 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
     return 0;
 }
 
+// Plan-time slab table of the forward DMA path (corr_body, `tabled`): for every tile position and every staging element e = tid + j * NTHR
+// of a chunk the byte offset of its image unit relative to the tile's first image and the chunk's first channel, or the out-of-range
+// offset for the halo.  Built once per (device, geometry, tile plan) and kept; NULL while a stream capture is under way and the plan
+// is not there yet (the launch then computes its descriptors in the kernel, as before).
+std::mutex g_xtab_mu;
+std::map<std::vector<int>, unsigned*> g_xtabs;
+
+const unsigned* fwd_slab_table(const CorrParams& P, int CK, int nthr, int su, hipStream_t s) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int xq = P.xq == 4 ? 4 : 1;
+    const int XE = XE_MAX * 256 / nthr;
+    const std::vector<int> key = {dev, P.CKtot, P.Hin, P.Win, P.TI, P.TR, P.TC, P.SR, P.SCp, P.CS, xq, P.row0, P.col0, CK, nthr, P.tiles_r, P.tiles_c, su};
+    std::lock_guard<std::mutex> lk(g_xtab_mu);
+    auto it = g_xtabs.find(key);
+    if (it != g_xtabs.end()) return it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    const int CSu = P.CS / xq, SCpu = P.SCp / xq, srsc = P.SR * SCpu, xe_cnt = CK * CSu;
+    const int npos = P.tiles_r * P.tiles_c;
+    std::vector<unsigned> tab((size_t)npos * XE * nthr, OOB);
+    for (int tr = 0; tr < P.tiles_r; ++tr)
+        for (int tc = 0; tc < P.tiles_c; ++tc) {
+            const int in_row0 = su * tr * P.TR + P.row0, in_col0 = su * tc * P.TC + P.col0;
+            for (int j = 0; j < XE; ++j)
+                for (int tid = 0; tid < nthr; ++tid) {
+                    const int e = tid + j * nthr;
+                    if (e >= xe_cnt) continue;
+                    const int ckl = e / CSu, r1 = e - ckl * CSu;
+                    const int img = r1 / srsc, r2 = r1 - img * srsc;
+                    const int r = r2 / SCpu, cc = (r2 - r * SCpu) * xq;
+                    const int ih = in_row0 + r, iw = in_col0 + cc;
+                    if (img >= P.TI || ih < 0 || ih >= P.Hin || iw < 0 || iw >= P.Win) continue;
+                    tab[((size_t)(tr * P.tiles_c + tc) * XE + j) * nthr + tid] = (unsigned)((((size_t)img * P.CKtot + ckl) * P.Hin + ih) * P.Win + iw) * 4u;
+                }
+        }
+    unsigned* d = nullptr;
+    if (hipMalloc((void**)&d, tab.size() * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemcpy(d, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return nullptr; }
+    g_xtabs[key] = d;
+    return d;
+}
+
 // common tail: wave-config choice, split-K fallback, launch
 template <int MODE>
 int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c, int ntaps, int groups, float* dst,
@@ -1079,6 +1224,16 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     size_t stage = MODE == 0 ? 2 * ((size_t)fwd_region(CK * P.CS, CK * P.CS / P.xq, P.xq) + (size_t)fwd_region(ntaps * CK * RS, ntaps * CK * (TNW / 4), 4))
                              : 2 * ((size_t)((CK * P.CS + 1 + 3) & ~3) + (size_t)((ntaps * CK * RS + 4 * RS + 3) & ~3));
     size_t red = (size_t)wc.KS * (MODE == 2 ? 4 : (MODE == 1 ? 2 : 1)) * TNW * TM;     // epilogue: [ks][class][cn][pixel]
+    P.nstg = 2;
+    if (MODE == 0 && P.dma && env_int("GGAN_CORR_NSTG", 2) >= 3 && stage / 2 * 3 * sizeof(float) <= 160 * 1024 && P.cps >= 3 * CK) {
+        // round 4 experiment (GGAN_CORR_NSTG=3): three staging buffers, fetched two chunks ahead.  Measured SLOWER than the two-buffer
+        // scheme on every forward layout (64->128 @16: 24.6 -> 26.1 us, chunk 3990 -> 4250 cycles, first barrier 5440 -> 6600; face 32->64
+        // at 128 images 40.3 -> 48.1 us; iteration 1.046 -> 1.057 ms): the loads dealt out from the first MFMA pair on already land within
+        // their chunk, and twice the bytes in flight only lengthen every request's queue.  Off by default.
+        P.nstg = 3;
+        stage = stage / 2 * 3;
+    }
+    if (MODE == 0 && P.dma && env_int("GGAN_CORR_XTAB", 1)) P.xtab = fwd_slab_table(P, CK, 64 * wc.WM * wc.WN * wc.KS, su, s);
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
     if (rc) return rc;

@@ -15,15 +15,18 @@
 //   * wave = (k quad of the chunk, 16-channel tile, 32-pixel half): 25 taps x 2 pixel fragments = 50 MFMAs per chunk and wave,
 //     1 filter fragment + 2 slab fragments (ds_read_b32 each, immediate offsets only: the slab row pitch is a template parameter)
 //     per tap; the k quads are combined through LDS at the end (4-way at 16 channels, 2-way at 32).
-//   * both operands by LDS-DMA into a ring of THREE stages, fetched two chunks ahead: the wait at the end of chunk c retires the
-//     loads issued during chunk c-1, which landed long ago; what the barrier costs is the skew of the waves, not a memory round
-//     trip (the two-buffer scheme of conv_corr.hip waited for loads issued in the same chunk).
+//   * both operands by LDS-DMA, one chunk ahead into the other of two staging buffers, the instructions dealt out between the MFMA
+//     pairs from the second pair on.  (First version: a ring of three buffers fetched TWO chunks ahead, so that the wait at a chunk's
+//     end would retire loads a whole chunk old.  Measured slower everywhere -- 24.0 vs 22.8 us on 128->64 @8->16, the first barrier
+//     at 5560 instead of 3740 cycles: twice the bytes in flight lengthen every request's queue, and the dealt-out loads land within
+//     their chunk anyway.  GGAN_DG16_AHEAD=2 still selects it.)
 //   * no per-launch descriptor arithmetic: the slab's per-lane byte offsets (halo lanes = out-of-range offset = zeros) depend on
 //     the geometry and the tile position only; they are built ONCE per geometry on the host (plan cache below) and read with one
 //     coalesced load per DMA instruction while the first filter blocks -- whose lane offsets are shifts of the lane id -- are
 //     already in flight.
-//   * MASKED variant (the critic's layers: gy * lrelu'(y) fused into the operand staging): the slab goes through registers (one
-//     chunk of extra run-ahead) with the select on the way, everything else as above.
+//   * MASKED variant (the critic's layers: gy * lrelu'(y) fused into the operand staging): the slab goes through registers with the
+//     select on the way -- loaded two chunks ahead, committed at the start of the chunk in between into a third buffer -- the filter
+//     as above.
 #include "common.h"
 #include "conv.h"
 #include <stdlib.h>
@@ -55,6 +58,8 @@ struct Dg16Params {
     int xinstr;            // slab wave-instructions per chunk (whole workgroup)
     int tiles_r, tiles_c;
     int nchunks;
+    int ahead;             // chunks the DMA runs ahead: 1 (2: experiment)
+    int nstage;            // staging buffers: 2, or 3 when something runs two chunks ahead (the MASKED slab's register loads, ahead == 2)
     unsigned in_bytes, w_bytes;
     int act;
     float alpha;
@@ -169,10 +174,11 @@ __device__ __forceinline__ void dg16_body(const Dg16Params& P, float* smem) {
     };
     // chunks 0 and 1 of the filter go out before anything else is known
     const int nch = P.nchunks;
+    const int AH = P.ahead, NST = P.nstage;
 #pragma unroll
     for (int q = 0; q < WQ; ++q)
         if (q < nw) dma_w(q, 0, 0);
-    if (nch > 1) {
+    if (nch > 1 && AH == 2) {
 #pragma unroll
         for (int q = 0; q < WQ; ++q)
             if (q < nw) dma_w(q, 1, 1);
@@ -235,7 +241,7 @@ __device__ __forceinline__ void dg16_body(const Dg16Params& P, float* smem) {
             if (j < nx) load_x(j, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         commit_x(0);
-        if (nch > 1) {
+        if (nch > 1) {       // (MASKED keeps the two-ahead timing)
 #pragma unroll
             for (int j = 0; j < XN_MAX; ++j)
                 if (j < nx) load_x(j, 1);
@@ -246,7 +252,7 @@ __device__ __forceinline__ void dg16_body(const Dg16Params& P, float* smem) {
 #pragma unroll
         for (int j = 0; j < XN_MAX; ++j)
             if (j < nx) dma_x(j, 0, 0);
-        if (nch > 1) {
+        if (nch > 1 && AH == 2) {
 #pragma unroll
             for (int j = 0; j < XN_MAX; ++j)
                 if (j < nx) dma_x(j, 1, 1);
@@ -263,13 +269,15 @@ __device__ __forceinline__ void dg16_body(const Dg16Params& P, float* smem) {
     const int nxi = nx;
     int stage = 0;
     for (int c = 0; c < nch; ++c) {
-        const int s2 = stage >= 1 ? stage - 1 : 2;         // (c + 2) % 3
-        const bool more = c + 2 < nch;
+        const int s1 = stage + 1 == NST ? 0 : stage + 1;  // the next chunk's buffer
+        const int s2 = AH == 2 ? (stage >= 1 ? stage - 1 : 2) : s1;         // the buffer of chunk c + AH (two ahead: NST == 3)
+        const bool more = c + AH < nch;                    // DMA (filter blocks; the slab when it goes by DMA): chunk c + AH
+        const bool more_x = MASKED ? c + 2 < nch : more;   // MASKED: the slab's register loads run two chunks ahead (committed in chunk c + 1)
         if constexpr (MASKED) {
             // the slab of chunk c + 1 sits in registers since chunk c - 1 (behind it in the queue: the filter blocks of chunk c + 1)
             if (c >= 1 && c + 1 < nch) {
-                wait_vm(nw);
-                commit_x(stage == 2 ? 0 : stage + 1);
+                if (AH == 2) wait_vm(nw);                  // (AH == 1: the end of the last chunk waited for everything)
+                commit_x(s1);
             }
         }
         const float* sb = smem + stage * STAGE;
@@ -279,14 +287,13 @@ __device__ __forceinline__ void dg16_body(const Dg16Params& P, float* smem) {
             b0[t] = sb[bfrag[0] + tap_slab_off(t, SCP)];
             b1[t] = sb[bfrag[1] + tap_slab_off(t, SCP)];
         };
-        auto item = [&](int it) {                          // staging instruction number `it` of this wave for chunk c + 2
-            if (!more) return;
+        auto item = [&](int it) {                          // staging instruction number `it` of this wave
             if (it < XN_MAX) {
-                if (it < nxi) {
-                    if constexpr (MASKED) load_x(it, c + 2); else dma_x(it, c + 2, s2);
+                if (more_x && it < nxi) {
+                    if constexpr (MASKED) load_x(it, c + 2); else dma_x(it, c + AH, s2);
                 }
             } else if (it - XN_MAX < WQ) {
-                if (it - XN_MAX < nw) dma_w(it - XN_MAX, c + 2, s2);
+                if (more && it - XN_MAX < nw) dma_w(it - XN_MAX, c + AH, s2);
             }
         };
         load(0);
@@ -303,11 +310,11 @@ __device__ __forceinline__ void dg16_body(const Dg16Params& P, float* smem) {
             __builtin_amdgcn_sched_group_barrier(0x030, 2, 0);   // the staging instruction dealt to this pair
         }
         // retire the loads of chunk c + 1 (issued during chunk c - 1); those of chunk c + 2 stay in flight
-        if (more) wait_vm(MASKED ? 2 * nxi + nw : nxi + nw);
+        if (more && AH == 2) wait_vm(MASKED ? 2 * nxi + nw : nxi + nw);     // (two ahead: the loads issued in this chunk stay in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (c < 8) stamp(4 + c);
-        stage = stage == 2 ? 0 : stage + 1;
+        stage = s1;
     }
     stamp(12);
 
@@ -501,6 +508,11 @@ int conv_dgrad_dg16(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     if (P.xinstr > XN_MAX * NWAVE) return 1;
     P.tiles_r = tiles_r; P.tiles_c = tiles_c;
     P.nchunks = CK / ckc;
+    // chunks the DMA runs ahead.  ONE: measured faster than two on every layer (128->64 @8->16, 64 images: 22.8 vs 24.0 us, first barrier
+    // 3740 vs 5560 cycles; 64->32 @16->32: 25.1 vs 28.0 us) -- as for the forward kinds (conv_corr.hip, GGAN_CORR_NSTG), more bytes in
+    // flight only lengthen every request's queue; the loads dealt out from the second MFMA pair on land within their chunk.
+    P.ahead = env_int("GGAN_DG16_AHEAD", 1) == 2 ? 2 : 1;
+    P.nstage = (masked || P.ahead == 2) ? 3 : 2;
     P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
     P.act = act; P.alpha = alpha;
     P.dbg = env_int("GGAN_DBG", 0);
@@ -518,7 +530,7 @@ int conv_dgrad_dg16(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     const int wreg = (nblk * WBLK + 3) & ~3;
     const size_t stage = (size_t)wreg + (size_t)P.xinstr * 256;
     const size_t red = (size_t)kq * 4 * (kq == 4 ? 16 : 32) * PS;
-    const size_t shmem = (3 * stage > red ? 3 * stage : red) * sizeof(float);
+    const size_t shmem = (P.nstage * stage > red ? P.nstage * stage : red) * sizeof(float);
     if (shmem > 160 * 1024) return 1;
     ws = ws_scratch(ws, ws_bytes);
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
