@@ -66,6 +66,7 @@ SIGNATURES = {
     'ggan_mix_rbf_mmd2_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'ggan_mix_rbf_mmd2_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'ggan_noise_fill': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'ggan_noise_fill_steps': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     'ggan_gmm_latent_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     'ggan_gmm_latent_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'ggan_gemm_split': (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _F, _P, _Z, _P]),

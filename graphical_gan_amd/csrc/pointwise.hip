@@ -1013,7 +1013,9 @@ struct NoiseTable {
     int kind[GGAN_NOISE_MAX];      // 0 normal(a, b) = a + b*N(0,1); 1 uniform [a, b); 2 one-hot rows of width K (n = rows * K)
     float a[GGAN_NOISE_MAX], b[GGAN_NOISE_MAX];
     int K[GGAN_NOISE_MAX];
-    int count;
+    int slot[GGAN_NOISE_MAX];      // the tensor's ordinal within ITS step's draw (part of the counter), ggan_noise_fill_steps; else the index
+    int step[GGAN_NOISE_MAX];      // which of the launch's `advance` steps the tensor belongs to: draw number = state + step
+    int count, advance;
 };
 
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
@@ -1031,18 +1033,18 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
 
 __global__ __launch_bounds__(256) void noise_fill_k(const NoiseTable t, unsigned long long* __restrict__ state) {
-    const int ti = blockIdx.y;
-    const unsigned long long seed = state[0], draw = state[1];
+    const int tb = blockIdx.y, ti = t.slot[tb];
+    const unsigned long long seed = state[0], draw0 = state[1], draw = draw0 + (unsigned long long)t.step[tb];
     const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-    float* dst = t.dst[ti];
-    const unsigned n = t.n[ti];
-    const int kind = t.kind[ti];
+    float* dst = t.dst[tb];
+    const unsigned n = t.n[tb];
+    const int kind = t.kind[tb];
     for (unsigned g = blockIdx.x * 256 + threadIdx.x; g * 4 < n; g += gridDim.x * 256) {
         unsigned r[4];
         float v[4];
         if (kind == 2) {
             // element e of a one-hot row: the row's component index comes from a draw keyed by the ROW
-            const int K = t.K[ti];
+            const int K = t.K[tb];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned e = g * 4 + q, row = e / (unsigned)K, col = e - row * (unsigned)K;
@@ -1057,11 +1059,11 @@ __global__ __launch_bounds__(256) void noise_fill_k(const NoiseTable t, unsigned
                 float s0, c0, s1, c1;
                 sincosf(6.28318530718f * u01(r[1]), &s0, &c0);
                 sincosf(6.28318530718f * u01(r[3]), &s1, &c1);
-                v[0] = t.a[ti] + t.b[ti] * r0 * c0; v[1] = t.a[ti] + t.b[ti] * r0 * s0;
-                v[2] = t.a[ti] + t.b[ti] * r1 * c1; v[3] = t.a[ti] + t.b[ti] * r1 * s1;
+                v[0] = t.a[tb] + t.b[tb] * r0 * c0; v[1] = t.a[tb] + t.b[tb] * r0 * s0;
+                v[2] = t.a[tb] + t.b[tb] * r1 * c1; v[3] = t.a[tb] + t.b[tb] * r1 * s1;
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = t.a[ti] + (t.b[ti] - t.a[ti]) * u01(r[q]);
+                for (int q = 0; q < 4; ++q) v[q] = t.a[tb] + (t.b[tb] - t.a[tb]) * u01(r[q]);
             }
         }
 #pragma unroll
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__(256) void noise_fill_k(const NoiseTable t, unsigned
         const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
         const unsigned long long prev = atomicAdd(&state[2], 1ull);
         if (prev == total - 1) {
-            state[1] = draw + 1;
+            state[1] = draw0 + (unsigned long long)t.advance;
             state[2] = 0;
         }
     }
@@ -1570,7 +1572,13 @@ int ggan_gmm_latent_bwd(const float* z, const float* mu, const float* k, const f
 
 int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
                     int count, uint64_t* state, ggan_stream_t stream) {
+    return ggan_noise_fill_steps(dsts, sizes, kinds, a, b, widths, nullptr, nullptr, count, 1, state, stream);
+}
+
+int ggan_noise_fill_steps(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
+                          const int* slots, const int* steps, int count, int advance, uint64_t* state, ggan_stream_t stream) {
     GGAN_CHECK_ARG(dsts && sizes && kinds && a && b && widths && state, "null pointer");
+    GGAN_CHECK_ARG(advance >= 1 && (advance == 1 || (slots && steps)), "several steps need the per-tensor slot / step tables");
     GGAN_CHECK_ARG(count > 0 && count <= GGAN_NOISE_MAX, "count out of range");
     NoiseTable t;
     size_t mx = 0, tot = 0;
@@ -1578,10 +1586,14 @@ int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, c
         GGAN_CHECK_ARG(dsts[i] && sizes[i] > 0 && sizes[i] < 0x7FFFFFFFull && kinds[i] >= 0 && kinds[i] <= 2, "bad noise spec");
         GGAN_CHECK_ARG(kinds[i] != 2 || (widths[i] > 0 && sizes[i] % (size_t)widths[i] == 0), "one-hot rows need a width dividing the size");
         t.dst[i] = dsts[i]; t.n[i] = (unsigned)sizes[i]; t.kind[i] = kinds[i]; t.a[i] = a[i]; t.b[i] = b[i]; t.K[i] = widths[i];
+        t.slot[i] = slots ? slots[i] : i;
+        t.step[i] = steps ? steps[i] : 0;
+        GGAN_CHECK_ARG(t.slot[i] >= 0 && t.step[i] >= 0 && t.step[i] < advance, "bad slot / step");
         if (sizes[i] > mx) mx = sizes[i];
         tot += sizes[i];
     }
     t.count = count;
+    t.advance = advance;
     int gx = (int)cdivz(mx, (size_t)1024);
     if (gx < 1) gx = 1;
     if (gx > 256) gx = 256;

@@ -79,7 +79,7 @@ def dp_graph_selftest(device, comm):
 
 
 class Trainer(object):
-    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None, sync_bn=False):
+    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None, sync_bn=False, pair_nets=None):
         """sync_bn: BatchNorm statistics over the global batch of all replicas (N GPUs x B/N then reproduce
         1 GPU x B).  The statistics exchange is a host-issued collective inside the forward and the backward, so this mode
         runs the steps eagerly (no HIP graphs); it is the parity mode, per-replica statistics stay the throughput default.
@@ -129,6 +129,13 @@ class Trainer(object):
         # backward pass (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
         self.single_contrib = bool(self.model.single_contribution)
         self._opts = None
+        # paired nets pass (models.GraphicalGAN.forward_nets_pair, _iteration_pair): ring mode, one graph per iteration.  OFF unless asked
+        # for (pair_nets=True / GGAN_PAIR_NETS=1): measured +3 % on the CIFAR iteration (1.068 vs 1.038 ms), +16 % with the mixture prior
+        # (its side-stream chains lose their partners), -1.6 % on the 64x64 script -- at 128 rows the layers gain less than the second
+        # pass cost, because the two B-row chains already share the chip side by side (profiles/r04_notes.md)
+        if pair_nets is None:
+            pair_nets = bool(os.environ.get('GGAN_PAIR_NETS'))
+        self.pair_nets = bool(pair_nets) and not self.sync_bn
         self.keep_outputs, self.last_out = False, {}
         self._pending = None         # (work handle, Adam graph) of a critic-step exchange still in flight (see step())
 
@@ -187,6 +194,7 @@ class Trainer(object):
         self.feed['ring'] = (ring, ctr['gen'], ctr.get('disc'), -taken)
         self._graphs = {}                      # (captured steps read the staging buffer)
         self._iter_graph = None
+        self._pair_entered = False
 
     def _sample_noise(self):
         self.model.sample_noise(self.feed)
@@ -200,9 +208,9 @@ class Trainer(object):
             self._sample_noise()
         return self.model.forward_nets(self.feed)
 
-    def _fwd_bwd(self, which, nets=None, fuse_update=False):
+    def _fwd_bwd(self, which, nets=None, fuse_update=False, feed=None):
         """fuse_update: the caller applies the update next with nothing but a (single-replica: empty) exchange in between"""
-        out = self.model.forward(self.feed, which, nets if nets is not None else self._nets())
+        out = self.model.forward(feed if feed is not None else self.feed, which, nets if nets is not None else self._nets())
         if self.keep_outputs:        # (tests: the critic logits of a captured step -- static graph memory, valid after every replay)
             det = lambda v: [t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()    # (no tape kept alive across steps)
             self.last_out[which] = {k: det(v) for k, v in out.items() if k in ('disc_fake', 'disc_real')}
@@ -295,10 +303,11 @@ class Trainer(object):
             if forkable:
                 self.model.fork_now = False
 
-    def _step_body(self, which):
-        """one whole step as it is captured into a single graph: forward, backward, pack, (gradient exchange), update"""
+    def _step_body(self, which, nets=None, feed=None):
+        """one whole step as it is captured into a single graph: forward, backward, pack, (gradient exchange), update.  nets / feed: the
+        step continues from a nets pass evaluated elsewhere (the paired pass of _pair_body) instead of running its own"""
         with self._launch_hint(which):
-            return self._step_body_impl(which)
+            return self._step_body_impl(which, nets, feed)
 
     @contextlib.contextmanager
     def _launch_hint(self, which):
@@ -315,12 +324,12 @@ class Trainer(object):
         finally:
             L.ggan_set_target_workgroups(prev)
 
-    def _step_body_impl(self, which):
+    def _step_body_impl(self, which, nets=None, feed=None):
         st = None
         if self.dp_graph and which == 'gen':
             # two gradient buckets inside the one graph: the Generator's bucket is on the wire (the process group's
             # stream: a parallel branch of the graph) while the Extractor's backward pass still runs
-            nets = self._nets()
+            nets = nets if nets is not None else self._nets()
             cut = self.model.cut_tensors(nets) if hasattr(self.model, 'cut_tensors') else None
             # (two buckets in the generator step mean two autograd passes, Generator half then Extractor half -- and those two backward
             #  chains otherwise run SIDE BY SIDE on two streams, planned for half the chip each: one rank, forced exchange, 1.20 ms with
@@ -337,22 +346,22 @@ class Trainer(object):
                     if w is not None:
                         w.wait()
             else:
-                cost, opt, keep = self._fwd_bwd(which, nets)
+                cost, opt, keep = self._fwd_bwd(which, nets, feed=feed)
                 opt.all_reduce()
         elif self.dp_graph and which == 'disc' and hasattr(self.model, 'critic_cut') and not os.environ.get('GGAN_ONE_BUCKET'):
-            cost, opt, keep = self._disc_two_buckets()
+            cost, opt, keep = self._disc_two_buckets(nets, feed)
         else:
-            cost, opt, keep = self._fwd_bwd(which, fuse_update=not self.dp_graph)
+            cost, opt, keep = self._fwd_bwd(which, nets, fuse_update=not self.dp_graph, feed=feed)
             if self.dp_graph:
                 opt.all_reduce()
         opt.update()
         return cost, opt, keep
 
-    def _disc_two_buckets(self):
+    def _disc_two_buckets(self, nets=None, feed=None):
         """critic step with two gradient buckets: autograd reaches the critic's tail first, and that is where most of the bytes
         are (Discriminator.zx1: 2.6 M of the 4.1 M parameters) -- its bucket is exchanged while the conv stack's backward pass
         (two thirds of the critic's backward time) still runs; the conv stack's bucket follows.  Same sums as one bucket."""
-        out = self.model.forward(self.feed, 'disc', self._nets())
+        out = self.model.forward(feed if feed is not None else self.feed, 'disc', nets if nets is not None else self._nets())
         op = out['disc_train_op']
         opt = op.optimizer
         cutinfo = self.model.critic_cut()
@@ -529,6 +538,67 @@ class Trainer(object):
             if forkable:
                 self.model.fork_now = False
 
+    # ---- paired nets pass (round 4): critic step `it` and generator step `it + 1` from ONE Extractor / Generator evaluation ------------
+    def _pair_body(self):
+        """[nets pass of both steps on 2B rows] -> critic step -> generator step (models.GraphicalGAN.forward_nets_pair)"""
+        self._sl0 = lib.second_leaf_count()
+        self.model._pair_inject = bool(self.inject_noise)
+        feed_d, nets_d, feed_g, nets_g = self.model.forward_nets_pair(self.feed)
+        costs, keeps = {}, []
+        for which, nets, feed in (('disc', nets_d, feed_d), ('gen', nets_g, feed_g)):
+            cost, opt, keep = self._step_body(which, nets, feed)
+            costs[which + '_cost'] = cost
+            keeps.append((opt, keep))
+        return costs, keeps
+
+    def _capture_pair(self):
+        forkable = hasattr(self.model, 'fork_now') and not self.sync_bn
+        if forkable:
+            self.model.fork_now = True
+        try:
+            if getattr(self, '_cap_stream', None) is None:
+                self._cap_stream = F.shared_stream(self.device, 'capture')
+            s = self._cap_stream
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                snap = [(o, o.theta.clone(), o.m.clone(), o.v.clone(), o.step.clone()) for o in self._optimizers()]
+                rng = self.feed.get('rng_state') if isinstance(self.feed, dict) else None
+                rng_snap = rng.clone() if torch.is_tensor(rng) else None
+                for _ in range(2):
+                    self._pair_body()
+                for o, th, m, v, st in snap:
+                    o.theta.copy_(th); o.m.copy_(m); o.v.copy_(v); o.step.copy_(st)
+                if rng_snap is not None:
+                    rng.copy_(rng_snap)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
+                costs, keeps = self._pair_body()
+            return dict(g=g, costs=costs, keep=keeps, kinds=('pair',))
+        finally:
+            if forkable:
+                self.model.fork_now = False
+
+    def _iteration_pair(self, it):
+        """Ring mode, one graph per iteration, paired nets pass: this call runs CRITIC step `it` and GENERATOR step `it + 1` -- the
+        flattened step sequence d0 g1 d1 g2 d2 ... of the reference loop is unchanged, the grouping into replays is shifted by one
+        step (one stand-alone generator step on entry), because it is the critic step and the generator step BEHIND it that share
+        the Extractor's / Generator's weights."""
+        if not getattr(self, '_pair_entered', False):
+            self._calls['gen'] += 1
+            self._eager('gen')                # generator step `it`: from here on the sequence continues with (d_it, g_it+1)
+            self._pair_entered = True
+        for k in ('disc', 'gen'):
+            self._calls[k] += 1
+        lib.end_build_phase()
+        rec = getattr(self, '_iter_graph', None)
+        if rec is None or rec['kinds'] != ('pair',):
+            self.flush()
+            rec = self._iter_graph = self._capture_pair()
+        rec['g'].replay()
+        return dict(rec['costs'])
+
     def iteration(self, it, batches):
         """batches: iterator of device minibatches (or feed dicts when inject_noise); ignored in ring mode (use_ring)."""
         feed = getattr(self, 'feed', None)
@@ -575,6 +645,9 @@ class Trainer(object):
                      and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
         if not one_graph:
             return {k + '_cost': self.step(k) for k in kinds}
+        if (self.pair_nets and hasattr(self.model, 'pair_supported') and self.model.pair_supported(self.feed)
+                and getattr(self, '_feeder', None) is None):       # (a host-fed ring is filled one iteration ahead, not one step beyond it)
+            return self._iteration_pair(it)
         for k in kinds:
             self._calls[k] += 1
         if all(self._calls[k] >= 2 for k in set(kinds)):

@@ -253,6 +253,85 @@ def _geom(t):
     return ConvGeom(*t)
 
 
+
+# ---------------------------------------------------------------------------------------------------
+# Paired nets pass (round 4, models.GraphicalGAN.forward_nets_pair).  A critic step does not touch the Generator's / Extractor's
+# weights, so the Extractor / Generator passes of a critic step and of the generator step that follows it read the SAME weights: they
+# are evaluated together, once, on 2 x B rows (each launch carries twice the work of a launch that has trouble filling the chip at
+# batch 64).  The pass runs without a tape (`Replay.record`: every layer leaves its outputs in a list); the generator step then calls the
+# same layer code on ITS B rows under `Replay.attach`, where every layer takes its output -- a row range of the recorded one -- from the
+# list instead of launching anything and registers its ordinary backward for those rows.  Statistics layers (BatchNorm) are evaluated
+# per group of B rows, as the two session.runs of the reference would.
+# ---------------------------------------------------------------------------------------------------
+class Replay(object):
+    def __init__(self, group_rows, groups=2):
+        self.B, self.G = int(group_rows), int(groups)
+        self.items, self.pos, self.mode, self.group = [], 0, 'record', None
+
+    def put(self, op, *pairs):
+        """pairs: (tensor, kind) -- 'rows': leading dimension = G x (rows of one group); 'group': leading dimension = G"""
+        self.items.append((op, pairs))
+
+    def take(self, op):
+        if self.pos >= len(self.items) or self.items[self.pos][0] != op:
+            raise _lib.GganError('paired nets pass: layer sequence of the attached pass differs from the recorded one at #%d (%s vs %s)' % (
+                self.pos, op, self.items[self.pos][0] if self.pos < len(self.items) else 'end'))
+        pairs = self.items[self.pos][1]
+        self.pos += 1
+        g, out = self.group, []
+        for t, kind in pairs:
+            if t is None:
+                out.append(None)
+            elif kind == 'group':
+                out.append(t[g])
+            else:
+                n = t.shape[0] // self.G
+                out.append(t[g * n:(g + 1) * n])
+        return out
+
+
+_REPLAY = [None]
+
+
+class replay_record(object):
+    def __init__(self, rp):
+        self.rp = rp
+
+    def __enter__(self):
+        self.prev, _REPLAY[0] = _REPLAY[0], self.rp
+        self.rp.mode, self.rp.items, self.rp.pos = 'record', [], 0
+        return self.rp
+
+    def __exit__(self, *a):
+        _REPLAY[0] = self.prev
+
+
+class replay_attach(object):
+    def __init__(self, rp, group):
+        self.rp, self.group = rp, int(group)
+
+    def __enter__(self):
+        self.prev, _REPLAY[0] = _REPLAY[0], self.rp
+        self.rp.mode, self.rp.pos, self.rp.group = 'attach', 0, self.group
+        return self.rp
+
+    def __exit__(self, et, ev, tb):
+        _REPLAY[0] = self.prev
+        if et is None and self.rp.pos != len(self.rp.items):
+            raise _lib.GganError('paired nets pass: the attached pass used %d of %d recorded layers' % (self.rp.pos, len(self.rp.items)))
+        self.rp.mode = None
+
+
+def _recording():
+    rp = _REPLAY[0]
+    return rp if (rp is not None and rp.mode == 'record') else None
+
+
+def _attaching():
+    rp = _REPLAY[0]
+    return rp if (rp is not None and rp.mode == 'attach') else None
+
+
 # ---------------------------------------------------------------------------------------------------
 # convolution family
 # ---------------------------------------------------------------------------------------------------
@@ -273,13 +352,19 @@ class ConvFwd(Function):
         N, Ci, H, W, Co, Ho, Wo = geom[:7]
         assert tuple(x.shape) == (N, Ci, H, W) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (x.shape, w.shape, geom)
         ctx.grad_rows = int(grad_rows) if grad_rows else None
-        y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
-        ws = workspace(x.device)
-        g = _geom(geom)
         ctx.target = _TARGET[0]
-        with _planned_for(ctx.target):
-            check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
-                                       act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
+        at = _attaching()
+        if at is not None:
+            (y,) = at.take('ConvFwd')
+        else:
+            y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+            ws = workspace(x.device)
+            g = _geom(geom)
+            with _planned_for(ctx.target):
+                check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
+                                           act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
+            if _recording() is not None:
+                _recording().put('ConvFwd', (y, 'rows'))
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
         ctx.w_param, ctx.b_param = _is_param(w), _is_param(bias)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -359,13 +444,20 @@ class ConvDgrad(Function):
         gy, w = _c(gy), _c(w)
         N, Ci, H, W, Co, Ho, Wo = geom[:7]
         assert tuple(gy.shape) == (N, Co, Ho, Wo) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (gy.shape, w.shape, geom)
-        gx = _new_out(slot, (N, Ci, H, W), gy.device)
-        ws = workspace(gy.device)
-        g = _geom(geom)
         ctx.target = _TARGET[0]
-        with _planned_for(ctx.target):
-            check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
-                                            _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
+        at = _attaching()
+        if at is not None:
+            (gx,) = at.take('ConvDgrad')
+            gx = gx.view(N, Ci, H, W)
+        else:
+            gx = _new_out(slot, (N, Ci, H, W), gy.device)
+            ws = workspace(gy.device)
+            g = _geom(geom)
+            with _planned_for(ctx.target):
+                check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
+                                                _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
+            if _recording() is not None:
+                _recording().put('ConvDgrad', (gx, 'rows'))
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
         ctx.save_for_backward(gy, w, gx if act != ACT_NONE else None)
         return gx
@@ -560,10 +652,18 @@ class Gemm(Function):
         M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
         K2, N = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
         assert K == K2, (a.shape, b.shape, ta, tb)
-        out = _new_out(slot, (M, N), a.device)
-        ws = workspace(a.device)
-        check(_L().ggan_gemm(int(ta), int(tb), M, N, K, _p(a), _p(b), _p(_c(bias)) if bias is not None else _p(None),
-                             _p(out), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm')
+        at = _attaching()
+        if at is not None:
+            (out,) = at.take('Gemm')
+            out = out.view(M, N)
+        else:
+            out = _new_out(slot, (M, N), a.device)
+            ws = workspace(a.device)
+            check(_L().ggan_gemm(int(ta), int(tb), M, N, K, _p(a), _p(b), _p(_c(bias)) if bias is not None else _p(None),
+                                 _p(out), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm')
+            if _recording() is not None:
+                assert not ta, 'paired nets pass: row-major left operand'
+                _recording().put('Gemm', (out, 'rows'))
         ctx.ta, ctx.tb, ctx.act, ctx.alpha, ctx.has_bias = ta, tb, act, alpha, bias is not None
         ctx.b_param, ctx.bias_param = _is_param(b), _is_param(bias)
         ctx.save_for_backward(a, b, out if act != ACT_NONE else None)
@@ -960,12 +1060,28 @@ class BatchNormTrain(Function):
         x = _c(x)
         N, Cc = x.shape[0], x.shape[1]
         HW = x.numel() // (N * Cc)
-        y = torch.empty_like(x)
-        mean = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-        invstd = torch.empty_like(mean)
         sc, of = _c(scale).reshape(-1), _c(offset).reshape(-1)
-        check(_L().ggan_bn_fwd_train(_p(x), _p(sc), _p(of), _p(y), _p(mean), _p(invstd), N, Cc, HW, eps, act, alpha,
-                                     _stream()), 'ggan_bn_fwd_train')
+        at, rec = _attaching(), _recording()
+        if at is not None:
+            y, mean, invstd = at.take('BatchNormTrain')
+            y = y.view(x.shape)
+        elif rec is not None:
+            # paired nets pass: batch statistics per group of rows (each group is one session.run's minibatch)
+            G, n = rec.G, N // rec.G
+            assert n * G == N
+            y = torch.empty_like(x)
+            mean = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            for gi in range(G):
+                check(_L().ggan_bn_fwd_train(_p(x[gi * n:(gi + 1) * n]), _p(sc), _p(of), _p(y[gi * n:(gi + 1) * n]), _p(mean[gi]), _p(invstd[gi]),
+                                             n, Cc, HW, eps, act, alpha, _stream()), 'ggan_bn_fwd_train')
+            rec.put('BatchNormTrain', (y, 'rows'), (mean, 'group'), (invstd, 'group'))
+        else:
+            y = torch.empty_like(x)
+            mean = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            check(_L().ggan_bn_fwd_train(_p(x), _p(sc), _p(of), _p(y), _p(mean), _p(invstd), N, Cc, HW, eps, act, alpha,
+                                         _stream()), 'ggan_bn_fwd_train')
         ctx.dims = (N, Cc, HW)
         ctx.act, ctx.alpha = act, alpha
         ctx.pshape = tuple(scale.shape)
@@ -1045,13 +1161,30 @@ class LinearBatchNormRows(Function):
         x, w = _c(x), _c(w)
         M, K = x.shape
         N = w.shape[1]
-        h = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        y = torch.empty_like(h)
-        mean = torch.empty((N,), dtype=torch.float32, device=x.device)
-        invstd = torch.empty_like(mean)
         sc, of = _c(scale).reshape(-1), _c(offset).reshape(-1)
-        check(_L().ggan_linear_bn_rows_fwd(_p(x), _p(w), _p(_c(b)) if b is not None else _p(None), _p(sc), _p(of), _p(h), _p(y), _p(mean),
-                                           _p(invstd), M, K, N, eps, act, alpha, _stream()), 'ggan_linear_bn_rows_fwd')
+        bp = _p(_c(b)) if b is not None else _p(None)
+        at, rec = _attaching(), _recording()
+        if at is not None:
+            h, y, mean, invstd = at.take('LinearBatchNormRows')
+        elif rec is not None:
+            G, n = rec.G, M // rec.G          # (statistics per group of rows, as for BatchNormTrain)
+            assert n * G == M
+            h = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            y = torch.empty_like(h)
+            mean = torch.empty((G, N), dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            for gi in range(G):
+                sl = slice(gi * n, (gi + 1) * n)
+                check(_L().ggan_linear_bn_rows_fwd(_p(x[sl]), _p(w), bp, _p(sc), _p(of), _p(h[sl]), _p(y[sl]), _p(mean[gi]), _p(invstd[gi]),
+                                                   n, K, N, eps, act, alpha, _stream()), 'ggan_linear_bn_rows_fwd')
+            rec.put('LinearBatchNormRows', (h, 'rows'), (y, 'rows'), (mean, 'group'), (invstd, 'group'))
+        else:
+            h = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            y = torch.empty_like(h)
+            mean = torch.empty((N,), dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            check(_L().ggan_linear_bn_rows_fwd(_p(x), _p(w), bp, _p(sc), _p(of), _p(h), _p(y), _p(mean),
+                                               _p(invstd), M, K, N, eps, act, alpha, _stream()), 'ggan_linear_bn_rows_fwd')
         ctx.act, ctx.alpha, ctx.has_bias, ctx.pshape = act, alpha, b is not None, tuple(scale.shape)
         ctx.save_for_backward(x, w, h, sc, mean, invstd, y if act != ACT_NONE else None)
         return y
@@ -1255,8 +1388,15 @@ class Axpby(Function):
     def forward(ctx, x, y, a, b, c, slot=None):
         x = _c(x)
         y = _c(y) if y is not None else None
-        out = _new_out(slot, x.shape, x.device)
-        check(_L().ggan_axpby(_p(x), _p(y), _p(out), x.numel(), a, b, c, _stream()), 'ggan_axpby')
+        at = _attaching()
+        if at is not None:
+            (out,) = at.take('Axpby')
+            out = out.view(x.shape)
+        else:
+            out = _new_out(slot, x.shape, x.device)
+            check(_L().ggan_axpby(_p(x), _p(y), _p(out), x.numel(), a, b, c, _stream()), 'ggan_axpby')
+            if _recording() is not None:
+                _recording().put('Axpby', (out, 'rows'))
         ctx.a, ctx.b, ctx.has_y = a, b, y is not None
         return out
 
@@ -1277,10 +1417,16 @@ class GmmLatent(Function):
         B, D = z.shape
         K = mu.shape[0]
         assert tuple(mu.shape) == (K, D) and tuple(gumbel_u.shape) == (B, K)
-        logits = torch.empty((B, K), dtype=torch.float32, device=z.device)
-        k = _new_out(slot, (B, K), z.device)
-        check(_L().ggan_gmm_latent_fwd(_p(z), _p(mu), _p(gumbel_u), _p(logits), _p(k), B, K, D, float(log_pi), float(temp),
-                                       _stream()), 'ggan_gmm_latent_fwd')
+        at = _attaching()
+        if at is not None:
+            logits, k = at.take('GmmLatent')
+        else:
+            logits = torch.empty((B, K), dtype=torch.float32, device=z.device)
+            k = _new_out(slot, (B, K), z.device)
+            check(_L().ggan_gmm_latent_fwd(_p(z), _p(mu), _p(gumbel_u), _p(logits), _p(k), B, K, D, float(log_pi), float(temp),
+                                           _stream()), 'ggan_gmm_latent_fwd')
+            if _recording() is not None:
+                _recording().put('GmmLatent', (logits, 'rows'), (k, 'rows'))
         ctx.temp = float(temp)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(z, mu, k)
@@ -1842,6 +1988,25 @@ def noise_fill_(state, specs):
     b = (C.c_float * n)(*[float(x) for _, _, _, x in specs])
     widths = (C.c_int * n)(*[int(t.shape[-1]) if k == NOISE_ONEHOT else 0 for t, k, _, _ in specs])
     check(_L().ggan_noise_fill(dsts, sizes, kinds, a, b, widths, n, _p(state), _stream()), 'ggan_noise_fill')
+
+
+def noise_fill_steps_(state, steps):
+    """The noise of several consecutive steps in one launch.  steps: a list (one entry per step, in order) of spec lists as for
+    noise_fill_; every tensor receives what noise_fill_(state, steps[i]) issued as the i-th of len(steps) launches would have written."""
+    assert state.dtype == torch.int64 and state.numel() == 3 and state.is_cuda
+    flat = [(t, k, a, b, si, st) for st, specs in enumerate(steps) for si, (t, k, a, b) in enumerate(specs)]
+    n = len(flat)
+    for t, *_ in flat:
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.device == state.device
+    dsts = (C.c_void_p * n)(*[f[0].data_ptr() for f in flat])
+    sizes = (C.c_size_t * n)(*[f[0].numel() for f in flat])
+    kinds = (C.c_int * n)(*[int(f[1]) for f in flat])
+    a = (C.c_float * n)(*[float(f[2]) for f in flat])
+    b = (C.c_float * n)(*[float(f[3]) for f in flat])
+    widths = (C.c_int * n)(*[int(f[0].shape[-1]) if f[1] == NOISE_ONEHOT else 0 for f in flat])
+    slots = (C.c_int * n)(*[int(f[4]) for f in flat])
+    stp = (C.c_int * n)(*[int(f[5]) for f in flat])
+    check(_L().ggan_noise_fill_steps(dsts, sizes, kinds, a, b, widths, slots, stp, n, len(steps), _p(state), _stream()), 'ggan_noise_fill_steps')
 
 
 def pack_(tensors, offsets, flat, bump=None, adam=None):

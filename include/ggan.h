@@ -370,6 +370,12 @@ int ggan_agg_div_bwd(int kind, const float* mu, const float* sd, const float* k_
 #define GGAN_NOISE_MAX 16
 int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
                     int count, uint64_t* state, ggan_stream_t stream);
+/* The same launch drawing the noise of SEVERAL consecutive session.runs at once (round 4: the Extractor / Generator passes of a critic
+ * step and of the generator step behind it are evaluated together, models.GraphicalGAN.forward_nets_pair): tensor i belongs to step
+ * steps[i] in [0, advance) and is tensor number slots[i] of that step's draw, i.e. it receives exactly the values a single-step launch
+ * of that step would have written; the draw number advances by `advance`. */
+int ggan_noise_fill_steps(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
+                          const int* slots, const int* steps, int count, int advance, uint64_t* state, ggan_stream_t stream);
 
 /* Mixture-of-Gaussians latent glue of the gmgan scripts (HyperExtractor, gmgan_inference_cifar10.py:156-173 with MODE_K =
  * 'CONCRETE'): logits[b,j] = -.5*||z_b - mu_j||^2 + log_pi and k[b,:] = softmax((logits[b,:] + gumbel(u[b,:])) / temp), gumbel(u) =
