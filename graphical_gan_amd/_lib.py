@@ -17,7 +17,11 @@ BCE_MAX = 16
 
 
 class ConvGeom(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('N', 'Ci', 'H', 'W', 'Co', 'Ho', 'Wo', 'k', 'stride', 'pad_t', 'pad_l')]
+    _fields_ = [(n, C.c_int) for n in ('N', 'Ci', 'H', 'W', 'Co', 'Ho', 'Wo', 'k', 'stride', 'pad_t', 'pad_l',
+                                       'plan_wgs', 'plan_wgs_filter', 'plan_flags')]      # (the last three default to 0)
+
+
+PLAN_PLAIN = 1
 
 
 class ProfRec(C.Structure):
@@ -39,9 +43,6 @@ _G = C.POINTER(ConvGeom)
 SIGNATURES = {
     'ggan_version': (_I, []),
     'ggan_last_error': (C.c_char_p, []),
-    'ggan_set_naive': (_I, [_I]),
-    'ggan_set_target_workgroups': (_I, [_I]),
-    'ggan_set_target_workgroups_filter_grad': (_I, [_I]),
     'ggan_conv2d_workspace': (_Z, [_G]),
     'ggan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),

@@ -11,10 +11,6 @@ namespace ggan {
 
 // ---- error plumbing: C ABI never throws -------------------------------------------------------
 void set_error(const char* fmt, ...);
-extern bool g_force_naive;
-// workgroups a conv launch plans for (ggan_set_target_workgroups; 0: GGAN_TARGET_WGS or 200, about one workgroup per CU)
-extern int g_target_wgs;
-extern int g_target_wgs_wgrad;      // the same for the filter-gradient kernels (0: GGAN_WGRAD_WGS or 256)
 
 #define GGAN_CHECK_ARG(cond, msg)                                  \
     do {                                                           \

@@ -23,7 +23,7 @@ int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const
                   float alpha, void* ws, size_t ws_bytes, hipStream_t s);
 int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx,
                     int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s);
-// all-class data gradient on 64-pixel x 16 / 32-channel tiles (conv_dg16.hip, round 4): same contract; target_wgs as ggan_set_target_workgroups
+// all-class data gradient on 64-pixel x 16 / 32-channel tiles (conv_dg16.hip, round 4): same contract; target_wgs = ggan_conv_geom.plan_wgs
 int conv_dgrad_dg16(const ggan_conv_geom& g, const float* gy, GyMask m, const float* w, const float* bias, float* gx, int act,
                     float alpha, int target_wgs, void* ws, size_t ws_bytes, hipStream_t s);
 // image side with <= 4 channels (conv_thin.hip): same contract as the MFMA paths

@@ -1,5 +1,5 @@
 // C-ABI entry points of the Conv2D / Deconv2D family: argument checks + dispatch between the MFMA kernels
-// (5x5 stride-2 hot path) and the plain kernels (everything else, or ggan_set_naive(1)).
+// (5x5 stride-2 hot path) and the plain kernels (everything else, or GGAN_PLAN_PLAIN in the call's geometry).
 #include "common.h"
 #include "conv.h"
 #include <stdlib.h>
@@ -34,7 +34,7 @@ int ggan_conv2d_fwd(const ggan_conv_geom* g, const float* x, const float* w, con
     if (check_geom(g)) return -1;
     GGAN_CHECK_ARG(x && w && y, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (!g_force_naive && !getenv("GGAN_NAIVE_FWD")) {
+    if (!(g->plan_flags & GGAN_PLAN_PLAIN) && !getenv("GGAN_NAIVE_FWD")) {
         int r = conv_fwd_thin(*g, x, w, bias, y, act, alpha, s);
         if (r <= 0) return r;
         r = conv_fwd_mfma(*g, x, w, bias, y, act, alpha, ws, ws ? ws_bytes : 0, s);
@@ -51,10 +51,10 @@ static int bwd_data(const ggan_conv_geom* g, const float* gy, GyMask m, const fl
     if (getenv("GGAN_TRACE_CONV"))
         fprintf(stderr, "[ggan] bwd_data N=%d Ci=%d H=%d W=%d Co=%d Ho=%d Wo=%d pad=(%d,%d) mask=%d act=%d\n", g->N, g->Ci, g->H, g->W, g->Co, g->Ho,
                 g->Wo, g->pad_t, g->pad_l, m.act, act);
-    if (!g_force_naive && !getenv("GGAN_NAIVE_DGRAD")) {
+    if (!(g->plan_flags & GGAN_PLAN_PLAIN) && !getenv("GGAN_NAIVE_DGRAD")) {
         int r = conv_dgrad_thin(*g, gy, m, w, bias, gx, act, alpha, s);
         if (r <= 0) return r;
-        r = conv_dgrad_dg16(*g, gy, m, w, bias, gx, act, alpha, g_target_wgs, ws, ws ? ws_bytes : 0, s);
+        r = conv_dgrad_dg16(*g, gy, m, w, bias, gx, act, alpha, g->plan_wgs, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
         r = conv_dgrad_mfma(*g, gy, m, w, bias, gx, act, alpha, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
@@ -120,7 +120,7 @@ static int bwd_filter(const ggan_conv_geom* g, const float* x, const float* gy, 
     if (check_geom(g)) return -1;
     if (!(x && gy && gw)) { set_error("ggan_conv2d_bwd_filter: null pointer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    if (!g_force_naive && !getenv("GGAN_NAIVE_WGRAD")) {
+    if (!(g->plan_flags & GGAN_PLAN_PLAIN) && !getenv("GGAN_NAIVE_WGRAD")) {
         int r = conv_wgrad_thin(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
         if (r <= 0) return r;
         r = conv_wgrad_mfma(*g, x, gy, m, gw, gbias, ws, ws ? ws_bytes : 0, s);
@@ -167,7 +167,7 @@ int ggan_conv2d_bwd_filter_parts(const ggan_conv_geom* g, const float* x, const 
     if (check_geom(g)) return -1;
     GGAN_CHECK_ARG(x && gy && part && n_parts && stride, "null pointer");
     GGAN_CHECK_ARG(y || y_act == GGAN_ACT_NONE, "null activation reference");
-    if (g_force_naive || getenv("GGAN_NAIVE_WGRAD")) return 1;
+    if ((g->plan_flags & GGAN_PLAN_PLAIN) || getenv("GGAN_NAIVE_WGRAD")) return 1;
     WgradParts po{part, part_cap, with_bias, 0, 0};
     int r = conv_wgrad_thin(*g, x, gy, GyMask{y, y_act, y_alpha}, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, &po);
     if (r == 1) r = conv_wgrad_mfma(*g, x, gy, GyMask{y, y_act, y_alpha}, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, &po);
@@ -180,7 +180,7 @@ int ggan_conv2d_fwd_masked(const ggan_conv_geom* g, const float* x, const float*
                            float ref_alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
     if (check_geom(g)) return -1;
     GGAN_CHECK_ARG(x && w && y && yref, "null pointer");
-    if (g_force_naive || getenv("GGAN_NAIVE_FWD") || getenv("GGAN_NO_FWD_MASK")) return 1;
+    if ((g->plan_flags & GGAN_PLAN_PLAIN) || getenv("GGAN_NAIVE_FWD") || getenv("GGAN_NO_FWD_MASK")) return 1;
     if ((((uintptr_t)yref) & 15) != 0) return 1;
     // (thin first layers too: the padded-channel MFMA launch with the mask measured 1 % of a wali-gp iteration shorter than
     //  conv_thin.hip + act_bwd; GGAN_NO_FWD_MASK_THIN selects that pair)

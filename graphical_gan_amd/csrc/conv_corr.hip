@@ -70,6 +70,7 @@ struct CorrParams {
     int dbg;
     int dma;                      // forward kinds: stage the slab and the filter slice by LDS-DMA (buffer_load ... lds)
     int xq;                       // 4: the slab is staged in 16-byte units of image rows (forward DMA path, see plan_and_launch), else 1
+    int plan_wgs;                 // ggan_conv_geom.plan_wgs of the call (0: default)
     int nstg;                     // forward DMA path: LDS staging buffers (3: ring fetched two chunks ahead, round 4; 2: the round-2 scheme)
     const unsigned* xtab;         // forward DMA path: plan-time slab offsets [tile position][XE][NTHR] (relative to the tile's first image), or NULL
     unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
@@ -1104,7 +1105,7 @@ template <int MODE>
 int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c, int ntaps, int groups, float* dst,
                     const float* bias, int act, float alpha, void* ws, size_t ws_bytes, hipStream_t s, const char* name,
                     double fl, const char* sk_env, const char* cfg_env) {
-    const int target = g_target_wgs > 0 ? g_target_wgs : env_int("GGAN_TARGET_WGS", 200);
+    const int target = P.plan_wgs > 0 ? P.plan_wgs : env_int("GGAN_TARGET_WGS", 200);
     const WaveCfg* kCfgs = MODE == 1 ? kCfgsDgrad : kCfgsFwd;
     int cfg = env_int(cfg_env, -1);
     if (cfg < 0 || cfg > (MODE == 1 ? 7 : 8)) {
@@ -1287,6 +1288,7 @@ int conv_fwd_mfma(const ggan_conv_geom& g, const float* x, const float* w, const
     CorrParams P;
     memset(&P, 0, sizeof(P));
     P.in = x; P.w = w;
+    P.plan_wgs = g.plan_wgs;
     P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
     P.N = g.N; P.CKtot = g.Ci; P.Hin = g.H; P.Win = g.W;
     P.CNtot = g.Co; P.Hout = g.Ho; P.Wout = g.Wo;
@@ -1313,6 +1315,7 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     CorrParams P;
     memset(&P, 0, sizeof(P));
     P.in = gy; P.w = w;
+    P.plan_wgs = g.plan_wgs;
     if (m.act != GGAN_ACT_NONE && m.act != GGAN_ACT_LRELU && m.act != GGAN_ACT_RELU) return 1;   // other masks: plain kernels
     if (m.act != GGAN_ACT_NONE) { P.in_ref = m.ref; P.in_act = m.act; P.in_alpha = m.alpha; }
     P.in_bytes = (unsigned)in_bytes; P.w_bytes = (unsigned)w_bytes;
@@ -1352,7 +1355,7 @@ int conv_dgrad_mfma(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     // otherwise balanced class pairs (twice the workgroups)
     const long wgs_all = (long)cdiv(g.N * Hu * Wv, 32) * cdiv(g.Ci, 32);
     int mode = env_int("GGAN_DGRAD_MODE", 0);
-    if (mode == 0) mode = wgs_all >= (g_target_wgs > 0 ? g_target_wgs : env_int("GGAN_TARGET_WGS", 200)) ? 2 : 1;
+    if (mode == 0) mode = wgs_all >= (g.plan_wgs > 0 ? g.plan_wgs : env_int("GGAN_TARGET_WGS", 200)) ? 2 : 1;
     if (mode == 2)
         return plan_and_launch<2>(P, Hu, Wv, 1, hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, 25, 1, gx, bias, act, alpha, ws, ws_bytes,
                                   s, "conv_dgrad_mfma", fl, "GGAN_DGRAD_SK", "GGAN_DGRAD_CFG");

@@ -1,7 +1,7 @@
 // Plain one-thread-per-output HIP convolution kernels for any (k, stride, padding).
 // They serve geometries the MFMA kernels do not cover (e.g. stride-1 or VALID convolutions used
 // outside the hot path, odd MNIST widths in the filter-gradient) and as an on-device cross-check
-// (ggan_set_naive).  Same arithmetic definition as SURVEY.md A.1 / A.2.
+// (ggan_conv_geom.plan_flags & GGAN_PLAN_PLAIN).  Same arithmetic definition as SURVEY.md A.1 / A.2.
 #include "common.h"
 #include "conv.h"
 using namespace ggan;

@@ -435,8 +435,8 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     const int gx = cdiv(g.Ci, TCI), gy_ = cdiv(g.Co, TCO);
     int sk = env_int("GGAN_WGRAD_SK", 0);
     if (sk <= 0) {
-        // (a caller running two conv chains side by side asks for fewer workgroups per launch: ggan_set_target_workgroups_filter_grad)
-        const int wg_target = g_target_wgs_wgrad > 0 ? g_target_wgs_wgrad : env_int("GGAN_WGRAD_WGS", 256);
+        // (a caller running two conv chains side by side asks for fewer workgroups per launch: ggan_conv_geom.plan_wgs_filter)
+        const int wg_target = g.plan_wgs_filter > 0 ? g.plan_wgs_filter : env_int("GGAN_WGRAD_WGS", 256);
         sk = cdiv(wg_target, gx * gy_);
         if (sk > P.chunks_total / 2) sk = P.chunks_total / 2;
         if (sk > 64) sk = 64;

@@ -7,9 +7,6 @@
 namespace ggan {
 
 static thread_local char t_err[512] = "";
-bool g_force_naive = false;
-int g_target_wgs = 0;
-int g_target_wgs_wgrad = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -104,23 +101,6 @@ extern "C" {
 
 int ggan_version(void) { return 100; }
 const char* ggan_last_error(void) { return t_err; }
-int ggan_set_naive(int on) {
-    g_force_naive = on != 0;
-    return 0;
-}
-
-int ggan_set_target_workgroups(int n) {
-    const int prev = g_target_wgs;
-    g_target_wgs = n > 0 ? n : 0;
-    return prev;
-}
-
-int ggan_set_target_workgroups_filter_grad(int n) {
-    const int prev = g_target_wgs_wgrad;
-    g_target_wgs_wgrad = n > 0 ? n : 0;
-    return prev;
-}
-
 int ggan_prof_enable(int on) {
     g_prof_on = on != 0;
     return 0;

@@ -317,12 +317,8 @@ class Trainer(object):
         if not hint:
             yield
             return
-        L = F._lib.load()
-        prev = L.ggan_set_target_workgroups(int(hint))
-        try:
+        with F.launch_hint(int(hint)):
             yield
-        finally:
-            L.ggan_set_target_workgroups(prev)
 
     def _step_body_impl(self, which, nets=None, feed=None):
         st = None

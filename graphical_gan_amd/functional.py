@@ -207,7 +207,7 @@ def _bwd_target(ctx):
 
 class target_workgroups(object):
     """with target_workgroups(n): the conv ops recorded inside plan their launches -- forward AND, later, backward -- for n workgroups
-    (ggan_set_target_workgroups) instead of about one per CU: for layers of two chains that run side by side on two streams"""
+    (ggan_conv_geom.plan_wgs / plan_wgs_filter of their calls) instead of about one per CU: for layers of two chains that run side by side on two streams"""
 
     def __init__(self, n):
         self.n = int(n or 0)
@@ -219,18 +219,63 @@ class target_workgroups(object):
         _TARGET[0] = self.prev
 
 
-class _planned_for(object):
+# The launch plan of a conv call (ggan_conv_geom.plan_wgs / plan_wgs_filter / plan_flags) is per CALL: it is filled into the geometry
+# struct from this thread's current setting -- autograd runs backward nodes on worker threads, each with its own -- and the library keeps
+# no process-wide plan (round 3 review: set / launch / restore sequences on C globals interleaved between threads).
+import threading as _threading
+_PLAN = _threading.local()
+_PLAIN = [False]       # force_plain(): debug cross-check on the plain kernels (process-wide on purpose: a test switch)
+
+
+def force_plain(on):
+    """every conv call from now on asks for the plain one-thread-per-output kernels (GGAN_PLAN_PLAIN); returns the old setting"""
+    old, _PLAIN[0] = _PLAIN[0], bool(on)
+    return old
+
+
+class launch_hint(object):
+    """with launch_hint(n): forward / data-gradient launches of conv calls made inside (and not under target_workgroups) plan for n
+    workgroups; filter gradients keep their default (engine.Trainer._launch_hint: the wali-gp critic step)"""
+
     def __init__(self, n):
-        self.n = n
+        self.n = int(n or 0)
 
     def __enter__(self):
-        if self.n:
-            self.prev = (_L().ggan_set_target_workgroups(self.n), _L().ggan_set_target_workgroups_filter_grad(self.n))
+        self.prev = getattr(_PLAN, 'hint', 0)
+        _PLAN.hint = self.n
 
     def __exit__(self, *a):
+        _PLAN.hint = self.prev
+
+
+def _carries_hint(cls):
+    """conv Functions: the launch hint in force when the layer was recorded also plans its backward launches -- autograd runs backward
+    nodes on its own worker threads, where this thread's setting is not visible"""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._hint = getattr(_PLAN, 'hint', 0)
+        return fwd(ctx, *args)
+
+    def backward(ctx, *gs):
+        with launch_hint(ctx._hint):
+            return bwd(ctx, *gs)
+    cls.forward = staticmethod(forward)
+    cls.backward = staticmethod(backward)
+    return cls
+
+
+class _planned_for(object):
+    def __init__(self, n):
+        self.n = int(n or 0)
+
+    def __enter__(self):
+        self.prev = getattr(_PLAN, 'both', 0)
         if self.n:
-            _L().ggan_set_target_workgroups(self.prev[0])
-            _L().ggan_set_target_workgroups_filter_grad(self.prev[1])
+            _PLAN.both = self.n
+
+    def __exit__(self, *a):
+        _PLAN.both = self.prev
 
 
 def same_geometry(size, k, stride, padding='SAME'):
@@ -250,7 +295,8 @@ def conv_geom(N, Ci, H, W, Co, k, stride, padding='SAME'):
 
 
 def _geom(t):
-    return ConvGeom(*t)
+    both = getattr(_PLAN, 'both', 0)
+    return ConvGeom(*(tuple(t[:11]) + ((both or getattr(_PLAN, 'hint', 0)), both, _lib.PLAN_PLAIN if _PLAIN[0] else 0)))
 
 
 
@@ -339,6 +385,7 @@ def _attaching():
 DEBUG_POISON_CHECK = bool(os.environ.get('GGAN_POISON_UNWRITTEN'))
 
 
+@_carries_hint
 @_skip_undefined
 class ConvFwd(Function):
     """y = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) + bias  (tf.nn.conv2d + bias_add; also the Deconv2D data-gradient)."""
@@ -359,8 +406,8 @@ class ConvFwd(Function):
         else:
             y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
             ws = workspace(x.device)
-            g = _geom(geom)
             with _planned_for(ctx.target):
+                g = _geom(geom)
                 check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
                                            act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
             if _recording() is not None:
@@ -386,7 +433,8 @@ class ConvFwd(Function):
                 and not ctx.grad_rows and not _os.environ.get('GGAN_NO_DGRAD_MASKED')):
             # a double backward is being recorded and only the data gradient is asked for (the gradient-penalty pass): the activation
             # derivative rides in the data-gradient launch, and in its backward's launches (ConvDgradMasked)
-            return ConvDgradMasked.apply(gy, y, w, ctx.geom, ctx.act, ctx.alpha), None, None, None, None, None, None
+            with _planned_for(_bwd_target(ctx)):        # (the plan remembered for this layer's backward launches)
+                return ConvDgradMasked.apply(gy, y, w, ctx.geom, ctx.act, ctx.alpha), None, None, None, None, None, None
         if ctx.act != ACT_NONE:
             gy = ActBwd.apply(gy, y, ctx.act, ctx.alpha)       # lrelu/relu: sign(y) == sign(pre-activation)
         gx = gw = gb = None
@@ -435,6 +483,7 @@ def _fused_conv_backward(ctx, gy, x, w, y):
     return gx, gw, gb, None, None, None
 
 
+@_carries_hint
 @_skip_undefined
 class ConvDgrad(Function):
     """gx[N,Ci,H,W] = conv^T(gy[N,Co,Ho,Wo], w) + bias[Ci]  (Conv2DBackpropInput; also the Deconv2D forward)."""
@@ -452,8 +501,8 @@ class ConvDgrad(Function):
         else:
             gx = _new_out(slot, (N, Ci, H, W), gy.device)
             ws = workspace(gy.device)
-            g = _geom(geom)
             with _planned_for(ctx.target):
+                g = _geom(geom)
                 check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
                                                 _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
             if _recording() is not None:
@@ -499,6 +548,7 @@ class ConvDgrad(Function):
         return (d_gy, d_w, d_b) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
+@_carries_hint
 @_skip_undefined
 class ConvDgradMasked(Function):
     """gx = conv^T(gy * act'(yref), w): ActBwd + ConvDgrad as one differentiable op (ggan_conv2d_bwd_data_act stages gy through the
@@ -513,6 +563,7 @@ class ConvDgradMasked(Function):
         assert tuple(gy.shape) == (N, Co, Ho, Wo) == tuple(yref.shape), (gy.shape, yref.shape, geom)
         gx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=gy.device)
         ws = workspace(gy.device)
+        ctx.target = getattr(_PLAN, 'both', 0)            # (set by the layer whose backward this op is; its own backward launches follow it)
         g = _geom(geom)
         check(_L().ggan_conv2d_bwd_data_act(C.byref(g), _p(gy), _p(yref), act, alpha, _p(w), _p(gx), _p(ws), ws.numel(), _stream()),
               'ggan_conv2d_bwd_data_act')
@@ -535,7 +586,8 @@ class ConvDgradMasked(Function):
             return d_gy, None, d_w, None, None, None
         h = _c(h)
         N, Ci, H, W, Co, Ho, Wo, k = geom[:8]
-        g = _geom(geom)
+        with _planned_for(ctx.target):
+            g = _geom(geom)
         L, ws = _L(), workspace(h.device)
         if ctx.needs_input_grad[0]:
             d_gy = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=h.device)
@@ -561,6 +613,7 @@ class ConvDgradMasked(Function):
         return d_gy, None, d_w, None, None, None
 
 
+@_carries_hint
 @_skip_undefined
 class ConvWgrad(Function):
     """gw[k,k,Ci,Co] = sum_n,oh,ow x (*) gy  (Conv2DBackpropFilter)."""

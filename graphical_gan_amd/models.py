@@ -102,7 +102,7 @@ class GraphicalGAN(object):
                                                 (self.cfg.mode == 'wali-gp' and not os.environ.get('GGAN_NO_SECOND_LEAF')))
 
     def launch_hint(self, which):
-        """workgroups per conv launch the step should plan for (engine.Trainer._step_body -> ggan_set_target_workgroups), 0 = default:
+        """workgroups per conv launch the step should plan for (engine.Trainer._step_body -> functional.launch_hint -> ggan_conv_geom.plan_wgs), 0 = default:
         128 in wali-gp critic steps while a step graph is built -- there the penalty pass runs beside the [fake; real] pass, and launches
         of ~128 workgroups let the two chains run on different CUs (measured -1 % of the iteration even with the generator step, which
         wants the default, planned the same way; GGAN_NO_LAUNCH_HINT)"""

@@ -36,18 +36,6 @@ enum { GGAN_ACT_NONE = 0, GGAN_ACT_LRELU = 1, GGAN_ACT_RELU = 2, GGAN_ACT_TANH =
 
 int ggan_version(void);
 const char* ggan_last_error(void);
-/* 0: MFMA kernels (default); 1: force the plain one-thread-per-output HIP kernels (debug cross-check). */
-int ggan_set_naive(int on);
-/* How many workgroups a conv launch plans for (tile size / split-K choice of the MFMA kernels): default 200, about one per CU, which is
- * what a launch running alone wants.  A caller that runs TWO chains of conv launches side by side on two streams (the wali-gp critic
- * step: gradient-penalty pass beside the [fake; real] pass) asks for ~128, so that each launch leaves CUs to the other chain.
- * n <= 0 restores the default; returns the previous setting.  Process-wide, read when a launch is planned. */
-int ggan_set_target_workgroups(int n);
-/* the same for the filter-gradient kernels (default 256 split-K workgroups): a separate setting, because the optimum differs -- the
- * generator / extractor passes of a step (64 images, two chains side by side) want 128 for both, the wali-gp critic step (128-image
- * filter gradients of the main pass beside the penalty pass) wants the default here. */
-int ggan_set_target_workgroups_filter_grad(int n);
-
 /* ---- convolution geometry ------------------------------------------------------------------
  * A strided cross-correlation y[N,Co,Ho,Wo] = conv(x[N,Ci,H,W], w[k,k,Ci,Co]) with explicit
  * top/left padding (TF 'SAME' puts the extra row/col at the bottom/right -- SURVEY.md A.1; the
@@ -56,7 +44,16 @@ typedef struct {
     int N, Ci, H, W;      /* the LARGE-spatial tensor (conv input / deconv output)  */
     int Co, Ho, Wo;       /* the SMALL-spatial tensor (conv output / deconv input)  */
     int k, stride, pad_t, pad_l;
+    /* The launch plan travels with the call (round 4: these were process-wide setters; the library keeps no mutable state besides the
+     * guarded profiler table and the caches of plan-time tables, so calls from several threads / streams do not interfere):
+     *   plan_wgs         workgroups the forward / data-gradient launch plans for (tile size, split-K); 0 = default (GGAN_TARGET_WGS or
+     *                    200, about one per CU: right for a launch that has the chip to itself).  A caller running TWO conv chains side
+     *                    by side on two streams asks for ~128, so that each launch leaves CUs to the other chain.
+     *   plan_wgs_filter  the same for the filter-gradient launch (0 = GGAN_WGRAD_WGS or 256 split-K workgroups)
+     *   plan_flags       GGAN_PLAN_PLAIN: the plain one-thread-per-output kernels (debug cross-check) */
+    int plan_wgs, plan_wgs_filter, plan_flags;
 } ggan_conv_geom;
+#define GGAN_PLAN_PLAIN 1
 
 /* tf.nn.conv2d(NCHW) + tf.nn.bias_add (tflib/ops/conv2d.py:106-120).  bias may be NULL.
  * act/alpha: optional fused pointwise epilogue (GGAN_ACT_NONE for reference behaviour). */

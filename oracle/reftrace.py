@@ -69,14 +69,17 @@ def det_batch(stream, index, spec):
     raise ValueError(spec)
 
 
-def sample_positions(name, size):
-    return _rs('s', name).randint(0, max(int(size), 1), size=SAMPLES)
+FINAL_SAMPLES = 64      # entries kept of every tensor of the weights after the last run (round 4: the trajectory criterion needs entries, not a norm)
 
 
-def digest(name, a):
-    """[L2 norm, max |a|, SAMPLES entries at fixed positions] of a tensor (float64)."""
+def sample_positions(name, size, count=SAMPLES):
+    return _rs('s', name).randint(0, max(int(size), 1), size=count)
+
+
+def digest(name, a, count=SAMPLES):
+    """[L2 norm, max |a|, `count` entries at fixed positions] of a tensor (float64)."""
     a = np.asarray(a, dtype=np.float64).ravel()
     if a.size == 0:
-        return [0.0, 0.0] + [0.0] * SAMPLES
-    pos = sample_positions(name, a.size)
+        return [0.0, 0.0] + [0.0] * count
+    pos = sample_positions(name, a.size, count)
     return [float(np.sqrt((a * a).sum())), float(np.abs(a).max())] + [float(a[p]) for p in pos]

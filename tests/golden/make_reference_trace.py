@@ -319,7 +319,7 @@ def trace_case(script, mode, extra):
           if k in glob and isinstance(glob[k], (int, float, bool))}
     return dict(constants={k: v for k, v in consts.items()}, script_constants=sc, params={v.name: list(v.value.shape) for v in g.variables},
                 optimizers=optimizer_records(g), critic_iters=glob.get('CRITIC_ITERS'), runs=runs,
-                final={v.name: RT.digest(v.name, v.value) for v in g.variables},
+                final={v.name: RT.digest(v.name, v.value, RT.FINAL_SAMPLES) for v in g.variables},
                 random_nodes=[[n.id, n.attrs['rkind'], list(n.attrs['rshape'])] for n in g.nodes if n.kind == 'random'],
                 seconds=round(time.time() - t0, 1))
 

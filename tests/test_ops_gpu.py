@@ -36,10 +36,10 @@ def _t(a, dev):
 
 @pytest.fixture(params=[0, 1], ids=['mfma', 'naive'])
 def naive(request, gpu):
-    from graphical_gan_amd import _lib
-    _lib.load().ggan_set_naive(request.param)
+    from graphical_gan_amd import functional as F
+    F.force_plain(request.param)
     yield request.param
-    _lib.load().ggan_set_naive(0)
+    F.force_plain(0)
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
@@ -1318,7 +1318,7 @@ def test_gradient_penalty_one_launch_forward_and_unit_gradient(gpu, B, D):
 @pytest.mark.parametrize('case', [(64, 64, 16, 128), (64, 128, 8, 256), (64, 32, 32, 64), (128, 64, 16, 128), (64, 3, 32, 64)])
 @pytest.mark.parametrize('target', [128, 100])
 def test_conv_family_planned_for_fewer_workgroups(gpu, case, target):
-    """functional.target_workgroups / ggan_set_target_workgroups[_filter_grad]: the tile and split-K choices a layer makes when it is
+    """functional.target_workgroups -> ggan_conv_geom.plan_wgs / plan_wgs_filter: the tile and split-K choices a layer makes when it is
     one of two conv chains running side by side (Generator / Extractor passes, wali-gp critic steps) -- other template instances and
     splits than the default plan at the same shapes, so: forward, data gradient (also as Deconv2D forward) and filter gradient against
     the float64 oracle again, through the autograd path that remembers the setting for the backward launches."""
@@ -1339,8 +1339,7 @@ def test_conv_family_planned_for_fewer_workgroups(gpu, case, target):
         tg = _t(gy, gpu).requires_grad_(True)
         tw2 = _t(w, gpu).requires_grad_(True)
         dx = F.ConvDgrad.apply(tg, tw2, None, geom, F.ACT_NONE, 0.0)          # Deconv2D forward
-    L = _lib.load()
-    assert L.ggan_set_target_workgroups(0) == 0 and L.ggan_set_target_workgroups_filter_grad(0) == 0      # nothing left set
+    assert F._geom(geom).plan_wgs == 0 and F._geom(geom).plan_wgs_filter == 0      # nothing left set outside the context
     assert _rel(y.detach().cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < 2e-5
     assert _rel(dx.detach().cpu().numpy(), O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME')) < 2e-5
     with torch.no_grad():
@@ -1351,7 +1350,7 @@ def test_conv_family_planned_for_fewer_workgroups(gpu, case, target):
     dg, dw2 = torch.autograd.grad(dx, [tg, tw2], grad_outputs=_t(x, gpu))      # Deconv2D backward: forward conv + filter gradient
     assert _rel(dg.cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < 2e-5
     assert _rel(dw2.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < 2e-5
-    assert L.ggan_set_target_workgroups(0) == 0 and L.ggan_set_target_workgroups_filter_grad(0) == 0
+    assert F._geom(geom).plan_wgs == 0 and F._geom(geom).plan_wgs_filter == 0
 
 
 DG16_CASES = [  # (N, Ci, H, Co): data gradient gy [N, Co, H/2, H/2] -> gx [N, Ci, H, H]

@@ -182,7 +182,7 @@ def test_restatement_reproduces_the_reference_run(key):
             assert close(RT.digest(n, g), rec['grads'][n], 1e-7, 1e-11), (key, r['run'], which, n, RT.digest(n, g)[:2], rec['grads'][n][:2])
         opt.apply(tr.P, grads)
     for n, dg in t['final'].items():
-        assert close(RT.digest(n, tr.P[n]), dg, 1e-8, 1e-10), (key, 'final', n)
+        assert close(RT.digest(n, tr.P[n], RT.FINAL_SAMPLES), dg, 1e-8, 1e-10), (key, 'final', n)
 
 
 def ss_case(key):
@@ -254,4 +254,4 @@ def test_state_space_restatement_reproduces_the_reference_run(key):
             assert close(RT.digest(n, grads[n]), rec['grads'][n], 1e-7, 1e-11), (key, r['run'], which, n)
         opt.apply(tr.P, grads)
     for n, dg in t['final'].items():
-        assert close(RT.digest(n, tr.P[n]), dg, 1e-8, 1e-10), (key, 'final', n)
+        assert close(RT.digest(n, tr.P[n], RT.FINAL_SAMPLES), dg, 1e-8, 1e-10), (key, 'final', n)

@@ -138,10 +138,23 @@ def test_hip_path_replays_the_reference_run(gpu, key):
     for n, dg in t['final'].items():
         if n in gscale and gscale[n] < 1e-9 * gall:
             continue                                     # mathematically zero gradient (a bias in front of a BatchNorm): Adam random-walks it on rounding noise
-        mine = RT.digest(n, P[n])
-        # weights moved by at most lr per Adam step; fp32 noise in tiny gradients can flip an entry's step: compare the norm
-        assert abs(mine[0] - dg[0]) <= 1e-4 * max(dg[0], 1e-3) + 1e-6, (key, n, mine[0], dg[0])
+        _final_check(key, n, P[n], dg, t['params'][n])
     _fresh()
+
+
+def _final_check(key, name, mine, ref_digest, shape):
+    """Weights after the last run against the reference's (round-3 review: one scalar per tensor was too little).  Relative to what
+    the runs did to the tensor, on the FINAL_SAMPLES entries the trace keeps: ||P - P_ref|| <= 0.02 ||P_ref - P_0|| + an fp32 floor
+    (P_0 = the trace's deterministic start), as tests/test_step_gpu.py::test_trajectory does against the oracle; the norm as before."""
+    m = RT.digest(name, mine, RT.FINAL_SAMPLES)
+    assert abs(m[0] - ref_digest[0]) <= 1e-4 * max(ref_digest[0], 1e-3) + 1e-6, (key, name, m[0], ref_digest[0])
+    w0 = RT.det_weight(name, shape, np.float32).astype(np.float64).ravel()
+    pos = RT.sample_positions(name, w0.size, RT.FINAL_SAMPLES)
+    ref, got, start = np.asarray(ref_digest[2:]), np.asarray(m[2:]), w0[pos]
+    upd = np.linalg.norm(ref - start)
+    err = np.linalg.norm(got - ref)
+    floor = 4e-7 * (np.abs(ref).max() + 1e-3) * np.sqrt(len(pos))
+    assert err <= 0.02 * upd + floor, (key, name, 'entries', err, upd, err / max(upd, 1e-30))
 
 
 @pytest.mark.parametrize('key', RC.SS_KEYS)
@@ -198,6 +211,5 @@ def test_hip_path_replays_the_state_space_reference_run(gpu, key):
     for n, dg in t['final'].items():
         if n in gscale and gscale[n] < 1e-9 * gall:
             continue
-        mine = RT.digest(n, P[n])
-        assert abs(mine[0] - dg[0]) <= 1e-4 * max(dg[0], 1e-3) + 1e-6, (key, n, mine[0], dg[0])
+        _final_check(key, n, P[n], dg, t['params'][n])
     _fresh()
