@@ -1425,3 +1425,24 @@ def test_dg16_agrees_with_the_class_kernels_at_full_size(gpu, case, monkeypatch)
         out[on] = (F.ConvDgrad.apply(gy, w, None, geom, F.ACT_NONE, 0.0), F.ConvDgradMasked.apply(gy, yref, w, geom, F.ACT_LRELU, 0.2))
     for a, b2 in zip(out['1'], out['0']):
         assert float((a - b2).abs().max() / b2.abs().max()) < 5e-6
+
+
+def test_tf_published_conv2d_transpose_known_answer(gpu):
+    """TensorFlow's own conv2d_transpose test (conv2d_transpose_test.py::testConv2DTransposeSame, ones [2,6,4,3] x ones [3,3,2,3], stride 2,
+    SAME -> 3 / 6 / 12 by how many of (h, w) are positive multiples of the stride) through the C ABI, and its 5x5 counterpart -- the
+    reference's filter size (tflib/ops/deconv2d.py:101-107) -- where the same count is taps kh = h + 1 - 2 i inside [0, 5)."""
+    from graphical_gan_amd import functional as F
+    for k, Cin, Cout, H, W in ((3, 3, 2, 6, 4), (5, 3, 2, 6, 4), (5, 16, 16, 8, 8)):
+        x = np.ones((2, Cin, H, W), np.float32)
+        w = np.ones((k, k, Cout, Cin), np.float32)
+        geom = F.conv_geom(2, Cout, 2 * H, 2 * W, Cin, k, 2, 'SAME')
+        y = F.ConvDgrad.apply(_t(x, gpu), _t(w, gpu), None, geom, F.ACT_NONE, 0.0).cpu().numpy()
+        pad = (k - 2) // 2                       # SAME: total k - 2, the smaller half in front
+        cnt = lambda o, n: sum(1 for kk in range(k) if (o + pad - kk) % 2 == 0 and 0 <= (o + pad - kk) // 2 < n)
+        ref = np.array([[Cin * cnt(h, H) * cnt(ww, W) for ww in range(2 * W)] for h in range(2 * H)], np.float64)
+        if k == 3:                               # the published statement itself
+            for h in range(2 * H):
+                for ww in range(2 * W):
+                    hi, wi = h % 2 == 0 and h > 0, ww % 2 == 0 and ww > 0
+                    assert ref[h, ww] == 3.0 + (9.0 if hi and wi else 3.0 if hi or wi else 0.0)
+        assert np.array_equal(y, np.broadcast_to(ref, y.shape)), (k, Cin, Cout)

@@ -309,3 +309,73 @@ def test_aggregated_divergence_oracle_known_answers_and_finite_differences(kind)
             ap[idx] += 1e-6; am[idx] -= 1e-6
             fd = (float((f(ap, sd) if which == 0 else f(mu, ap)).v) - float((f(am, sd) if which == 0 else f(mu, am)).v)) / 2e-6
             assert abs(fd - g.v[idx]) <= 1e-6 * max(1.0, abs(fd)), (kind, which, idx, fd, g.v[idx])
+
+
+# ---- known answers TensorFlow itself publishes for the primitives the reference selects (round-3 review, missing #3).  The oracle's
+#      TF-primitive arithmetic cannot be pinned by running TensorFlow here (absent; the shim binds tf.nn.* to the oracle's own ops), so
+#      these are the numeric statements of TensorFlow's documentation and its own unit tests, restated -- labelled "TF-published". ----
+def test_tf_published_conv2d_transpose_same_stride2_ones():
+    """tensorflow/python/kernel_tests/nn_ops/conv2d_transpose_test.py::testConv2DTransposeSame: x = ones [2, 6, 4, 3] (NHWC), filter =
+    ones [3, 3, out 2, in 3], strides 2, SAME, output [2, 12, 8, 2]: every output is 3 (the input depth), +3 where exactly one of
+    (h, w) is a positive multiple of the stride, +9 where both are.  (tflib/ops/deconv2d.py:101-107 calls this op.)"""
+    x = np.ones((2, 3, 6, 4))                       # NCHW here
+    w = np.ones((3, 3, 2, 3))                       # [kh, kw, out, in]
+    y = O.deconv2d(x, w, stride=2, padding='SAME')
+    assert y.shape == (2, 2, 12, 8)
+    for h in range(12):
+        for ww in range(8):
+            target = 3.0
+            h_in = h % 2 == 0 and 0 < h < 12
+            w_in = ww % 2 == 0 and 0 < ww < 8
+            if h_in and w_in:
+                target += 9.0
+            elif h_in or w_in:
+                target += 3.0
+            assert np.all(y[:, :, h, ww] == target), (h, ww, y[0, 0, h, ww], target)
+
+
+def test_tf_published_conv2d_same_padding_rule():
+    """TensorFlow's documented SAME rule (tf.nn.convolution, "Padding" notes): out = ceil(in / stride), total padding
+    max((out - 1) * stride + k - in, 0), the smaller half in front -- so a 5x5 / stride-2 conv of an all-ones 4x4 image with an all-ones
+    filter counts the taps inside the image: rows/cols covered from offset -1 (pad_top = 1, pad_bottom = 2)."""
+    assert O.conv_geometry(4, 5, 2, 'SAME')[:2] == (2, 1) and O.conv_geometry(7, 5, 2, 'SAME')[:2] == (4, 2)
+    y = O.conv2d(np.ones((1, 1, 4, 4)), np.ones((5, 5, 1, 1)), 2, 'SAME')[0, 0]
+    # output (0,0): window rows -1..3 -> 4 inside; output (1,1): window rows 1..5 -> 3 inside
+    assert np.array_equal(y, np.array([[16., 12.], [12., 9.]]))
+
+
+def test_tf_published_fused_batch_norm_training_formula():
+    """nn_fused_batchnorm_test.py::_training_ref / the tf.nn.fused_batch_norm documentation: y = (x - mean) / sqrt(var + epsilon) *
+    scale + offset with mean and the BIASED variance taken over N, H, W (the Bessel-corrected variance is only what the op RETURNS for
+    the moving average, which the scripts never use).  (tflib/ops/batchnorm.py:30.)"""
+    x = np.arange(2 * 2 * 1 * 2, dtype=np.float64).reshape(2, 2, 1, 2)        # channel 0: {0,1,4,5}, channel 1: {2,3,6,7}
+    y = O.batchnorm_train(x, np.array([2.0, 0.5]), np.array([1.0, -1.0]), (0, 2, 3), eps=0.001)
+    m0, v0 = 2.5, ((2.5 ** 2 + 1.5 ** 2) * 2) / 4                               # mean 2.5, biased variance 4.25
+    assert abs(y[0, 0, 0, 0] - ((0 - m0) / np.sqrt(v0 + 0.001) * 2.0 + 1.0)) < 1e-14
+    assert abs(y[1, 1, 0, 1] - ((7 - 4.5) / np.sqrt(v0 + 0.001) * 0.5 - 1.0)) < 1e-14
+
+
+def test_tf_published_adam_update_rule():
+    """tf.train.AdamOptimizer docstring: t <- t + 1; lr_t <- learning_rate * sqrt(1 - beta2^t) / (1 - beta1^t); m_t <- beta1 * m +
+    (1 - beta1) * g; v_t <- beta2 * v + (1 - beta2) * g * g; variable <- variable - lr_t * m_t / (sqrt(v_t) + epsilon) -- the
+    "epsilon hat" form, two steps by hand.  (tflib/objs/gan_inference.py:108-117.)"""
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    th, m, v = 1.0, 0.0, 0.0
+    T, M, V = np.array([1.0]), np.zeros(1), np.zeros(1)
+    for t, g in ((1, 0.5), (2, -0.25)):
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        th = th - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+        T, M, V = O.adam_update(T, np.array([g]), M, V, t, lr, b1, b2, eps)
+        assert abs(T[0] - th) < 1e-15
+
+
+def test_tf_published_sigmoid_cross_entropy_formula():
+    """tf.nn.sigmoid_cross_entropy_with_logits documentation: z * -log(sigmoid(x)) + (1 - z) * -log(1 - sigmoid(x)), evaluated as
+    max(x, 0) - x * z + log(1 + exp(-abs(x))).  (tflib/objs/gan_inference.py:104-117.)"""
+    x = np.array([-30.0, -2.0, 0.0, 0.5, 40.0])
+    for z in (0.0, 1.0, 0.3):
+        s = 1.0 / (1.0 + np.exp(-x[1:4]))
+        direct = z * -np.log(s) + (1 - z) * -np.log(1 - s)
+        assert np.abs(O.bce_with_logits(x, z)[1:4] - direct).max() < 1e-14
+    assert abs(O.bce_with_logits(np.array([40.0]), 0.0)[0] - 40.0) < 1e-12 and O.bce_with_logits(np.array([-30.0]), 0.0)[0] < 1e-12
