@@ -289,13 +289,17 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
 
     tr.flush()
     fence()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(steps):
-        last = tr.iteration(it, bi); it += 1
-    tr.flush()                                         # (DP: the last critic step's exchange + Adam belong to the timed work)
-    fence()
-    dt = time.perf_counter() - t0
+    import contextlib
+    # (--no-graph, the mode the rocprofv3 --pmc passes run in: eager steps on the launch plan of the graphs, so that the counters see the
+    #  timed configuration's kernel mix -- the forked nets passes and their 128-workgroup plans)
+    with (tr.eager_as_captured() if args.no_graph else contextlib.nullcontext()):
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = tr.iteration(it, bi); it += 1
+        tr.flush()                                         # (DP: the last critic step's exchange + Adam belong to the timed work)
+        fence()
+        dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

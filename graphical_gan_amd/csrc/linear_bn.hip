@@ -136,9 +136,15 @@ extern "C" int ggan_linear_bn_rows_fwd(const float* x, const float* w, const flo
     hipStream_t s = (hipStream_t)stream;
     const double fl = 2.0 * M * K * (double)N, bytes = 4.0 * ((double)M * K + (double)K * N + 2.0 * M * N);
     static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!once) {      // (every instantiation: a request above the 64 KB default must not depend on which row count came first)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
     const dim3 grid(N / LB_COLS), block(LB_THR);
@@ -153,5 +159,5 @@ extern "C" int ggan_linear_bn_rows_fwd(const float* x, const float* w, const flo
         case 8: GGAN_LAUNCH("linear_bn_rows_k", fl, bytes, linear_bn_rows_k<8>, grid, block, shmem, s, P); break;
         default: return 1;
     }
-    return 0;
+    return 0;     // (GGAN_LAUNCH checks the launch: a refused one returns -2 with the error text)
 }

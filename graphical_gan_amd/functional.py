@@ -1204,10 +1204,16 @@ class LinearBatchNormRows(Function):
 
     @staticmethod
     def usable(x, w):
+        """mirrors the limits of ggan_linear_bn_rows_fwd (linear_bn.hip): whole minibatch in one workgroup's LDS -- x [M, K + 4], the weight
+        slice [K, 32] and the row-group partials must fit 160 KB (M = 128 with K >= 252 does not) -- rows in 16 equal groups, 16-byte
+        aligned operands; anything else takes Linear + Batchnorm"""
+        if x.dim() != 2 or _os.environ.get('GGAN_NO_LINEAR_BN'):
+            return False
         M, K = x.shape
         N = w.shape[1]
-        return (x.dim() == 2 and M <= 128 and M % 16 == 0 and K <= 256 and K % 4 == 0 and N % 32 == 0 and x.is_contiguous()
-                and not _os.environ.get('GGAN_NO_LINEAR_BN'))
+        lds = (M * (K + 4) + K * 32 + 16 * 32) * 4
+        return (M <= 128 and M % 16 == 0 and K <= 256 and K % 4 == 0 and N % 32 == 0 and x.is_contiguous() and w.is_contiguous()
+                and lds <= 160 * 1024 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
     @staticmethod
     def forward(ctx, x, w, b, scale, offset, eps, act, alpha):

@@ -1446,3 +1446,25 @@ def test_tf_published_conv2d_transpose_known_answer(gpu):
                     hi, wi = h % 2 == 0 and h > 0, ww % 2 == 0 and ww > 0
                     assert ref[h, ww] == 3.0 + (9.0 if hi and wi else 3.0 if hi or wi else 0.0)
         assert np.array_equal(y, np.broadcast_to(ref, y.shape)), (k, Cin, Cout)
+
+
+@pytest.mark.parametrize('M,K,N', [(128, 256, 64), (128, 252, 64), (64, 256, 64)])
+def test_linear_batchnorm_rows_layer_falls_back_where_the_kernel_cannot(gpu, M, K, N):
+    """tflib.ops.linear.LinearBatchnormRows at shapes around the one-launch kernel's LDS limit (advisor finding, round 3: batch 128 with a
+    256-wide latent needs 167,936 B of LDS; usable() used to say yes and the layer raised): usable() mirrors the C-side limits, the layer
+    takes Linear + Batchnorm there, and the result is the oracle's either way."""
+    import torch
+    from graphical_gan_amd import functional as F, tflib as lib
+    from oracle import ops as O
+    lib.delete_all_params()
+    rng = np.random.default_rng(M + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    tx = torch.as_tensor(x).to(gpu)
+    np.random.seed(3)
+    y = lib.ops.linear.LinearBatchnormRows('T.Input', K, N, tx, 'T.BN', activation=F.ACT_RELU)
+    w = lib.param('T.Input.W', None).detach().cpu().numpy().astype(np.float64)
+    lds = (M * (K + 4) + K * 32 + 16 * 32) * 4
+    assert F.LinearBatchNormRows.usable(tx, lib.param('T.Input.W', None)) == (lds <= 160 * 1024)
+    ref = np.maximum(O.batchnorm_train(x.astype(np.float64) @ w, np.ones(N), np.zeros(N), (0,)), 0.0)
+    assert np.abs(y.detach().cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    lib.delete_all_params()
