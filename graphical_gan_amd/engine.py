@@ -19,6 +19,7 @@ import torch.distributed as dist
 
 from . import tflib as lib
 from . import functional as F
+from . import optim as _optim
 from .models import GraphicalGAN
 
 
@@ -336,10 +337,12 @@ class Trainer(object):
             if st is not None:
                 opt, cost = st['opt'], st['cost']
                 w1 = opt.all_reduce(async_op=True, lo=0, hi=st['off'])
+                _optim._xlog('backward', 'Extractor')
                 keep = (st['keep'], self._bwd_phase2(st), st, nets)
                 w2 = opt.all_reduce(async_op=True, lo=st['off'], hi=None)
                 for w in (w1, w2):
                     if w is not None:
+                        _optim._xlog('wait')
                         w.wait()
             else:
                 cost, opt, keep = self._fwd_bwd(which, nets, feed=feed)
@@ -379,11 +382,13 @@ class Trainer(object):
             g = torch.autograd.grad(op.cost, list(opt.params[k:]) + [cut], grad_outputs=opt._one, allow_unused=True)
             keep_a = opt.pack_subset(g[:-1], k, len(opt.params), bump=True)
             w1 = opt.all_reduce(async_op=True, lo=off, hi=None)
+            _optim._xlog('backward', 'critic conv stack')
             g2 = torch.autograd.grad([cut], opt.params[:k], grad_outputs=[g[-1]], allow_unused=True)
             keep_b = opt.pack_subset(g2, 0, k, bump=False)
             w2 = opt.all_reduce(async_op=True, lo=0, hi=off)
         for w in (w1, w2):
             if w is not None:
+                _optim._xlog('wait')
                 w.wait()
         return out['disc_cost'].detach(), opt, (keep_a, keep_b, g, g2, out)
 

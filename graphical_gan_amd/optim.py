@@ -27,6 +27,18 @@ def layout_slots(sizes, align=_ALIGN):
     return slots, off
 
 
+# Issue-order log of a step's gradient exchange (tests, tools/dp_one_rank_check.py): when a list is installed here, the optimizer appends
+# what it enqueues -- ('pack', lo, hi) gradient ranges written into the flat bucket (parameter indices), ('exchange', lo, hi, async) the
+# all-reduce of flat[lo:hi] handed to the communicator, ('update',) the Adam launch -- and the engine adds ('backward', what) / ('wait',)
+# marks.  What overlaps what is decided by this order (the exchange runs on the communicator's stream from the point it is issued).
+EXCHANGE_LOG = [None]
+
+
+def _xlog(*ev):
+    if EXCHANGE_LOG[0] is not None:
+        EXCHANGE_LOG[0].append(tuple(ev))
+
+
 class GradBucket(object):
     """The data-parallel exchange step: ONE sum-all-reduce of a flat gradient buffer per optimizer step
     (SURVEY.md 8e).  Every replica holds the full model and an equal-size local minibatch, so
@@ -47,6 +59,7 @@ class GradBucket(object):
         if _os.environ.get('GGAN_SKIP_ALLREDUCE'):        # measurement only (bench.py: a step without its exchange; replicas drift apart)
             return None
         if self.world > 1 or (_os.environ.get('GGAN_FORCE_ALLREDUCE') and dist.is_available() and dist.is_initialized()):
+            _xlog('exchange', int(lo), int(hi) if hi is not None else int(self.flat.numel()), bool(async_op))
             buf = self.flat if (lo == 0 and hi is None) else self.flat[lo:hi]
             from . import rccl
             comm = rccl.get(create=False) if buf.is_cuda else None
@@ -127,6 +140,7 @@ class AdamOptimizer(object):
         it, the update is applied by the pack launch and the following update() call does nothing"""
         cc = lambda g: None if g is None else (g if g.is_contiguous() else g.contiguous())
         gs = [(cc(g[0]), cc(g[1])) if isinstance(g, tuple) else cc(g) for g in grads]
+        _xlog('pack', 0, len(self.params))
         self._updated = False            # (a fused pack whose update() call never came must not swallow the next one)
         if fuse_update and self.can_fuse_update():
             if self._arrive is None:
@@ -152,6 +166,7 @@ class AdamOptimizer(object):
         return k, self.slots[k][0]
 
     def pack_subset(self, grads, lo, hi, bump):
+        _xlog('pack', int(lo), int(hi))
         self._updated = False
         gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
         F.pack_(gs, self.slots[lo:hi], self.g, bump=self.step if bump else None)
@@ -160,7 +175,9 @@ class AdamOptimizer(object):
     def update(self):
         if self._updated:            # applied by the pack launch (pack(fuse_update=True))
             self._updated = False
+            _xlog('update', 'in the pack launch')
             return
+        _xlog('update')
         F.adam_step_(self.theta, self.g, self.m, self.v, self.step, self.lr, self.beta1, self.beta2, self.eps,
                      self.bucket.scale, counted=True)
 

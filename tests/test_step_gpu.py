@@ -517,12 +517,17 @@ def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
 
 def test_in_graph_exchange_two_buckets_one_rank_bit_identical(gpu):
     """tools/dp_one_rank_check.py: six one-graph iterations with the gradient exchange inside the graph (one rank over RCCL) --
-    generator step and critic step in two buckets each, the same with GGAN_ONE_BUCKET=1, and no exchange at all -- end in
-    bit-identical weights (the bucket boundaries only decide WHEN a gradient range is summed over the replicas)."""
-    import os, subprocess, sys
+    critic step in two buckets (generator step in one: the default), both in two (GGAN_GEN_TWO_BUCKETS=1), everything in one
+    (GGAN_ONE_BUCKET=1), and no exchange at all -- end in bit-identical weights (the bucket boundaries only decide WHEN a gradient range
+    is summed over the replicas).  And the ISSUE ORDER of the captured iteration (optim.EXCHANGE_LOG), which is what decides the overlap:
+    a bucket's all-reduce is handed to the communicator's stream before the part of the backward pass it is meant to run under is issued,
+    the update is issued after the waits for every bucket of its step (round-3 review: assert the structure, not only the sums)."""
+    import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sums = []
-    for i, extra in enumerate((dict(GGAN_FORCE_ALLREDUCE='1'), dict(GGAN_FORCE_ALLREDUCE='1', GGAN_ONE_BUCKET='1'), dict())):
+    sums, logs = [], []
+    cases = (dict(GGAN_FORCE_ALLREDUCE='1'), dict(GGAN_FORCE_ALLREDUCE='1', GGAN_GEN_TWO_BUCKETS='1'),
+             dict(GGAN_FORCE_ALLREDUCE='1', GGAN_ONE_BUCKET='1'), dict())
+    for i, extra in enumerate(cases):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra)
         r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
                             '127.0.0.1', '--master-port', str(29300 + (os.getpid() % 200) + i), os.path.join(root, 'tools', 'dp_one_rank_check.py'),
@@ -531,7 +536,36 @@ def test_in_graph_exchange_two_buckets_one_rank_bit_identical(gpu):
         assert r.returncode == 0 and line, (r.stdout[-500:], r.stderr[-2000:])
         assert ('dp_graph=True' in line[0]) == bool(extra) and 'one_graph=True' in line[0], line[0]
         sums.append(line[0].split()[-1])
-    assert sums[0] == sums[1] == sums[2], sums
+        logs.append([tuple(e) for e in json.loads([l for l in r.stdout.splitlines() if l.startswith('XLOG')][0][5:])])
+    assert sums[0] == sums[1] == sums[2] == sums[3], sums
+
+    def steps_of(log):
+        """the captured iteration = the last two steps of the log (generator step, critic step), each ending with its update"""
+        ends = [i for i, e in enumerate(log) if e[0] == 'update']
+        assert len(ends) >= 2
+        a = ends[-3] + 1 if len(ends) >= 3 else 0
+        return log[a:ends[-2] + 1], log[ends[-2] + 1:ends[-1] + 1]
+
+    def kinds(step):
+        return [e[0] if e[0] != 'exchange' else ('exchange_async' if e[3] else 'exchange') for e in step]
+    one = ['pack', 'exchange', 'update']
+    two = lambda what: ['pack', 'exchange_async', 'backward', 'pack', 'exchange_async', 'wait', 'wait', 'update']
+    # default: generator step one bucket, critic step two (tail first: it is on the wire while the conv stack's backward pass is issued)
+    g, d = steps_of(logs[0])
+    assert kinds(g) == one and kinds(d) == two('critic'), (g, d)
+    assert d[2] == ('backward', 'critic conv stack')
+    (_, lo_a, hi_a, _), (_, lo_b, hi_b, _) = d[1], d[4]
+    assert lo_b == 0 and hi_b == lo_a and hi_a > lo_a > 0               # tail bucket [off, total) first, then the conv stack's [0, off)
+    assert d[0][1] > 0 and d[3][1] == 0 and d[3][2] == d[0][1]          # parameters [k, n) packed before [0, k)
+    # both steps in two buckets: the Generator's bucket goes out before the Extractor's backward pass is issued
+    g, d = steps_of(logs[1])
+    assert kinds(g) == two('gen') and g[2] == ('backward', 'Extractor') and kinds(d) == two('critic'), (g, d)
+    assert g[1][1] == 0 and g[4][1] == g[1][2] and g[4][2] > g[4][1]
+    # one bucket everywhere / no exchange at all
+    g, d = steps_of(logs[2])
+    assert kinds(g) == one and kinds(d) == one
+    g, d = steps_of(logs[3])
+    assert kinds(g) == ['pack', 'update'] and kinds(d) == ['pack', 'update']
 
 
 def test_direct_rccl_communicator_eager_and_captured(gpu):

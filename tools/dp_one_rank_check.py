@@ -19,12 +19,21 @@ b = iter(ring * 40)
 for it in range(2):
     tr.iteration(it, b)
 tr.use_ring(ring)
+from graphical_gan_amd import optim as _optim
 for it in range(2, 8):
+    if it == 7:
+        tr._iter_graph = None          # re-capture the iteration once more with the exchange's issue order logged
+        _optim.EXCHANGE_LOG[0] = []
     res = tr.iteration(it, b)
+    if it == 7:
+        log, _optim.EXCHANGE_LOG[0] = _optim.EXCHANGE_LOG[0], None
 tr.flush(); torch.cuda.synchronize()
 h = hashlib.sha256()
 for k, v in sorted(tr.get_params().items()):
     h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
+import json
+# (the capture's warm-up steps log too: the LAST captured iteration's events are the tail)
+print('XLOG ' + json.dumps(log))
 print('CHECK dp_graph=%s one_graph=%s sync_bn=%s %s' % (tr.dp_graph, getattr(tr, '_iter_graph', None) is not None, tr.sync_bn, h.hexdigest()))
 if dist.is_initialized():
     dist.destroy_process_group()
