@@ -971,6 +971,78 @@ class CriticHead(Function):
                 d_bout, None)
 
 
+@_skip_undefined
+class MlpChain(Function):
+    """logits[M] = Linear(H -> 1)(lrelu(Linear(H -> H)(lrelu(Linear(H -> H)(lrelu(Linear([x1 | x2] -> H))))))), H = 512: the mixture critic
+    on codes of the gmgan scripts (HyperDiscriminator, gmgan_inference_cifar10.py:255-271) as ONE launch per direction
+    (ggan_mlp_chain_fwd / _bwd: a workgroup carries 16 rows through the whole chain; backward = [head kernel, or riding in the cost
+    launch as for CriticHead] + chain kernel + one grouped launch for the three weight-gradient products).  x2 may be None.
+    Not differentiable twice (no script differentiates this critic twice)."""
+
+    @staticmethod
+    def usable(x1, x2, hidden):
+        if x1.dim() != 2 or (x2 is not None and (x2.dim() != 2 or x2.shape[0] != x1.shape[0])) or not x1.is_cuda:
+            return False
+        return bool(_L().ggan_mlp_chain_ok(x1.shape[0], x1.shape[1], x2.shape[1] if x2 is not None else 0, hidden))
+
+    @staticmethod
+    def forward(ctx, x1, x2, w1, b1, w2, b2, w3, b3, w_out, b_out, alpha):
+        x1, w1, b1, w2, b2, w3, b3, w_out, b_out = [_c(t) for t in (x1, w1, b1, w2, b2, w3, b3, w_out, b_out)]
+        x2 = _c(x2) if x2 is not None else None
+        M, K1 = x1.shape
+        K2 = x2.shape[1] if x2 is not None else 0
+        H = w2.shape[0]
+        assert w1.shape == (K1 + K2, H) and w2.shape == (H, H) and w3.shape == (H, H) and w_out.numel() == H, (x1.shape, w1.shape, w2.shape)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x1.device)
+        h1, h2, h3, logits = new(M, H), new(M, H), new(M, H), new(M)
+        # (the backward launch reads the weights transposed: the forward launch's spare workgroups write them into wt)
+        wt = new(_L().ggan_mlp_chain_scratch(K1, K2) // 4) if any(ctx.needs_input_grad) else None
+        check(_L().ggan_mlp_chain_fwd(M, K1, K2, H, _p(x1), _p(x2), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(w_out), _p(b_out),
+                                      float(alpha), _p(h1), _p(h2), _p(h3), _p(logits), _p(wt), _stream()), 'ggan_mlp_chain_fwd')
+        ctx.alpha, ctx.has_x2 = float(alpha), x2 is not None
+        ctx.save_for_backward(x1, x2, wt, w_out, h1, h2, h3)
+        # (as CriticHead: a BCE cost on exactly these logits takes the head kernel of this op's backward into its own launch)
+        ctx.rec = None
+        if M <= _lib.HEAD_BCE_MAX_ROWS and any(ctx.needs_input_grad) and not os.environ.get('GGAN_NO_HEAD_BCE'):
+            ctx.rec = dict(ptr=logits.data_ptr(), M=M, H=H, h=weakref.ref(h3), w_out=weakref.ref(w_out), alpha=float(alpha),
+                           want_out=ctx.needs_input_grad[8], want_bout=ctx.needs_input_grad[9], g_ptr=None)
+            if len(HEAD_LOGITS) >= 8:
+                HEAD_LOGITS.clear()
+            HEAD_LOGITS[ctx.rec['ptr']] = ctx.rec
+        return logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x1, x2, wt, w_out, h1, h2, h3 = ctx.saved_tensors
+        g = _c(g)
+        M, K1 = x1.shape
+        K2 = x2.shape[1] if x2 is not None else 0
+        H = h1.shape[1]
+        need = ctx.needs_input_grad
+        dev = g.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        rec = ctx.rec
+        fused = rec is not None and rec['g_ptr'] is not None and rec['g_ptr'] == g.data_ptr() and rec.get('g_version') == g._version
+        gh3 = rec['gh'] if fused else new(M, H)
+        want_w = any(need[2:8])
+        want_x = need[0] or (x2 is not None and need[1])
+        gh2 = new(M, H) if want_w else None
+        gh1 = new(M, H) if want_w else None
+        d_x1 = new(M, K1) if want_x else None
+        d_x2 = new(M, K2) if (want_x and x2 is not None) else None
+        d_w1, d_b1, d_w2, d_b2, d_w3, d_b3 = (new(K1 + K2, H), new(H), new(H, H), new(H), new(H, H), new(H)) if want_w else (None,) * 6
+        d_wout = (rec['d_wout'].view(w_out.shape) if fused else new(*w_out.shape)) if need[8] else None
+        d_bout = (rec['d_bout'] if fused else new(1)) if need[9] else None
+        ws = workspace(dev)
+        check(_L().ggan_mlp_chain_bwd(M, K1, K2, H, _p(None if fused else g), _p(x1), _p(x2), _p(wt), _p(w_out), _p(h1), _p(h2),
+                                      _p(h3), ctx.alpha, _p(gh3), _p(gh2), _p(gh1), _p(d_x1), _p(d_x2), _p(d_w1), _p(d_b1), _p(d_w2), _p(d_b2),
+                                      _p(d_w3), _p(d_b3), _p(d_wout), _p(d_bout), _p(ws), ws.numel(), _stream()), 'ggan_mlp_chain_bwd')
+        pick = lambda t, i: t if need[i] else None
+        return (pick(d_x1, 0), pick(d_x2, 1) if x2 is not None else None, pick(d_w1, 2), pick(d_b1, 3), pick(d_w2, 4), pick(d_b2, 5),
+                pick(d_w3, 6), pick(d_b3, 7), d_wout, d_bout, None)
+
+
 class DynScan(Function):
     """zs[B, T+1, dl]: the transition operator of the state-space scripts applied T times (ggan_dyn_scan_fwd / _bwd: one scan
     launch per direction, the weight gradients as products over all T*B rows).  zw / b_zw None: OP_DYN_MODE 'res'."""

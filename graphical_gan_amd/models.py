@@ -468,6 +468,12 @@ class GraphicalGAN(object):
 
     def HyperDiscriminator(self, z, k):
         c = self.cfg
+        if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION') and os.environ.get('GGAN_MLP_CHAIN'):
+            # the whole net as one op (ggan_mlp_chain_*: one launch per direction).  OPT-IN: measured slower than the composed launches at
+            # the scripts' 128 rows (a row-local workgroup is bound by one CU's fp32 MFMA rate: 40 / 46 us against 29 / 49 us, gmgan
+            # iteration 1.22 against 1.14 ms; profiles/r04_notes.md)
+            return lib.ops.linear.MlpLReLUChain(['Discriminator.HyperInput', 'Discriminator.Hyper2', 'Discriminator.Hyper3'],
+                                                c.dim_latent + c.K, 512, 'Discriminator.HyperOutput', (z, k))
         out = self._lin('Discriminator.HyperInput', c.dim_latent + c.K, 512, (z, k), LRELU)     # Linear on concat([z, k], 1)
         out = self._lin('Discriminator.Hyper2', 512, 512, out, LRELU)
         if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):
