@@ -41,8 +41,18 @@ struct WgradParts {
 };
 int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                     size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
+// cast (optional): the input is an int32 minibatch in a device ring, scaled while it is staged and written to cast->x_out (x is ignored)
+struct ThinCastSrc {
+    const int32_t* ring;     // [nslots][N*Ci*H*W]
+    const int32_t* ctr_a;    // slot = (offset + *ctr_a + *ctr_b) mod nslots (either counter may be null)
+    const int32_t* ctr_b;
+    const float* noise;      // [N*Ci*H*W] or null
+    float* x_out;            // [N][Ci][H][W]
+    int nslots, offset;
+    float div, mul;
+};
 int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
-                  hipStream_t s);
+                  hipStream_t s, const ThinCastSrc* cast = nullptr);
 int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                     size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
 // Output mask of a forward launch (conv_corr.hip epilogue): while *g_out_mask is set, conv_fwd_mfma stores act_grad(value, ref[i]) instead of

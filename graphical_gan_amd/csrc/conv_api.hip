@@ -43,6 +43,21 @@ int ggan_conv2d_fwd(const ggan_conv_geom* g, const float* x, const float* w, con
     return conv_fwd_naive(*g, x, w, bias, y, act, alpha, s);
 }
 
+// Conv2D on a minibatch that still sits in the device ring as int32: real_x = mul*(float(v)/div - .5) (+ noise) is formed while the
+// first layer stages its input and written to x_out for the other readers (the critic's [fake; real] input, the filter gradient) --
+// ggan_cast_scale_ring_i32 + ggan_conv2d_fwd in one launch.  Returns 1 (nothing launched) where the thin-channel forward kernel does
+// not cover the geometry: the caller issues the two calls.
+int ggan_conv2d_fwd_cast_ring(const ggan_conv_geom* g, const int32_t* ring, int nslots, const int32_t* ctr_a, const int32_t* ctr_b, int offset,
+                              const float* noise, float div, float mul, float* x_out, const float* w, const float* bias, float* y, int act,
+                              float alpha, ggan_stream_t stream) {
+    if (check_geom(g)) return -1;
+    GGAN_CHECK_ARG(ring && x_out && w && y && nslots > 0, "bad argument");
+    if ((g->plan_flags & GGAN_PLAN_PLAIN) || getenv("GGAN_NAIVE_FWD") || getenv("GGAN_NO_CAST_FUSION")) return 1;
+    ThinCastSrc c;
+    c.ring = ring; c.ctr_a = ctr_a; c.ctr_b = ctr_b; c.noise = noise; c.x_out = x_out; c.nslots = nslots; c.offset = offset; c.div = div; c.mul = mul;
+    return conv_fwd_thin(*g, nullptr, w, bias, y, act, alpha, (hipStream_t)stream, &c);
+}
+
 static int bwd_data(const ggan_conv_geom* g, const float* gy, GyMask m, const float* w, const float* bias, float* gx, int act,
                     float alpha, void* ws, size_t ws_bytes, ggan_stream_t stream) {
     if (check_geom(g)) return -1;

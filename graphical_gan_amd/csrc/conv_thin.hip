@@ -408,6 +408,10 @@ struct ThinFwdParams {
     FastDiv d_Wo, d_W4, d_SR, d_Ci, d_5, d_c4;
     unsigned x_bytes;
     int dbg;
+    // optional: the input is an int32 minibatch in a device-resident ring, scaled on the way into LDS (the reference's
+    // real_x = 2*((tf.cast(real_x_int, tf.float32)/255.)-.5), gan_inference_cifar10.py:342, in front of Extractor.1): x = mul*(float(v)/div - .5)
+    // (+ noise), written to x_out as well (every input row by the one band that owns it) -- no cast launch, no float read of the images
+    ThinCastSrc cast;
 };
 
 template <int NTN, int MPW>
@@ -428,23 +432,37 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     constexpr unsigned OOB = 0x7FFFFFF0u;
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, (short)0, (int)P.x_bytes, 0x00020000);
-    u32x4 xreg[XU_MAX];
-    int xlds[XU_MAX];
+    const bool casting = P.cast.ring != nullptr;         // (uniform)
+    const void* xsrc = P.x;
+    if (casting) {
+        // (nothing in this launch writes the counters: every workgroup sees the same slot -- as cast_scale_ring_k)
+        const long long cc = (long long)P.cast.offset + (P.cast.ctr_a ? *P.cast.ctr_a : 0) + (P.cast.ctr_b ? *P.cast.ctr_b : 0);
+        const int slot = (int)(((cc % P.cast.nslots) + P.cast.nslots) % P.cast.nslots);
+        xsrc = P.cast.ring + (size_t)slot * ((size_t)P.N * P.Ci * HW);
+    }
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xsrc, (short)0, (int)P.x_bytes, 0x00020000);
+    const auto rn = __builtin_amdgcn_make_buffer_rsrc((void*)(P.cast.noise ? (const void*)P.cast.noise : xsrc), (short)0, (int)P.x_bytes, 0x00020000);
+    u32x4 xreg[XU_MAX], nreg[XU_MAX];
+    int xlds[XU_MAX], xgo[XU_MAX];                        // xgo: float index in x_out of a unit this band owns (-1: halo row / not casting)
+    bool xin[XU_MAX];
     const int xbase = n * P.Ci * HW + in_row0 * P.W;
 #pragma unroll
     for (int j = 0; j < XU_MAX; ++j) {
         const int u = tid + j * NTHR;
         unsigned vo = OOB;
-        int l = -1;
+        int l = -1, go = -1;
         if (u < P.xunits) {
             const int t = fdiv(u, P.d_W4), f4 = u - t * W4;
             const int c = fdiv(t, P.d_SR), row = t - c * P.SR;
             l = c * P.XCS + row * P.XRS + 2 + f4 * 4;
-            if ((unsigned)(in_row0 + row) < (unsigned)P.H) vo = (unsigned)(xbase + c * HW + row * P.W + f4 * 4) * 4u;
+            if ((unsigned)(in_row0 + row) < (unsigned)P.H) {
+                vo = (unsigned)(xbase + c * HW + row * P.W + f4 * 4) * 4u;
+                if (casting && row >= P.pad_t && row < P.pad_t + 2 * P.GBR) go = xbase + c * HW + row * P.W + f4 * 4;
+            }
         }
-        xlds[j] = l;
+        xlds[j] = l; xgo[j] = go; xin[j] = vo != OOB;
         xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+        if (casting) nreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rn, P.cast.noise ? vo : OOB, 0, 0);
     }
     for (int e = tid; e < cbase; e += NTHR) xs[e] = 0.f;
     if (tid == 0) { xs[cbase] = 1.f; xs[cbase + 1] = 0.f; }
@@ -458,6 +476,22 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
         }
     }
     __syncthreads();                                     // zeros before the rows land on top of them
+    if (casting) {
+#pragma unroll
+        for (int j = 0; j < XU_MAX; ++j) {
+            // the expression of cast_scale_ring_k, element by element (rows outside the image stay 0: SAME padding pads the SCALED image)
+            float4 v;
+            v.x = P.cast.mul * (((float)(int)xreg[j].x / P.cast.div) - 0.5f); v.y = P.cast.mul * (((float)(int)xreg[j].y / P.cast.div) - 0.5f);
+            v.z = P.cast.mul * (((float)(int)xreg[j].z / P.cast.div) - 0.5f); v.w = P.cast.mul * (((float)(int)xreg[j].w / P.cast.div) - 0.5f);
+            if (P.cast.noise) {
+                v.x += __uint_as_float(nreg[j].x); v.y += __uint_as_float(nreg[j].y);
+                v.z += __uint_as_float(nreg[j].z); v.w += __uint_as_float(nreg[j].w);
+            }
+            if (!xin[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            xreg[j] = (u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            if (xgo[j] >= 0) *reinterpret_cast<float4*>(P.cast.x_out + xgo[j]) = v;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < XU_MAX; ++j) {
         if (xlds[j] >= 0) {
@@ -678,15 +712,20 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
 }
 
 int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
-                  hipStream_t s) {
+                  hipStream_t s, const ThinCastSrc* cast) {
     if (g.k != 5 || g.stride != 2 || g.pad_l < 1 || g.pad_l > 2 || g.Ci > 4 || (g.W & 3)) return 1;
     if ((g.Co != 32 && g.Co != 64) || ((g.Ho * g.Wo) & 3) || getenv("GGAN_NO_THIN")) return 1;
+    if (cast) {
+        x = cast->x_out;       // (alignment / size checks below: the ring slots and the noise have the float tensor's extent)
+        if ((((uintptr_t)cast->ring) & 15) || (cast->noise && (((uintptr_t)cast->noise) & 15)) || (((size_t)g.N * g.Ci * g.H * g.W) & 3)) return 1;
+    }
     if ((((uintptr_t)x) & 15) || (((uintptr_t)w) & 15) || (((uintptr_t)y) & 15)) return 1;
     const size_t xb = (size_t)g.N * g.Ci * g.H * g.W * 4;
     if (xb >= 0x7FFFFFF0ull) return 1;
     ThinFwdParams P;
     memset(&P, 0, sizeof(P));
     P.x = x; P.w = w; P.bias = bias; P.y = y; P.act = act; P.alpha = alpha; P.x_bytes = (unsigned)xb;
+    if (cast) P.cast = *cast;
     { const char* d = getenv("GGAN_THIN_DBG"); P.dbg = d ? atoi(d) : 0; }
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo; P.pad_t = g.pad_t; P.pad_l = g.pad_l;
     P.d_c4 = make_fastdiv((uint32_t)(g.Co / 4 > 0 ? g.Co / 4 : 1));

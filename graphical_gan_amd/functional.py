@@ -385,6 +385,37 @@ def _attaching():
 DEBUG_POISON_CHECK = bool(os.environ.get('GGAN_POISON_UNWRITTEN'))
 
 
+class PendingCast(object):
+    """The scaled minibatch real_x = mul*(float(x_int)/div - .5) (+ noise) of a device ring, NOT YET COMPUTED: `out` is the float tensor it
+    will live in (tflib.ops.act.cast_scale(..., defer=True)).  The first consumer decides who writes it: ConvFwd on a thin-channel first
+    layer forms it while it stages its input (ggan_conv2d_fwd_cast_ring: one launch instead of two); anything else calls materialize()
+    (the plain ggan_cast_scale_ring_i32 launch).  Data, never differentiated."""
+
+    def __init__(self, x_int, noise, div, mul, slot, ring):
+        self.x_int, self.noise, self.div, self.mul, self.ring = x_int, noise, float(div), float(mul), ring
+        self.out = _new_out(slot, x_int.shape, x_int.device)
+        self.done = False
+        self.shape = tuple(x_int.shape)
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        n = self.out.numel()
+        known = 1
+        for d in shape:
+            known *= d if d != -1 else 1
+        self.shape = tuple((n // known) if d == -1 else d for d in shape)
+        return self
+
+    def materialize(self):
+        if not self.done:
+            rt, ca, cb, off = self.ring
+            nz = _p(_c(self.noise)) if self.noise is not None else _p(None)
+            check(_L().ggan_cast_scale_ring_i32(_p(rt), rt.shape[0], _p(ca), _p(cb), int(off), nz, _p(self.out), self.out.numel(), self.div,
+                                                self.mul, _stream()), 'ggan_cast_scale_ring_i32')
+            self.done = True
+        return self.out
+
+
 @_carries_hint
 @_skip_undefined
 class ConvFwd(Function):
@@ -395,8 +426,16 @@ class ConvFwd(Function):
         """grad_rows (optional): only images [0, grad_rows) of x need a gradient (the rest of the batch is data); a plain
         backward pass with frozen weights then runs the data-gradient on that sub-batch and leaves the other rows of
         the returned gradient unwritten -- the caller promises nothing reads them."""
-        x, w = _c(x), _c(w)
         N, Ci, H, W, Co, Ho, Wo = geom[:7]
+        pend = x if isinstance(x, PendingCast) else None
+        if pend is not None:
+            # the input is a minibatch still waiting in the device ring as int32: this layer scales it on the way in (one launch less at
+            # the head of the Extractor chain) unless the geometry -- or a recorded / attached pass -- needs the float tensor first
+            x = pend.out.view(N, Ci, H, W)
+            if pend.done or _attaching() is not None or _recording() is not None:
+                pend.materialize()
+                pend = None
+        x, w = _c(x), _c(w)
         assert tuple(x.shape) == (N, Ci, H, W) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (x.shape, w.shape, geom)
         ctx.grad_rows = int(grad_rows) if grad_rows else None
         ctx.target = _TARGET[0]
@@ -408,8 +447,20 @@ class ConvFwd(Function):
             ws = workspace(x.device)
             with _planned_for(ctx.target):
                 g = _geom(geom)
-                check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), _p(_c(bias)) if bias is not None else _p(None), _p(y),
-                                           act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
+                bp = _p(_c(bias)) if bias is not None else _p(None)
+                if pend is not None:
+                    rt, ca, cb, off = pend.ring
+                    nz = _p(_c(pend.noise)) if pend.noise is not None else _p(None)
+                    rc = _L().ggan_conv2d_fwd_cast_ring(C.byref(g), _p(rt), rt.shape[0], _p(ca), _p(cb), int(off), nz, pend.div, pend.mul,
+                                                        _p(x), _p(w), bp, _p(y), act, alpha, _stream())
+                    if rc == 1:
+                        pend.materialize()          # (geometry outside the thin-channel kernel: the two launches)
+                        pend = None
+                    else:
+                        check(rc, 'ggan_conv2d_fwd_cast_ring')
+                        pend.done = True
+                if pend is None:
+                    check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), bp, _p(y), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
             if _recording() is not None:
                 _recording().put('ConvFwd', (y, 'rows'))
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None

@@ -358,9 +358,10 @@ class GraphicalGAN(object):
             ch = cout
         return out.reshape(-1, c.output_dim)
 
-    def Extractor(self, inputs, out_slot=None, eps=None):
+    def Extractor(self, inputs, out_slot=None, eps=None, after_first=None):
         """eps given (TYPE_Q = 'learn_std', gan_inference_cifar10.py:173-188): returns (mean + eps * std, mean, std), std = exp(Linear
-        'Extractor.Std')"""
+        'Extractor.Std').  inputs may be a functional.PendingCast (the minibatch still int32 in the device ring: the first layer scales
+        it while staging); after_first: called once the first layer is issued (real_x exists from there on)."""
         c = self.cfg
         out = inputs.reshape(-1, c.C, c.S, c.S)
         ch = c.C
@@ -372,6 +373,8 @@ class GraphicalGAN(object):
                 out = self._bn('Extractor.BN%d' % (i + 1), [0, 2, 3], out, LRELU)
             else:
                 out = self._conv(name, ch, cout, out, LRELU)
+            if i == 0 and after_first is not None:
+                after_first()
             ch = cout
         out = out.reshape(-1, c.flat)
         if eps is not None:
@@ -503,14 +506,16 @@ class GraphicalGAN(object):
                 lib.params_with_name('Discriminator'))
 
     # ---- loss wiring ------------------------------------------------------------------------------------
-    def real_x(self, feed, out_slot=None):
+    def real_x(self, feed, out_slot=None, defer=False):
+        """defer: with a device ring, a functional.PendingCast -- the Extractor's first layer scales the minibatch while it stages it"""
         c = self.cfg
         if c.dataset == 'mnist':
             return feed['real_x']
         ring = feed.get('ring')            # Trainer.use_ring: minibatches pre-staged in HBM, walked by the optimizers' step counts
+        defer = defer and c.fuse and not os.environ.get('GGAN_NO_CAST_FUSION')
         if c.dataset == 'face':
-            return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'], out=out_slot, ring=ring)
-        return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2., out=out_slot, ring=ring)
+            return lib.ops.act.cast_scale(feed['real_x_int'], 256., 2., noise=feed['dequant_u'], out=out_slot, ring=ring, defer=defer)
+        return lib.ops.act.cast_scale(feed['real_x_int'], 255., 2., out=out_slot, ring=ring, defer=defer)
 
     def begin_nets(self, feed):
         """Called by the Trainer BEFORE the noise launch of a step.  When the two nets passes are going to run as parallel
@@ -583,10 +588,11 @@ class GraphicalGAN(object):
             with torch.cuda.stream(self._side):
                 if c.dataset == 'face' or c.K:
                     self._side.wait_event(ev_noise)       # (dequantisation noise of the 64x64 scripts / Gumbel noise of the mixture scripts)
-                real_x = self.real_x(feed, xs[1])
+                real_x = self.real_x(feed, xs[1], defer=True)
                 ev_x = torch.cuda.Event()
-                ev_x.record(self._side)
-                q_z = self.Extractor(real_x, zs[1])
+                q_z = self.Extractor(real_x, zs[1], after_first=lambda: ev_x.record(self._side))
+                if isinstance(real_x, F.PendingCast):
+                    real_x = real_x.out
                 out = dict(real_x=real_x, q_z=q_z, p_z=p_z)
                 if c.K:
                     ks = F.RowSlot(feed['k_pair'], B, 2 * B) if (c.batch_critic and 'k_pair' in feed) else None
@@ -603,11 +609,13 @@ class GraphicalGAN(object):
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 fake_x = self.Generator(p_z, xs[0])
-        real_x = self.real_x(feed, xs[1])
+        real_x = self.real_x(feed, xs[1], defer=not c.agg)
         if c.agg:                      # (no critic, no fake_x: TF prunes the Generator(p_z) branch these modes never fetch)
             q_z, q_mean, q_std = self.Extractor(real_x, eps=feed['q_eps'])
             return dict(real_x=real_x, q_z=q_z, q_z_mean=q_mean, q_z_std=q_std, p_z=p_z)
         q_z = self.Extractor(real_x, zs[1])
+        if isinstance(real_x, F.PendingCast):
+            real_x = real_x.out
         out = dict(real_x=real_x, q_z=q_z, p_z=p_z)
         if c.K:
             ks = F.RowSlot(feed['k_pair'], B, 2 * B) if (c.batch_critic and 'k_pair' in feed) else None

@@ -28,7 +28,11 @@ def dropout(x, rate=0.0, training=False):
     return x
 
 
-def cast_scale(x_int, div=255., mul=2., noise=None, out=None, ring=None):
+def cast_scale(x_int, div=255., mul=2., noise=None, out=None, ring=None, defer=False):
     """2*((float(x)/255.)-.5) (+ dequantisation noise for the 64x64 scripts).  out: optional functional.RowSlot.
-    ring: read the minibatch from a device-resident ring instead of x_int (functional.CastScaleI32)."""
+    ring: read the minibatch from a device-resident ring instead of x_int (functional.CastScaleI32).
+    defer (with a ring): returns a functional.PendingCast -- the first conv layer that consumes it scales the minibatch while it stages its
+    input (no launch of its own); `.out` is the float tensor, valid once that layer (or .materialize()) has run."""
+    if defer and ring is not None:
+        return F.PendingCast(x_int, noise, div, mul, out, ring)
     return F.CastScaleI32.apply(x_int, noise, float(div), float(mul), out, ring)

@@ -281,6 +281,13 @@ int ggan_cast_scale_i32(const int32_t* x, const float* noise /* may be NULL */, 
  * with the data already in HBM. */
 int ggan_cast_scale_ring_i32(const int32_t* ring, int nslots, const int32_t* ctr_a, const int32_t* ctr_b, int offset,
                              const float* noise /* may be NULL */, float* y, size_t n, float div, float mul, ggan_stream_t stream);
+/* ggan_cast_scale_ring_i32 and the ggan_conv2d_fwd that reads its result, in ONE launch: real_x = 2*((tf.cast(real_x_int, tf.float32)/255.)-.5)
+ * in front of lib.ops.conv2d.Conv2D('Extractor.1', 3, DIM, 5, ., stride=2) (/root/reference/gan_inference_cifar10.py:342,155-157).  The
+ * scaled image x_out [N,Ci,H,W] is still written (the critic's input and the layer's filter gradient read it).  Returns 1 without
+ * launching where the geometry is outside the thin-channel forward kernel (Ci <= 4, Co 32 | 64, k 5, stride 2): issue the two calls. */
+int ggan_conv2d_fwd_cast_ring(const ggan_conv_geom* g, const int32_t* ring, int nslots, const int32_t* ctr_a, const int32_t* ctr_b, int offset,
+                              const float* noise /* may be NULL */, float div, float mul, float* x_out, const float* w,
+                              const float* bias /* may be NULL */, float* y, int act, float alpha, ggan_stream_t stream);
 /* out = a*x + b*y (+c) elementwise (interpolates, residuals). */
 int ggan_axpby(const float* x, const float* y, float* out, size_t n, float a, float b, float c,
                ggan_stream_t stream);

@@ -1139,6 +1139,47 @@ def test_critic_head(gpu, M, K1, K2, H, need):
         assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
 
 
+@pytest.mark.parametrize('N,Ci,S,Co,noise', [(64, 3, 32, 64, False), (8, 3, 64, 32, True), (5, 1, 28, 64, False), (3, 3, 32, 64, True),
+                                             (4, 3, 32, 128, False)])
+def test_first_layer_scales_the_ring_minibatch_itself(gpu, N, Ci, S, Co, noise):
+    """ggan_conv2d_fwd_cast_ring (functional.PendingCast -> ConvFwd): the int32 minibatch of a device ring scaled while Extractor.1
+    stages it.  The layer's output and the float image it leaves for the other readers are BIT-identical to ggan_cast_scale_ring_i32 +
+    ggan_conv2d_fwd, for every ring slot the counters select, with and without dequantisation noise; a geometry outside the
+    thin-channel kernel (Co = 128) takes the two launches; the filter gradient flows as before."""
+    import torch
+    from graphical_gan_amd import functional as F
+    from graphical_gan_amd.tflib.ops import act as A
+    rng = np.random.default_rng(N * 100 + S)
+    R = 3
+    ring = torch.as_tensor(rng.integers(0, 256, size=(R, N, Ci * S * S)).astype(np.int32), device=gpu)
+    x_int = torch.zeros((N, Ci * S * S), dtype=torch.int32, device=gpu)
+    nz = _t(rng.random((N, Ci * S * S)) / 128, gpu) if noise else None
+    w = _t(rng.standard_normal((5, 5, Ci, Co)) / np.sqrt(25 * Ci), gpu).requires_grad_(True)
+    b = _t(rng.standard_normal(Co), gpu).requires_grad_(True)
+    geom = F.conv_geom(N, Ci, S, S, Co, 5, 2, 'SAME')
+    ca = torch.zeros(1, dtype=torch.int32, device=gpu)
+    cb = torch.zeros(1, dtype=torch.int32, device=gpu)
+    for step in range(4):
+        ca.fill_(step)
+        cb.fill_(2 * step)
+        r = (ring, ca, cb, 1)
+        x_ref = A.cast_scale(x_int, 255., 2., noise=nz, ring=r)
+        y_ref = F.ConvFwd.apply(x_ref.view(N, Ci, S, S), w, b, geom, F.ACT_LRELU, 0.2)
+        slot = (1 + 3 * step) % R
+        expect = 2. * (ring[slot].float() / 255. - .5) + (nz if noise else 0.)
+        assert float((x_ref - expect).abs().max()) < 1e-6           # (the slot the counters select)
+        pend = A.cast_scale(x_int, 255., 2., noise=nz, ring=r, defer=True)
+        assert isinstance(pend, F.PendingCast) and not pend.done
+        y = F.ConvFwd.apply(pend.reshape(-1, Ci, S, S), w, b, geom, F.ACT_LRELU, 0.2)
+        assert pend.done
+        assert torch.equal(pend.out, x_ref), step
+        assert torch.equal(y, y_ref), step
+    gy = _t(rng.standard_normal(tuple(y.shape)), gpu)
+    g1 = torch.autograd.grad(y, [w, b], grad_outputs=gy)
+    g0 = torch.autograd.grad(y_ref, [w, b], grad_outputs=gy)
+    assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1])
+
+
 @pytest.mark.parametrize('M,K1,K2,need', [(128, 128, 30, 'all'), (128, 128, 30, 'data'), (128, 128, 10, 'weights'), (100, 128, 30, 'all'),
                                           (64, 128, 100, 'all'), (7, 64, 5, 'all'), (33, 250, 0, 'all'), (16, 8, 0, 'data')])
 def test_mlp_chain(gpu, M, K1, K2, need):
