@@ -105,6 +105,7 @@ SIGNATURES = {
     'ggan_cast_scale_i32': (_I, [_P, _P, _P, _Z, _F, _F, _P]),
     'ggan_cast_scale_ring_i32': (_I, [_P, _I, _P, _P, _I, _P, _P, _Z, _F, _F, _P]),
     'ggan_axpby': (_I, [_P, _P, _P, _Z, _F, _F, _F, _P]),
+    'ggan_mix_mean': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'ggan_row_lerp': (_I, [_P, _P, _P, _P, _I, _I, _P]),
     'ggan_bce_logits_fwd': (_I, [_P, _F, _F, _P, _I, _I, _P]),
     'ggan_bce_logits_bwd': (_I, [_P, _F, _F, _P, _P, _I, _P]),

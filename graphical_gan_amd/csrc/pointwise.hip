@@ -126,6 +126,27 @@ __global__ void axpby_k(const float* __restrict__ x, const float* __restrict__ y
     for (size_t j = i; j < n; j += stride) out[j] = a * x[j] + (y ? b * y[j] : 0.f) + c;
 }
 
+// out[b][d] = sum_j k[b][j] * mu[j][d] + noise[b][d]: HyperGenerator of the gmgan scripts, tf.add(tf.matmul(tf.cast(hyper_k, tf.float32), com_mu),
+// hyper_noise) (gmgan_inference_cifar10.py:150-153), as ONE pointwise launch instead of a 30-deep GEMM launch and an addition launch at the head of
+// the Generator chain.  The fmaf chain in j order is what the MFMA GEMM computes; with one-hot rows it is the selected mean exactly.
+__global__ void mix_mean_k(const float* __restrict__ k, const float* __restrict__ mu, const float* __restrict__ noise, float* __restrict__ out,
+                           int B, int K, int D4) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D4) return;
+    const int b = idx / D4, d4 = idx - b * D4;
+    const float* kr = k + (size_t)b * K;
+    const float4* m = reinterpret_cast<const float4*>(mu) + d4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < K; ++j) {
+        const float kv = kr[j];
+        const float4 mv = m[(size_t)j * D4];
+        acc.x = fmaf(kv, mv.x, acc.x); acc.y = fmaf(kv, mv.y, acc.y); acc.z = fmaf(kv, mv.z, acc.z); acc.w = fmaf(kv, mv.w, acc.w);
+    }
+    const float4 nv = reinterpret_cast<const float4*>(noise)[idx];
+    acc.x += nv.x; acc.y += nv.y; acc.z += nv.z; acc.w += nv.w;
+    reinterpret_cast<float4*>(out)[idx] = acc;
+}
+
 __global__ void row_lerp_k(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ alpha,
                            float* __restrict__ out, int rows, int cols) {
     size_t total = (size_t)rows * cols;
@@ -1235,6 +1256,15 @@ int ggan_axpby(const float* x, const float* y, float* out, size_t n, float a, fl
     GGAN_CHECK_ARG(x && out, "null pointer");
     if (n == 0) return 0;
     GGAN_LAUNCH("axpby", 0, 12.0 * n, axpby_k, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, out, n, a, b, c);
+    return 0;
+}
+
+int ggan_mix_mean(const float* k, const float* mu, const float* noise, float* out, int B, int K, int D, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(k && mu && noise && out && B > 0 && K > 0 && D > 0, "bad argument");
+    GGAN_CHECK_ARG((D & 3) == 0 && !(((uintptr_t)mu | (uintptr_t)noise | (uintptr_t)out) & 15), "D a multiple of 4, 16-byte aligned buffers");
+    const int n = B * (D / 4);
+    GGAN_LAUNCH("mix_mean", 2.0 * B * K * D, 4.0 * (2.0 * B * D + (double)K * D), mix_mean_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, k,
+                mu, noise, out, B, K, D / 4);
     return 0;
 }
 

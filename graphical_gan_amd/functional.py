@@ -1589,6 +1589,38 @@ class Axpby(Function):
         return (gx, gy) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+@_skip_undefined
+class MixMean(Function):
+    """p_z[B,D] = k[B,K] @ mu[K,D] + noise[B,D]: HyperGenerator of the gmgan scripts (gmgan_inference_cifar10.py:150-153) as ONE pointwise
+    launch (ggan_mix_mean) instead of Gemm + Axpby at the head of the Generator chain; backward: d mu = k^T g (one product), d noise = g."""
+
+    @staticmethod
+    def usable(k, mu, noise):
+        return k.dim() == 2 and mu.dim() == 2 and mu.shape[1] % 4 == 0 and k.is_cuda and _attaching() is None and _recording() is None
+
+    @staticmethod
+    def forward(ctx, k, mu, noise, slot=None):
+        k, mu, noise = _c(k), _c(mu), _c(noise)
+        B, K = k.shape
+        D = mu.shape[1]
+        assert mu.shape[0] == K and tuple(noise.shape) == (B, D), (k.shape, mu.shape, noise.shape)
+        out = _new_out(slot, (B, D), k.device)
+        check(_L().ggan_mix_mean(_p(k), _p(mu), _p(noise), _p(out), B, K, D, _stream()), 'ggan_mix_mean')
+        ctx.mu_param = _is_param(mu)
+        ctx.save_for_backward(k, mu)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        k, mu = ctx.saved_tensors
+        dk = dmu = None
+        if ctx.needs_input_grad[1] and not (_DATA_ONLY[0] and ctx.mu_param):
+            dmu = Gemm.apply(k, g, None, True, False, ACT_NONE, 0.0)          # k^T g
+        if ctx.needs_input_grad[0]:
+            dk = Gemm.apply(g, mu, None, False, True, ACT_NONE, 0.0)          # g mu^T
+        return dk, dmu, (g if ctx.needs_input_grad[2] else None), None
+
+
 class GmmLatent(Function):
     """HyperExtractor of the gmgan scripts in one launch per direction (ggan_gmm_latent_*): component logits of z under the
     mixture prior and the Gumbel-softmax relaxation of the component assignment.  Returns (logits, k)."""

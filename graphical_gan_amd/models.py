@@ -491,7 +491,10 @@ class GraphicalGAN(object):
 
     def HyperGenerator(self, hyper_k, hyper_noise, out_slot=None):
         """gmgan_inference_cifar10.py:150-153: onehot(k) @ Mu + eps."""
-        return F.Axpby.apply(F.Gemm.apply(hyper_k, self._mu(), None, False, False, F.ACT_NONE, 0.0), hyper_noise, 1.0, 1.0, 0.0, out_slot)
+        mu = self._mu()
+        if self.cfg.fuse and F.MixMean.usable(hyper_k, mu, hyper_noise) and not os.environ.get('GGAN_NO_MIX_MEAN'):
+            return F.MixMean.apply(hyper_k, mu, hyper_noise, out_slot)           # one pointwise launch (ggan_mix_mean)
+        return F.Axpby.apply(F.Gemm.apply(hyper_k, mu, None, False, False, F.ACT_NONE, 0.0), hyper_noise, 1.0, 1.0, 0.0, out_slot)
 
     def HyperExtractor(self, latent_z, gumbel_u, out_slot=None):
         """gmgan_inference_cifar10.py:156-173 (MODE_K='CONCRETE'): component logits and the Gumbel-softmax assignment, one

@@ -288,6 +288,9 @@ int ggan_cast_scale_ring_i32(const int32_t* ring, int nslots, const int32_t* ctr
 int ggan_conv2d_fwd_cast_ring(const ggan_conv_geom* g, const int32_t* ring, int nslots, const int32_t* ctr_a, const int32_t* ctr_b, int offset,
                               const float* noise /* may be NULL */, float div, float mul, float* x_out, const float* w,
                               const float* bias /* may be NULL */, float* y, int act, float alpha, ggan_stream_t stream);
+/* out[B,D] = k[B,K] mu[K,D] + noise[B,D] in one pointwise launch: HyperGenerator of the gmgan scripts, tf.add(tf.matmul(tf.cast(hyper_k,
+ * tf.float32), com_mu), hyper_noise) (/root/reference/gmgan_inference_cifar10.py:150-153).  D a multiple of 4, buffers 16-byte aligned. */
+int ggan_mix_mean(const float* k, const float* mu, const float* noise, float* out, int B, int K, int D, ggan_stream_t stream);
 /* out = a*x + b*y (+c) elementwise (interpolates, residuals). */
 int ggan_axpby(const float* x, const float* y, float* out, size_t n, float a, float b, float c,
                ggan_stream_t stream);

@@ -1139,6 +1139,36 @@ def test_critic_head(gpu, M, K1, K2, H, need):
         assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
 
 
+@pytest.mark.parametrize('B,K,D,onehot', [(64, 30, 128, True), (50, 10, 128, True), (7, 100, 64, False)])
+def test_mix_mean(gpu, B, K, D, onehot):
+    """ggan_mix_mean (functional.MixMean: HyperGenerator, gmgan_inference_cifar10.py:150-153, as one pointwise launch): k @ mu + noise
+    against float64 -- exact for one-hot rows -- bit-identical to the Gemm + Axpby composition it replaces, gradients w.r.t. mu (k^T g),
+    noise (g) and k (g mu^T)."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(B + K)
+    k = np.zeros((B, K), np.float32)
+    if onehot:
+        k[np.arange(B), rng.integers(0, K, B)] = 1.0
+    else:
+        k = rng.random((B, K)).astype(np.float32)
+    mu = rng.standard_normal((K, D)).astype(np.float32)
+    nz = rng.standard_normal((B, D)).astype(np.float32)
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    tk, tm, tn = _t(k, gpu).requires_grad_(True), _t(mu, gpu).requires_grad_(True), _t(nz, gpu).requires_grad_(True)
+    out = F.MixMean.apply(tk, tm, tn)
+    ref = k.astype(np.float64) @ mu.astype(np.float64) + nz
+    if onehot:
+        assert np.array_equal(out.detach().cpu().numpy(), (mu[k.argmax(1)] + nz).astype(np.float32))
+    assert _rel(out.detach().cpu().numpy(), ref) < 2e-6
+    comp = F.Axpby.apply(F.Gemm.apply(_t(k, gpu), _t(mu, gpu), None, False, False, F.ACT_NONE, 0.0), _t(nz, gpu), 1.0, 1.0, 0.0)
+    assert torch.equal(out.detach(), comp) if onehot else _rel(out.detach().cpu().numpy(), comp.cpu().numpy()) < 1e-6
+    dk, dm, dn = torch.autograd.grad(out, [tk, tm, tn], grad_outputs=_t(g, gpu))
+    assert _rel(dm.cpu().numpy(), k.astype(np.float64).T @ g) < 2e-5
+    assert _rel(dk.cpu().numpy(), g.astype(np.float64) @ mu.astype(np.float64).T) < 2e-5
+    assert torch.equal(dn, _t(g, gpu))
+
+
 @pytest.mark.parametrize('N,Ci,S,Co,noise', [(64, 3, 32, 64, False), (8, 3, 64, 32, True), (5, 1, 28, 64, False), (3, 3, 32, 64, True),
                                              (4, 3, 32, 128, False)])
 def test_first_layer_scales_the_ring_minibatch_itself(gpu, N, Ci, S, Co, noise):
