@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+T=r04
+bash tools/prof_round.sh ${T}
+bash tools/prof_round.sh ${T}_face --dataset face
+SPI=6 bash tools/prof_round.sh ${T}_waligp --mode wali-gp
+bash tools/prof_round.sh ${T}_gmgan --mode local_ep --n-coms 10
+SPI=2 bash tools/prof_round.sh ${T}_ssgan --dataset moving_mnist
+SPI=2 bash tools/prof_round.sh ${T}_ssgan3d --dataset moving_mnist --ssgan-mode ali:3dcnn
+python bench.py > gpurun_out/${T}_bench_line.log 2> gpurun_out/${T}_bench_line.err
+cp gpurun_out/bench_full.json gpurun_out/${T}/bench.json
+tail -c 400 gpurun_out/${T}_bench_line.log
