@@ -142,20 +142,22 @@ constexpr unsigned GOOB = 0x7FFFFFF0u;
 // VEC == false: the same unit as four dword loads, each with its own range test -- operands whose rows are not 16-byte aligned
 // (leading dimension or extent not a multiple of 4: the state-space critics' Linear on [features | latent | 10 labels], K = 4618)
 // stay on the branch-free path instead of the generic loader.
-template <bool KCONTIG, bool VEC>
+// U = 16-byte units per thread and step: 2 with 256 threads, 1 with 512 (the eight-wave tile)
+template <bool KCONTIG, bool VEC, int U = 2>
 __device__ __forceinline__ void load_step_tile_fast(__amdgpu_buffer_rsrc_t rs, int ld, int R, int r0, int k0, int kend,
-                                                    float4 (&reg)[2]) {
+                                                    float4 (&reg)[U]) {
     const int tid = threadIdx.x;
+    constexpr int NT_ = 512 / U;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         int row, k;
         unsigned off;
         if (KCONTIG) {
-            const int unit = tid + 256 * u;
+            const int unit = tid + NT_ * u;
             row = r0 + (unit >> 3); k = k0 + (unit & 7) * 4;
             off = (unsigned)(row * ld + k) * 4u;
         } else {
-            row = r0 + (tid & 15) * 4; k = k0 + u * BK + (tid >> 4);
+            row = r0 + (tid & 15) * 4; k = k0 + u * (NT_ / 16) + (tid >> 4);
             off = (unsigned)(k * ld + row) * 4u;
         }
         if (VEC) {
@@ -173,21 +175,22 @@ __device__ __forceinline__ void load_step_tile_fast(__amdgpu_buffer_rsrc_t rs, i
     }
 }
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_step_tile(float* T, const float4 (&reg)[2]) {
+template <bool KCONTIG, int U = 2>
+__device__ __forceinline__ void store_step_tile(float* T, const float4 (&reg)[U]) {
     const int tid = threadIdx.x;
+    constexpr int NT_ = 512 / U;
     if (KCONTIG) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int unit = tid + 256 * u, row = unit >> 3, kq = unit & 7;
+        for (int u = 0; u < U; ++u) {
+            const int unit = tid + NT_ * u, row = unit >> 3, kq = unit & 7;
             float* d = T + (kq * 4) * LDPK + row;
             d[0] = reg[u].x; d[LDPK] = reg[u].y; d[2 * LDPK] = reg[u].z; d[3 * LDPK] = reg[u].w;
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int kk = tid >> 4, r = (tid & 15) * 4;
-            *reinterpret_cast<float4*>(T + (u * BK + kk) * LDP + r) = reg[u];
+            *reinterpret_cast<float4*>(T + (u * (NT_ / 16) + kk) * LDP + r) = reg[u];
         }
     }
 }
@@ -212,14 +215,23 @@ __device__ __forceinline__ void store_tile(float* T, const float4& reg) {
 // MASK: 0 none, 1 activation-derivative mask on A, 2 on B
 constexpr int TSZ = KSTEP * LDP;                           // one LDS step tile (sized for the wider row)
 
-template <bool TA, bool TB, int MASK, int FAST>
+// NWAVE = 8 (round 4): two waves per SIMD -- waves 4..7 take the second half of every 32-k step (in-workgroup split of the reduction,
+// combined through LDS in the epilogue), each thread stages one 16-byte unit per operand and step instead of two.  For the products whose
+// grid leaves a CU with ONE workgroup (the critic tail's data gradient: 144 workgroups walking 16 serial steps), where a step is
+// bound by its own LDS / L2 round trips with nothing else on the SIMD to issue meanwhile.  FAST operand paths only.
+template <bool TA, bool TB, int MASK, int FAST, int NWAVE = 4>
 __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, const int by, const int split, float* As, float* Bs) {
+    static_assert(NWAVE == 4 || (NWAVE == 8 && FAST != 0), "eight waves: branch-free operand loads only");
+    constexpr int U = NWAVE == 4 ? 2 : 1;                  // staging units per thread and step
+    constexpr int KG = NWAVE / 4;                          // k-groups of a step
+    constexpr int NT_ = 64 * NWAVE;
     // LDS double-buffered so a step costs ONE barrier: the next step's global loads are issued before the MFMA block, parked in
     // registers, and committed to the other buffer after it
     constexpr bool AK = !TA, BKc = TB;                     // operand is k-contiguous in memory
     constexpr int LA = AK ? LDPK : LDP, LB = BKc ? LDPK : LDP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1, half = lane >> 5, l31 = lane & 31;
+    const int wsub = wave & 3, kg = wave >> 2;
+    const int wm = wsub & 1, wn = wsub >> 1, half = lane >> 5, l31 = lane & 31;
     const int m0 = by * BM, n0 = bx * BN;
     const int kb = split * P.kps, ke = min(kb + P.kps, P.K);
 
@@ -231,13 +243,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     // register ring two steps deep: the loads of step k+2 are issued before the MFMA block of step k, the loads of step k+1
     // (issued one iteration earlier) are committed to the other LDS buffer after it.  A workgroup's step was bound by the
     // latency of ONE prefetch (~1.3 us per 32-k step measured against 0.43 us of MFMA issue); two in flight cover it.
-    float4 ra[2][2], rb[2][2], rma[2][2], rmb[2][2];
+    float4 ra[2][U], rb[2][U], rma[2][U], rmb[2][U];
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, (short)0, (int)P.a_bytes, 0x00020000);
     const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A2 ? P.A2 : P.A), (short)0, (int)(P.A2 ? P.a2_bytes : P.a_bytes), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, (short)0, (int)P.b_bytes, 0x00020000);
     const auto rsAr = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK == 1 ? P.a_ref : P.A), (short)0, (int)P.a_bytes, 0x00020000);
     const auto rsBr = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK == 2 ? P.b_ref : P.B), (short)0, (int)P.b_bytes, 0x00020000);
-    auto load_step = [&](int k0, float4 (&xa)[2], float4 (&xb)[2], float4 (&xma)[2], float4 (&xmb)[2]) {
+    auto load_step = [&](int k0, float4 (&xa)[U], float4 (&xb)[U], float4 (&xma)[U], float4 (&xmb)[U]) {
         if constexpr (FAST != 0) {
             constexpr bool V = FAST == 1;
             // (source selection by scalar selects, ONE load sequence: no branches around the loads)
@@ -249,12 +261,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
                 if (AK) { kk0 = second ? k0 - P.a_split : k0; kke = second ? ke - P.a_split : min(ke, P.a_split); }
                 else { R = second ? P.M - P.a_split : P.a_split; r0 = second ? m0 - P.a_split : m0; }
             }
-            load_step_tile_fast<AK, V>(rs, ld, R, r0, kk0, kke, xa);
-            if (MASK == 1) load_step_tile_fast<AK, V>(rsAr, P.lda, P.M, m0, k0, ke, xma);
-            load_step_tile_fast<BKc, V>(rsB, P.ldb, P.N, n0, k0, ke, xb);
-            if (MASK == 2) load_step_tile_fast<BKc, V>(rsBr, P.ldb, P.N, n0, k0, ke, xmb);
+            load_step_tile_fast<AK, V, U>(rs, ld, R, r0, kk0, kke, xa);
+            if (MASK == 1) load_step_tile_fast<AK, V, U>(rsAr, P.lda, P.M, m0, k0, ke, xma);
+            load_step_tile_fast<BKc, V, U>(rsB, P.ldb, P.N, n0, k0, ke, xb);
+            if (MASK == 2) load_step_tile_fast<BKc, V, U>(rsBr, P.ldb, P.N, n0, k0, ke, xmb);
             return;
-        }
+        } else {
         if (P.A2 == nullptr) {
             load_step_tile<AK>(P.A, P.lda, P.M, m0, k0, ke, P.vecA, xa);
         } else if (AK) {        // element (m, k) at A[m*lda + k]: the sources split the k range
@@ -269,18 +281,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
         if (MASK == 1) load_step_tile<AK>(P.a_ref, P.lda, P.M, m0, k0, ke, P.vecA, xma);
         load_step_tile<BKc>(P.B, P.ldb, P.N, n0, k0, ke, P.vecB, xb);
         if (MASK == 2) load_step_tile<BKc>(P.b_ref, P.ldb, P.N, n0, k0, ke, P.vecB, xmb);
+        }
     };
-    auto store_step = [&](int buf, float4 (&xa)[2], float4 (&xb)[2], float4 (&xma)[2], float4 (&xmb)[2]) {
+    auto store_step = [&](int buf, float4 (&xa)[U], float4 (&xb)[U], float4 (&xma)[U], float4 (&xmb)[U]) {
         if (MASK == 1) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) xa[u] = apply_mask<true>(xa[u], xma[u], P.ref_act, P.ref_alpha);
+            for (int u = 0; u < U; ++u) xa[u] = apply_mask<true>(xa[u], xma[u], P.ref_act, P.ref_alpha);
         }
         if (MASK == 2) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) xb[u] = apply_mask<true>(xb[u], xmb[u], P.ref_act, P.ref_alpha);
+            for (int u = 0; u < U; ++u) xb[u] = apply_mask<true>(xb[u], xmb[u], P.ref_act, P.ref_alpha);
         }
-        store_step_tile<AK>(As + buf * TSZ, xa);
-        store_step_tile<BKc>(Bs + buf * TSZ, xb);
+        store_step_tile<AK, U>(As + buf * TSZ, xa);
+        store_step_tile<BKc, U>(Bs + buf * TSZ, xb);
     };
     auto mma_step = [&](int buf) {
         const float* Ab = As + buf * TSZ;
@@ -293,15 +306,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
         // straightforward loop compiles to "2 ds_read; s_waitcnt lgkmcnt(0); v_mfma" per k-pair: one LDS round trip of matrix-pipe
         // idle per MFMA (measured 1.07 us per step where the MFMAs need 0.43 us) -- nothing else hides it when the grid puts
         // one or two workgroups on a CU, which is the regime of the step's Linear layers.
-        float fa[KSTEP / 2], fb[KSTEP / 2];
+        constexpr int NM = KSTEP / 2 / KG;                       // MFMAs of this wave per step (its k-group's half of the step with 8 waves)
+        float fa[NM], fb[NM];
+        const int kbase = kg * (KSTEP / KG);
 #pragma unroll
-        for (int i = 0; i < KSTEP / 2; ++i) {
-            fa[i] = Ab[(2 * i + half) * LA + wm * 32 + l31];
-            fb[i] = Bb[(2 * i + half) * LB + wn * 32 + l31];
+        for (int i = 0; i < NM; ++i) {
+            fa[i] = Ab[(kbase + 2 * i + half) * LA + wm * 32 + l31];
+            fb[i] = Bb[(kbase + 2 * i + half) * LB + wn * 32 + l31];
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // 12 DS reads first
+        __builtin_amdgcn_sched_group_barrier(0x100, 12 / KG, 0); // the first DS reads
 #pragma unroll
-        for (int i = 0; i < KSTEP / 2; ++i) {
+        for (int i = 0; i < NM; ++i) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // ... then the next two reads still to issue
@@ -328,10 +343,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     // the tile goes through LDS and leaves as one float4 row segment per thread and pass (4 passes)
     constexpr int LC = BN + 4;
     float* Cs = As;                                   // 64 x 68 floats <= 2 * TSZ (all waves are past the last barrier)
+    float* Cs2 = Bs;                                  // eight waves: the second k-group's partial tile, added in the store passes
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        Cs[ml * LC + wn * 32 + l31] = acc[r];
+        (kg ? Cs2 : Cs)[ml * LC + wn * 32 + l31] = acc[r];
     }
     __syncthreads();
     const bool direct = P.SK == 1;
@@ -343,11 +359,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& P, const int bx, con
     }
     const bool vec_out = (ldc & 3) == 0 && ((uintptr_t)Cp & 15) == 0;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int idx = tid + pass * 256, ml = idx >> 4, c4 = (idx & 15) * 4;
+    for (int pass = 0; pass < 1024 / NT_; ++pass) {
+        const int idx = tid + pass * NT_, ml = idx >> 4, c4 = (idx & 15) * 4;
         const int m = m0 + ml, n = n0 + c4;
         if (m >= P.M || n >= P.N) continue;
         float4 v = *reinterpret_cast<const float4*>(Cs + ml * LC + c4);
+        if constexpr (KG == 2) {
+            const float4 w2 = *reinterpret_cast<const float4*>(Cs2 + ml * LC + c4);
+            v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
+        }
         float* vv = reinterpret_cast<float*>(&v);
         if (direct) {
 #pragma unroll
@@ -374,6 +394,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     gemm_tile<TA, TB, MASK, FAST>(P, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
+template <bool TA, bool TB, int MASK = 0, int FAST = 1>
+__global__ __launch_bounds__(512) void gemm_kernel8(const GemmParams P) {
+    warm_kernarg(P);
+    __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
+    gemm_tile<TA, TB, MASK, FAST, 8>(P, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
 // Independent products in ONE launch (a Linear layer's weight gradient next to its data gradient: both consume the same
 // upstream gradient, neither fills the chip, and every launch of a step graph costs ~5 us before it does any work).
 // Workgroups [first[j], first[j+1]) belong to problem j; FAST operands, no split-K.
@@ -385,7 +413,8 @@ struct GemmGroup {
     GemmParams p[3];
 };
 
-__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
+template <int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void gemm_group_kernel(const GemmGroup G) {
     warm_kernarg(G);
     __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
@@ -396,11 +425,20 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroup G) {
     const int bx = local % G.gx[j], by = local / G.gx[j];
     const GemmParams& P = G.p[j];
     switch (G.kind[j]) {
-        case 0: gemm_tile<true, false, 0, 1>(P, bx, by, 0, As, Bs); break;
-        case 1: gemm_tile<false, true, 0, 1>(P, bx, by, 0, As, Bs); break;
-        default: gemm_tile<false, false, 0, 1>(P, bx, by, 0, As, Bs); break;
+        case 0: gemm_tile<true, false, 0, 1, NWAVE>(P, bx, by, 0, As, Bs); break;
+        case 1: gemm_tile<false, true, 0, 1, NWAVE>(P, bx, by, 0, As, Bs); break;
+        default: gemm_tile<false, false, 0, 1, NWAVE>(P, bx, by, 0, As, Bs); break;
     }
 }
+static bool group_w8() {
+    static const bool v = [] { const char* e = getenv("GGAN_GEMM_GROUP_W8"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+#define GGAN_LAUNCH_GROUP(fl, nwg, s, GG)                                                                                        \
+    do {                                                                                                                          \
+        if (group_w8()) { GGAN_LAUNCH("gemm_group_kernel<8>", fl, 0, gemm_group_kernel<8>, dim3(nwg), dim3(512), 0, s, GG); }    \
+        else { GGAN_LAUNCH("gemm_group_kernel", fl, 0, gemm_group_kernel<4>, dim3(nwg), dim3(256), 0, s, GG); }                  \
+    } while (0)
 
 // ---- the critics' heads: Linear + LeakyReLU + Linear(H -> 1) -------------------------------------------------------------------
 // forward tail: h = lrelu(sum of the split-K slabs of the first Linear + b), logits = h . w_out + b_out.  One workgroup per two rows.
@@ -586,21 +624,30 @@ static int gemm_launch_planned(const GemmPlan& G, int ta, int tb, hipStream_t s)
     const GemmParams& P = G.P;
     const double fl = 2.0 * P.M * P.N * (double)P.K;
     const dim3 grid(G.gx, G.gy, P.SK), block(256);
+    // eight waves (in-workgroup split of every k-step) where the grid leaves at most ~one workgroup per CU: nothing else on the SIMD
+    // hides a step's LDS / L2 round trips there.  GGAN_GEMM_W8 = 0: never, N: grids up to N workgroups (default 256)
+    static const int w8_max = [] { const char* e = getenv("GGAN_GEMM_W8"); return e ? atoi(e) : (1 << 30); }();
+    static const bool w8_colsum = [] { const char* e = getenv("GGAN_GEMM_W8_COLSUM"); return e ? atoi(e) != 0 : true; }();
+    static const int w8_min_steps = [] { const char* e = getenv("GGAN_GEMM_W8_MIN_STEPS"); return e ? atoi(e) : 2; }();
+    // (a workgroup that walks ONE step has no round trip between steps to hide: the split would only add its combine)
+    const bool w8 = P.fast != 0 && (long)G.gx * G.gy * P.SK <= (long)w8_max && (!P.colsum || w8_colsum) && P.kps >= w8_min_steps * KSTEP;
 #define GGAN_GEMM_CASE(TA_, TB_, MK_, NAME_)                                                                                      \
     do {                                                                                                                           \
-        if (P.fast == 1) { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 1>), grid, block, 0, s, P); }                    \
-        else if (P.fast == 2) { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 2>), grid, block, 0, s, P); }               \
-        else { GGAN_LAUNCH(NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 0>), grid, block, 0, s, P); }                                \
+        if (w8 && P.fast == 1) { GGAN_LAUNCH("gemm_kernel8" NAME_, fl, 0, (gemm_kernel8<TA_, TB_, MK_, 1>), grid, dim3(512), 0, s, P); }   \
+        else if (w8) { GGAN_LAUNCH("gemm_kernel8" NAME_, fl, 0, (gemm_kernel8<TA_, TB_, MK_, 2>), grid, dim3(512), 0, s, P); }            \
+        else if (P.fast == 1) { GGAN_LAUNCH("gemm_kernel" NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 1>), grid, block, 0, s, P); }              \
+        else if (P.fast == 2) { GGAN_LAUNCH("gemm_kernel" NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 2>), grid, block, 0, s, P); }               \
+        else { GGAN_LAUNCH("gemm_kernel" NAME_, fl, 0, (gemm_kernel<TA_, TB_, MK_, 0>), grid, block, 0, s, P); }                                \
     } while (0)
     if (P.a_ref || P.b_ref) {
-        if (P.a_ref && !P.b_ref && !ta && tb) GGAN_GEMM_CASE(false, true, 1, "gemm_kernel<false, true, 1>");
-        else if (P.b_ref && !P.a_ref && ta && !tb) GGAN_GEMM_CASE(true, false, 2, "gemm_kernel<true, false, 2>");
+        if (P.a_ref && !P.b_ref && !ta && tb) GGAN_GEMM_CASE(false, true, 1, "<false, true, 1>");
+        else if (P.b_ref && !P.a_ref && ta && !tb) GGAN_GEMM_CASE(true, false, 2, "<true, false, 2>");
         else { set_error("gemm: unsupported mask/transposition combination"); return -1; }
     } else
-    if (!ta && !tb) GGAN_GEMM_CASE(false, false, 0, "gemm_kernel<false, false>");
-    else if (!ta && tb) GGAN_GEMM_CASE(false, true, 0, "gemm_kernel<false, true>");
-    else if (ta && !tb) GGAN_GEMM_CASE(true, false, 0, "gemm_kernel<true, false>");
-    else GGAN_GEMM_CASE(true, true, 0, "gemm_kernel<true, true>");
+    if (!ta && !tb) GGAN_GEMM_CASE(false, false, 0, "<false, false>");
+    else if (!ta && tb) GGAN_GEMM_CASE(false, true, 0, "<false, true>");
+    else if (ta && !tb) GGAN_GEMM_CASE(true, false, 0, "<true, false>");
+    else GGAN_GEMM_CASE(true, true, 0, "<true, true>");
 #undef GGAN_GEMM_CASE
     return 0;
 }
@@ -694,7 +741,7 @@ int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const flo
         GG.kind[0] = 1; GG.gx[0] = Ga.gx; GG.p[0] = Ga.P; GG.first[0] = 0;
         GG.kind[1] = 0; GG.gx[1] = Gw.gx; GG.p[1] = Gw.P; GG.first[1] = Ga.gx * Ga.gy;
         GG.first[2] = GG.first[1] + Gw.gx * Gw.gy;
-        GGAN_LAUNCH("gemm_group_kernel", 4.0 * M * K * (double)H, 0, gemm_group_kernel, dim3(GG.first[2]), dim3(256), 0, s, GG);
+        GGAN_LAUNCH_GROUP(4.0 * M * K * (double)H, GG.first[2], s, GG);
         return 0;
     }
     if (nw) { int rc = gemm_launch_planned(Gw, 1, 0, s); if (rc) return rc; }
@@ -763,7 +810,7 @@ int ggan_mlp_chain_bwd(int M, int K1, int K2, int H, const float* g, const float
             first += pl[i]->gx * pl[i]->gy;
         }
         GG.first[3] = first;
-        GGAN_LAUNCH("gemm_group_kernel", 2.0 * M * H * (2.0 * H + K1 + K2), 0, gemm_group_kernel, dim3(first), dim3(256), 0, s, GG);
+        GGAN_LAUNCH_GROUP(2.0 * M * H * (2.0 * H + K1 + K2), first, s, GG);
         return 0;
     }
     rc = gemm_launch_planned(G3, 1, 0, s); if (rc) return rc;

@@ -19,9 +19,9 @@ print('%-44s %.4f ms  -> %+.1f us' % (k, v, 1e3*(b-v)))
 P
   done
 done <<'L'
-gemm_kernel<false, false|8
-gemm_kernel<true, false|3
-gemm_kernel<false, true|3
+kernel<false, false|8
+kernel<true, false|3
+kernel<false, true|3
 gemm_group_kernel|1
 splitk_reduce|5
 head_out_fwd_k|2
