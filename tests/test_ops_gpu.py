@@ -122,7 +122,9 @@ def test_deconv_delta_alignment(gpu):
 
 
 GEMM_CASES = [(64, 4096, 128), (64, 128, 4096), (128, 512, 4608), (64, 512, 158), (64, 1, 512), (50, 30, 7),
-              (4608, 512, 64), (158, 512, 64), (512, 1, 64), (1, 1, 1), (65, 67, 33)]
+              (4608, 512, 64), (158, 512, 64), (512, 1, 64), (1, 1, 1), (65, 67, 33),
+              # the one-launch skinny products (gemm_skinny_k: 16x16 tiles, K split over the waves): code-space critic shapes, ragged edges
+              (128, 512, 512), (128, 158, 512), (128, 512, 128), (100, 70, 1000), (33, 33, 72), (128, 512, 1024)]
 
 
 @pytest.mark.parametrize('mnk', GEMM_CASES)
@@ -366,7 +368,7 @@ def test_distance(gpu, p):
     assert _rel(gx.cpu().numpy(), rg) < 1e-6 and _rel(gy.cpu().numpy(), -rg) < 1e-6 and gx.shape == tx.shape
 
 
-@pytest.mark.parametrize('mnk', [(64, 512, 128), (128, 512, 640), (37, 50, 19)])
+@pytest.mark.parametrize('mnk', [(64, 512, 128), (128, 512, 640), (37, 50, 19), (128, 512, 512), (128, 500, 158), (50, 66, 70)])
 def test_linear_backward_with_fused_activation_mask(gpu, mnk):
     """ggan_linear_bwd_data_act / _weight_act: dx = (g*act'(y)) w^T, dw = x^T (g*act'(y)), db = colsum."""
     import torch

@@ -9,7 +9,7 @@ from graphical_gan_amd import functional as F
 dev = torch.device('cuda:0')
 SHAPES = [  # (ta, tb, M, N, K) as issued by fwd / dX / dW of the critic + generator/extractor Linears
     (0, 0, 64, 512, 4608), (0, 0, 128, 512, 4608), (0, 0, 64, 128, 4096), (0, 0, 64, 512, 512), (0, 0, 128, 512, 128),
-    (0, 0, 64, 4096, 128), (0, 1, 64, 4608, 512), (0, 1, 128, 4608, 512), (0, 1, 64, 512, 512), (0, 1, 64, 4096, 128),
+    (0, 0, 64, 4096, 128), (0, 0, 128, 512, 512), (0, 0, 128, 512, 158), (0, 1, 128, 512, 512), (0, 1, 128, 158, 512), (0, 1, 128, 128, 512), (0, 1, 64, 4608, 512), (0, 1, 128, 4608, 512), (0, 1, 64, 512, 512), (0, 1, 64, 4096, 128),
     (1, 0, 4608, 512, 128), (1, 0, 512, 512, 64), (1, 0, 4096, 128, 64), (1, 0, 128, 4096, 64),
 ]
 sks = sys.argv[1:] or ['auto']
