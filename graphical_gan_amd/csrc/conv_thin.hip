@@ -466,6 +466,12 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     }
     for (int e = tid; e < cbase; e += NTHR) xs[e] = 0.f;
     if (tid == 0) { xs[cbase] = 1.f; xs[cbase + 1] = 0.f; }
+    int* jtab = reinterpret_cast<int*>(wsm + P.KS * 4 * P.WS);     // [KS*4] operand-row table (behind the filter)
+    if (tid < P.KS * 4) {
+        const int j = tid;
+        const int tap = fdiv(j, P.d_Ci), c = j - tap * P.Ci, kh = fdiv(tap, P.d_5), kw = tap - kh * 5;
+        jtab[j] = j < P.J ? c * P.XCS + kh * P.XRS + kw + 2 - P.pad_l : (int)(0x80000000u | (unsigned)(cbase + 1));
+    }
     if (!(P.dbg & 2)) {
         const int c4 = P.Co >> 2, rows = P.KS * 4;
         for (int u = tid; u < rows * c4; u += NTHR) {
@@ -518,27 +524,31 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
         for (int t = 0; t < NTN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* bp = wsm + q * P.WS + l15;
     float av[2][MPW], bv[2][NTN];
-    auto load_step = [&](int ks, float* a, float* bb) {
-        const int j = ks * 4 + q;
-        const int tap = fdiv(j, P.d_Ci), c = j - tap * P.Ci, kh = fdiv(tap, P.d_5), kw = tap - kh * 5;
-        const bool real = j < P.J;
-        const int joff = real ? c * P.XCS + kh * P.XRS + kw + 2 - P.pad_l : cbase + 1;
-        const int pm = real ? -1 : 0;
+    // slab offset of operand row j = (tap, channel) -- geometry only: the table built during staging (one entry per row, sign bit = a
+    // padding row that reads the constant 0.0), read a step ahead; computed per lane and step it was ~15 VALU instructions in front
+    // of every A-fragment read of a loop whose single wave per SIMD has nothing to hide them under
+    auto row_entry = [&](int ks) { return jtab[min(ks, P.KS - 1) * 4 + q]; };
+    auto load_step = [&](int e, int ks, float* a, float* bb) {
+        const int joff = e & 0x7fffffff, pm = ~(e >> 31);
 #pragma unroll
         for (int i = 0; i < MPW; ++i) a[i] = xs[joff + (pix[i] & pm)];
 #pragma unroll
         for (int t = 0; t < NTN; ++t) bb[t] = bp[ks * 4 * P.WS + t * 16];
     };
-    load_step(0, av[0], bv[0]);
+    int e0 = row_entry(0), e1 = row_entry(1);
+    load_step(e0, 0, av[0], bv[0]);
+    e0 = row_entry(2);
     for (int ks = 0; ks < ((P.dbg & 1) ? 0 : P.KS); ks += 2) {               // KS is even (K padded to a multiple of 8 with zero rows)
-        load_step(ks + 1, av[1], bv[1]);
+        load_step(e1, ks + 1, av[1], bv[1]);
+        e1 = row_entry(ks + 3);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MPW; ++i)
 #pragma unroll
             for (int t = 0; t < NTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i], bv[0][t], acc[i][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        load_step(min(ks + 2, P.KS - 1), av[0], bv[0]);
+        load_step(e0, min(ks + 2, P.KS - 1), av[0], bv[0]);
+        e0 = row_entry(ks + 4);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MPW; ++i)
@@ -752,8 +762,8 @@ int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const
     if (P.xunits > XU_MAX * NTHR) return 1;
     P.d_Wo = make_fastdiv(g.Wo); P.d_W4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR); P.d_Ci = make_fastdiv(g.Ci);
     P.d_5 = make_fastdiv(5);
-    const size_t shmem = ((((size_t)g.Ci * P.XCS + 2 + 3) & ~(size_t)3) + (size_t)P.KS * 4 * P.WS) * sizeof(float);
-    if (shmem > 64 * 1024) return 1;
+    const size_t shmem = ((((size_t)g.Ci * P.XCS + 2 + 3) & ~(size_t)3) + (size_t)P.KS * 4 * P.WS + (size_t)P.KS * 4) * sizeof(float);
+    if (shmem > 64 * 1024 || P.KS * 4 > NTHR) return 1;
     const int NTN = g.Co / 16, MPW = cdiv(P.MT, 4);
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     const dim3 grid(P.nb, g.N);

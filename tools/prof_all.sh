@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-T=r04
+T=${T:-r04}
 bash tools/prof_round.sh ${T}
 bash tools/prof_round.sh ${T}_face --dataset face
 SPI=6 bash tools/prof_round.sh ${T}_waligp --mode wali-gp
