@@ -405,12 +405,87 @@ __global__ __launch_bounds__(512) void gemm_kernel8(const GemmParams P) {
 // Independent products in ONE launch (a Linear layer's weight gradient next to its data gradient: both consume the same
 // upstream gradient, neither fills the chip, and every launch of a step graph costs ~5 us before it does any work).
 // Workgroups [first[j], first[j+1]) belong to problem j; FAST operands, no split-K.
+// The BCE terms of a cost whose logits are the rows of ONE critic head, known before the head runs (the caller's hint: consecutive
+// row ranges, label, weight -- tflib/objs/gan_inference.py:104-117).  The cost's gradient for a unit upstream gradient is row-local,
+// g[r] = w_k / n_k * (sigmoid(logit[r]) - z_k), so the forward tail can leave g and gh = g w_out^T lrelu'(h) behind at once and the
+// head's backward products follow it directly: one launch less on the chain  tail product -> logits -> cost -> head backward -> products
+// of every step.  What needs all rows (the cost itself, d_wout = h^T g, d_bout) rides in the products' launch (head_tail_wg).
+struct HeadTerms { int count; int rows[4]; float z[4]; float w[4]; };
+
+// What the cost and the head's own parameters need from ALL rows, as extra workgroups of the products' launch (or head_tail_k):
+// workgroup 0: the cost -- bce_multi_fwd_k's loop and summation order on 256 threads (pointwise.hip);  workgroups 1..: 16 columns of
+// d_wout = h^T g each, the first of them d_bout too -- head_out_bwd_k's loop and combination order without the gh store.  Threads
+// beyond 256 (eight-wave launches) only keep the barriers company: their partial sums are exact zeros.
+struct HeadTail {
+    const float* logits; const float* g; const float* h;
+    float* d_wout; float* d_bout; float* loss;
+    int M, H, first;
+    HeadTerms terms;
+};
+
+__device__ __forceinline__ void head_tail_wg(const HeadTail& T, const int local, float* lds /* >= 16 * 16 + 32 floats */) {
+    const int tid = threadIdx.x;
+    const bool on = tid < 256;
+    if (local == 0) {
+        float* sm = lds;
+        float tot = 0.f;
+        int r0 = 0;
+        for (int k = 0; k < T.terms.count; ++k) {
+            const float z = T.terms.z[k];
+            const int n = T.terms.rows[k];
+            float s = 0.f;
+            if (on)
+                for (int i = tid; i < n; i += 256) {
+                    const float v = T.logits[r0 + i];
+                    s += fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)));
+                }
+            s = block_sum(s, sm);
+            const float r = T.terms.w[k] * (s / (float)n);
+            tot = k ? tot + r : r;
+            r0 += n;
+        }
+        if (tid == 0 && T.loss) T.loss[0] = tot;
+        return;
+    }
+    float (*red)[16] = reinterpret_cast<float (*)[16]>(lds);
+    const int cl = tid & 15, rg = (tid >> 4) & 15;
+    const int c = (local - 1) * 16 + cl;
+    float acc = 0.f, gs = 0.f;
+    if (on && c < T.H) {
+#pragma unroll 8
+        for (int r = rg; r < T.M; r += 16) {
+            const float gr = T.g[r], hv = T.h[(size_t)r * T.H + c];
+            acc = fmaf(gr, hv, acc);
+            gs += gr;
+        }
+    }
+    if (on) red[rg][cl] = acc;
+    __syncthreads();
+    if (on && rg == 0 && c < T.H && T.d_wout)
+        T.d_wout[c] = (((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]))) +
+                      (((red[8][cl] + red[9][cl]) + (red[10][cl] + red[11][cl])) + ((red[12][cl] + red[13][cl]) + (red[14][cl] + red[15][cl])));
+    if (local == 1 && T.d_bout) {
+        __syncthreads();
+        if (on && cl == 0) red[rg][0] = gs;
+        __syncthreads();
+        if (tid == 0) T.d_bout[0] = (((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) + ((red[4][0] + red[5][0]) + (red[6][0] + red[7][0]))) +
+                                    (((red[8][0] + red[9][0]) + (red[10][0] + red[11][0])) + ((red[12][0] + red[13][0]) + (red[14][0] + red[15][0])));
+    }
+}
+
+__global__ __launch_bounds__(256) void head_tail_k(const HeadTail T) {
+    __shared__ float lds[16 * 16 + 32];
+    head_tail_wg(T, blockIdx.x, lds);
+}
+
 struct GemmGroup {
     int n;
     int first[4];
     int kind[3];        // 0: A^T B (ta)   1: A B^T (tb)   2: A B
     int gx[3];
     GemmParams p[3];
+    int has_tail;       // extra workgroups behind the products: head_tail_wg (tail.first = their first workgroup)
+    HeadTail tail;
 };
 
 template <int NWAVE>
@@ -418,6 +493,10 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_group_kernel(const GemmGroup 
     warm_kernarg(G);
     __shared__ __attribute__((aligned(16))) float As[2 * TSZ];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TSZ];
+    if (G.has_tail && (int)blockIdx.x >= G.tail.first) {
+        head_tail_wg(G.tail, (int)blockIdx.x - G.tail.first, As);
+        return;
+    }
     int j = 0;
     if (G.n > 1 && (int)blockIdx.x >= G.first[1]) j = 1;
     if (G.n > 2 && (int)blockIdx.x >= G.first[2]) j = 2;
@@ -472,6 +551,64 @@ __global__ __launch_bounds__(256) void head_out_fwd_k(const float* __restrict__ 
     if ((tid & 63) == 0) red[tid >> 6] = dot;
     __syncthreads();
     if (t == 0 && row < M) logits[row] = (red[2 * rl] + red[2 * rl + 1]) + b_out[0];
+}
+
+// head_out_fwd_k + g[r] + gh[r,:] (H <= 2048: the row's h values stay in registers).  Same expressions as bce_multi_fwd_k / head_out_bwd_k.
+__global__ __launch_bounds__(256) void head_out_fwd_bce_k(const float* __restrict__ part, int SK, size_t slab, const float* __restrict__ b,
+                                                          const float* __restrict__ w_out, const float* __restrict__ b_out, float alpha,
+                                                          float* __restrict__ h, float* __restrict__ logits, int M, int H,
+                                                          const HeadTerms T, float* __restrict__ g_out, float* __restrict__ gh) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, rl = tid >> 7, t = tid & 127;
+    const int row = blockIdx.x * 2 + rl;
+    float dot = 0.f;
+    float4 hv[4], wv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = t * 4 + it * 512;
+        if (row < M && c < H) {
+            const size_t o = (size_t)row * H + c;
+            float4 v = *reinterpret_cast<const float4*>(part + o);
+#pragma unroll 8
+            for (int s = 1; s < SK; ++s) {
+                const float4 u = *reinterpret_cast<const float4*>(part + (size_t)s * slab + o);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const float4 bb = *reinterpret_cast<const float4*>(b + c);
+            const float4 ww = *reinterpret_cast<const float4*>(w_out + c);
+            v.x = fmaxf(alpha * (v.x + bb.x), v.x + bb.x); v.y = fmaxf(alpha * (v.y + bb.y), v.y + bb.y);
+            v.z = fmaxf(alpha * (v.z + bb.z), v.z + bb.z); v.w = fmaxf(alpha * (v.w + bb.w), v.w + bb.w);
+            *reinterpret_cast<float4*>(h + o) = v;
+            dot = fmaf(v.x, ww.x, fmaf(v.y, ww.y, fmaf(v.z, ww.z, fmaf(v.w, ww.w, dot))));
+            hv[it] = v; wv[it] = ww;
+        }
+    }
+    dot = wave_sum(dot);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (row >= M) return;
+    const float lg = (red[2 * rl] + red[2 * rl + 1]) + b_out[0];
+    if (t == 0) logits[row] = lg;
+    float z = 0.f, sc = 0.f;
+    {
+        int r0 = 0;
+        for (int k = 0; k < T.count; ++k) {
+            if (row >= r0 && row < r0 + T.rows[k]) { z = T.z[k]; sc = 1.f * T.w[k] / (float)T.rows[k]; }
+            r0 += T.rows[k];
+        }
+    }
+    const float gr = sc * (1.f / (1.f + expf(-lg)) - z);
+    if (t == 0) g_out[row] = gr;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = t * 4 + it * 512;
+        if (c < H) {
+            float4 o4;
+            o4.x = gr * wv[it].x * (hv[it].x > 0.f ? 1.f : alpha); o4.y = gr * wv[it].y * (hv[it].y > 0.f ? 1.f : alpha);
+            o4.z = gr * wv[it].z * (hv[it].z > 0.f ? 1.f : alpha); o4.w = gr * wv[it].w * (hv[it].w > 0.f ? 1.f : alpha);
+            *reinterpret_cast<float4*>(gh + (size_t)row * H + c) = o4;
+        }
+    }
 }
 
 // backward head: gh[r,c] = g[r] * w_out[c] * lrelu'(h[r,c]);  d_wout[c] = sum_r g[r] h[r,c];  d_bout = sum_r g[r].
@@ -810,15 +947,56 @@ int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const fl
     return 0;
 }
 
+static int head_terms(HeadTerms& T, int M, int nterms, const int* rows, const float* labels, const float* weights) {
+    memset(&T, 0, sizeof(T));
+    if (nterms < 1 || nterms > 4 || !rows || !labels || !weights) return -1;
+    int tot = 0;
+    for (int k = 0; k < nterms; ++k) {
+        if (rows[k] <= 0) return -1;
+        T.rows[k] = rows[k]; T.z[k] = labels[k]; T.w[k] = weights[k];
+        tot += rows[k];
+    }
+    T.count = nterms;
+    return tot == M ? 0 : -1;
+}
+
+// ggan_critic_head_fwd for a head whose logits are known to feed ONE sigmoid-cross-entropy cost with these terms (consecutive row
+// ranges of the logits: rows, label, weight; the cost = sum_k w_k * mean(bce(logits of term k, z_k)), gan_inference.py:104-117): the
+// tail kernel also leaves g[M] = d cost / d logits for a unit upstream gradient and gh[M,H] = g w_out^T lrelu'(h), so that
+// ggan_critic_head_bwd_tail can follow at once.  H <= 2048.
+int ggan_critic_head_fwd_bce(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* b,
+                             const float* w_out, const float* b_out, float alpha, float* h, float* logits, int nterms,
+                             const int* term_rows, const float* labels, const float* weights, float* g, float* gh, void* ws,
+                             size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(a1 && w && b && w_out && b_out && h && logits && g && gh, "null pointer");
+    GGAN_CHECK_ARG(M > 0 && K1 > 0 && K2 >= 0 && H > 0 && (H % 4) == 0 && H <= 2048 && (a2 || K2 == 0), "bad shape");
+    GGAN_CHECK_ARG(al16(b) && al16(w_out) && al16(h) && al16(gh), "b, w_out, h, gh must be 16-byte aligned");
+    HeadTerms T;
+    GGAN_CHECK_ARG(head_terms(T, M, nterms, term_rows, labels, weights) == 0, "terms must be 1..4 row ranges covering the M rows");
+    hipStream_t s = (hipStream_t)stream;
+    GemmPlan G;
+    { const char* e = getenv("GGAN_HEAD_WGS"); g_split_target = e ? atoi(e) : 512; }
+    int rc = gemm_plan(G, 0, 0, 0, M, H, K1 + K2, a1, w, nullptr, h, nullptr, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
+                       K2 ? a2 : nullptr, K2 ? K1 : 0);
+    g_split_target = 256;
+    if (rc) return rc;
+    rc = gemm_launch_planned(G, 0, 0, s);
+    if (rc) return rc;
+    const float* part = G.P.SK > 1 ? (const float*)G.ws : h;
+    GGAN_LAUNCH("head_out_fwd_bce_k", 5.0 * M * H, 4.0 * M * H * (G.P.SK + 2), head_out_fwd_bce_k, dim3(cdiv(M, 2)), dim3(256), 0, s, part,
+                G.P.SK, G.P.slab_stride, b, w_out, b_out, alpha, h, logits, M, H, T, g, gh);
+    return 0;
+}
+
 // Backward of the same head from g = d cost / d logits [M]:
 //   gh = g w_out^T * lrelu'(h)                      (scratch [M,H], caller-owned: also what the two products below consume)
 //   d_wout[H] = h^T g, d_bout = sum g               (NULL: not wanted)
 //   d_w[K1+K2,H] = [a1|a2]^T gh, d_b[H] = colsum gh (d_w NULL in generator steps: the critic's weights are not in the var_list)
 //   [d_a1 | d_a2] = gh w^T                          (NULL: the inputs need no gradient)
 // head kernel + ONE grouped launch for the two products (separate launches when an operand does not take the FAST loads).
-int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const float* a1, const float* a2, const float* w, const float* h,
-                         const float* w_out, float alpha, float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b, float* d_wout,
-                         float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+static int critic_head_bwd_impl(int M, int K1, int K2, int H, const float* g, const float* a1, const float* a2, const float* w, const float* h,
+                                const float* w_out, float alpha, float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b, float* d_wout,
+                                float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream, const HeadTail* tail) {
     GGAN_CHECK_ARG(a1 && w && h && w_out && gh, "null pointer");
     GGAN_CHECK_ARG(M > 0 && K1 > 0 && K2 >= 0 && H > 0 && (a2 || K2 == 0), "bad shape");
     GGAN_CHECK_ARG(!d_a1 || K2 == 0 || d_a2, "d_a2 missing");
@@ -852,12 +1030,47 @@ int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const flo
         GG.kind[0] = 1; GG.gx[0] = Ga.gx; GG.p[0] = Ga.P; GG.first[0] = 0;
         GG.kind[1] = 0; GG.gx[1] = Gw.gx; GG.p[1] = Gw.P; GG.first[1] = Ga.gx * Ga.gy;
         GG.first[2] = GG.first[1] + Gw.gx * Gw.gy;
-        GGAN_LAUNCH_GROUP(4.0 * M * K * (double)H, GG.first[2], s, GG);
+        int nwg = GG.first[2];
+        if (tail) {
+            GG.has_tail = 1;
+            GG.tail = *tail;
+            GG.tail.first = nwg;
+            nwg += 1 + cdiv(H, 16);
+        }
+        GGAN_LAUNCH_GROUP(4.0 * M * K * (double)H, nwg, s, GG);
         return 0;
+    }
+    if (tail) {
+        HeadTail T = *tail;
+        T.first = 0;
+        GGAN_LAUNCH("head_tail_k", 3.0 * M * H, 4.0 * M * H, head_tail_k, dim3(1 + cdiv(H, 16)), dim3(256), 0, s, T);
     }
     if (nw) { int rc = gemm_launch_planned(Gw, 1, 0, s); if (rc) return rc; }
     if (na) { int rc = gemm_launch_planned(Ga, 0, 1, s); if (rc) return rc; }
     return 0;
+}
+
+int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const float* a1, const float* a2, const float* w, const float* h,
+                         const float* w_out, float alpha, float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b, float* d_wout,
+                         float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    return critic_head_bwd_impl(M, K1, K2, H, g, a1, a2, w, h, w_out, alpha, gh, d_a1, d_a2, d_w, d_b, d_wout, d_bout, ws, ws_bytes, stream,
+                                nullptr);
+}
+
+// The backward of a head run through ggan_critic_head_fwd_bce (g and gh are given): the two products, and -- as extra workgroups of
+// their launch -- what the cost needs from all rows: loss[0] (the cost, bit-identical to ggan_bce_logits_multi_fwd on the same
+// terms), d_wout[H] = h^T g, d_bout = sum g (NULL: not wanted).
+int ggan_critic_head_bwd_tail(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* h,
+                              const float* w_out, float alpha, const float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b,
+                              float* d_wout, float* d_bout, const float* logits, const float* g, int nterms, const int* term_rows,
+                              const float* labels, const float* weights, float* loss, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(logits && g && gh, "null pointer");
+    HeadTail T;
+    memset(&T, 0, sizeof(T));
+    GGAN_CHECK_ARG(head_terms(T.terms, M, nterms, term_rows, labels, weights) == 0, "terms must be 1..4 row ranges covering the M rows");
+    T.logits = logits; T.g = g; T.h = h; T.d_wout = d_wout; T.d_bout = d_bout; T.loss = loss; T.M = M; T.H = H;
+    return critic_head_bwd_impl(M, K1, K2, H, nullptr, a1, a2, w, h, w_out, alpha, const_cast<float*>(gh), d_a1, d_a2, d_w, d_b, d_wout,
+                                d_bout, ws, ws_bytes, stream, &T);
 }
 
 // The 512-wide three-layer critic on codes, Linear -> LeakyReLU x 3 -> Linear(512 -> 1), as ONE launch per direction

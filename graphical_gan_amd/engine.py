@@ -209,9 +209,18 @@ class Trainer(object):
             self._sample_noise()
         return self.model.forward_nets(self.feed)
 
+    def _forward(self, feed, which, nets):
+        """model.forward for a step whose backward follows at once: the critic head may then leave its cost's gradient behind with
+        its own forward and take the cost's value into its backward launch (functional.head_bce_hint, models.GraphicalGAN.head_hint)"""
+        self.model.head_hint = True
+        try:
+            return self.model.forward(feed, which, nets)
+        finally:
+            self.model.head_hint = False
+
     def _fwd_bwd(self, which, nets=None, fuse_update=False, feed=None):
         """fuse_update: the caller applies the update next with nothing but a (single-replica: empty) exchange in between"""
-        out = self.model.forward(feed if feed is not None else self.feed, which, nets if nets is not None else self._nets())
+        out = self._forward(feed if feed is not None else self.feed, which, nets if nets is not None else self._nets())
         if self.keep_outputs:        # (tests: the critic logits of a captured step -- static graph memory, valid after every replay)
             det = lambda v: [t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()    # (no tape kept alive across steps)
             self.last_out[which] = {k: det(v) for k, v in out.items() if k in ('disc_fake', 'disc_real')}
@@ -234,7 +243,7 @@ class Trainer(object):
     def _bwd_phase1(self, nets):
         """generator step up to the cut: critic pass, backward to the Generator's parameters and to the Extractor's outputs,
         Generator gradients packed.  Returns everything phase 2 needs."""
-        out = self.model.forward(self.feed, 'gen', nets)
+        out = self._forward(self.feed, 'gen', nets)
         op = out['gen_train_op']
         opt = op.optimizer
         plan = self._two_bucket_plan(opt, nets)
@@ -360,7 +369,7 @@ class Trainer(object):
         """critic step with two gradient buckets: autograd reaches the critic's tail first, and that is where most of the bytes
         are (Discriminator.zx1: 2.6 M of the 4.1 M parameters) -- its bucket is exchanged while the conv stack's backward pass
         (two thirds of the critic's backward time) still runs; the conv stack's bucket follows.  Same sums as one bucket."""
-        out = self.model.forward(feed if feed is not None else self.feed, 'disc', nets if nets is not None else self._nets())
+        out = self._forward(feed if feed is not None else self.feed, 'disc', nets if nets is not None else self._nets())
         op = out['disc_train_op']
         opt = op.optimizer
         cutinfo = self.model.critic_cut()

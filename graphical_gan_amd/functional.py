@@ -957,6 +957,30 @@ class Gemm2Dgrad(Function):
         return dg, dw, None
 
 
+HEAD_BCE_HINT = [None]
+
+
+class head_bce_hint(object):
+    """`with head_bce_hint([(rows, label, weight), ...]):` -- the caller knows that the logits of the critic head evaluated inside are
+    going to be the terms (consecutive row ranges, in order) of ONE BceSum cost that a train op differentiates with a unit seed.  The
+    head's forward then leaves the cost's gradient and gh behind in its tail launch (ggan_critic_head_fwd_bce) and its backward's
+    product launch carries the cost itself (ggan_critic_head_bwd_tail): one launch less on the critical chain of the step, values
+    bit-identical.  The cost's value exists once the head's backward has run -- only for steps that run it (engine.Trainer).  A cost
+    built from other terms than hinted ignores the hint's by-products (BceSum launches as always)."""
+
+    def __init__(self, terms):
+        self.terms = tuple((int(n), float(z), float(w)) for n, z, w in terms) if terms else None
+
+    def __enter__(self):
+        self.prev = HEAD_BCE_HINT[0]
+        HEAD_BCE_HINT[0] = self.terms
+        return self
+
+    def __exit__(self, *exc):
+        HEAD_BCE_HINT[0] = self.prev
+        return False
+
+
 @_skip_undefined
 class CriticHead(Function):
     """logits[M] = Linear(H -> 1)(lrelu(Linear([a1 | a2] -> H))): the tail of a critic as one op (ggan_critic_head_fwd/bwd:
@@ -975,16 +999,31 @@ class CriticHead(Function):
         h = torch.empty((M, H), dtype=torch.float32, device=a1.device)
         logits = torch.empty((M,), dtype=torch.float32, device=a1.device)
         ws = workspace(a1.device)
-        check(_L().ggan_critic_head_fwd(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(b), _p(w_out), _p(b_out), float(alpha), _p(h),
-                                        _p(logits), _p(ws), ws.numel(), _stream()), 'ggan_critic_head_fwd')
+        registers = M <= _lib.HEAD_BCE_MAX_ROWS and any(ctx.needs_input_grad) and not os.environ.get('GGAN_NO_HEAD_BCE')
+        hint = HEAD_BCE_HINT[0]
+        hinted = None
+        if (registers and hint is not None and 1 <= len(hint) <= 4 and sum(n for n, _, _ in hint) == M and H <= 2048
+                and not os.environ.get('GGAN_NO_HEAD_HINT')):
+            # the caller vouches for the cost these logits feed (head_bce_hint): its gradient and gh leave with the tail launch
+            g = torch.empty((M,), dtype=torch.float32, device=a1.device)
+            gh = torch.empty((M, H), dtype=torch.float32, device=a1.device)
+            nt = len(hint)
+            tabs = ((C.c_int * nt)(*[n for n, _, _ in hint]), (C.c_float * nt)(*[z for _, z, _ in hint]), (C.c_float * nt)(*[wt for _, _, wt in hint]))
+            check(_L().ggan_critic_head_fwd_bce(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(b), _p(w_out), _p(b_out), float(alpha), _p(h),
+                                                _p(logits), nt, tabs[0], tabs[1], tabs[2], _p(g), _p(gh), _p(ws), ws.numel(), _stream()),
+                  'ggan_critic_head_fwd_bce')
+            hinted = dict(terms=hint, g=g, gh=gh)
+        else:
+            check(_L().ggan_critic_head_fwd(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(b), _p(w_out), _p(b_out), float(alpha), _p(h),
+                                            _p(logits), _p(ws), ws.numel(), _stream()), 'ggan_critic_head_fwd')
         ctx.alpha, ctx.has_a2 = float(alpha), a2 is not None
         ctx.save_for_backward(a1, a2, w, w_out, h)
         # a BCE cost on exactly these logits may take the head kernel of this op's backward into its own launch (BceSum)
         ctx.rec = None
-        if M <= _lib.HEAD_BCE_MAX_ROWS and any(ctx.needs_input_grad) and not os.environ.get('GGAN_NO_HEAD_BCE'):
+        if registers:
             ctx.rec = dict(ptr=logits.data_ptr(), M=M, H=H, h=weakref.ref(h), w_out=weakref.ref(w_out), alpha=float(alpha),
                            want_out=ctx.needs_input_grad[4],
-                           want_bout=ctx.needs_input_grad[5], g_ptr=None)
+                           want_bout=ctx.needs_input_grad[5], g_ptr=None, hinted=hinted, tail=None)
             if len(HEAD_LOGITS) >= 8:            # (heads whose logits never met a BCE cost: Wasserstein modes)
                 HEAD_LOGITS.clear()
             HEAD_LOGITS[ctx.rec['ptr']] = ctx.rec
@@ -1014,6 +1053,31 @@ class CriticHead(Function):
         d_wout = (rec['d_wout'].view(w_out.shape) if fused else new(*w_out.shape)) if need[4] else None
         d_bout = (rec['d_bout'] if fused else new(1)) if need[5] else None
         ws = workspace(dev)
+        tail = rec.get('tail') if rec is not None else None
+        if tail is not None:
+            rec['tail'] = None
+            if fused:
+                # hinted head: gh and g left with the forward's tail launch; the products' launch carries the cost, d_wout, d_bout
+                nt = len(tail['terms'])
+                tabs = ((C.c_int * nt)(*[n for n, _, _ in tail['terms']]), (C.c_float * nt)(*[z for _, z, _ in tail['terms']]),
+                        (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]))
+                check(_L().ggan_critic_head_bwd_tail(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1), _p(d_a2),
+                                                     _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(tail['logits']), _p(tail['g']), nt, tabs[0],
+                                                     tabs[1], tabs[2], _p(tail['loss']), _p(ws), ws.numel(), _stream()),
+                      'ggan_critic_head_bwd_tail')
+                return (d_a1 if need[0] else None, d_a2 if (a2 is not None and need[1]) else None, d_w if need[2] else None, d_b, d_wout,
+                        d_bout, None)
+            # (another upstream gradient than the unit seed reached this head: the cost's value is still owed)
+            nt = len(tail['terms'])
+            lg = tail['logits']
+            xs, o = [], 0
+            for n, _, _ in tail['terms']:
+                xs.append(lg.data_ptr() + 4 * o)
+                o += n
+            check(_L().ggan_bce_logits_multi_fwd((C.c_void_p * nt)(*xs), (C.c_float * nt)(*[z for _, z, _ in tail['terms']]),
+                                                 (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]),
+                                                 (C.c_int * nt)(*[n for n, _, _ in tail['terms']]), nt, _p(tail['loss']), _stream()),
+                  'ggan_bce_logits_multi_fwd')
         # (fused: gh, d_wout, d_bout left with the cost's launch -- ggan_bce_head_bwd; g = NULL launches the products only)
         check(_L().ggan_critic_head_bwd(M, K1, K2, H, _p(None if fused else g), _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1),
                                         _p(d_a2), _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(ws), ws.numel(), _stream()),
@@ -1999,7 +2063,23 @@ class BceSum(Function):
             outs = BceSum._grad_buffers(logits, loss.device)
             gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
             heads = BceSum._heads_of(logits)
-            if heads is not None:
+            hrec = heads[0][0] if (heads is not None and len(heads) == 1) else None
+            if (hrec is not None and hrec.get('hinted') is not None
+                    and hrec['hinted']['terms'] == tuple((x.numel(), float(z), float(wt)) for x, z, wt in zip(logits, labels, weights))):
+                # the head ran with this cost's terms as its hint (head_bce_hint): g and gh exist already, the cost's value, d_wout and
+                # d_bout come with the head's backward products (ggan_critic_head_bwd_tail) -- nothing to launch here
+                hh = hrec['hinted']
+                new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=loss.device)
+                outs, o = [], 0
+                for x in logits:
+                    outs.append(hh['g'][o:o + x.numel()])
+                    o += x.numel()
+                hrec['gh'] = hh['gh']
+                hrec['d_wout'] = new(hrec['H']) if hrec['want_out'] else None
+                hrec['d_bout'] = new(1) if hrec['want_bout'] else None
+                hrec['g_ptr'], hrec['g_version'] = outs[0].data_ptr(), outs[0]._version
+                hrec['tail'] = dict(terms=hh['terms'], logits=logits[0], g=hh['g'], loss=loss)
+            elif heads is not None:
                 # every term is a row range of a critic head's logits (one head, or the two heads of the mixture scripts): the head
                 # kernels of those ops' backward ride along
                 new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=loss.device)

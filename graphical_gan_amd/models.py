@@ -683,7 +683,15 @@ class GraphicalGAN(object):
             self._gp_stream.wait_stream(cur)                          # fake_x, p_z (Generator branch)
             with torch.cuda.stream(self._gp_stream):
                 gp_early = self._penalty(J, batched, real_x, fake_x, q_z, p_z, feed)
-        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()):
+        # MODE ali on the batched critic: the cost of this step is known before the critic runs -- sigmoid cross-entropy of its [fake; real]
+        # logits with labels (1, 0) in a generator step, (0, 1) in a critic step (tflib/objs/gan_inference.py:47-79) -- and the caller
+        # (engine.Trainer, head_hint) runs the backward at once: the critic head leaves that cost's gradient behind with its forward
+        hint = None
+        if (getattr(self, 'head_hint', False) and c.mode == 'ali' and not c.K and batched and c.fuse and real_x.is_cuda
+                and not os.environ.get('GGAN_NO_HEAD_HINT')):
+            fl, rl = (1.0, 0.0) if which == 'gen' else (0.0, 1.0)
+            hint = [(c.B, fl, 1.0), (c.B, rl, 1.0)]
+        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()), F.head_bce_hint(hint):
             d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None,
                                           detach=which == 'disc')
         if gp_early is not None:

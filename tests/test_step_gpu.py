@@ -831,6 +831,7 @@ def test_cost_launch_carrying_the_head_backward_is_bit_identical(gpu, monkeypatc
     from graphical_gan_amd.models import Config
     from graphical_gan_amd.engine import Trainer
     finals, fused_launches = [], []
+    monkeypatch.setenv('GGAN_NO_HEAD_HINT', '1')      # (MODE ali otherwise takes the hinted head: the test below)
     for fused in (False, True):
         if fused:
             monkeypatch.delenv('GGAN_NO_HEAD_BCE', raising=False)
@@ -858,6 +859,66 @@ def test_cost_launch_carrying_the_head_backward_is_bit_identical(gpu, monkeypatc
         finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}))
     assert fused_launches == [0, 1 if mode == 'ali' else 2]      # (the mixture scripts: joint critic + mixture critic in one cost)
     assert finals[0][1] == finals[1][1]
+    for k in finals[0][0]:
+        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('dataset', ['cifar10', 'face'])
+def test_head_that_knows_its_cost_is_bit_identical(gpu, monkeypatch, dataset, graph):
+    """MODE ali on the batched critic: the step's cost is known before the critic runs (functional.head_bce_hint, set by
+    models.forward for engine.Trainer's steps), so the head's forward tail leaves g = d cost / d logits and gh behind
+    (ggan_critic_head_fwd_bce) and the products' launch of its backward carries the cost, d_wout and d_bout
+    (ggan_critic_head_bwd_tail) -- one launch less per step than tail + cost/head launch + products.  Same expressions in the same
+    order => bit-identical costs and weights, eager and graph-replayed."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    finals, counts = [], []
+    for hinted in (False, True):
+        if hinted:
+            monkeypatch.delenv('GGAN_NO_HEAD_HINT', raising=False)
+        else:
+            monkeypatch.setenv('GGAN_NO_HEAD_HINT', '1')
+        _fresh()
+        np.random.seed(0)
+        cfg = Config(dataset, batch_size=16, mode='ali', dim=16, dim_latent=32)
+        tr = Trainer(cfg, device=gpu, graph=graph, seed=4321)
+        batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 40)
+        lib_, calls = _lib.load(), {'fwd': 0, 'bwd': 0, 'old': 0}
+        e_fwd, e_bwd, e_old = lib_.ggan_critic_head_fwd_bce, lib_.ggan_critic_head_bwd_tail, lib_.ggan_bce_heads_bwd
+
+        def c_fwd(*a):
+            calls['fwd'] += 1
+            return e_fwd(*a)
+
+        def c_bwd(*a):
+            calls['bwd'] += 1
+            return e_bwd(*a)
+
+        def c_old(*a):
+            calls['old'] += 1
+            return e_old(*a)
+        monkeypatch.setattr(lib_, 'ggan_critic_head_fwd_bce', c_fwd)
+        monkeypatch.setattr(lib_, 'ggan_critic_head_bwd_tail', c_bwd)
+        monkeypatch.setattr(lib_, 'ggan_bce_heads_bwd', c_old)
+        costs = []
+        for it in range(6):
+            res = tr.iteration(it, batches)
+            if not graph:
+                costs.append({k: float(v) for k, v in res.items()})
+        monkeypatch.setattr(lib_, 'ggan_critic_head_fwd_bce', e_fwd)
+        monkeypatch.setattr(lib_, 'ggan_critic_head_bwd_tail', e_bwd)
+        monkeypatch.setattr(lib_, 'ggan_bce_heads_bwd', e_old)
+        tr.flush()
+        torch.cuda.synchronize()
+        counts.append(dict(calls))
+        finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}, costs))
+    assert counts[0]['fwd'] == 0 and counts[0]['bwd'] == 0 and counts[0]['old'] > 0
+    assert counts[1]['fwd'] > 0 and counts[1]['bwd'] == counts[1]['fwd'] and counts[1]['old'] == 0
+    assert finals[0][1] == finals[1][1] and finals[0][2] == finals[1][2]
+    assert all(np.isfinite(v) for v in finals[1][1].values())
     for k in finals[0][0]:
         assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
 
