@@ -899,6 +899,8 @@ __global__ void pack_adam_k(PackTable t, float* __restrict__ flat, float* __rest
 #undef ADAM1
     // arrival in two levels (same-address atomics are served one at a time, ~13 ns each, and the workgroups of this one-round
     // launch all finish together): 32 group counters 4 KB apart, the last workgroup of each group reports to counter 0
+    // (arrive == NULL: this launch applies PART of an update -- the ordinal stays step[0] + 1 for the launch that completes it)
+    if (!arrive) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int grp = blockIdx.x & 31, members = ((int)gridDim.x - grp + 31) >> 5, groups = gridDim.x < 32 ? (int)gridDim.x : 32;
@@ -1543,7 +1545,7 @@ int ggan_pack_adam(const float* const* srcs, const size_t* sizes, const size_t* 
                    const float* const* srcs2, const int* parts2, const size_t* strides2, int count, float* flat, float* theta,
                    float* m, float* v, int32_t* step, int32_t* arrive, float lr, float beta1, float beta2, float eps,
                    float grad_scale, ggan_stream_t stream) {
-    GGAN_CHECK_ARG(srcs && sizes && offsets && flat && theta && m && v && step && arrive, "null pointer");
+    GGAN_CHECK_ARG(srcs && sizes && offsets && flat && theta && m && v && step, "null pointer");
     GGAN_CHECK_ARG(count > 0 && count <= GGAN_PACK_MAX, "count out of range");
     PackTable t;
     size_t mx = 0, tot = 0, all = 0;

@@ -358,12 +358,51 @@ class Trainer(object):
                 opt.all_reduce()
         elif self.dp_graph and which == 'disc' and hasattr(self.model, 'critic_cut') and not os.environ.get('GGAN_ONE_BUCKET'):
             cost, opt, keep = self._disc_two_buckets(nets, feed)
+        elif (which == 'disc' and hasattr(self.model, 'critic_cut') and self.model.fork_now and self.world == 1
+              and os.environ.get('GGAN_EARLY_TAIL_UPDATE', '0') == '1'):      # (opt-in: measured slower, below)
+            cost, opt, keep = self._disc_early_tail(nets, feed)
         else:
             cost, opt, keep = self._fwd_bwd(which, nets, fuse_update=not self.dp_graph, feed=feed)
             if self.dp_graph:
                 opt.all_reduce()
         opt.update()
         return cost, opt, keep
+
+    def _disc_early_tail(self, nets=None, feed=None):
+        """single-replica critic step inside a step graph: autograd reaches the critic's tail first and that is where most of the
+        parameters are (Discriminator.zx1: 2.4 M of the 4.1 M) -- their pack + Adam launch (HBM-bound: 28 B per parameter) goes to
+        the second stream, beside the conv stack's backward pass (MFMA-bound), and the launch at the end of the step is left with the
+        conv stack's 1 M parameters and their filter-gradient slabs.  Same arithmetic per parameter: bit-identical to one launch.
+        Measured (three alternating pairs, same box): headline 1.002 -> 1.018 ms, gmgan 1.107 -> 1.156 -- the second autograd pass and
+        the fork / join pair cost more than the 12 us the last launch gets shorter, as every split of a step's backward has so far
+        (profiles/r03_notes.md, r04_notes.md).  Opt-in: GGAN_EARLY_TAIL_UPDATE=1."""
+        out = self._forward(feed if feed is not None else self.feed, 'disc', nets if nets is not None else self._nets())
+        op = out['disc_train_op']
+        opt = op.optimizer
+        cutinfo = self.model.critic_cut()
+        sp = None
+        if cutinfo is not None and opt.can_fuse_update() and lib.second_leaf_count() == getattr(self, '_sl0', lib.second_leaf_count()):
+            conv = tuple('Discriminator.%d.' % (i + 1) for i in range(cutinfo[1]))
+            sp = opt.split_at(lambda p: getattr(p, 'param_name', '').startswith(conv))
+        if sp is None:
+            with F.defer_wgrad_reduce(self.single_contrib):
+                keep = opt.pack(opt.compute_gradients(op.cost), fuse_update=True)
+            return out['disc_cost'].detach(), opt, (keep, out)
+        k, _ = sp
+        cut = cutinfo[0]
+        if opt._one is None or opt._one.shape != op.cost.shape:
+            opt._one = F.unit_seed(op.cost)
+        cur = torch.cuda.current_stream(self.device)
+        side = F.shared_stream(self.device, 'side')
+        with F.defer_wgrad_reduce(self.single_contrib):
+            g = torch.autograd.grad(op.cost, list(opt.params[k:]) + [cut], grad_outputs=opt._one, allow_unused=True)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                keep_a = opt.pack_update_subset(g[:-1], k, len(opt.params), last=False)
+            g2 = torch.autograd.grad([cut], opt.params[:k], grad_outputs=[g[-1]], allow_unused=True)
+            cur.wait_stream(side)
+            keep_b = opt.pack_update_subset(g2, 0, k, last=True)
+        return out['disc_cost'].detach(), opt, (keep_a, keep_b, g, g2, out)
 
     def _disc_two_buckets(self, nets=None, feed=None):
         """critic step with two gradient buckets: autograd reaches the critic's tail first, and that is where most of the bytes

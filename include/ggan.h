@@ -494,7 +494,8 @@ int ggan_pack_parts2(const float* const* srcs, const size_t* sizes, const size_t
  * The summed gradient is still written to `flat`; theta / m / v are the optimizer's flat buffers with the same offsets.  Every
  * workgroup uses step[0] + 1 as the update's ordinal and the last one to finish advances step[0]; `arrive` is
  * GGAN_PACK_ARRIVE_INTS int32 of device memory (arrival counters) that are zero before the call and are left zero.  Same
- * arithmetic, in the same order, as the two launches. */
+ * arithmetic, in the same order, as the two launches.  arrive == NULL: the launch applies PART of an update (a subset of the
+ * tensors) and leaves step[0] alone -- the launch that completes the update, ordered behind it, passes the counters. */
 #define GGAN_PACK_ARRIVE_STRIDE 1024
 #define GGAN_PACK_ARRIVE_INTS (33 * GGAN_PACK_ARRIVE_STRIDE)
 int ggan_pack_adam(const float* const* srcs, const size_t* sizes, const size_t* offsets, const int* parts, const size_t* strides,

@@ -963,3 +963,45 @@ def test_paired_nets_pass_continues_the_same_step_sequence(gpu):
         upd = np.linalg.norm(Pa[n] - P1[n])
         assert np.linalg.norm(Pa[n] - Pb[n]) <= 0.05 * upd + 1e-6, (n, np.linalg.norm(Pa[n] - Pb[n]), upd)
     optim.reset_optimizers(); lib.delete_all_params()
+
+
+@pytest.mark.parametrize('dataset,mode', [('cifar10', 'ali'), ('cifar10', 'local_ep')])
+def test_critic_tail_updated_beside_the_conv_backward_is_bit_identical(gpu, monkeypatch, dataset, mode):
+    """engine.Trainer._disc_early_tail: in a single-replica step graph the critic's tail parameters (most of the critic) take their
+    pack + Adam launch on the second stream as soon as the head's backward produced their gradients, the conv stack's follow at the
+    end of the step (AdamOptimizer.pack_update_subset: ggan_pack_adam with arrive = NULL leaves the step counter alone).  Same
+    arithmetic per parameter => bit-identical weights, Adam moments and step counts."""
+    import torch
+    from graphical_gan_amd import _lib
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    finals, partial = [], []
+    for early in (False, True):
+        monkeypatch.setenv('GGAN_EARLY_TAIL_UPDATE', '1' if early else '0')
+        _fresh()
+        np.random.seed(0)
+        cfg = Config(dataset, batch_size=16, n_coms=10 if mode == 'local_ep' else 0, mode=mode, dim=16, dim_latent=32)
+        tr = Trainer(cfg, device=gpu, graph=True, seed=4321)
+        batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 40)
+        lib_, calls = _lib.load(), []
+        entry = lib_.ggan_pack_adam
+
+        def counted(*args):
+            calls.append(bool(args[14]))           # arrive pointer: None / 0 = a partial update
+            return entry(*args)
+        monkeypatch.setattr(lib_, 'ggan_pack_adam', counted)
+        for it in range(6):
+            res = tr.iteration(it, batches)
+        monkeypatch.setattr(lib_, 'ggan_pack_adam', entry)
+        tr.flush()
+        torch.cuda.synchronize()
+        partial.append(sum(1 for c in calls if not c))
+        opts = tr._optimizers()
+        finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()},
+                       [(o.m.cpu().numpy().copy(), o.v.cpu().numpy().copy(), int(o.step)) for o in opts]))
+    assert partial[0] == 0 and partial[1] > 0
+    assert finals[0][1] == finals[1][1]
+    for k in finals[0][0]:
+        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
+    for a, b in zip(finals[0][2], finals[1][2]):
+        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
