@@ -1141,6 +1141,65 @@ def test_critic_head(gpu, M, K1, K2, H, need):
         assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
 
 
+@pytest.mark.parametrize('M,K1,K2,H,terms,need', [
+    (128, 4096, 512, 512, [(64, 1.0, 1.0), (64, 0.0, 1.0)], 'data'),        # generator step of the image scripts: [fake; real], labels (1, 0)
+    (128, 4096, 512, 512, [(64, 0.0, 1.0), (64, 1.0, 1.0)], 'all'),         # critic step
+    (100, 192, 64, 256, [(50, 0.0, 0.5), (30, 1.0, 0.5), (20, 1.0, 2.0)], 'all'),
+    (37, 70, 0, 36, [(37, 1.0, 1.0)], 'all'),
+])
+def test_critic_head_that_knows_its_cost(gpu, M, K1, K2, H, terms, need):
+    """ggan_critic_head_fwd_bce / ggan_critic_head_bwd_tail (functional.head_bce_hint around CriticHead, consumed by BceSum): the cost
+    sum_k w_k mean(bce(logits of term k, z_k)), the logits and every gradient of the cost against numpy float64; the cost's value is
+    bit-identical to ggan_bce_logits_multi_fwd on the same logits."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(M + K1 + K2 + H)
+    a1 = rng.standard_normal((M, K1)).astype(np.float32)
+    a2 = rng.standard_normal((M, K2)).astype(np.float32) if K2 else None
+    w = (rng.standard_normal((K1 + K2, H)) / np.sqrt(K1 + K2)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    wo = (rng.standard_normal((H, 1)) / np.sqrt(H) * 3).astype(np.float32)
+    bo = rng.standard_normal(1).astype(np.float32)
+    A = np.concatenate([a1, a2], 1).astype(np.float64) if K2 else a1.astype(np.float64)
+    pre = A @ w.astype(np.float64) + b
+    h = np.maximum(0.2 * pre, pre)
+    logits = (h @ wo.astype(np.float64)).reshape(-1) + bo
+    cost, g, r0 = 0.0, np.zeros(M), 0
+    for n, z, wt in terms:
+        x = logits[r0:r0 + n]
+        cost += wt * np.mean(np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x))))
+        g[r0:r0 + n] = wt / n * (1.0 / (1.0 + np.exp(-x)) - z)
+        r0 += n
+    gh = g[:, None] * wo.astype(np.float64).reshape(1, -1) * np.where(pre > 0, 1.0, 0.2)
+    ref = dict(a=gh @ w.astype(np.float64).T, w=A.T @ gh, b=gh.sum(0), wo=h.T @ g, bo=g.sum())
+    wt_grad = need == 'all'
+    t = lambda v, rg: None if v is None else _t(v, gpu).requires_grad_(rg)
+    ta1, ta2 = t(a1, True), t(a2, True)
+    tw, tb, two, tbo = t(w, wt_grad), t(b, wt_grad), t(wo, wt_grad), t(bo, wt_grad)
+    with F.head_bce_hint(terms):
+        out = F.CriticHead.apply(ta1, ta2, tw, tb, two, tbo, 0.2)
+    parts, r0 = [], 0
+    for n, _, _ in terms:
+        parts.append(out[r0:r0 + n])
+        r0 += n
+    loss = F.BceSum.apply(tuple(z for _, z, _ in terms), tuple(wt for _, _, wt in terms), *parts)
+    ins = [x for x in (ta1, ta2, tw, tb, two, tbo) if x is not None and x.requires_grad]
+    grads = dict(zip([id(x) for x in ins], torch.autograd.grad(loss, ins, grad_outputs=F.unit_seed(loss))))
+    torch.cuda.synchronize()
+    assert np.abs(out.detach().cpu().numpy() - logits).max() <= 2e-5 * max(1.0, np.abs(logits).max())
+    assert abs(float(loss.detach()) - cost) <= 1e-5 * max(1.0, abs(cost))
+    plain = F.BceSum.apply(tuple(z for _, z, _ in terms), tuple(wt for _, _, wt in terms), *[p.detach() for p in parts])
+    assert float(plain) == float(loss.detach())
+    assert _rel(grads[id(ta1)].cpu().numpy(), ref['a'][:, :K1]) < 2e-5
+    if K2:
+        assert _rel(grads[id(ta2)].cpu().numpy(), ref['a'][:, K1:]) < 2e-5
+    if wt_grad:
+        assert _rel(grads[id(tw)].cpu().numpy(), ref['w']) < 2e-5
+        assert _rel(grads[id(tb)].cpu().numpy(), ref['b']) < 2e-5
+        assert _rel(grads[id(two)].cpu().numpy().reshape(-1), ref['wo'].reshape(-1)) < 2e-5
+        assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
+
+
 @pytest.mark.parametrize('B,K,D,onehot', [(64, 30, 128, True), (50, 10, 128, True), (7, 100, 64, False)])
 def test_mix_mean(gpu, B, K, D, onehot):
     """ggan_mix_mean (functional.MixMean: HyperGenerator, gmgan_inference_cifar10.py:150-153, as one pointwise launch): k @ mu + noise
