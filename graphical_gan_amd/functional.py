@@ -1573,6 +1573,34 @@ class JoinRows(Function):
         return g[:ctx.n], g[ctx.n:]
 
 
+class Fanout(Function):
+    """n aliases of a tensor that several branches of a step read (the mixture scripts: the code p_z feeds the Generator and the
+    critics, q_z the mixture posterior and the critics, [p_z; q_z] both critics, the component means both hyper nets).  Their
+    gradients are summed HERE, in alias order, by this library's pointwise launch (ggan_axpby through Axpby, differentiable) --
+    not by at::add wherever autograd happens to meet the second contribution."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for g in gs[1:]:
+            acc = Axpby.apply(acc, g, 1.0, 1.0, 0.0)
+        return acc, None
+
+
+def fanout(x, n=2):
+    """n aliases of x whose gradients meet in one Fanout node (x itself n times where no gradient can flow)"""
+    if (not torch.is_tensor(x) or not x.is_cuda or not x.requires_grad or not torch.is_grad_enabled() or os.environ.get('GGAN_NO_FANOUT')):
+        return (x,) * n
+    return Fanout.apply(x, n)
+
+
 class SplitRows(Function):
     """(x[:n], x[n:]) for the critic evaluated once on [fake; real]; the backward is ONE concatenation instead of two
     zero-padded slice gradients and their sum."""

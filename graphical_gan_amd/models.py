@@ -116,7 +116,8 @@ class GraphicalGAN(object):
         """tensors through which EVERY gradient of the Extractor's parameters flows (None if there is no such cut: the
         reconstruction modes apply the Extractor a second time) -- lets a data-parallel generator step exchange the
         Generator's gradients while the Extractor's backward pass is still running (engine.Trainer)."""
-        return [nets['q_z']] if self.cfg.mode in ('ali', 'local_ep', 'wali', 'wali-gp') else None   # (vegan: G(q_z) re-enters)
+        # (q_z_src: the Extractor's output in front of the aliases the mixture scripts hand its readers, functional.fanout)
+        return [nets.get('q_z_src', nets['q_z'])] if self.cfg.mode in ('ali', 'local_ep', 'wali', 'wali-gp') else None   # (vegan: G(q_z) re-enters)
 
     def critic_cut(self):
         """(tensor, number of conv layers) through which every gradient of the image critic's conv stack flows in the critic step
@@ -485,13 +486,18 @@ class GraphicalGAN(object):
         out = lib.ops.linear.Linear('Discriminator.HyperOutput', 512, 1, out)
         return out.reshape(-1)
 
-    def _mu(self):
+    def _mu(self, use=None):
+        """the component means; use = 0 (HyperGenerator) / 1 (HyperExtractor) inside a nets pass: that net's alias of them, so that the two
+        gradient contributions meet in one functional.Fanout node"""
         c = self.cfg
+        fan = getattr(self, '_mu_fan', None)
+        if fan is not None and use is not None:
+            return fan[use]
         return lib.param('Generator.Hyper.Mu', np.random.normal(size=(c.K, c.dim_latent)).astype('float32'))
 
     def HyperGenerator(self, hyper_k, hyper_noise, out_slot=None):
         """gmgan_inference_cifar10.py:150-153: onehot(k) @ Mu + eps."""
-        mu = self._mu()
+        mu = self._mu(0)
         if self.cfg.fuse and F.MixMean.usable(hyper_k, mu, hyper_noise) and not os.environ.get('GGAN_NO_MIX_MEAN'):
             return F.MixMean.apply(hyper_k, mu, hyper_noise, out_slot)           # one pointwise launch (ggan_mix_mean)
         return F.Axpby.apply(F.Gemm.apply(hyper_k, mu, None, False, False, F.ACT_NONE, 0.0), hyper_noise, 1.0, 1.0, 0.0, out_slot)
@@ -500,7 +506,7 @@ class GraphicalGAN(object):
         """gmgan_inference_cifar10.py:156-173 (MODE_K='CONCRETE'): component logits and the Gumbel-softmax assignment, one
         launch per direction (ggan_gmm_latent_*; the TF graph spends a dozen [B,K] / [B,K,D] pointwise ops on it)."""
         c = self.cfg
-        return F.GmmLatent.apply(latent_z, self._mu(), gumbel_u, float(np.log(np.float32(1.0) / np.float32(c.K))), c.temp, out_slot)
+        return F.GmmLatent.apply(latent_z, self._mu(1), gumbel_u, float(np.log(np.float32(1.0) / np.float32(c.K))), c.temp, out_slot)
 
     @staticmethod
     def _var_lists():
@@ -565,6 +571,15 @@ class GraphicalGAN(object):
         # latency-bound launches that leave most of the chip idle between them; side by side they fill each other's gaps
         # (+2.8 % on the headline step).  autograd runs each pass's backward on the stream of its forward, so the two backward
         # chains of a generator step overlap the same way.  (Requested by the Trainer for single-graph steps only.)
+        # (mixture scripts: tensors two branches of the step read hand each branch an alias -- functional.fanout -- so that their gradient
+        #  contributions are summed by this library's launch in one place)
+        self._mu_fan = F.fanout(self._mu(), 2) if (c.K and c.fuse) else None
+        try:
+            return self._forward_nets_k(feed, c, B, xs, zs)
+        finally:
+            self._mu_fan = None
+
+    def _forward_nets_k(self, feed, c, B, xs, zs):
         p_z = self.HyperGenerator(feed['k_onehot'], feed['p_z_noise'], zs[0]) if c.K else feed['p_z_noise']
         fork = self.fork_nets and self.fork_now and p_z.is_cuda
         nets_target = int(os.environ.get('GGAN_NETS_TARGET_WGS', '128'))
@@ -579,6 +594,8 @@ class GraphicalGAN(object):
 
     def _forward_nets(self, feed, c, B, xs, zs, p_z, fork):
         early, self._early = self._early, False
+        p_z, p_z_gen = F.fanout(p_z, 2) if (c.K and c.fuse) else (p_z, p_z)          # (critics | Generator)
+        fan_q = (lambda q: F.fanout(q, 2)) if (c.K and c.fuse) else (lambda q: (q, q))     # (critics | HyperExtractor)
         if fork and early:
             # begin_nets() forked before the noise launch: the Extractor pass (which reads no noise) is a ROOT branch of the step
             # graph on the second stream, the Generator pass follows the noise launch on this one.  The branches are joined
@@ -593,17 +610,18 @@ class GraphicalGAN(object):
                     self._side.wait_event(ev_noise)       # (dequantisation noise of the 64x64 scripts / Gumbel noise of the mixture scripts)
                 real_x = self.real_x(feed, xs[1], defer=True)
                 ev_x = torch.cuda.Event()
-                q_z = self.Extractor(real_x, zs[1], after_first=lambda: ev_x.record(self._side))
+                q_src = self.Extractor(real_x, zs[1], after_first=lambda: ev_x.record(self._side))
+                q_z, q_z_h = fan_q(q_src)
                 if isinstance(real_x, F.PendingCast):
                     real_x = real_x.out
-                out = dict(real_x=real_x, q_z=q_z, p_z=p_z)
+                out = dict(real_x=real_x, q_z=q_z, p_z=p_z, q_z_src=q_src)
                 if c.K:
                     ks = F.RowSlot(feed['k_pair'], B, 2 * B) if (c.batch_critic and 'k_pair' in feed) else None
-                    _, out['q_k'] = self.HyperExtractor(q_z, feed['gumbel_u'], ks)
+                    _, out['q_k'] = self.HyperExtractor(q_z_h, feed['gumbel_u'], ks)
                 ev_end = torch.cuda.Event()
                 ev_end.record(self._side)
             self._pending_join = [cur, ev_x, ev_end]
-            out['fake_x'] = self.Generator(p_z, xs[0])
+            out['fake_x'] = self.Generator(p_z_gen, xs[0])
             return out
         if fork:
             cur = torch.cuda.current_stream(p_z.device)
@@ -611,23 +629,24 @@ class GraphicalGAN(object):
                 self._side = F.shared_stream(p_z.device, 'side')
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
-                fake_x = self.Generator(p_z, xs[0])
+                fake_x = self.Generator(p_z_gen, xs[0])
         real_x = self.real_x(feed, xs[1], defer=not c.agg)
         if c.agg:                      # (no critic, no fake_x: TF prunes the Generator(p_z) branch these modes never fetch)
             q_z, q_mean, q_std = self.Extractor(real_x, eps=feed['q_eps'])
             return dict(real_x=real_x, q_z=q_z, q_z_mean=q_mean, q_z_std=q_std, p_z=p_z)
-        q_z = self.Extractor(real_x, zs[1])
+        q_src = self.Extractor(real_x, zs[1])
+        q_z, q_z_h = fan_q(q_src)
         if isinstance(real_x, F.PendingCast):
             real_x = real_x.out
-        out = dict(real_x=real_x, q_z=q_z, p_z=p_z)
+        out = dict(real_x=real_x, q_z=q_z, p_z=p_z, q_z_src=q_src)
         if c.K:
             ks = F.RowSlot(feed['k_pair'], B, 2 * B) if (c.batch_critic and 'k_pair' in feed) else None
-            _, q_k = self.HyperExtractor(q_z, feed['gumbel_u'], ks)
+            _, q_k = self.HyperExtractor(q_z_h, feed['gumbel_u'], ks)
             out['q_k'] = q_k
         if fork:
             cur.wait_stream(self._side)
         else:
-            fake_x = self.Generator(p_z, xs[0])
+            fake_x = self.Generator(p_z_gen, xs[0])
         out['fake_x'] = fake_x
         return out
 
@@ -757,6 +776,7 @@ class GraphicalGAN(object):
         assert detach or not real_x.requires_grad, 'batched critic with grad_rows: real_x must not require a gradient'
         self.join_side(x_only=True)
         x_cat, z_cat = F.JoinRows.apply(fake_x, real_x), F.JoinRows.apply(p_z, q_z)
+        z_cat, z_cat_h = F.fanout(z_cat, 2) if (c.K and c.fuse) else (z_cat, z_cat)          # (joint critic | mixture critic)
         z_out = None
         pj = self._pending_join
         gp_on_side = self._gp_stream is not None and self.cfg.mode == 'wali-gp' and detach and self.fork_now
@@ -785,7 +805,7 @@ class GraphicalGAN(object):
                     ev_z.record(self._side)
                 else:
                     ev_z = None
-                h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
+                h = self.HyperDiscriminator(z_cat_h, F.JoinRows.apply(onehot, q_k))
             before = (lambda: cur.wait_event(ev_z)) if ev_z is not None else self.join_side
             d = self.Discriminator(x_cat, z_cat, grad_rows=None if detach else B, before_z=before, z_out=z_out)
         else:
@@ -793,7 +813,7 @@ class GraphicalGAN(object):
         if fork_h:
             cur.wait_stream(self._side)
         elif c.K:
-            h = self.HyperDiscriminator(z_cat, F.JoinRows.apply(onehot, q_k))
+            h = self.HyperDiscriminator(z_cat_h, F.JoinRows.apply(onehot, q_k))
         if c.K:
             (hf, hr), (df, dr) = F.SplitRows.apply(h, B), F.SplitRows.apply(d, B)
             return [hf, df], [hr, dr]
