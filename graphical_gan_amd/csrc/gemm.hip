@@ -671,9 +671,12 @@ __global__ __launch_bounds__(256) void gemv_rows_k(const float* __restrict__ A, 
 // tiles are added through LDS in wave order (deterministic), + bias + activation, 64-byte store runs.
 struct SkinnyParams {
     const float* A; const float* B; const float* bias; float* C; const float* a_ref;
+    const float* A2;       // optional: columns k >= a_split (a multiple of 16: a 16-k step has ONE source) of A come from A2 [M, K - a_split]
+    float* C2;             // optional: output columns >= c_split (a multiple of 16) go to C2 [M, N - c_split], the others to C [M, c_split]
+    int a_split, c_split, vecA2;
     int M, N, K, lda, ldb, act, ref_act, vecA, vecB;
     float alpha, ref_alpha;
-    unsigned a_bytes, b_bytes;
+    unsigned a_bytes, b_bytes, a2_bytes;
 };
 
 template <bool TB, bool MASK, int NS>
@@ -686,25 +689,28 @@ __global__ __launch_bounds__(512) void gemm_skinny_k(const SkinnyParams P) {
     const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, (short)0, (int)P.a_bytes, 0x00020000);
     const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK ? P.a_ref : P.A), (short)0, (int)P.a_bytes, 0x00020000);
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, (short)0, (int)P.b_bytes, 0x00020000);
+    const auto ra2 = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A2 ? P.A2 : P.A), (short)0, (int)(P.A2 ? P.a2_bytes : P.a_bytes), 0x00020000);
+    const int KA = P.A2 ? P.a_split : P.K;               // k extent of the first source
     float a[NS][4], b[NS][4], r[MASK ? NS : 1][4];
-    // k-contiguous operand: row `row` (valid when row_ok), 4 consecutive k from kk
-    auto load_kc = [&](decltype(ra) rs, bool vec, int row, bool row_ok, int ld, int kk, float* dst) {
+    // k-contiguous operand: row `row` (valid when row_ok), 4 consecutive k from kk of the kend the source holds
+    auto load_kc = [&](decltype(ra) rs, bool vec, int row, bool row_ok, int ld, int kk, int kend, float* dst) {
         const unsigned base = (unsigned)(row * ld + kk) * 4u;
         if (vec) {
-            const u32x4g t = __builtin_amdgcn_raw_buffer_load_b128(rs, (row_ok && kk < P.K) ? base : SOOB, 0, 0);
+            const u32x4g t = __builtin_amdgcn_raw_buffer_load_b128(rs, (row_ok && kk < kend) ? base : SOOB, 0, 0);
             dst[0] = __uint_as_float(t.x); dst[1] = __uint_as_float(t.y); dst[2] = __uint_as_float(t.z); dst[3] = __uint_as_float(t.w);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                dst[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && kk + j < P.K) ? base + 4u * j : SOOB, 0, 0));
+                dst[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && kk + j < kend) ? base + 4u * j : SOOB, 0, 0));
         }
     };
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int kk = (wave + 8 * i) * 16 + 4 * kq;
-        load_kc(ra, P.vecA != 0, m, m < P.M, P.lda, kk, a[i]);
-        if (MASK) load_kc(rr, P.vecA != 0, m, m < P.M, P.lda, kk, r[i]);
-        if (TB) load_kc(rb, P.vecB != 0, n, n < P.N, P.ldb, kk, b[i]);
+        if (P.A2 && (wave + 8 * i) * 16 >= P.a_split) load_kc(ra2, P.vecA2 != 0, m, m < P.M, P.K - P.a_split, kk - P.a_split, P.K - P.a_split, a[i]);
+        else load_kc(ra, P.vecA != 0, m, m < P.M, P.lda, kk, KA, a[i]);
+        if (MASK) load_kc(rr, P.vecA != 0, m, m < P.M, P.lda, kk, P.K, r[i]);
+        if (TB) load_kc(rb, P.vecB != 0, n, n < P.N, P.ldb, kk, P.K, b[i]);
         else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -731,7 +737,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_k(const SkinnyParams P) {
         const int row = blockIdx.y * 16 + 4 * kq + q;
         if (row < P.M && n < P.N) {
             if (P.bias) v += P.bias[n];
-            P.C[(size_t)row * P.N + n] = act_apply(v, P.act, P.alpha);
+            v = act_apply(v, P.act, P.alpha);
+            if (P.C2 && n >= P.c_split) P.C2[(size_t)row * (P.N - P.c_split) + (n - P.c_split)] = v;
+            else P.C[(size_t)row * (P.C2 ? P.c_split : P.N) + n] = v;
         }
     }
 }
@@ -880,17 +888,21 @@ static int gemm_launch(int ta, int tb, int M, int N, int K, const float* A, cons
     // (M >= 32: the scripts' minibatches are 50-128 rows.  The 8-row trajectory fixture `vegan-wgan-gp` is bimodal under fp32 rounding --
     //  a pre-activation within rounding of its LeakyReLU kink, profiles/r04_notes.md -- and ANY other legal summation order of its
     //  products, this one or GGAN_GEMM_SK=16 on the old kernel, lands it on the other branch: products that small keep their order)
-    if (skinny && !ta && !colsum && !A2 && !C2 && !b_ref && (!a_ref || tb) && M >= 32 && K >= 64 && K <= 1024 && cdiv(M, BM) * cdiv(N, BN) < 64 &&
+    if (skinny && !ta && !colsum && (!A2 || (a_split % 16 == 0 && !a_ref)) && (!C2 || c_split % 16 == 0) && !b_ref && (!a_ref || tb) && M >= 32 &&
+        K >= 64 && K <= 1024 && cdiv(M, BM) * cdiv(N, BN) < 64 &&
         cdiv(M, 16) * cdiv(N, 16) <= 1024 && !(K <= 128 && cdiv(M, BM) * cdiv(N, BN) >= 32) && (size_t)M * K * 4 < 0x7FFFFFF0ull &&
         (size_t)N * K * 4 < 0x7FFFFFF0ull) {
         SkinnyParams P;
         memset(&P, 0, sizeof(P));
         P.A = A; P.B = B; P.bias = bias; P.C = C; P.a_ref = a_ref;
-        P.M = M; P.N = N; P.K = K; P.lda = K; P.ldb = tb ? K : N;
+        P.M = M; P.N = N; P.K = K; P.lda = A2 ? a_split : K; P.ldb = tb ? K : N;
         P.act = act; P.alpha = alpha; P.ref_act = ref_act; P.ref_alpha = ref_alpha;
-        P.vecA = al16(A) && (K % 4 == 0) && (!a_ref || al16(a_ref));
+        P.A2 = A2; P.a_split = a_split; P.C2 = C2; P.c_split = c_split;
+        P.vecA = al16(A) && (P.lda % 4 == 0) && (!a_ref || al16(a_ref));
+        P.vecA2 = A2 && al16(A2) && ((K - a_split) % 4 == 0);
         P.vecB = tb && al16(B) && (K % 4 == 0);
-        P.a_bytes = (unsigned)((size_t)M * K * 4); P.b_bytes = (unsigned)((size_t)N * K * 4);
+        P.a_bytes = (unsigned)((size_t)M * P.lda * 4); P.a2_bytes = A2 ? (unsigned)((size_t)M * (K - a_split) * 4) : 0u;
+        P.b_bytes = (unsigned)((size_t)N * K * 4);
         const int steps = cdiv(cdiv(K, 16), 8);
         const int ns = steps <= 1 ? 1 : (steps <= 2 ? 2 : (steps <= 4 ? 4 : 8));
         const dim3 grid(cdiv(N, 16), cdiv(M, 16));

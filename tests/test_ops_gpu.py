@@ -690,7 +690,7 @@ def test_batchnorm_second_derivative(gpu, shape, act):
     assert _rel(ds.cpu().numpy().reshape(-1), rs.v.reshape(-1)) < 5e-5
 
 
-@pytest.mark.parametrize('M,K1,K2,N', [(128, 4096, 512, 512), (8, 128, 16, 40), (37, 64, 36, 70)])
+@pytest.mark.parametrize('M,K1,K2,N', [(128, 4096, 512, 512), (8, 128, 16, 40), (37, 64, 36, 70), (128, 128, 30, 512), (64, 192, 64, 256)])
 def test_linear_on_a_pair_of_inputs_equals_linear_on_their_concatenation(gpu, M, K1, K2, N):
     """functional.Gemm2 / ggan_gemm_split: [a1 | a2] @ w + b (+ LeakyReLU) with the operands left where they are -- forward, both
     data gradients (split output), weight and bias gradient (two-source transposed operand) -- against float64 numpy."""
