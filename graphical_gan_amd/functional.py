@@ -957,7 +957,7 @@ class Gemm2Dgrad(Function):
         return dg, dw, None
 
 
-HEAD_BCE_HINT = [None]
+_HEAD_HINT = _threading.local()      # .terms: the cost hint in force on this thread (head_bce_hint)
 
 
 class head_bce_hint(object):
@@ -972,12 +972,12 @@ class head_bce_hint(object):
         self.terms = tuple((int(n), float(z), float(w)) for n, z, w in terms) if terms else None
 
     def __enter__(self):
-        self.prev = HEAD_BCE_HINT[0]
-        HEAD_BCE_HINT[0] = self.terms
+        self.prev = getattr(_HEAD_HINT, 'terms', None)
+        _HEAD_HINT.terms = self.terms
         return self
 
     def __exit__(self, *exc):
-        HEAD_BCE_HINT[0] = self.prev
+        _HEAD_HINT.terms = self.prev
         return False
 
 
@@ -1000,7 +1000,7 @@ class CriticHead(Function):
         logits = torch.empty((M,), dtype=torch.float32, device=a1.device)
         ws = workspace(a1.device)
         registers = M <= _lib.HEAD_BCE_MAX_ROWS and any(ctx.needs_input_grad) and not os.environ.get('GGAN_NO_HEAD_BCE')
-        hint = HEAD_BCE_HINT[0]
+        hint = getattr(_HEAD_HINT, 'terms', None)
         hinted = None
         if (registers and hint is not None and 1 <= len(hint) <= 4 and sum(n for n, _, _ in hint) == M and H <= 2048
                 and not os.environ.get('GGAN_NO_HEAD_HINT')):
