@@ -414,8 +414,12 @@ struct ThinFwdParams {
     ThinCastSrc cast;
 };
 
-template <int NTN, int MPW>
-__global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
+// NWV waves: 4 (one per SIMD), or 8 -- waves w and w + 4 share an m-tile and split the channel tiles, so that every SIMD has a second wave
+// to issue under the first one's LDS round trips (the loop is 20 steps of 5 fragment reads + 4 MFMAs).
+template <int NTN, int MPW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void thin_fwd_kernel(const ThinFwdParams P) {
+    constexpr int FT = 64 * NWV, NTW = NTN / (NWV / 4), XUF = (XU_MAX * NTHR + FT - 1) / FT;
+    static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
     warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -442,13 +446,13 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     }
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xsrc, (short)0, (int)P.x_bytes, 0x00020000);
     const auto rn = __builtin_amdgcn_make_buffer_rsrc((void*)(P.cast.noise ? (const void*)P.cast.noise : xsrc), (short)0, (int)P.x_bytes, 0x00020000);
-    u32x4 xreg[XU_MAX], nreg[XU_MAX];
-    int xlds[XU_MAX], xgo[XU_MAX];                        // xgo: float index in x_out of a unit this band owns (-1: halo row / not casting)
-    bool xin[XU_MAX];
+    u32x4 xreg[XUF], nreg[XUF];
+    int xlds[XUF], xgo[XUF];                        // xgo: float index in x_out of a unit this band owns (-1: halo row / not casting)
+    bool xin[XUF];
     const int xbase = n * P.Ci * HW + in_row0 * P.W;
 #pragma unroll
-    for (int j = 0; j < XU_MAX; ++j) {
-        const int u = tid + j * NTHR;
+    for (int j = 0; j < XUF; ++j) {
+        const int u = tid + j * FT;
         unsigned vo = OOB;
         int l = -1, go = -1;
         if (u < P.xunits) {
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
         xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
         if (casting) nreg[j] = __builtin_amdgcn_raw_buffer_load_b128(rn, P.cast.noise ? vo : OOB, 0, 0);
     }
-    for (int e = tid; e < cbase; e += NTHR) xs[e] = 0.f;
+    for (int e = tid; e < cbase; e += FT) xs[e] = 0.f;
     if (tid == 0) { xs[cbase] = 1.f; xs[cbase + 1] = 0.f; }
     int* jtab = reinterpret_cast<int*>(wsm + P.KS * 4 * P.WS);     // [KS*4] operand-row table (behind the filter)
     if (tid < P.KS * 4) {
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     }
     if (!(P.dbg & 2)) {
         const int c4 = P.Co >> 2, rows = P.KS * 4;
-        for (int u = tid; u < rows * c4; u += NTHR) {
+        for (int u = tid; u < rows * c4; u += FT) {
             const int j = (int)fdiv((uint32_t)u, P.d_c4), f = u - j * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < P.J) v = *reinterpret_cast<const float4*>(P.w + (size_t)j * P.Co + f * 4);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     __syncthreads();                                     // zeros before the rows land on top of them
     if (casting) {
 #pragma unroll
-        for (int j = 0; j < XU_MAX; ++j) {
+        for (int j = 0; j < XUF; ++j) {
             // the expression of cast_scale_ring_k, element by element (rows outside the image stay 0: SAME padding pads the SCALED image)
             float4 v;
             v.x = P.cast.mul * (((float)(int)xreg[j].x / P.cast.div) - 0.5f); v.y = P.cast.mul * (((float)(int)xreg[j].y / P.cast.div) - 0.5f);
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < XU_MAX; ++j) {
+    for (int j = 0; j < XUF; ++j) {
         if (xlds[j] >= 0) {
             *reinterpret_cast<u32x2*>(xs + xlds[j]) = (u32x2){xreg[j].x, xreg[j].y};
             *reinterpret_cast<u32x2*>(xs + xlds[j] + 2) = (u32x2){xreg[j].z, xreg[j].w};
@@ -507,23 +511,24 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
     }
     __syncthreads();
 
-    // ---- wave w: m-tiles w, w+4 (16 pixels each) x all NTN channel tiles ------------------------------------------------
+    const int mw = wave & 3, half = wave >> 2;
+    // ---- wave w: m-tiles (w & 3), (w & 3) + 4 (16 pixels each) x its NTW channel tiles ------------------------------------------------
     int pix[MPW];
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
-        const int mt = wave + 4 * i;
+        const int mt = mw + 4 * i;
         int p = mt * 16 + l15;
         if (mt >= P.MT) p = 0;                            // (results of a tile past the band are never stored)
         const int r = fdiv(p, P.d_Wo), ow = p - r * P.Wo;
         pix[i] = 2 * r * P.XRS + 2 * ow;
     }
-    f32x4 acc[MPW][NTN];
+    f32x4 acc[MPW][NTW];
 #pragma unroll
     for (int i = 0; i < MPW; ++i)
 #pragma unroll
-        for (int t = 0; t < NTN; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* bp = wsm + q * P.WS + l15;
-    float av[2][MPW], bv[2][NTN];
+    float av[2][MPW], bv[2][NTW];
     // slab offset of operand row j = (tap, channel) -- geometry only: the table built during staging (one entry per row, sign bit = a
     // padding row that reads the constant 0.0), read a step ahead; computed per lane and step it was ~15 VALU instructions in front
     // of every A-fragment read of a loop whose single wave per SIMD has nothing to hide them under
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
 #pragma unroll
         for (int i = 0; i < MPW; ++i) a[i] = xs[joff + (pix[i] & pm)];
 #pragma unroll
-        for (int t = 0; t < NTN; ++t) bb[t] = bp[ks * 4 * P.WS + t * 16];
+        for (int t = 0; t < NTW; ++t) bb[t] = bp[ks * 4 * P.WS + (half * NTW + t) * 16];
     };
     int e0 = row_entry(0), e1 = row_entry(1);
     load_step(e0, 0, av[0], bv[0]);
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
 #pragma unroll
         for (int i = 0; i < MPW; ++i)
 #pragma unroll
-            for (int t = 0; t < NTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i], bv[0][t], acc[i][t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][i], bv[0][t], acc[i][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         load_step(e0, min(ks + 2, P.KS - 1), av[0], bv[0]);
         e0 = row_entry(ks + 4);
@@ -553,19 +558,19 @@ __global__ __launch_bounds__(NTHR) void thin_fwd_kernel(const ThinFwdParams P) {
 #pragma unroll
         for (int i = 0; i < MPW; ++i)
 #pragma unroll
-            for (int t = 0; t < NTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i], bv[1][t], acc[i][t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i], bv[1][t], acc[i][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- lane (q, l15) holds pixels 4q..4q+3 of channel l15 of each tile: bias, activation, one 16-byte store ----------
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
-        const int mt = wave + 4 * i;
+        const int mt = mw + 4 * i;
         const int pp = oh0 * P.Wo + mt * 16 + 4 * q;     // pixel index within the channel plane (a multiple of 4)
         if (mt < P.MT && mt * 16 + 4 * q < P.PB && pp < HoWo && !(P.dbg & 4)) {
 #pragma unroll
-            for (int t = 0; t < NTN; ++t) {
-                const int co = t * 16 + l15;
+            for (int t = 0; t < NTW; ++t) {
+                const int co = (half * NTW + t) * 16 + l15;
                 const float bs = P.bias ? P.bias[co] : 0.f;
                 float4 v;
                 v.x = act_apply(acc[i][t][0] + bs, P.act, P.alpha);
@@ -767,10 +772,15 @@ int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const
     const int NTN = g.Co / 16, MPW = cdiv(P.MT, 4);
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     const dim3 grid(P.nb, g.N);
-    if (NTN == 4 && MPW == 1) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 1>), grid, dim3(NTHR), shmem, s, P); }
-    else if (NTN == 4 && MPW == 2) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 2>), grid, dim3(NTHR), shmem, s, P); }
-    else if (NTN == 2 && MPW == 1) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<2, 1>), grid, dim3(NTHR), shmem, s, P); }
-    else if (NTN == 2 && MPW == 2) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<2, 2>), grid, dim3(NTHR), shmem, s, P); }
+    // (eight waves where a wave still owns two channel tiles: 3->64 @32 at 64 / 128 images 10.3 -> 9.2 / 13.1 -> 12.3 us; with 32 output
+    //  channels a wave would be left with ONE tile -- two fragment reads per MFMA -- and the face layer measured 12.3 -> 13.9 us)
+    static const int w8 = [] { const char* e = getenv("GGAN_THIN_FWD_W8"); return e ? atoi(e) : 1; }();
+    if (w8 && NTN == 4 && MPW == 1) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 1, 8>), grid, dim3(512), shmem, s, P); }
+    else if (w8 && NTN == 4 && MPW == 2) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 2, 8>), grid, dim3(512), shmem, s, P); }
+    else if (NTN == 4 && MPW == 1) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 1, 4>), grid, dim3(NTHR), shmem, s, P); }
+    else if (NTN == 4 && MPW == 2) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<4, 2, 4>), grid, dim3(NTHR), shmem, s, P); }
+    else if (NTN == 2 && MPW == 1) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<2, 1, 4>), grid, dim3(NTHR), shmem, s, P); }
+    else if (NTN == 2 && MPW == 2) { GGAN_LAUNCH("thin_fwd_kernel", fl, 0, (thin_fwd_kernel<2, 2, 4>), grid, dim3(NTHR), shmem, s, P); }
     else return 1;
     return 0;
 }
