@@ -54,8 +54,13 @@ struct ThinDgradParams {
     FastDiv d_k4, d_w4, d_W;     // staging / gather index splits (a division by a run-time value is ~35 instructions, ~17 per thread)
 };
 
-template <int NT, bool TWO>
-__global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams P) {
+// NWV waves: 4, or 8 -- waves w and w + 4 share their m-tiles and take the channel tiles t = (w >> 2) + 2 j: a second wave per SIMD under the
+// LDS round trips of the MFMA loop, and twice the threads for the staging and gather phases.  (The filter image in LDS has one tile of
+// zero rows behind the last real one: with an odd tile count the upper waves multiply it and drop the result.)
+template <int NT, bool TWO, int NWV>
+__global__ __launch_bounds__(64 * NWV) void thin_dgrad_kernel(const ThinDgradParams P) {
+    constexpr int FT = 64 * NWV, NH = NWV / 4, NTW = (NT + NH - 1) / NH, NTP = NTW * NH;     // NTP: tiles incl. the padding one
+    static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
     warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -64,13 +69,13 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     const int g0 = blockIdx.x * 2, n = blockIdx.y;
     const int K = P.K, Wo = P.Wo, J = 25 * P.Ci;
     const float mslope = P.mask_act == GGAN_ACT_LRELU ? P.mask_alpha : 0.f;
-    float* Ws = smem;                          // [NT*16][KP]
-    float* As = smem + NT * 16 * P.KP;         // [K][PS]; later T [MT*16][TS]
+    float* Ws = smem;                          // [NTP*16][KP]
+    float* As = smem + NTP * 16 * P.KP;        // [K][PS]; later T [MT*16][TS]
 
     // ---- stage the filter (rows >= 25*Ci zero) and the 4 gy rows g0-1 .. g0+2 (rows outside the image zero) ----
     if (!(P.dbg & 4)) {
         const int k4 = K >> 2;
-        for (int u = tid; u < NT * 16 * k4; u += NTHR) {
+        for (int u = tid; u < NTP * 16 * k4; u += FT) {
             const int j = (int)fdiv((uint32_t)u, P.d_k4), c4 = u - j * k4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < J) v = *reinterpret_cast<const float4*>(P.w + (size_t)j * K + c4 * 4);
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
         const size_t img = (size_t)n * K * P.Ho * Wo;
         if ((Wo & 3) == 0) {
             const int w4 = Wo >> 2;
-            for (int u = tid; u < K * 4 * w4; u += NTHR) {
+            for (int u = tid; u < K * 4 * w4; u += FT) {
                 const int t = (int)fdiv((uint32_t)u, P.d_w4), c4 = u - t * w4, r = t & 3, k = t >> 2;
                 const int oh = g0 - 1 + r;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
                 *reinterpret_cast<float4*>(As + k * P.PS + r * Wo + c4 * 4) = v;
             }
         } else {
-            for (int u = tid; u < K * P4; u += NTHR) {
+            for (int u = tid; u < K * P4; u += FT) {
                 const int p = u % P4, k = u / P4, r = p / Wo, col = p - r * Wo;
                 const int oh = g0 - 1 + r;
                 float v = 0.f;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
         }
         // pixel slots P4 .. MT*16-1 of every channel (only when 4*Wo is not a multiple of 16)
         const int tail = P.MT * 16 - P4;
-        for (int u = tid; u < K * tail; u += NTHR) {
+        for (int u = tid; u < K * tail; u += FT) {
             const int k = u / tail, p = P4 + (u - k * tail);
             As[k * P.PS + p] = 0.f;
         }
@@ -120,28 +125,29 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     __syncthreads();
 
     // ---- T = gy_tile^T x W^T: wave w owns m-tiles w, w+4 ----------------------------------------------------
-    f32x4 acc[2][NT];
+    const int mw = wave & 3, half = wave >> 2;
+    f32x4 acc[2][NTW];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (wave < P.MT && !(P.dbg & 1)) {
+        for (int t = 0; t < NTW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (mw < P.MT && !(P.dbg & 1)) {
         // (TWO: MT == 8, every wave owns two m-tiles; otherwise MT <= 4 and one)
-        const float* ap = As + q * P.PS + wave * 16 + l15;
-        const float* bp = Ws + l15 * P.KP + q;
+        const float* ap = As + q * P.PS + mw * 16 + l15;
+        const float* bp = Ws + (half * 16 + l15) * P.KP + q;          // (tile t of this wave: half + NH * t)
         const int nks = K >> 2;
         for (int ks = 0; ks < nks; ++ks) {
             const float a0 = ap[ks * 4 * P.PS];
             float a1 = 0.f;
             if (TWO) a1 = ap[ks * 4 * P.PS + 64];
-            float b[NT];
+            float b[NTW];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = bp[t * 16 * P.KP + ks * 4];
+            for (int t = 0; t < NTW; ++t) b[t] = bp[t * NH * 16 * P.KP + ks * 4];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], acc[0][t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], acc[0][t], 0, 0, 0);
             if (TWO) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], acc[1][t], 0, 0, 0);
+                for (int t = 0; t < NTW; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], acc[1][t], 0, 0, 0);
             }
         }
     }
@@ -149,19 +155,23 @@ __global__ __launch_bounds__(NTHR) void thin_dgrad_kernel(const ThinDgradParams 
     float* Ts = As;
 #pragma unroll
     for (int i = 0; i < (TWO ? 2 : 1); ++i) {
-        const int mt = wave + 4 * i;
+        const int mt = mw + 4 * i;
         if (mt < P.MT) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NTW; ++t) {
+                const int tile = half + NH * t;
+                if (tile < NT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ts[(mt * 16 + 4 * q + r) * P.TS + t * 16 + l15] = acc[i][t][r];
+                    for (int r = 0; r < 4; ++r) Ts[(mt * 16 + 4 * q + r) * P.TS + tile * 16 + l15] = acc[i][t][r];
+                }
+            }
         }
     }
     __syncthreads();
 
     // ---- gather: output rows 2*g0 .. 2*g0+3; SAME padding (1, 2): 2*oh + kh - 1 = y ----------------------------
     const int W = P.W, Ci = P.Ci;
-    for (int idx = tid; idx < Ci * 4 * W; idx += NTHR) {
+    for (int idx = tid; idx < Ci * 4 * W; idx += FT) {
         const int t = (int)fdiv((uint32_t)idx, P.d_W), x = idx - t * W, yy = t & 3, c = t >> 2;
         float s = 0.f;
         for (int kh = (P.dbg & 2) ? 5 : ((yy + 1) & 1); kh < 5; kh += 2) {
@@ -609,14 +619,18 @@ int conv_dgrad_thin(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     P.TS = NT * 16 + 4;
     P.d_k4 = make_fastdiv((uint32_t)(g.Co / 4)); P.d_w4 = make_fastdiv((uint32_t)(g.Wo / 4 > 0 ? g.Wo / 4 : 1)); P.d_W = make_fastdiv((uint32_t)g.W);
     const size_t tile = (size_t)g.Co * P.PS, tt = (size_t)P.MT * 16 * P.TS;
-    const size_t shmem = ((size_t)NT * 16 * P.KP + (tile > tt ? tile : tt)) * sizeof(float);
+    static const int w8 = [] { const char* e = getenv("GGAN_THIN_DGRAD_W8"); return e ? atoi(e) : 1; }();
+    const int ntp = w8 ? 2 * cdiv(NT, 2) : NT;      // (eight waves: the filter image padded to an even number of tiles)
+    const size_t shmem = ((size_t)ntp * 16 * P.KP + (tile > tt ? tile : tt)) * sizeof(float);
     if (shmem > 64 * 1024) return 1;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     const dim3 grid(g.Ho / 2, g.N);
     if (P.MT > 4 && P.MT != 8) return 1;       // one m-tile per wave, or exactly two
 #define THIN_DGRAD(NT_) \
-    if (P.MT == 8) { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, true>), grid, dim3(NTHR), shmem, s, P); } \
-    else { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, false>), grid, dim3(NTHR), shmem, s, P); }
+    if (w8 && P.MT == 8) { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, true, 8>), grid, dim3(512), shmem, s, P); } \
+    else if (w8) { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, false, 8>), grid, dim3(512), shmem, s, P); } \
+    else if (P.MT == 8) { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, true, 4>), grid, dim3(NTHR), shmem, s, P); } \
+    else { GGAN_LAUNCH("thin_dgrad_kernel", fl, 0, (thin_dgrad_kernel<NT_, false, 4>), grid, dim3(NTHR), shmem, s, P); }
     switch (NT) {
         case 2: THIN_DGRAD(2); break;
         case 4: THIN_DGRAD(4); break;
