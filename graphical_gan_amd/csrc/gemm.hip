@@ -1052,6 +1052,19 @@ static int critic_head_bwd_impl(int M, int K1, int K2, int H, const float* g, co
         GGAN_LAUNCH_GROUP(4.0 * M * K * (double)H, nwg, s, GG);
         return 0;
     }
+    if (tail && na && !nw && Ga.P.fast == 1 && !getenv("GGAN_NO_GEMM_GROUP")) {
+        // generator steps (the critic's weights are frozen: the data-gradient product alone): the cost still rides in its launch
+        GemmGroup GG;
+        memset(&GG, 0, sizeof(GG));
+        GG.n = 1;
+        GG.kind[0] = 1; GG.gx[0] = Ga.gx; GG.p[0] = Ga.P; GG.first[0] = 0;
+        GG.first[1] = Ga.gx * Ga.gy;
+        GG.has_tail = 1;
+        GG.tail = *tail;
+        GG.tail.first = GG.first[1];
+        GGAN_LAUNCH_GROUP(2.0 * M * K * (double)H, GG.first[1] + 1 + cdiv(H, 16), s, GG);
+        return 0;
+    }
     if (tail) {
         HeadTail T = *tail;
         T.first = 0;
