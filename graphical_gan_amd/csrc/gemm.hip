@@ -410,7 +410,10 @@ __global__ __launch_bounds__(512) void gemm_kernel8(const GemmParams P) {
 // g[r] = w_k / n_k * (sigmoid(logit[r]) - z_k), so the forward tail can leave g and gh = g w_out^T lrelu'(h) behind at once and the
 // head's backward products follow it directly: one launch less on the chain  tail product -> logits -> cost -> head backward -> products
 // of every step.  What needs all rows (the cost itself, d_wout = h^T g, d_bout) rides in the products' launch (head_tail_wg).
-struct HeadTerms { int count; int rows[4]; float z[4]; float w[4]; };
+// kind 0: sigmoid cross-entropy terms (label z); kind 1: plain means (the Wasserstein costs, gan_inference.py:4-45: g[r] = w_k / n_k).
+// ext[k] != NULL: term k is not a row range of the logits but `rows[k]` values elsewhere (the one-element gradient penalty of a wali-gp
+// critic cost): it only enters the cost's value.
+struct HeadTerms { int count, kind; int rows[4]; float z[4]; float w[4]; const float* ext[4]; };
 
 // What the cost and the head's own parameters need from ALL rows, as extra workgroups of the products' launch (or head_tail_k):
 // workgroup 0: the cost -- bce_multi_fwd_k's loop and summation order on 256 threads (pointwise.hip);  workgroups 1..: 16 columns of
@@ -433,16 +436,17 @@ __device__ __forceinline__ void head_tail_wg(const HeadTail& T, const int local,
         for (int k = 0; k < T.terms.count; ++k) {
             const float z = T.terms.z[k];
             const int n = T.terms.rows[k];
+            const float* x = T.terms.ext[k] ? T.terms.ext[k] : T.logits + r0;
             float s = 0.f;
             if (on)
                 for (int i = tid; i < n; i += 256) {
-                    const float v = T.logits[r0 + i];
-                    s += fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)));
+                    const float v = x[i];
+                    s += T.terms.kind == 1 ? v : fmaxf(v, 0.f) - v * z + log1pf(expf(-fabsf(v)));
                 }
             s = block_sum(s, sm);
             const float r = T.terms.w[k] * (s / (float)n);
             tot = k ? tot + r : r;
-            r0 += n;
+            if (!T.terms.ext[k]) r0 += n;
         }
         if (tid == 0 && T.loss) T.loss[0] = tot;
         return;
@@ -593,11 +597,12 @@ __global__ __launch_bounds__(256) void head_out_fwd_bce_k(const float* __restric
     {
         int r0 = 0;
         for (int k = 0; k < T.count; ++k) {
+            if (T.ext[k]) continue;
             if (row >= r0 && row < r0 + T.rows[k]) { z = T.z[k]; sc = 1.f * T.w[k] / (float)T.rows[k]; }
             r0 += T.rows[k];
         }
     }
-    const float gr = sc * (1.f / (1.f + expf(-lg)) - z);
+    const float gr = T.kind == 1 ? sc : sc * (1.f / (1.f + expf(-lg)) - z);
     if (t == 0) g_out[row] = gr;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -959,16 +964,18 @@ int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const fl
     return 0;
 }
 
-static int head_terms(HeadTerms& T, int M, int nterms, const int* rows, const float* labels, const float* weights) {
+static int head_terms(HeadTerms& T, int M, int kind, int nterms, const int* rows, const float* labels, const float* weights,
+                      const float* const* ext) {
     memset(&T, 0, sizeof(T));
-    if (nterms < 1 || nterms > 4 || !rows || !labels || !weights) return -1;
+    if (nterms < 1 || nterms > 4 || !rows || !labels || !weights || kind < 0 || kind > 1) return -1;
     int tot = 0;
     for (int k = 0; k < nterms; ++k) {
         if (rows[k] <= 0) return -1;
         T.rows[k] = rows[k]; T.z[k] = labels[k]; T.w[k] = weights[k];
-        tot += rows[k];
+        T.ext[k] = ext ? ext[k] : nullptr;
+        if (!T.ext[k]) tot += rows[k];
     }
-    T.count = nterms;
+    T.count = nterms; T.kind = kind;
     return tot == M ? 0 : -1;
 }
 
@@ -977,14 +984,14 @@ static int head_terms(HeadTerms& T, int M, int nterms, const int* rows, const fl
 // tail kernel also leaves g[M] = d cost / d logits for a unit upstream gradient and gh[M,H] = g w_out^T lrelu'(h), so that
 // ggan_critic_head_bwd_tail can follow at once.  H <= 2048.
 int ggan_critic_head_fwd_bce(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* b,
-                             const float* w_out, const float* b_out, float alpha, float* h, float* logits, int nterms,
+                             const float* w_out, const float* b_out, float alpha, float* h, float* logits, int kind, int nterms,
                              const int* term_rows, const float* labels, const float* weights, float* g, float* gh, void* ws,
                              size_t ws_bytes, ggan_stream_t stream) {
     GGAN_CHECK_ARG(a1 && w && b && w_out && b_out && h && logits && g && gh, "null pointer");
     GGAN_CHECK_ARG(M > 0 && K1 > 0 && K2 >= 0 && H > 0 && (H % 4) == 0 && H <= 2048 && (a2 || K2 == 0), "bad shape");
     GGAN_CHECK_ARG(al16(b) && al16(w_out) && al16(h) && al16(gh), "b, w_out, h, gh must be 16-byte aligned");
     HeadTerms T;
-    GGAN_CHECK_ARG(head_terms(T, M, nterms, term_rows, labels, weights) == 0, "terms must be 1..4 row ranges covering the M rows");
+    GGAN_CHECK_ARG(head_terms(T, M, kind, nterms, term_rows, labels, weights, nullptr) == 0, "terms must be 1..4 row ranges covering the M rows");
     hipStream_t s = (hipStream_t)stream;
     GemmPlan G;
     { const char* e = getenv("GGAN_HEAD_WGS"); g_split_target = e ? atoi(e) : 512; }
@@ -1087,12 +1094,14 @@ int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const flo
 // terms), d_wout[H] = h^T g, d_bout = sum g (NULL: not wanted).
 int ggan_critic_head_bwd_tail(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* h,
                               const float* w_out, float alpha, const float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b,
-                              float* d_wout, float* d_bout, const float* logits, const float* g, int nterms, const int* term_rows,
-                              const float* labels, const float* weights, float* loss, void* ws, size_t ws_bytes, ggan_stream_t stream) {
+                              float* d_wout, float* d_bout, const float* logits, const float* g, int kind, int nterms, const int* term_rows,
+                              const float* labels, const float* weights, const float* const* ext, float* loss, void* ws, size_t ws_bytes,
+                              ggan_stream_t stream) {
     GGAN_CHECK_ARG(logits && g && gh, "null pointer");
     HeadTail T;
     memset(&T, 0, sizeof(T));
-    GGAN_CHECK_ARG(head_terms(T.terms, M, nterms, term_rows, labels, weights) == 0, "terms must be 1..4 row ranges covering the M rows");
+    GGAN_CHECK_ARG(head_terms(T.terms, M, kind, nterms, term_rows, labels, weights, ext) == 0,
+                   "terms must be 1..4: row ranges covering the M rows, plus terms read elsewhere (ext)");
     T.logits = logits; T.g = g; T.h = h; T.d_wout = d_wout; T.d_bout = d_bout; T.loss = loss; T.M = M; T.H = H;
     return critic_head_bwd_impl(M, K1, K2, H, nullptr, a1, a2, w, h, w_out, alpha, const_cast<float*>(gh), d_a1, d_a2, d_w, d_b, d_wout,
                                 d_bout, ws, ws_bytes, stream, &T);

@@ -968,8 +968,10 @@ class head_bce_hint(object):
     bit-identical.  The cost's value exists once the head's backward has run -- only for steps that run it (engine.Trainer).  A cost
     built from other terms than hinted ignores the hint's by-products (BceSum launches as always)."""
 
-    def __init__(self, terms):
-        self.terms = tuple((int(n), float(z), float(w)) for n, z, w in terms) if terms else None
+    def __init__(self, terms, kind='bce'):
+        """kind 'bce': terms (rows, label, weight) of a BceSum cost; kind 'mean': terms (rows, 0, weight) of a MeanSum cost (the
+        Wasserstein costs; further one-element terms of weight 1 -- the gradient penalty -- may follow the head's rows in that cost)"""
+        self.terms = (kind, tuple((int(n), float(z), float(w)) for n, z, w in terms)) if terms else None
 
     def __enter__(self):
         self.prev = getattr(_HEAD_HINT, 'terms', None)
@@ -1002,17 +1004,19 @@ class CriticHead(Function):
         registers = M <= _lib.HEAD_BCE_MAX_ROWS and any(ctx.needs_input_grad) and not os.environ.get('GGAN_NO_HEAD_BCE')
         hint = getattr(_HEAD_HINT, 'terms', None)
         hinted = None
-        if (registers and hint is not None and 1 <= len(hint) <= 4 and sum(n for n, _, _ in hint) == M and H <= 2048
+        hkind, hterms = hint if hint is not None else (None, ())
+        if (registers and hint is not None and 1 <= len(hterms) <= 3 and sum(n for n, _, _ in hterms) == M and H <= 2048
                 and not os.environ.get('GGAN_NO_HEAD_HINT')):
             # the caller vouches for the cost these logits feed (head_bce_hint): its gradient and gh leave with the tail launch
             g = torch.empty((M,), dtype=torch.float32, device=a1.device)
             gh = torch.empty((M, H), dtype=torch.float32, device=a1.device)
-            nt = len(hint)
-            tabs = ((C.c_int * nt)(*[n for n, _, _ in hint]), (C.c_float * nt)(*[z for _, z, _ in hint]), (C.c_float * nt)(*[wt for _, _, wt in hint]))
+            nt = len(hterms)
+            tabs = ((C.c_int * nt)(*[n for n, _, _ in hterms]), (C.c_float * nt)(*[z for _, z, _ in hterms]),
+                    (C.c_float * nt)(*[wt for _, _, wt in hterms]))
             check(_L().ggan_critic_head_fwd_bce(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(b), _p(w_out), _p(b_out), float(alpha), _p(h),
-                                                _p(logits), nt, tabs[0], tabs[1], tabs[2], _p(g), _p(gh), _p(ws), ws.numel(), _stream()),
-                  'ggan_critic_head_fwd_bce')
-            hinted = dict(terms=hint, g=g, gh=gh)
+                                                _p(logits), 1 if hkind == 'mean' else 0, nt, tabs[0], tabs[1], tabs[2], _p(g), _p(gh), _p(ws),
+                                                ws.numel(), _stream()), 'ggan_critic_head_fwd_bce')
+            hinted = dict(kind=hkind, terms=hterms, g=g, gh=gh)
         else:
             check(_L().ggan_critic_head_fwd(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(b), _p(w_out), _p(b_out), float(alpha), _p(h),
                                             _p(logits), _p(ws), ws.numel(), _stream()), 'ggan_critic_head_fwd')
@@ -1061,23 +1065,32 @@ class CriticHead(Function):
                 nt = len(tail['terms'])
                 tabs = ((C.c_int * nt)(*[n for n, _, _ in tail['terms']]), (C.c_float * nt)(*[z for _, z, _ in tail['terms']]),
                         (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]))
+                ext = tail.get('ext')
+                pext = (C.c_void_p * nt)(*[(e.data_ptr() if e is not None else 0) for e in ext]) if ext else None
                 check(_L().ggan_critic_head_bwd_tail(M, K1, K2, H, _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1), _p(d_a2),
-                                                     _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(tail['logits']), _p(tail['g']), nt, tabs[0],
-                                                     tabs[1], tabs[2], _p(tail['loss']), _p(ws), ws.numel(), _stream()),
-                      'ggan_critic_head_bwd_tail')
+                                                     _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(tail['logits']), _p(tail['g']),
+                                                     1 if tail.get('kind') == 'mean' else 0, nt, tabs[0], tabs[1], tabs[2], pext,
+                                                     _p(tail['loss']), _p(ws), ws.numel(), _stream()), 'ggan_critic_head_bwd_tail')
                 return (d_a1 if need[0] else None, d_a2 if (a2 is not None and need[1]) else None, d_w if need[2] else None, d_b, d_wout,
                         d_bout, None)
             # (another upstream gradient than the unit seed reached this head: the cost's value is still owed)
             nt = len(tail['terms'])
             lg = tail['logits']
+            ext = tail.get('ext') or [None] * nt
             xs, o = [], 0
-            for n, _, _ in tail['terms']:
-                xs.append(lg.data_ptr() + 4 * o)
-                o += n
-            check(_L().ggan_bce_logits_multi_fwd((C.c_void_p * nt)(*xs), (C.c_float * nt)(*[z for _, z, _ in tail['terms']]),
-                                                 (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]),
-                                                 (C.c_int * nt)(*[n for n, _, _ in tail['terms']]), nt, _p(tail['loss']), _stream()),
-                  'ggan_bce_logits_multi_fwd')
+            for (n, _, _), e in zip(tail['terms'], ext):
+                if e is not None:
+                    xs.append(e.data_ptr())
+                else:
+                    xs.append(lg.data_ptr() + 4 * o)
+                    o += n
+            pw, pn = (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]), (C.c_int * nt)(*[n for n, _, _ in tail['terms']])
+            if tail.get('kind') == 'mean':
+                check(_L().ggan_mean_multi_fwd_grad((C.c_void_p * nt)(*xs), pw, pn, nt, _p(tail['loss']), None, _stream()),
+                      'ggan_mean_multi_fwd_grad')
+            else:
+                check(_L().ggan_bce_logits_multi_fwd((C.c_void_p * nt)(*xs), (C.c_float * nt)(*[z for _, z, _ in tail['terms']]), pw, pn, nt,
+                                                     _p(tail['loss']), _stream()), 'ggan_bce_logits_multi_fwd')
         # (fused: gh, d_wout, d_bout left with the cost's launch -- ggan_bce_head_bwd; g = NULL launches the products only)
         check(_L().ggan_critic_head_bwd(M, K1, K2, H, _p(None if fused else g), _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1),
                                         _p(d_a2), _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(ws), ws.numel(), _stream()),
@@ -2092,7 +2105,7 @@ class BceSum(Function):
             gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
             heads = BceSum._heads_of(logits)
             hrec = heads[0][0] if (heads is not None and len(heads) == 1) else None
-            if (hrec is not None and hrec.get('hinted') is not None
+            if (hrec is not None and hrec.get('hinted') is not None and hrec['hinted']['kind'] == 'bce'
                     and hrec['hinted']['terms'] == tuple((x.numel(), float(z), float(wt)) for x, z, wt in zip(logits, labels, weights))):
                 # the head ran with this cost's terms as its hint (head_bce_hint): g and gh exist already, the cost's value, d_wout and
                 # d_bout come with the head's backward products (ggan_critic_head_bwd_tail) -- nothing to launch here
@@ -2106,7 +2119,7 @@ class BceSum(Function):
                 hrec['d_wout'] = new(hrec['H']) if hrec['want_out'] else None
                 hrec['d_bout'] = new(1) if hrec['want_bout'] else None
                 hrec['g_ptr'], hrec['g_version'] = outs[0].data_ptr(), outs[0]._version
-                hrec['tail'] = dict(terms=hh['terms'], logits=logits[0], g=hh['g'], loss=loss)
+                hrec['tail'] = dict(kind='bce', terms=hh['terms'], logits=logits[0], g=hh['g'], loss=loss)
             elif heads is not None:
                 # every term is a row range of a critic head's logits (one head, or the two heads of the mixture scripts): the head
                 # kernels of those ops' backward ride along
@@ -2180,6 +2193,27 @@ class MeanSum(Function):
     """sum_i weight_i * mean(x_i) -> 0-dim tensor (Wasserstein costs)."""
 
     @staticmethod
+    def _hinted_head(xs, weights):
+        """the CriticHead record whose 'mean' hint these terms fulfil: the leading terms are the hinted row ranges of its logits (sizes and
+        weights as hinted), every further term has one element and weight 1 (the gradient penalty) -- else None"""
+        rec = HEAD_LOGITS.get(xs[0].data_ptr()) if HEAD_LOGITS else None
+        if rec is None or rec['g_ptr'] is not None or rec['h']() is None or rec['w_out']() is None:
+            return None
+        hh = rec.get('hinted')
+        if hh is None or hh['kind'] != 'mean' or len(xs) < len(hh['terms']):
+            return None
+        rows = 0
+        for x, wt, (n, _, hw) in zip(xs, weights, hh['terms']):
+            if x.numel() != n or float(wt) != hw or x.data_ptr() != rec['ptr'] + 4 * rows:
+                return None
+            rows += n
+        nh = len(hh['terms'])
+        if rows != rec['M'] or any(x.numel() != 1 or float(wt) != 1.0 for x, wt in zip(xs[nh:], weights[nh:])):
+            return None
+        HEAD_LOGITS.pop(rec['ptr'], None)
+        return rec
+
+    @staticmethod
     def forward(ctx, weights, *xs):
         ctx.shapes = [x.shape for x in xs]
         xs = [_c(x).reshape(-1) for x in xs]
@@ -2189,6 +2223,27 @@ class MeanSum(Function):
         ctx.dev = xs[0].device
         ctx.unit_grads = None
         n = len(xs)
+        hrec = MeanSum._hinted_head(xs, weights) if (any(ctx.needs_input_grad[1:]) and n <= 4) else None
+        if hrec is not None:
+            # the critic head ran with this cost's row terms as its hint (head_bce_hint(kind='mean')): g and gh exist, the cost's value
+            # (with the one-element terms that follow the head's rows: the gradient penalty), d_wout and d_bout come with the head's
+            # backward products -- nothing to launch here
+            hh = hrec['hinted']
+            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=loss.device)
+            nh = len(hh['terms'])
+            outs, o = [], 0
+            for x in xs[:nh]:
+                outs.append(hh['g'][o:o + x.numel()])
+                o += x.numel()
+            outs += [cached_const(1.0, (1,), loss.device) for _ in xs[nh:]]      # (d cost / d term = its weight, 1)
+            hrec['gh'] = hh['gh']
+            hrec['d_wout'] = new(hrec['H']) if hrec['want_out'] else None
+            hrec['d_bout'] = new(1) if hrec['want_bout'] else None
+            hrec['g_ptr'], hrec['g_version'] = outs[0].data_ptr(), outs[0]._version
+            hrec['tail'] = dict(kind='mean', terms=hh['terms'] + tuple((1, 0.0, 1.0) for _ in xs[nh:]), logits=xs[0], g=hh['g'], loss=loss,
+                                ext=[None] * nh + list(xs[nh:]))
+            ctx.unit_grads = outs
+            return loss.reshape(())
         if n <= _lib.BCE_MAX and not os.environ.get('GGAN_NO_BCE_FWD_GRAD'):
             # one launch for all terms; with it (as BceSum) the gradients for the unit seed of a train op, in ONE buffer so that
             # the halves of a batched critic's logits get adjacent slices (SplitRows.backward: no concatenation)

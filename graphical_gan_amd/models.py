@@ -705,12 +705,17 @@ class GraphicalGAN(object):
         # MODE ali on the batched critic: the cost of this step is known before the critic runs -- sigmoid cross-entropy of its [fake; real]
         # logits with labels (1, 0) in a generator step, (0, 1) in a critic step (tflib/objs/gan_inference.py:47-79) -- and the caller
         # (engine.Trainer, head_hint) runs the backward at once: the critic head leaves that cost's gradient behind with its forward
-        hint = None
-        if (getattr(self, 'head_hint', False) and c.mode == 'ali' and not c.K and batched and c.fuse and real_x.is_cuda
-                and not os.environ.get('GGAN_NO_HEAD_HINT')):
-            fl, rl = (1.0, 0.0) if which == 'gen' else (0.0, 1.0)
-            hint = [(c.B, fl, 1.0), (c.B, rl, 1.0)]
-        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()), F.head_bce_hint(hint):
+        hint, hkind = None, 'bce'
+        if (getattr(self, 'head_hint', False) and not c.K and batched and c.fuse and real_x.is_cuda and not os.environ.get('GGAN_NO_HEAD_HINT')):
+            if c.mode == 'ali':
+                fl, rl = (1.0, 0.0) if which == 'gen' else (0.0, 1.0)
+                hint = [(c.B, fl, 1.0), (c.B, rl, 1.0)]
+            elif c.mode == 'wali-gp':
+                # the Wasserstein costs (tflib/objs/gan_inference.py:28-45): -mean(fake) + mean(real) for the generator step, the opposite
+                # signs (+ the one-element penalty, which only enters the cost's value) for the critic step
+                sg = -1.0 if which == 'gen' else 1.0
+                hint, hkind = [(c.B, 0.0, sg), (c.B, 0.0, -sg)], 'mean'
+        with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()), F.head_bce_hint(hint, hkind):
             d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None,
                                           detach=which == 'disc')
         if gp_early is not None:

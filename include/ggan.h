@@ -157,15 +157,20 @@ int ggan_critic_head_bwd(int M, int K1, int K2, int H, const float* g, const flo
  * row-local, so the forward's tail launch also leaves g[M] = d cost / d logits and gh[M,H] = g w_out^T * lrelu'(h), and the backward's
  * product launch carries, as extra workgroups, what needs all rows: loss[0] (bit-identical to ggan_bce_logits_multi_fwd on the same
  * terms), d_wout[H] = h^T g, d_bout[1] = sum g.  One launch less per step on the chain  tail product -> logits -> cost -> head backward ->
- * products  than ggan_critic_head_fwd + ggan_bce_head_bwd + ggan_critic_head_bwd(g = NULL); same values bit for bit.  H <= 2048. */
+ * products  than ggan_critic_head_fwd + ggan_bce_head_bwd + ggan_critic_head_bwd(g = NULL); same values bit for bit.  H <= 2048.
+ * kind 0: sigmoid cross-entropy terms; kind 1: plain means (the Wasserstein costs of gan_inference.py:4-45, sum_k w_k * reduce_mean(rows of term k);
+ * labels unused).  ext (backward only, may be NULL): ext[k] != NULL makes term k a value read THERE (term_rows[k] floats) instead of a row range -- the
+ * one-element gradient penalty that a wali-gp critic cost adds (gan_inference_cifar10.py:365); such a term only enters loss[0].  The cost's value is
+ * bit-identical to ggan_bce_logits_multi_fwd / ggan_mean_multi_fwd_grad on the same terms. */
 int ggan_critic_head_fwd_bce(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* b,
-                             const float* w_out, const float* b_out, float alpha, float* h, float* logits, int nterms,
+                             const float* w_out, const float* b_out, float alpha, float* h, float* logits, int kind, int nterms,
                              const int* term_rows, const float* labels, const float* weights, float* g, float* gh, void* ws,
                              size_t ws_bytes, ggan_stream_t stream);
 int ggan_critic_head_bwd_tail(int M, int K1, int K2, int H, const float* a1, const float* a2, const float* w, const float* h,
                               const float* w_out, float alpha, const float* gh, float* d_a1, float* d_a2, float* d_w, float* d_b,
-                              float* d_wout, float* d_bout, const float* logits, const float* g, int nterms, const int* term_rows,
-                              const float* labels, const float* weights, float* loss, void* ws, size_t ws_bytes, ggan_stream_t stream);
+                              float* d_wout, float* d_bout, const float* logits, const float* g, int kind, int nterms, const int* term_rows,
+                              const float* labels, const float* weights, const float* const* ext, float* loss, void* ws, size_t ws_bytes,
+                              ggan_stream_t stream);
 
 /* The mixture critic on codes as ONE launch per direction: Linear ([x1 | x2] -> 512) -> LeakyReLU -> Linear (512 -> 512) -> LeakyReLU ->
  * Linear (512 -> 512) -> LeakyReLU -> Linear (512 -> 1).  Replaces tf.concat([z, k], 1) + lib.ops.linear.Linear('Discriminator.HyperInput')
