@@ -1073,8 +1073,8 @@ class CriticHead(Function):
                                                      _p(tail['loss']), _p(ws), ws.numel(), _stream()), 'ggan_critic_head_bwd_tail')
                 return (d_a1 if need[0] else None, d_a2 if (a2 is not None and need[1]) else None, d_w if need[2] else None, d_b, d_wout,
                         d_bout, None)
-            # (another upstream gradient than the unit seed reached this head: the cost's value is still owed)
-            nt = len(tail['terms'])
+            # (another upstream gradient than the unit seed reached this head: the cost's value is still owed -- by the head that carries it)
+            nt = len(tail['terms']) if tail['loss'] is not None else 0
             lg = tail['logits']
             ext = tail.get('ext') or [None] * nt
             xs, o = [], 0
@@ -1085,7 +1085,9 @@ class CriticHead(Function):
                     xs.append(lg.data_ptr() + 4 * o)
                     o += n
             pw, pn = (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]), (C.c_int * nt)(*[n for n, _, _ in tail['terms']])
-            if tail.get('kind') == 'mean':
+            if nt == 0:
+                pass
+            elif tail.get('kind') == 'mean':
                 check(_L().ggan_mean_multi_fwd_grad((C.c_void_p * nt)(*xs), pw, pn, nt, _p(tail['loss']), None, _stream()),
                       'ggan_mean_multi_fwd_grad')
             else:
@@ -2104,22 +2106,41 @@ class BceSum(Function):
             outs = BceSum._grad_buffers(logits, loss.device)
             gxs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
             heads = BceSum._heads_of(logits)
-            hrec = heads[0][0] if (heads is not None and len(heads) == 1) else None
-            if (hrec is not None and hrec.get('hinted') is not None and hrec['hinted']['kind'] == 'bce'
-                    and hrec['hinted']['terms'] == tuple((x.numel(), float(z), float(wt)) for x, z, wt in zip(logits, labels, weights))):
-                # the head ran with this cost's terms as its hint (head_bce_hint): g and gh exist already, the cost's value, d_wout and
-                # d_bout come with the head's backward products (ggan_critic_head_bwd_tail) -- nothing to launch here
-                hh = hrec['hinted']
+            all_terms = tuple((x.numel(), float(z), float(wt)) for x, z, wt in zip(logits, labels, weights))
+
+            def hinted_ok():
+                # every head ran with ITS terms of this cost as its hint (head_bce_hint); four terms at most in the carrying launch
+                if heads is None or len(all_terms) > 4:
+                    return False
+                k0 = 0
+                for rec, nt in heads:
+                    hh = rec.get('hinted')
+                    if hh is None or hh['kind'] != 'bce' or hh['terms'] != all_terms[k0:k0 + nt]:
+                        return False
+                    k0 += nt
+                return True
+            if hinted_ok():
+                # g and gh of every head exist already; d_wout / d_bout come with each head's backward products, and the LAST head's products
+                # carry the cost's value -- all terms in order, the other heads' logits read in place (ext terms) -- nothing to launch here
                 new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=loss.device)
-                outs, o = [], 0
-                for x in logits:
-                    outs.append(hh['g'][o:o + x.numel()])
-                    o += x.numel()
-                hrec['gh'] = hh['gh']
-                hrec['d_wout'] = new(hrec['H']) if hrec['want_out'] else None
-                hrec['d_bout'] = new(1) if hrec['want_bout'] else None
-                hrec['g_ptr'], hrec['g_version'] = outs[0].data_ptr(), outs[0]._version
-                hrec['tail'] = dict(kind='bce', terms=hh['terms'], logits=logits[0], g=hh['g'], loss=loss)
+                outs, k0 = [], 0
+                for hi, (rec, nt) in enumerate(heads):
+                    hh = rec['hinted']
+                    mine, o = [], 0
+                    for x in logits[k0:k0 + nt]:
+                        mine.append(hh['g'][o:o + x.numel()])
+                        o += x.numel()
+                    outs += mine
+                    rec['gh'] = hh['gh']
+                    rec['d_wout'] = new(rec['H']) if rec['want_out'] else None
+                    rec['d_bout'] = new(1) if rec['want_bout'] else None
+                    rec['g_ptr'], rec['g_version'] = mine[0].data_ptr(), mine[0]._version
+                    if hi == len(heads) - 1:
+                        rec['tail'] = dict(kind='bce', terms=all_terms, logits=logits[k0], g=hh['g'], loss=loss,
+                                           ext=[logits[j] for j in range(k0)] + [None] * nt)
+                    else:
+                        rec['tail'] = dict(kind='bce', terms=hh['terms'], logits=logits[k0], g=hh['g'], loss=None, ext=None)
+                    k0 += nt
             elif heads is not None:
                 # every term is a row range of a critic head's logits (one head, or the two heads of the mixture scripts): the head
                 # kernels of those ops' backward ride along

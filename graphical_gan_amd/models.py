@@ -706,11 +706,16 @@ class GraphicalGAN(object):
         # logits with labels (1, 0) in a generator step, (0, 1) in a critic step (tflib/objs/gan_inference.py:47-79) -- and the caller
         # (engine.Trainer, head_hint) runs the backward at once: the critic head leaves that cost's gradient behind with its forward
         hint, hkind = None, 'bce'
-        if (getattr(self, 'head_hint', False) and not c.K and batched and c.fuse and real_x.is_cuda and not os.environ.get('GGAN_NO_HEAD_HINT')):
-            if c.mode == 'ali':
+        if (getattr(self, 'head_hint', False) and batched and c.fuse and real_x.is_cuda and not os.environ.get('GGAN_NO_HEAD_HINT')):
+            if c.mode == 'ali' and not c.K:
                 fl, rl = (1.0, 0.0) if which == 'gen' else (0.0, 1.0)
                 hint = [(c.B, fl, 1.0), (c.B, rl, 1.0)]
-            elif c.mode == 'wali-gp':
+            elif c.mode == 'local_ep' and c.K:
+                # the mixture scripts: two critic heads (on codes, on (x, z) pairs), each evaluated on [fake; real]; their four terms weigh 1/2
+                # each (tflib/objs/gan_inference.py:81-119).  Both heads read the same hint: each one's own two terms
+                fl, rl = (1.0, 0.0) if which == 'gen' else (0.0, 1.0)
+                hint = [(c.B, fl, 0.5), (c.B, rl, 0.5)]
+            elif c.mode == 'wali-gp' and not c.K:
                 # the Wasserstein costs (tflib/objs/gan_inference.py:28-45): -mean(fake) + mean(real) for the generator step, the opposite
                 # signs (+ the one-element penalty, which only enters the cost's value) for the critic step
                 sg = -1.0 if which == 'gen' else 1.0

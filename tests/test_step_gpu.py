@@ -864,7 +864,7 @@ def test_cost_launch_carrying_the_head_backward_is_bit_identical(gpu, monkeypatc
 
 
 @pytest.mark.parametrize('graph', [False, True])
-@pytest.mark.parametrize('dataset,mode', [('cifar10', 'ali'), ('face', 'ali'), ('cifar10', 'wali-gp')])
+@pytest.mark.parametrize('dataset,mode', [('cifar10', 'ali'), ('face', 'ali'), ('cifar10', 'wali-gp'), ('cifar10', 'local_ep')])
 def test_head_that_knows_its_cost_is_bit_identical(gpu, monkeypatch, dataset, mode, graph):
     """MODE ali / wali-gp on the batched critic: the step's cost is known before the critic runs (functional.head_bce_hint, set by
     models.forward for engine.Trainer's steps; sigmoid cross-entropy terms, or the Wasserstein means with the gradient penalty as a
@@ -884,7 +884,7 @@ def test_head_that_knows_its_cost_is_bit_identical(gpu, monkeypatch, dataset, mo
             monkeypatch.setenv('GGAN_NO_HEAD_HINT', '1')
         _fresh()
         np.random.seed(0)
-        cfg = Config(dataset, batch_size=16, mode=mode, dim=16, dim_latent=32)
+        cfg = Config(dataset, batch_size=16, n_coms=10 if mode == 'local_ep' else 0, mode=mode, dim=16, dim_latent=32)
         tr = Trainer(cfg, device=gpu, graph=graph, seed=4321)
         batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 40)
         lib_, calls = _lib.load(), {'fwd': 0, 'bwd': 0, 'old': 0}
@@ -916,7 +916,7 @@ def test_head_that_knows_its_cost_is_bit_identical(gpu, monkeypatch, dataset, mo
         torch.cuda.synchronize()
         counts.append(dict(calls))
         finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}, costs))
-    assert counts[0]['fwd'] == 0 and counts[0]['bwd'] == 0 and (counts[0]['old'] > 0 or mode != 'ali')     # (Wasserstein costs: ggan_mean_multi_fwd_grad)
+    assert counts[0]['fwd'] == 0 and counts[0]['bwd'] == 0 and (counts[0]['old'] > 0 or mode == 'wali-gp')     # (Wasserstein costs: ggan_mean_multi_fwd_grad)
     assert counts[1]['fwd'] > 0 and counts[1]['bwd'] == counts[1]['fwd'] and counts[1]['old'] == 0
     assert finals[0][1] == finals[1][1] and finals[0][2] == finals[1][2]
     assert all(np.isfinite(v) for v in finals[1][1].values())
