@@ -53,6 +53,7 @@ SIGNATURES = {
     'ggan_conv2d_fwd_cast_ring': (_I, [_G, _P, _I, _P, _P, _I, _P, _F, _F, _P, _P, _P, _P, _I, _F, _P]),
     'ggan_conv2d_fwd_masked': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_linear_bn_rows_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P]),
+    'ggan_linear_bn_rows_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     'ggan_deconv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _F, _P, _Z, _P]),
     'ggan_deconv2d_bwd_data': (_I, [_G, _P, _P, _P, _P, _Z, _P]),
     'ggan_deconv2d_bwd_filter': (_I, [_G, _P, _P, _P, _P, _P, _Z, _P]),

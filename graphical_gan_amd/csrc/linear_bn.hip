@@ -118,7 +118,131 @@ __global__ __launch_bounds__(LB_THR) void linear_bn_rows_k(const LinBnParams P) 
     }
 }
 
+// ---- the backward of the same head, where the input needs no gradient (the generators' input is noise): ggan_bn_bwd_act on [M, N] rows
+//      + the weight-gradient product x^T gh (+ its column sums) were two launches at the very END of the Generator's backward chain, in
+//      front of the step's pack + Adam launch.  A workgroup again owns 32 features for all rows: BatchNorm's backward needs nothing
+//      but its own columns (sum g, sum g xh over the rows), and dW[:, its columns] = x^T gh[:, its columns] needs x (staged once, as the
+//      forward does) and the gh columns it has just formed (kept in LDS).  gh itself is never written: nothing else reads it.
+struct LinBnBwdParams {
+    const float* x;        // [M][K]
+    const float* gy;       // [M][N]
+    const float* h;        // [M][N] the Linear output kept by the forward
+    const float* y;        // [M][N] forward output (activation reference) or null
+    const float* scale;    // [N]
+    const float* mean;     // [N]
+    const float* invstd;   // [N]
+    float* dw;             // [K][N]
+    float* db;             // [N] or null
+    float* dscale;         // [N]
+    float* doffset;        // [N]
+    int M, K, N, XS, R;
+    int act;
+    float alpha;
+};
+
+template <int KPT>      // k values per thread of the product phase: K = 16 * KPT
+__global__ __launch_bounds__(LB_THR) void linear_bn_rows_bwd_k(const LinBnBwdParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                          // [M][XS]
+    float* ghs = smem + P.M * P.XS;            // [M][32]
+    float* red = ghs + P.M * LB_COLS;          // [16][32]
+    const int tid = threadIdx.x, c = tid & (LB_COLS - 1), g = tid >> 5;
+    const int n0 = blockIdx.x * LB_COLS, col = n0 + c;
+    const int K = P.K, K4 = K >> 2, R = P.R;
+    for (int u = tid; u < P.M * K4; u += LB_THR) {
+        const int m = u / K4, k4 = u - m * K4;
+        *reinterpret_cast<float4*>(xs + m * P.XS + k4 * 4) = *reinterpret_cast<const float4*>(P.x + (size_t)m * K + k4 * 4);
+    }
+    // ---- BatchNorm backward of column `col` over all rows: my R rows, then the 16 row groups in order (as the forward) ----------------
+    const float mean = P.mean[col], invstd = P.invstd[col];
+    float g1[8], xh[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        g1[i] = 0.f; xh[i] = 0.f;
+        if (i < R) {
+            const size_t idx = (size_t)(g * R + i) * P.N + col;
+            const float gv = P.gy[idx];
+            g1[i] = P.y ? act_grad(gv, P.y[idx], P.act, P.alpha) : gv;
+            xh[i] = (P.h[idx] - mean) * invstd;
+            s1 += g1[i];
+            s2 += g1[i] * xh[i];
+        }
+    }
+    red[g * LB_COLS + c] = s1;
+    __syncthreads();
+    float sum_g = 0.f;
+#pragma unroll
+    for (int j = 0; j < LB_GROUPS; ++j) sum_g += red[j * LB_COLS + c];
+    __syncthreads();
+    red[g * LB_COLS + c] = s2;
+    __syncthreads();
+    float sum_gx = 0.f;
+#pragma unroll
+    for (int j = 0; j < LB_GROUPS; ++j) sum_gx += red[j * LB_COLS + c];
+    const float inv_cnt = 1.f / (float)P.M;
+    const float kk = P.scale[col] * invstd, mg = sum_g * inv_cnt, mgx = sum_gx * inv_cnt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < R) ghs[(g * R + i) * LB_COLS + c] = kk * (g1[i] - mg - xh[i] * mgx);
+    if (g == 0) {
+        P.dscale[col] = sum_gx;
+        P.doffset[col] = sum_g;
+    }
+    __syncthreads();                           // (x staged, gh columns complete)
+    // ---- dW[k][col] = sum_m x[m][k] gh[m][col] for my KPT values of k, rows in order ------------------------------------------------
+    float acc[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) acc[j] = 0.f;
+    const float* xk = xs + g * KPT;
+    float bsum = 0.f;
+    for (int m = 0; m < P.M; ++m) {
+        const float gv = ghs[m * LB_COLS + c];
+        bsum += gv;
+#pragma unroll
+        for (int j4 = 0; j4 < KPT / 4; ++j4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xk + m * P.XS + j4 * 4);
+            acc[j4 * 4 + 0] = fmaf(xv.x, gv, acc[j4 * 4 + 0]);
+            acc[j4 * 4 + 1] = fmaf(xv.y, gv, acc[j4 * 4 + 1]);
+            acc[j4 * 4 + 2] = fmaf(xv.z, gv, acc[j4 * 4 + 2]);
+            acc[j4 * 4 + 3] = fmaf(xv.w, gv, acc[j4 * 4 + 3]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) P.dw[(size_t)(g * KPT + j) * P.N + col] = acc[j];
+    if (g == 0 && P.db) P.db[col] = bsum;
+}
+
 }  // namespace
+
+extern "C" int ggan_linear_bn_rows_bwd(const float* x, const float* gy, const float* h, const float* y, const float* scale,
+                                       const float* save_mean, const float* save_invstd, float* dw, float* db, float* dscale,
+                                       float* doffset, int M, int K, int N, int act, float alpha, ggan_stream_t stream) {
+    GGAN_CHECK_ARG(x && gy && h && scale && save_mean && save_invstd && dw && dscale && doffset, "null pointer");
+    GGAN_CHECK_ARG(M > 0 && K > 0 && N > 0 && (y || act == GGAN_ACT_NONE), "bad shape");
+    if (M > 128 || (M & 15) || (K != 64 && K != 128 && K != 256) || (N & 31)) return 1;
+    if (((uintptr_t)x) & 15) return 1;
+    LinBnBwdParams P;
+    P.x = x; P.gy = gy; P.h = h; P.y = act != GGAN_ACT_NONE ? y : nullptr; P.scale = scale; P.mean = save_mean; P.invstd = save_invstd;
+    P.dw = dw; P.db = db; P.dscale = dscale; P.doffset = doffset;
+    P.M = M; P.K = K; P.N = N; P.XS = K + 4; P.R = M / LB_GROUPS; P.act = act; P.alpha = alpha;
+    const size_t shmem = ((size_t)M * P.XS + (size_t)M * LB_COLS + LB_GROUPS * LB_COLS) * sizeof(float);
+    if (shmem > 160 * 1024) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    const double fl = 2.0 * M * K * (double)N, bytes = 4.0 * ((double)M * K + (double)K * N + 3.0 * M * N);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_bwd_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_bwd_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bn_rows_bwd_k<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    const dim3 grid(N / LB_COLS), block(LB_THR);
+    if (K == 64) { GGAN_LAUNCH("linear_bn_rows_bwd_k", fl, bytes, linear_bn_rows_bwd_k<4>, grid, block, shmem, s, P); }
+    else if (K == 128) { GGAN_LAUNCH("linear_bn_rows_bwd_k", fl, bytes, linear_bn_rows_bwd_k<8>, grid, block, shmem, s, P); }
+    else { GGAN_LAUNCH("linear_bn_rows_bwd_k", fl, bytes, linear_bn_rows_bwd_k<16>, grid, block, shmem, s, P); }
+    return 0;
+}
 
 extern "C" int ggan_linear_bn_rows_fwd(const float* x, const float* w, const float* b, const float* scale, const float* offset, float* h,
                                        float* y, float* save_mean, float* save_invstd, int M, int K, int N, float eps, int act,

@@ -1456,13 +1456,23 @@ class LinearBatchNormRows(Function):
         x, w, h, sc, mean, invstd, y = ctx.saved_tensors
         M, N = h.shape
         gy = _c(gy)
-        gh = torch.empty_like(h)
         gs = torch.empty((N,), dtype=torch.float32, device=h.device)
         go = torch.empty_like(gs)
+        need = ctx.needs_input_grad
+        if (not need[0] and need[1] and mean.dim() == 1 and x.shape[1] in (64, 128, 256) and M <= 128 and M % 16 == 0 and N % 32 == 0
+                and x.data_ptr() % 16 == 0 and not _os.environ.get('GGAN_NO_LINEAR_BN_BWD')):
+            # the input is noise (no data gradient): BatchNorm's backward and the weight-gradient product in one launch
+            dw = torch.empty((x.shape[1], N), dtype=torch.float32, device=h.device)
+            db = torch.empty((N,), dtype=torch.float32, device=h.device) if (ctx.has_bias and need[2]) else None
+            rc = _L().ggan_linear_bn_rows_bwd(_p(x), _p(gy), _p(h), _p(y) if ctx.act != ACT_NONE else _p(None), _p(sc), _p(mean), _p(invstd),
+                                              _p(dw), _p(db), _p(gs), _p(go), M, x.shape[1], N, ctx.act, ctx.alpha, _stream())
+            if rc != 1:
+                check(rc, 'ggan_linear_bn_rows_bwd')
+                return (None, dw, db, gs.view(ctx.pshape) if need[3] else None, go.view(ctx.pshape) if need[4] else None, None, None, None)
+        gh = torch.empty_like(h)
         check(_L().ggan_bn_bwd_act(_p(h), _p(gy), _p(y) if ctx.act != ACT_NONE else _p(None), ctx.act, ctx.alpha, _p(sc), _p(mean),
                                    _p(invstd), _p(gh), _p(gs), _p(go), _p(None), M, N, 1, _stream()), 'ggan_bn_bwd_act')
         dx = dw = db = None
-        need = ctx.needs_input_grad
         if need[1] or (ctx.has_bias and need[2]):
             dw, db = gemm_colsum_(x, gh, True)                         # dW = x^T gh and db = column sums of gh in one launch
             if not need[1]:

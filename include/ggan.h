@@ -253,6 +253,14 @@ int ggan_conv2d_fwd_masked(const ggan_conv_geom* g, const float* x, const float*
 int ggan_linear_bn_rows_fwd(const float* x, const float* w, const float* b, const float* scale, const float* offset, float* h,
                             float* y, float* save_mean, float* save_invstd, int M, int K, int N, float eps, int act,
                             float alpha, ggan_stream_t stream);
+/* The backward of that head where its input needs no gradient (the generators' input is noise): ggan_bn_bwd_act over the rows + the
+ * weight-gradient product x^T gh + its column sums in ONE launch (the last two launches of the Generator's backward chain, in front of
+ * the step's pack + Adam launch).  gy [M,N] = d cost / d y, h / y / save_mean / save_invstd as the forward left them (y: the activation
+ * reference, NULL for act == NONE); dw [K,N], db [N] (may be NULL), dscale [N], doffset [N].  Returns 1 when the shape is not covered
+ * (K in {64, 128, 256}, M <= 128 in 16 equal row groups, N a multiple of 32): the caller composes ggan_bn_bwd_act + ggan_gemm_colsum. */
+int ggan_linear_bn_rows_bwd(const float* x, const float* gy, const float* h, const float* y, const float* scale, const float* save_mean,
+                            const float* save_invstd, float* dw, float* db, float* dscale, float* doffset, int M, int K, int N, int act,
+                            float alpha, ggan_stream_t stream);
 
 /* Second derivative of ggan_bn_bwd_act w.r.t. its inputs, for objectives that differentiate a network containing BatchNorm twice
  * (MODE vegan-wgan-gp: the gradient penalty on the latent critic, gan_inference_cifar10.py:305-317 with BN_FLAG = True).  h =

@@ -1405,12 +1405,14 @@ def test_dyn_scan(gpu, B, T, dl, dt, res_w):
         assert _rel(a.cpu().numpy(), b.numpy()) < 5e-5, n
 
 
-@pytest.mark.parametrize('M,K,N', [(64, 128, 4096), (128, 128, 4096), (16, 16, 64), (32, 128, 512), (48, 256, 96)])
+@pytest.mark.parametrize('M,K,N', [(64, 128, 4096), (128, 128, 4096), (16, 16, 64), (32, 128, 512), (48, 256, 96), (64, 64, 160)])
 @pytest.mark.parametrize('act', ['relu', 'none'])
-def test_linear_batchnorm_rows_fused_op(gpu, M, K, N, act):
+@pytest.mark.parametrize('noise_input', [False, True])
+def test_linear_batchnorm_rows_fused_op(gpu, M, K, N, act, noise_input):
     """ggan_linear_bn_rows_fwd (Linear 'Generator.Input' + Batchnorm([0]) + relu in one launch) and its backward against the
     float64 oracle tape: output, and the gradients of the input, the weight, the bias (mathematically zero: it feeds a BatchNorm),
-    scale and offset; and against the two-op composition it replaces."""
+    scale and offset; and against the two-op composition it replaces.  noise_input: the input needs no gradient (the generators'
+    input is noise) -- the backward is then ONE launch (ggan_linear_bn_rows_bwd) where K is 64 / 128 / 256."""
     import torch
     from graphical_gan_amd import functional as F
     from oracle import tape as tp
@@ -1431,12 +1433,18 @@ def test_linear_batchnorm_rows_fused_op(gpu, M, K, N, act):
     dev = lambda a: torch.as_tensor(a).to(gpu).requires_grad_(True)
     a = F.ACT_RELU if act == 'relu' else F.ACT_NONE
     dx, dw, db_, ds, do = dev(x), dev(w), dev(b), dev(sc), dev(of)
+    if noise_input:
+        dx = torch.as_tensor(x).to(gpu)
     assert F.LinearBatchNormRows.usable(dx, dw)
     out = F.LinearBatchNormRows.apply(dx, dw, db_, ds, do, 1e-5, a, 0.0)
-    g = torch.autograd.grad(out, [dx, dw, db_, ds, do], grad_outputs=torch.as_tensor(gy).to(gpu))
+    ins = [dw, db_, ds, do] if noise_input else [dx, dw, db_, ds, do]
+    g = torch.autograd.grad(out, ins, grad_outputs=torch.as_tensor(gy).to(gpu))
     assert np.abs(out.detach().cpu().numpy() - y.v).max() <= 2e-5 * max(1.0, np.abs(y.v).max())
     gmax = max(np.abs(r.v).max() for r in ref)
-    for name, mine, r in zip(('x', 'w', 'b', 'scale', 'offset'), g, ref):
+    names = ('x', 'w', 'b', 'scale', 'offset')
+    if noise_input:
+        names, ref = names[1:], ref[1:]
+    for name, mine, r in zip(names, g, ref):
         err = np.abs(mine.cpu().numpy().reshape(r.v.shape) - r.v).max()
         assert err <= 1e-4 * max(np.abs(r.v).max(), 1e-2 * gmax), (name, err, np.abs(r.v).max())
     # the composition it replaces (MFMA GEMM, then the BatchNorm kernel): same numbers to fp32 summation order
