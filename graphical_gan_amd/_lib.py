@@ -80,10 +80,6 @@ SIGNATURES = {
     'ggan_critic_head_bwd': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_critic_head_fwd_bce': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'ggan_critic_head_bwd_tail': (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    'ggan_mlp_chain_ok': (_I, [_I, _I, _I, _I]),
-    'ggan_mlp_chain_scratch': (_Z, [_I, _I]),
-    'ggan_mlp_chain_fwd': (_I, [_I, _I, _I, _I] + [_P] * 10 + [_F] + [_P] * 5 + [_P]),
-    'ggan_mlp_chain_bwd': (_I, [_I, _I, _I, _I] + [_P] * 8 + [_F] + [_P] * 13 + [_P, _Z, _P]),
     'ggan_linear_bwd_data_act': (_I, [_I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_linear_bwd_weight_act': (_I, [_I, _I, _I, _P, _P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'ggan_colsum': (_I, [_P, _P, _I, _I, _P]),

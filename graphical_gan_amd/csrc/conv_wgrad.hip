@@ -369,6 +369,338 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgradParams P) {
     stamp(14);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same product on FOUR waves -- one per SIMD, so a wave has the whole 512-register file -- with a 16 ci x 32 co tile
+// for all 25 taps per wave (200 accumulator registers).  What that buys over the eight-wave kernel above:
+//   * the x slab is staged once for twice the MFMAs (each x element feeds 32 output channels instead of 16), and a k-step is
+//     25 x-fragment + 2 gy-fragment LDS reads for 50 MFMAs instead of 26 reads for 25;
+//   * a chunk carries twice the MFMA issue time (12 800 cycles per 128 pixels) between the barrier-synchronous chunk ends;
+//   * gy is the MFMA's A operand here, so an accumulator quad is 4 CONSECUTIVE output channels of one (tap, ci): the four
+//     pixel-split waves combine in the accumulators' own layout with 16-byte LDS accesses (every wave parks the 3/4 it does not
+//     own, adds the three foreign copies of the quarter it owns in wave order) and store float4 runs straight from registers --
+//     no transposed round trip;
+//   * the geometry is a template parameter (square images of width 8 / 16 / 32 / 64, the layers of the scripts): every fragment
+//     read is one base register + an immediate offset, and the chunk body has no branch, so the fragment reads of the next quad
+//     and the global loads of the chunk after next are dealt out between the MFMAs of ONE scheduling region (one wave per SIMD
+//     hides at most ~5 single-issue instructions per 32-cycle MFMA: MI355X_MICROARCH.md);
+//   * workgroups are numbered split-fastest: the (ci, co) tiles that read the same image range sit on ONE XCD (id % 8), whose L2
+//     then fetches that range of x and gy once for all of them.
+// Workgroup = (16 ci) x (32 co) x (a split-K range of pixel chunks); the four waves take the pixel quads w, w + 4, ... of a chunk.
+constexpr int W4_NW = 4, W4_NTHR = 64 * W4_NW, W4_TCO = 32;
+constexpr int W4_RED_BYTES = 4 * 3 * 13 * 64 * 16;      // epilogue: [owner][foreign slot][unit / 4][lane] accumulator quads
+
+template <int W_> struct W4Geom {
+    static constexpr int W = W_, H = W_, Wo = W_ / 2, Ho = W_ / 2;
+    static constexpr int PC = W_ == 8 ? 64 : 128;                    // pixels per chunk (two staging buffers must fit 160 KB)
+    static constexpr int TR = PC / Wo < Ho ? PC / Wo : Ho;            // output rows per chunk
+    static constexpr int TI = PC / (TR * Wo);                         // images per chunk
+    static constexpr int SR = 2 * (TR - 1) + 5, SCp = W + 8, SCh = SCp / 2;
+    static constexpr int CS0 = TI * SR * SCp;
+    static constexpr int CS = CS0 + ((34 - (CS0 & 31)) & 31);         // == 2 (mod 32): conflict-free 16 ci x 2 px fragment reads
+    static constexpr int NQ = PC / 16;                                // pixel quads per wave and chunk
+    static constexpr int ROWT = Ho / TR;                              // chunks per image group
+    static constexpr int F4 = W / 4;
+    static constexpr int XUNITS = TCI * TI * SR * F4;                 // float4 slab units per chunk
+    static constexpr int XU = (XUNITS + W4_NTHR - 1) / W4_NTHR;
+    static constexpr int PC4 = PC / 4, PCp = PC + 4;
+    static constexpr int GU = W4_TCO * PC4 / W4_NTHR;                 // gy float4 units per thread and chunk
+    static constexpr int GSTEP = W4_NTHR / PC4;                       // output channels between a thread's gy units
+    static constexpr int STG = TCI * CS + W4_TCO * PCp;               // one staging buffer: x slab + gy tile (floats)
+    // pixel quad qd = wave + 4 q of a chunk -> slab offset of its first pixel = wave part (run time) + q part (compile time)
+    static constexpr int q_img(int q) { return (16 * q) / (TR * Wo); }
+    static constexpr int q_row(int q) { return ((16 * q) % (TR * Wo)) / Wo; }
+    static constexpr int q_col(int q) { return (16 * q) % Wo; }
+    static constexpr int q_off(int q) { return (q_img(q) * SR + 2 * q_row(q)) * SCp + q_col(q); }
+    static_assert(Wo >= 4 && (Wo & (Wo - 1)) == 0 && TR * Wo * TI == PC && Ho % TR == 0, "power-of-two chunk geometry");
+    static_assert(2 * STG * 4 <= 160 * 1024 && TCI * CS * 4 < 65536, "two staging buffers in LDS, slab within the immediate range");
+};
+
+template <int W> struct WaveTag { static constexpr int value = W; };
+
+template <int GW>
+__global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
+    using G = W4Geom<GW>;
+    warm_kernarg(P);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 5, NT = 25, NA = 2 * NT, NQ = G::NQ;
+    constexpr int XU = G::XU, GU = G::GU, NTHR = W4_NTHR, NITEM = XU + 2 * GU;
+    constexpr int HW = G::H * G::W, HoWo = G::Ho * G::Wo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, qq = lane >> 4;
+    // split-fastest numbering (XCD = id % 8): the tiles of one image range share an L2
+    const int split = blockIdx.x % P.SK, tile = blockIdx.x / P.SK;
+    const int gxt = (P.Ci + TCI - 1) / TCI;
+    const int ci0 = (tile % gxt) * TCI, co0 = (tile / gxt) * W4_TCO;
+
+    const bool stamping = P.stamps != nullptr && tid == 0;
+    auto stamp = [&](int i) { if (stamping) P.stamps[(size_t)blockIdx.x * 16 + i] = __builtin_readcyclecounter(); };
+    stamp(0);
+
+    // (the x buffer starts pad_t rows above the tensor: slab row 0 of the first row tile is a padding row, and every offset stays >= 0)
+    const int lead = P.pad_t * G::W;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(P.x - lead), (short)0, (int)(P.x_bytes + 4u * lead), 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)P.gy, (short)0, (int)P.gy_bytes, 0x00020000);
+    const bool masked = P.gy_ref != nullptr;
+    // the mask is a select  ref > 0 ? g : g * mslope  on every path: unmasked launches fetch no reference (zeros) and multiply by 1
+    const float mslope = !masked ? 1.f : (P.gy_act == GGAN_ACT_LRELU ? P.gy_alpha : 0.f);
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)(masked ? P.gy_ref : P.gy), (short)0, (int)P.gy_bytes, 0x00020000);
+    const bool do_bias = P.gbias != nullptr && ci0 == 0;
+    float bsum[GU];
+#pragma unroll
+    for (int j = 0; j < GU; ++j) bsum[j] = 0.f;
+
+    // ---- staging descriptors: slab unit u = tid + j * NTHR -> (channel, image, slab row, float4 column); all divisors compile-time.
+    //      Units past the slab duplicate its last unit (same bytes to the same place: no predicate anywhere in the chunk body).
+    //      A load is ONE instruction in the chunk body: voffset = the unit's byte offset inside a chunk (fixed for the launch; bit 31 set
+    //      where nothing is to be fetched -- channel past Ci, padding row: past every buffer, the load returns zeros), soffset = the
+    //      chunk's base (scalar).  One wave per SIMD hides nothing: every VALU instruction between two MFMAs costs ~6 cycles of the
+    //      matrix pipe (profiles/r05_notes.md), so the chunk body computes no addresses. ----
+    constexpr unsigned DEAD = 0x80000000u;
+    unsigned xvo[XU];                   // global byte offset of the unit relative to the chunk's x base
+    int xl[XU];                         // LDS float index (even plane) in staging buffer 0
+    unsigned xrow[XU];                  // ROWT > 1 only: bit 31 / 30 = a padding row in the first / last row tile of an image
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+        const int u = min(tid + j * NTHR, G::XUNITS - 1);
+        const int row = u / G::F4, f4 = u % G::F4;
+        const int t = row / G::SR, r = row % G::SR;
+        const int cil = t / G::TI, img = t % G::TI;
+        xl[j] = cil * G::CS + (img * G::SR + r) * G::SCp + 2 * f4 + 2;           // even-plane index of slab col 4*f4+4
+        // x row of slab row r in row tile rt: 2 * TR * rt - pad_t + r; with one row tile per image the padding rows are fixed
+        const bool top = r < P.pad_t, bot = 2 * G::TR * (G::ROWT - 1) - P.pad_t + r >= G::H;
+        unsigned vo = (unsigned)((img * P.Ci + cil) * HW + r * G::W + f4 * 4) * 4u;
+        if (ci0 + cil >= P.Ci) vo |= DEAD;
+        if (G::ROWT == 1 && (top || bot)) vo |= DEAD;
+        xvo[j] = vo;
+        xrow[j] = G::ROWT > 1 ? ((top ? DEAD : 0u) | (bot ? 0x40000000u : 0u)) : 0u;
+    }
+    // gy tile: unit j of a thread = one float4 (4 consecutive pixels) of channel gcol0 + j*GSTEP
+    const int gcol0 = tid / G::PC4, gp4 = tid % G::PC4;
+    const int gimg = (gp4 * 4) / (G::TR * G::Wo), gr = ((gp4 * 4) % (G::TR * G::Wo)) / G::Wo, gc = (gp4 * 4) % G::Wo;
+    unsigned gvo[GU];
+#pragma unroll
+    for (int j = 0; j < GU; ++j) {
+        const int col = gcol0 + j * G::GSTEP;
+        gvo[j] = (unsigned)((gimg * P.Co + col) * HoWo + gr * G::Wo + gc) * 4u | (co0 + col < P.Co ? 0u : DEAD);
+    }
+    const int gl = TCI * G::CS + gcol0 * G::PCp + gp4 * 4;      // LDS float index of unit 0 in staging buffer 0 (unit j: + j*GSTEP*PCp)
+
+    f32x4 acc[NA];
+#pragma unroll
+    for (int t = 0; t < NA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment lane bases (floats): x (ci = lane & 15, pixel = lane >> 4) + this wave's first quad; gy (co = lane & 15, pixel) likewise
+    const int wrow = ((4 * wave) % (G::TR * G::Wo)) / G::Wo, wcol = (4 * wave) % G::Wo;
+    const int xa = l15 * G::CS + qq + 2 * wrow * G::SCp + wcol;
+    const int gb = TCI * G::CS + l15 * G::PCp + qq + 4 * wave;
+
+    u32x4 sreg[NITEM];                  // staging registers: x units, gy units, their mask references
+
+    // chunk -> scalar bases (bytes) and the row-tile mask; the chunk after the last one is the last one again (valid addresses, its
+    // bytes land in the buffer nobody reads any more)
+    struct ChunkBase { unsigned xs, gs, rowmask, gdead; };
+    auto chunk_base = [&](int ch, bool live) {
+        ChunkBase b;
+        b.gdead = live ? 0u : DEAD;          // (gy of the repeated chunk reads as zeros: its rows must not enter the bias sums twice)
+        const int ig = ch / G::ROWT, rt = ch % G::ROWT;
+        b.xs = (unsigned)((ig * G::TI * P.Ci + ci0) * HW + 2 * G::TR * rt * G::W) * 4u;
+        b.gs = (unsigned)((ig * G::TI * P.Co + co0) * HoWo + G::TR * rt * G::Wo) * 4u;
+        b.rowmask = (rt == 0 ? DEAD : 0u) | (rt == G::ROWT - 1 ? 0x40000000u : 0u);
+        return b;
+    };
+    const unsigned rdead = masked ? 0u : DEAD;
+    auto pf_item = [&](const ChunkBase& b, int i) {
+        if (i < XU) {
+            unsigned vo = xvo[i];
+            if constexpr (G::ROWT > 1) {       // bit 31 or 30 of the flags that apply in this row tile -> bit 31 of the offset
+                const unsigned f = xrow[i] & b.rowmask;
+                vo |= f | (f << 1);
+            }
+            sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, b.xs, 0);
+        } else if (i < XU + GU) {
+            sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, gvo[i - XU] | b.gdead, b.gs, 0);
+        } else {
+            sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rr, gvo[i - XU - GU] | rdead, b.gs, 0);   // (unmasked: no fetch)
+        }
+    };
+    // the LDS side of the same items.  The gy unit is committed with its reference (item XU + GU + j; item XU + j alone commits nothing)
+    auto commit_item = [&](int bo, int i) {        // bo: float offset of the staging buffer
+        if (i < XU) {
+            unsigned* d = reinterpret_cast<unsigned*>(smem) + bo + xl[i];
+            d[0] = sreg[i].x; d[1] = sreg[i].z;
+            d[G::SCh] = sreg[i].y; d[G::SCh + 1] = sreg[i].w;
+        } else if (i >= XU + GU) {
+            const int j = i - XU - GU;
+            const u32x4 g = sreg[XU + j], rf = sreg[i];
+            float4 gv = make_float4(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z), __uint_as_float(g.w));
+            gv.x = __uint_as_float(rf.x) > 0.f ? gv.x : gv.x * mslope;
+            gv.y = __uint_as_float(rf.y) > 0.f ? gv.y : gv.y * mslope;
+            gv.z = __uint_as_float(rf.z) > 0.f ? gv.z : gv.z * mslope;
+            gv.w = __uint_as_float(rf.w) > 0.f ? gv.w : gv.w * mslope;
+            *reinterpret_cast<float4*>(smem + bo + gl + j * G::GSTEP * G::PCp) = gv;
+            bsum[j] += (gv.x + gv.y) + (gv.z + gv.w);
+        }
+    };
+
+    const int c_begin = split * P.chunks_per_split;
+    const int c_end = min(c_begin + P.chunks_per_split, P.chunks_total);
+    stamp(1);
+    if (c_begin >= c_end) return;        // (the host plans no empty split)
+    {
+        const ChunkBase b0 = chunk_base(c_begin, true);
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) pf_item(b0, i);
+    }
+    {   // zero the slabs once (halo columns and padded channels are never written again), under the latency of the first loads
+        constexpr int n4 = (TCI * G::CS) >> 2;
+        float4* z0 = reinterpret_cast<float4*>(smem);
+        float4* z1 = reinterpret_cast<float4*>(smem + G::STG);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < n4; e += NTHR) { z0[e] = z; z1[e] = z; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) commit_item(0, i);
+    __syncthreads();
+    stamp(2);
+
+    // A chunk: NQ blocks of 50 MFMAs out of buffer `buf`.  Chunk ch + 1 travels through registers meanwhile: its loads are dealt out over
+    // the first blocks, each item's LDS write follows LAG blocks behind its load (3 200 cycles at LAG = 2: a load that misses every cache
+    // is back in ~1 000), so an item occupies registers for a fraction of the chunk and the file holds no second set.
+    constexpr int LAG = 2, LB = NQ - LAG;                 // load blocks 0 .. LB-1, commit blocks LAG .. NQ-1
+    constexpr int IPB = (NITEM + LB - 1) / LB;
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int buf = (ch - c_begin) & 1;
+        const float* xq = smem + buf * G::STG + xa;        // + q_off(q) + tap offset: immediates
+        const float* gq = smem + buf * G::STG + gb;        // + 16 q (+ 16 * PCp for the second channel tile)
+        const int obo = (buf ^ 1) * G::STG;
+        float av[2][NT], bv[2][2];
+        auto load_quad = [&](int q, float* a, float* b) {
+            if (GGAN_ABL & 4) { b[0] = __int_as_float(gb + q); b[1] = b[0]; for (int t = 0; t < NT; ++t) a[t] = __int_as_float(xa + t); return; }
+            b[0] = gq[16 * q];
+            b[1] = gq[16 * q + 16 * G::PCp];
+            const int o = G::q_off(q);
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)   // slab col = 2*ow+kw+3 -> parity plane (kw+3)&1, index ow+((kw+3)>>1)
+                    a[kh * KS + kw] = xq[o + kh * G::SCp + ((kw + 3) & 1) * G::SCh + ((kw + 3) >> 1)];
+        };
+        const ChunkBase nb = chunk_base(min(ch + 1, c_end - 1), ch + 1 < c_end);
+        load_quad(0, av[0], bv[0]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float* a = av[q & 1];
+            const float* b = bv[q & 1];
+            if (q + 1 < NQ) load_quad(q + 1, av[(q + 1) & 1], bv[(q + 1) & 1]);
+            if (!(GGAN_ABL & 1)) {
+#pragma unroll
+                for (int i = (q - LAG) * IPB; i < (q - LAG + 1) * IPB; ++i)
+                    if (i >= 0 && i < NITEM) commit_item(obo, i);
+#pragma unroll
+                for (int i = q * IPB; i < (q + 1) * IPB; ++i)
+                    if (i < NITEM && q < LB) pf_item(nb, i);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[t], acc[t], 0, 0, 0);
+                acc[NT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[t], acc[NT + t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q + 1 < NQ && t < NT + 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (t % 8 == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // a global load
+                if (t % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS write
+            }
+        }
+        __syncthreads();
+        if (ch - c_begin < 8) stamp(4 + ch - c_begin);
+    }
+
+    stamp(12);
+    if (do_bias) {
+        // lanes gcol*PC4 .. +PC4-1 hold the partial sums of one channel: xor-shuffle within that lane group (PC4 = 32 / 16)
+#pragma unroll
+        for (int j = 0; j < GU; ++j) {
+            float b = bsum[j];
+#pragma unroll
+            for (int o = G::PC4 >> 1; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+            const int co = co0 + gcol0 + j * G::GSTEP;
+            if (gp4 == 0 && co < P.Co) {
+                if (P.SK == 1) P.gbias[co] = b;
+                else P.out[(size_t)split * P.slab_stride + P.out_elems + co] = b;
+            }
+        }
+    }
+
+    // ---- combine the four pixel-split waves in the accumulators' own layout (the loop's last barrier retired every staging read).
+    //      Unit j (an accumulator quad) is owned by wave j & 3; region [owner][foreign slot] holds 13 units x 64 lanes x 16 bytes.
+    //      The parking stores read the accumulators where they live (AGPRs): written as the instruction, because the compiler's own
+    //      stores first copied all 200 quads into VGPRs (800 v_accvgpr_read, ~1 700 cycles, and spills once both files were full). ----
+    constexpr int REGION = 13 * 64 * 16;           // bytes
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    auto park = [&](auto tag) {
+        constexpr int W = decltype(tag)::value;
+        const unsigned lane16 = (unsigned)lane * 16u;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o == W) continue;
+            const unsigned base = lane16 + (unsigned)(o * 3 * REGION);
+#pragma unroll
+            for (int j = o; j < NA; j += 4) {
+                const f32x4 q = acc[j];         // (an asm operand cannot name a captured variable)
+                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "a"(q), "n"((((W - o) & 3) - 1) * REGION + (j >> 2) * 1024) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    float* outp = P.out + (size_t)split * P.slab_stride;
+    const bool vec = (P.Co & 3) == 0;
+    auto sum_store = [&](auto tag) {
+        constexpr int W = decltype(tag)::value;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            if ((j & 3) != W) continue;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {      // wave order: the sum does not depend on which wave owns the unit
+                const f32x4 o = s == W ? acc[j] : red[((W * 3 + (((s - W) & 3) - 1)) * 13 + (j >> 2)) * 64 + lane];
+                if (s == 0) v = o;
+                else { v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (one unit at a time)
+            const int t = j % NT, ct = j / NT;
+            const int ci = ci0 + l15, co = co0 + ct * 16 + 4 * qq;
+            if (ci >= P.Ci || co >= P.Co || P.dbg_nostore) continue;
+            float* dst = outp + ((size_t)t * P.Ci + ci) * P.Co + co;
+            if (vec) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+                dst[0] = v[0];
+                if (co + 1 < P.Co) dst[1] = v[1];
+                if (co + 2 < P.Co) dst[2] = v[2];
+                if (co + 3 < P.Co) dst[3] = v[3];
+            }
+        }
+    };
+    switch (wave) {
+        case 0: park(WaveTag<0>{}); break;
+        case 1: park(WaveTag<1>{}); break;
+        case 2: park(WaveTag<2>{}); break;
+        default: park(WaveTag<3>{}); break;
+    }
+    __syncthreads();
+    stamp(13);
+    switch (wave) {
+        case 0: sum_store(WaveTag<0>{}); break;
+        case 1: sum_store(WaveTag<1>{}); break;
+        case 2: sum_store(WaveTag<2>{}); break;
+        default: sum_store(WaveTag<3>{}); break;
+    }
+    stamp(14);
+}
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -406,7 +738,8 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     // pixel chunk: after every barrier all eight waves fetch their first quad's fragments at once (~800 cycles of LDS pipe with the
     // matrix pipes idle); 128 pixels per chunk instead of 64 halves the number of those bursts per MFMA (when two such staging
     // buffers fit the LDS)
-    auto plan_chunk = [&](int pcmax) {
+    // tco: output channels per workgroup (16: eight-wave kernel, 32: four-wave kernel), nthr: its threads
+    auto plan_chunk = [&](int pcmax, int tco, int nthr) {
         P.TR = pcmax / g.Wo; if (P.TR > g.Ho) P.TR = g.Ho;
         P.TI = pcmax / (P.TR * g.Wo); if (P.TI < 1) P.TI = 1; if (P.TI > g.N) P.TI = g.N;
         for (;;) {
@@ -423,16 +756,31 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         while ((P.CS & 31) != 2) P.CS += 1;     // == 2 (mod 32): conflict-free 16ci x 2px fragment reads; even for b64 stores
         P.PC = P.TI * P.TR * g.Wo;
         P.PCp = P.PC + 4;
-        if ((P.PC & 3) || TCO * (P.PC / 4) > NTHR) return false;
+        if ((P.PC & 3) || (tco == TCO && tco * (P.PC / 4) > nthr)) return false;   // (eight-wave kernel: one gy unit per thread)
         if (gbias && ((P.PC / 4) & (P.PC / 4 - 1))) return false;      // lane-group shuffle needs a power-of-two group
-        return 2 * ((size_t)TCI * P.CS + (size_t)TCO * P.PCp) * sizeof(float) <= 160 * 1024;
+        return 2 * ((size_t)TCI * P.CS + (size_t)tco * P.PCp) * sizeof(float) <= 160 * 1024;
     };
-    if (!(env_int("GGAN_WGRAD_PC", 128) >= 128 && plan_chunk(128)) && !plan_chunk(64)) return 1;
+    // the four-wave kernel is compiled per image width (square images of 8 / 16 / 32 / 64: every layer of the scripts); a minibatch that is
+    // not a whole number of its chunks' image groups and every other geometry stay on the eight-wave kernel
+    auto geom_is = [&](auto tag) {
+        using G = decltype(tag);
+        return g.W == G::W && g.H == G::H && g.Ho == G::Ho && g.Wo == G::Wo && g.N % G::TI == 0 && plan_chunk(G::PC, W4_TCO, W4_NTHR) &&
+               P.TR == G::TR && P.TI == G::TI && P.SR == G::SR && P.SCp == G::SCp && P.CS == G::CS && P.PC == G::PC;
+    };
+    int four = 0;
+    if (env_int("GGAN_WGRAD_W4", 1) != 0) {
+        if (geom_is(W4Geom<16>{})) four = 16;
+        else if (geom_is(W4Geom<8>{})) four = 8;
+        else if (geom_is(W4Geom<32>{})) four = 32;
+        else if (geom_is(W4Geom<64>{})) four = 64;
+    }
+    if (!four && !(env_int("GGAN_WGRAD_PC", 128) >= 128 && plan_chunk(128, TCO, NTHR)) && !plan_chunk(64, TCO, NTHR)) return 1;
+    const int tco = four ? W4_TCO : TCO;
     P.d_F4 = make_fastdiv(g.W / 4); P.d_SR = make_fastdiv(P.SR); P.d_TI = make_fastdiv(P.TI);
     P.d_PC4 = make_fastdiv(P.PC / 4); P.d_TRWo = make_fastdiv(P.TR * g.Wo); P.d_Wo = make_fastdiv(g.Wo);
     P.row_tiles = cdiv(g.Ho, P.TR);
     P.chunks_total = cdiv(g.N, P.TI) * P.row_tiles;
-    const int gx = cdiv(g.Ci, TCI), gy_ = cdiv(g.Co, TCO);
+    const int gx = cdiv(g.Ci, TCI), gy_ = cdiv(g.Co, tco);
     int sk = env_int("GGAN_WGRAD_SK", 0);
     if (sk <= 0) {
         // (a caller running two conv chains side by side asks for fewer workgroups per launch: ggan_conv_geom.plan_wgs_filter)
@@ -448,8 +796,8 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     P.chunks_per_split = cdiv(P.chunks_total, sk);
     P.SK = cdiv(P.chunks_total, P.chunks_per_split);
     P.out = P.SK > 1 ? (float*)ws : gw;
-    size_t stage = 2 * ((size_t)TCI * P.CS + (size_t)TCO * P.PCp);      // double-buffered
-    size_t red = (size_t)(NW / 2) * 100 * 64;
+    size_t stage = 2 * ((size_t)TCI * P.CS + (size_t)tco * P.PCp);      // double-buffered
+    size_t red = four ? (size_t)W4_RED_BYTES / sizeof(float) : (size_t)(NW / 2) * 100 * 64;
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     if (shmem > 160 * 1024) return 1;
     static bool attr_set = false;
@@ -457,6 +805,10 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int nit = env_int("GGAN_WGRAD_DEAL", 1) ? (P.PC == 128 ? 2 : (P.PC == 64 ? 1 : 0)) : 0;
@@ -464,7 +816,12 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     const double ab = 4.0 * ((double)g.N * g.Ci * g.H * g.W + (double)g.N * g.Co * g.Ho * g.Wo + 25.0 * g.Ci * g.Co);
     if (parts && ws_bytes < P.slab_stride * sizeof(float)) { set_error("conv_wgrad: partial-slab buffer too small"); return -1; }
     if (want_stamps && !parts && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
-    if (nit == 2) { GGAN_LAUNCH("wgrad_kernel<2>", fl, ab, wgrad_kernel<2>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
+    const dim3 grid4(gx * gy_ * P.SK);       // split-fastest workgroup numbering (decoded in the kernel)
+    if (four == 16) { GGAN_LAUNCH("wgrad4_kernel<16>", fl, ab, wgrad4_kernel<16>, grid4, dim3(W4_NTHR), shmem, s, P); }
+    else if (four == 8) { GGAN_LAUNCH("wgrad4_kernel<8>", fl, ab, wgrad4_kernel<8>, grid4, dim3(W4_NTHR), shmem, s, P); }
+    else if (four == 32) { GGAN_LAUNCH("wgrad4_kernel<32>", fl, ab, wgrad4_kernel<32>, grid4, dim3(W4_NTHR), shmem, s, P); }
+    else if (four == 64) { GGAN_LAUNCH("wgrad4_kernel<64>", fl, ab, wgrad4_kernel<64>, grid4, dim3(W4_NTHR), shmem, s, P); }
+    else if (nit == 2) { GGAN_LAUNCH("wgrad_kernel<2>", fl, ab, wgrad_kernel<2>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
     else if (nit == 1) { GGAN_LAUNCH("wgrad_kernel<1>", fl, ab, wgrad_kernel<1>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
     else { GGAN_LAUNCH("wgrad_kernel<0>", fl, ab, wgrad_kernel<0>, dim3(gx, gy_, P.SK), dim3(NTHR), shmem, s, P); }
     if (parts) {

@@ -9,7 +9,6 @@
 // deterministic split-K (partial slabs + launch_splitk_reduce, no atomics).
 #include "common.h"
 #include "conv.h"
-#include "mlp.h"
 #include <stdlib.h>
 using namespace ggan;
 
@@ -1105,75 +1104,6 @@ int ggan_critic_head_bwd_tail(int M, int K1, int K2, int H, const float* a1, con
     T.logits = logits; T.g = g; T.h = h; T.d_wout = d_wout; T.d_bout = d_bout; T.loss = loss; T.M = M; T.H = H;
     return critic_head_bwd_impl(M, K1, K2, H, nullptr, a1, a2, w, h, w_out, alpha, const_cast<float*>(gh), d_a1, d_a2, d_w, d_b, d_wout,
                                 d_bout, ws, ws_bytes, stream, &T);
-}
-
-// The 512-wide three-layer critic on codes, Linear -> LeakyReLU x 3 -> Linear(512 -> 1), as ONE launch per direction
-// (mlp_chain.hip; /root/reference/gmgan_inference_cifar10.py:255-271 HyperDiscriminator).  Returns 1 when the shape is not covered
-// (the caller composes the layers).
-int ggan_mlp_chain_ok(int M, int K1, int K2, int H) {
-    return M > 0 && H == kMlpHidden && K1 > 0 && K2 >= 0 && K1 + K2 <= kMlpMaxIn && (K2 == 0 || (K1 % 64) == 0);
-}
-
-size_t ggan_mlp_chain_scratch(int K1, int K2) { return mlp_chain_wt_floats(K1, K2) * sizeof(float); }
-
-int ggan_mlp_chain_fwd(int M, int K1, int K2, int H, const float* x1, const float* x2, const float* w1, const float* b1, const float* w2,
-                       const float* b2, const float* w3, const float* b3, const float* w_out, const float* b_out, float alpha, float* h1,
-                       float* h2, float* h3, float* logits, float* wt, ggan_stream_t stream) {
-    GGAN_CHECK_ARG(x1 && w1 && b1 && w2 && b2 && w3 && b3 && w_out && b_out && h1 && h2 && h3 && logits, "null pointer");
-    GGAN_CHECK_ARG(x2 || K2 == 0, "x2 missing");
-    if (!ggan_mlp_chain_ok(M, K1, K2, H)) return 1;
-    const float* w[3] = {w1, w2, w3};
-    const float* b[3] = {b1, b2, b3};
-    float* h[3] = {h1, h2, h3};
-    return mlp_chain_fwd_launch(M, K1, K2, x1, x2, w, b, w_out, b_out, alpha, h, logits, wt, (hipStream_t)stream);
-}
-
-// Backward of the same chain from g = d cost / d logits [M] (NULL: gh3, d_wout, d_bout were produced with the cost, ggan_bce_head[s]_bwd):
-//   [head kernel: gh3 = g w_out^T * lrelu'(h3), d_wout, d_bout]  ->  chain kernel (on the transposed weights wt the forward launch left): gh2, gh1, [d_x1 | d_x2]
-//   ->  ONE grouped launch: d_w3 = h2^T gh3, d_w2 = h1^T gh2, d_w1 = [x1 | x2]^T gh1, each with its column sums d_b (all or none: d_w1 NULL in
-//   generator steps, where the critic's weights are not in the var_list; gh2 / gh1 may then be NULL too).  d_x1 NULL: inputs are data.
-int ggan_mlp_chain_bwd(int M, int K1, int K2, int H, const float* g, const float* x1, const float* x2, const float* wt, const float* w_out,
-                       const float* h1, const float* h2, const float* h3, float alpha, float* gh3,
-                       float* gh2, float* gh1, float* d_x1, float* d_x2, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3,
-                       float* d_b3, float* d_wout, float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream) {
-    GGAN_CHECK_ARG(x1 && wt && w_out && h1 && h2 && h3 && gh3, "null pointer");
-    GGAN_CHECK_ARG((x2 || K2 == 0) && (!d_x1 || K2 == 0 || d_x2), "x2 / d_x2 missing");
-    GGAN_CHECK_ARG((d_w1 != nullptr) == (d_w2 != nullptr) && (d_w2 != nullptr) == (d_w3 != nullptr), "weight gradients: all or none");
-    GGAN_CHECK_ARG(!d_w1 || (gh2 && gh1 && d_b1 && d_b2 && d_b3), "weight gradients need gh2, gh1 and the bias gradients");
-    if (!ggan_mlp_chain_ok(M, K1, K2, H)) return 1;
-    hipStream_t s = (hipStream_t)stream;
-    if (g) {
-        GGAN_LAUNCH("head_out_bwd_k", 3.0 * M * H, 8.0 * M * H, head_out_bwd_k, dim3(cdiv(H, 16)), dim3(256), 0, s, g, h3, w_out, alpha, gh3,
-                    d_wout, d_bout, M, H);
-    }
-    int rc = mlp_chain_bwd_launch(M, K1, K2, gh3, wt, h1, h2, alpha, gh2, gh1, d_x1, d_x2, s);
-    if (rc) return rc;
-    if (!d_w1) return 0;
-    GemmPlan G3, G2, G1;
-    rc = gemm_plan(G3, 1, 1, 0, H, H, M, h2, gh3, nullptr, d_w3, d_b3, GGAN_ACT_NONE, 0.f, ws, ws_bytes);
-    if (rc) return rc;
-    rc = gemm_plan(G2, 1, 1, 0, H, H, M, h1, gh2, nullptr, d_w2, d_b2, GGAN_ACT_NONE, 0.f, ws, ws_bytes);
-    if (rc) return rc;
-    rc = gemm_plan(G1, 1, 1, 0, K1 + K2, H, M, x1, gh1, nullptr, d_w1, d_b1, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
-                   K2 ? x2 : nullptr, K2 ? K1 : 0);
-    if (rc) return rc;
-    if (G3.P.fast == 1 && G2.P.fast == 1 && G1.P.fast == 1 && !getenv("GGAN_NO_GEMM_GROUP")) {
-        GemmGroup GG;
-        memset(&GG, 0, sizeof(GG));
-        GG.n = 3;
-        const GemmPlan* pl[3] = {&G3, &G2, &G1};
-        int first = 0;
-        for (int i = 0; i < 3; ++i) {
-            GG.kind[i] = 0; GG.gx[i] = pl[i]->gx; GG.p[i] = pl[i]->P; GG.first[i] = first;
-            first += pl[i]->gx * pl[i]->gy;
-        }
-        GG.first[3] = first;
-        GGAN_LAUNCH_GROUP(2.0 * M * H * (2.0 * H + K1 + K2), first, s, GG);
-        return 0;
-    }
-    rc = gemm_launch_planned(G3, 1, 0, s); if (rc) return rc;
-    rc = gemm_launch_planned(G2, 1, 0, s); if (rc) return rc;
-    return gemm_launch_planned(G1, 1, 0, s);
 }
 
 int ggan_gemm(int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias, float* C, int act,

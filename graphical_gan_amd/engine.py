@@ -80,7 +80,7 @@ def dp_graph_selftest(device, comm):
 
 
 class Trainer(object):
-    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None, sync_bn=False, pair_nets=None):
+    def __init__(self, cfg, device=None, graph=True, seed=1234, inject_noise=False, model=None, sync_bn=False):
         """sync_bn: BatchNorm statistics over the global batch of all replicas (N GPUs x B/N then reproduce
         1 GPU x B).  The statistics exchange is a host-issued collective inside the forward and the backward, so this mode
         runs the steps eagerly (no HIP graphs); it is the parity mode, per-replica statistics stay the throughput default.
@@ -130,13 +130,6 @@ class Trainer(object):
         # backward pass (true when the critic sees [fake; real] as one batch; the wali-gp penalty re-enters the critic)
         self.single_contrib = bool(self.model.single_contribution)
         self._opts = None
-        # paired nets pass (models.GraphicalGAN.forward_nets_pair, _iteration_pair): ring mode, one graph per iteration.  OFF unless asked
-        # for (pair_nets=True / GGAN_PAIR_NETS=1): measured +3 % on the CIFAR iteration (1.068 vs 1.038 ms), +16 % with the mixture prior
-        # (its side-stream chains lose their partners), -1.6 % on the 64x64 script -- at 128 rows the layers gain less than the second
-        # pass cost, because the two B-row chains already share the chip side by side (profiles/r04_notes.md)
-        if pair_nets is None:
-            pair_nets = bool(os.environ.get('GGAN_PAIR_NETS'))
-        self.pair_nets = bool(pair_nets) and not self.sync_bn
         self.keep_outputs, self.last_out = False, {}
         self._pending = None         # (work handle, Adam graph) of a critic-step exchange still in flight (see step())
 
@@ -195,7 +188,6 @@ class Trainer(object):
         self.feed['ring'] = (ring, ctr['gen'], ctr.get('disc'), -taken)
         self._graphs = {}                      # (captured steps read the staging buffer)
         self._iter_graph = None
-        self._pair_entered = False
 
     def _sample_noise(self):
         self.model.sample_noise(self.feed)
@@ -212,15 +204,25 @@ class Trainer(object):
     def _forward(self, feed, which, nets):
         """model.forward for a step whose backward follows at once: the critic head may then leave its cost's gradient behind with
         its own forward and take the cost's value into its backward launch (functional.head_bce_hint, models.GraphicalGAN.head_hint)"""
+        F.drop_pending_costs()
         self.model.head_hint = True
         try:
             return self.model.forward(feed, which, nets)
         finally:
             self.model.head_hint = False
 
-    def _fwd_bwd(self, which, nets=None, fuse_update=False, feed=None):
+    @staticmethod
+    def _costs_settled():
+        """after a step's backward: every cost a hinted critic head owed has been written (functional.settle_cost); a cost tensor handed
+        out while its value is still owed would be unwritten memory"""
+        if F.pending_costs():
+            F.drop_pending_costs()
+            raise RuntimeError('a hinted critic head still owes its cost value after the backward pass (functional.head_bce_hint): '
+                               'the cost was not differentiated through that head')
+
+    def _fwd_bwd(self, which, nets=None, fuse_update=False):
         """fuse_update: the caller applies the update next with nothing but a (single-replica: empty) exchange in between"""
-        out = self._forward(feed if feed is not None else self.feed, which, nets if nets is not None else self._nets())
+        out = self._forward(self.feed, which, nets if nets is not None else self._nets())
         if self.keep_outputs:        # (tests: the critic logits of a captured step -- static graph memory, valid after every replay)
             det = lambda v: [t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()    # (no tape kept alive across steps)
             self.last_out[which] = {k: det(v) for k, v in out.items() if k in ('disc_fake', 'disc_real')}
@@ -230,6 +232,7 @@ class Trainer(object):
         with F.defer_wgrad_reduce(self.single_contrib):
             grads = opt.compute_gradients(op.cost)
             keep = opt.pack(grads, fuse_update=fuse_update)
+        self._costs_settled()
         return out[which + '_cost'].detach(), opt, keep
 
     def _two_bucket_plan(self, opt, nets):
@@ -256,6 +259,7 @@ class Trainer(object):
         with F.defer_wgrad_reduce(self.single_contrib), F.serial_backward():      # (Generator half, then Extractor half: one chain at a time)
             g = torch.autograd.grad(op.cost, list(opt.params[:k]) + cut, grad_outputs=opt._one, allow_unused=True)
             keep = opt.pack_subset(g[:k], 0, k, bump=True)
+        self._costs_settled()
         return dict(cost=out['gen_cost'].detach(), opt=opt, k=k, off=off, cut=cut, g_cut=g[k:], keep=keep)
 
     def _bwd_phase2(self, st):
@@ -313,11 +317,10 @@ class Trainer(object):
             if forkable:
                 self.model.fork_now = False
 
-    def _step_body(self, which, nets=None, feed=None):
-        """one whole step as it is captured into a single graph: forward, backward, pack, (gradient exchange), update.  nets / feed: the
-        step continues from a nets pass evaluated elsewhere (the paired pass of _pair_body) instead of running its own"""
+    def _step_body(self, which):
+        """one whole step as it is captured into a single graph: forward, backward, pack, (gradient exchange), update"""
         with self._launch_hint(which):
-            return self._step_body_impl(which, nets, feed)
+            return self._step_body_impl(which)
 
     @contextlib.contextmanager
     def _launch_hint(self, which):
@@ -330,8 +333,8 @@ class Trainer(object):
         with F.launch_hint(int(hint)):
             yield
 
-    def _step_body_impl(self, which, nets=None, feed=None):
-        st = None
+    def _step_body_impl(self, which):
+        st, nets = None, None
         if self.dp_graph and which == 'gen':
             # two gradient buckets inside the one graph: the Generator's bucket is on the wire (the process group's
             # stream: a parallel branch of the graph) while the Extractor's backward pass still runs
@@ -354,61 +357,22 @@ class Trainer(object):
                         _optim._xlog('wait')
                         w.wait()
             else:
-                cost, opt, keep = self._fwd_bwd(which, nets, feed=feed)
+                cost, opt, keep = self._fwd_bwd(which, nets)
                 opt.all_reduce()
         elif self.dp_graph and which == 'disc' and hasattr(self.model, 'critic_cut') and not os.environ.get('GGAN_ONE_BUCKET'):
-            cost, opt, keep = self._disc_two_buckets(nets, feed)
-        elif (which == 'disc' and hasattr(self.model, 'critic_cut') and self.model.fork_now and self.world == 1
-              and os.environ.get('GGAN_EARLY_TAIL_UPDATE', '0') == '1'):      # (opt-in: measured slower, below)
-            cost, opt, keep = self._disc_early_tail(nets, feed)
+            cost, opt, keep = self._disc_two_buckets(nets)
         else:
-            cost, opt, keep = self._fwd_bwd(which, nets, fuse_update=not self.dp_graph, feed=feed)
+            cost, opt, keep = self._fwd_bwd(which, nets, fuse_update=not self.dp_graph)
             if self.dp_graph:
                 opt.all_reduce()
         opt.update()
         return cost, opt, keep
 
-    def _disc_early_tail(self, nets=None, feed=None):
-        """single-replica critic step inside a step graph: autograd reaches the critic's tail first and that is where most of the
-        parameters are (Discriminator.zx1: 2.4 M of the 4.1 M) -- their pack + Adam launch (HBM-bound: 28 B per parameter) goes to
-        the second stream, beside the conv stack's backward pass (MFMA-bound), and the launch at the end of the step is left with the
-        conv stack's 1 M parameters and their filter-gradient slabs.  Same arithmetic per parameter: bit-identical to one launch.
-        Measured (three alternating pairs, same box): headline 1.002 -> 1.018 ms, gmgan 1.107 -> 1.156 -- the second autograd pass and
-        the fork / join pair cost more than the 12 us the last launch gets shorter, as every split of a step's backward has so far
-        (profiles/r03_notes.md, r04_notes.md).  Opt-in: GGAN_EARLY_TAIL_UPDATE=1."""
-        out = self._forward(feed if feed is not None else self.feed, 'disc', nets if nets is not None else self._nets())
-        op = out['disc_train_op']
-        opt = op.optimizer
-        cutinfo = self.model.critic_cut()
-        sp = None
-        if cutinfo is not None and opt.can_fuse_update() and lib.second_leaf_count() == getattr(self, '_sl0', lib.second_leaf_count()):
-            conv = tuple('Discriminator.%d.' % (i + 1) for i in range(cutinfo[1]))
-            sp = opt.split_at(lambda p: getattr(p, 'param_name', '').startswith(conv))
-        if sp is None:
-            with F.defer_wgrad_reduce(self.single_contrib):
-                keep = opt.pack(opt.compute_gradients(op.cost), fuse_update=True)
-            return out['disc_cost'].detach(), opt, (keep, out)
-        k, _ = sp
-        cut = cutinfo[0]
-        if opt._one is None or opt._one.shape != op.cost.shape:
-            opt._one = F.unit_seed(op.cost)
-        cur = torch.cuda.current_stream(self.device)
-        side = F.shared_stream(self.device, 'side')
-        with F.defer_wgrad_reduce(self.single_contrib):
-            g = torch.autograd.grad(op.cost, list(opt.params[k:]) + [cut], grad_outputs=opt._one, allow_unused=True)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                keep_a = opt.pack_update_subset(g[:-1], k, len(opt.params), last=False)
-            g2 = torch.autograd.grad([cut], opt.params[:k], grad_outputs=[g[-1]], allow_unused=True)
-            cur.wait_stream(side)
-            keep_b = opt.pack_update_subset(g2, 0, k, last=True)
-        return out['disc_cost'].detach(), opt, (keep_a, keep_b, g, g2, out)
-
-    def _disc_two_buckets(self, nets=None, feed=None):
+    def _disc_two_buckets(self, nets=None):
         """critic step with two gradient buckets: autograd reaches the critic's tail first, and that is where most of the bytes
         are (Discriminator.zx1: 2.6 M of the 4.1 M parameters) -- its bucket is exchanged while the conv stack's backward pass
         (two thirds of the critic's backward time) still runs; the conv stack's bucket follows.  Same sums as one bucket."""
-        out = self._forward(feed if feed is not None else self.feed, 'disc', nets if nets is not None else self._nets())
+        out = self._forward(self.feed, 'disc', nets if nets is not None else self._nets())
         op = out['disc_train_op']
         opt = op.optimizer
         cutinfo = self.model.critic_cut()
@@ -422,6 +386,7 @@ class Trainer(object):
             with F.defer_wgrad_reduce(self.single_contrib):
                 keep = opt.pack(opt.compute_gradients(op.cost))
             opt.all_reduce()
+            self._costs_settled()
             return out['disc_cost'].detach(), opt, (keep, out)
         k, off = sp
         cut = cutinfo[0]
@@ -438,6 +403,7 @@ class Trainer(object):
             if w is not None:
                 _optim._xlog('wait')
                 w.wait()
+        self._costs_settled()
         return out['disc_cost'].detach(), opt, (keep_a, keep_b, g, g2, out)
 
     def _capture_impl(self, which):
@@ -587,67 +553,6 @@ class Trainer(object):
             if forkable:
                 self.model.fork_now = False
 
-    # ---- paired nets pass (round 4): critic step `it` and generator step `it + 1` from ONE Extractor / Generator evaluation ------------
-    def _pair_body(self):
-        """[nets pass of both steps on 2B rows] -> critic step -> generator step (models.GraphicalGAN.forward_nets_pair)"""
-        self._sl0 = lib.second_leaf_count()
-        self.model._pair_inject = bool(self.inject_noise)
-        feed_d, nets_d, feed_g, nets_g = self.model.forward_nets_pair(self.feed)
-        costs, keeps = {}, []
-        for which, nets, feed in (('disc', nets_d, feed_d), ('gen', nets_g, feed_g)):
-            cost, opt, keep = self._step_body(which, nets, feed)
-            costs[which + '_cost'] = cost
-            keeps.append((opt, keep))
-        return costs, keeps
-
-    def _capture_pair(self):
-        forkable = hasattr(self.model, 'fork_now') and not self.sync_bn
-        if forkable:
-            self.model.fork_now = True
-        try:
-            if getattr(self, '_cap_stream', None) is None:
-                self._cap_stream = F.shared_stream(self.device, 'capture')
-            s = self._cap_stream
-            s.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(s):
-                snap = [(o, o.theta.clone(), o.m.clone(), o.v.clone(), o.step.clone()) for o in self._optimizers()]
-                rng = self.feed.get('rng_state') if isinstance(self.feed, dict) else None
-                rng_snap = rng.clone() if torch.is_tensor(rng) else None
-                for _ in range(2):
-                    self._pair_body()
-                for o, th, m, v, st in snap:
-                    o.theta.copy_(th); o.m.copy_(m); o.v.copy_(v); o.step.copy_(st)
-                if rng_snap is not None:
-                    rng.copy_(rng_snap)
-            torch.cuda.current_stream(self.device).wait_stream(s)
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
-                costs, keeps = self._pair_body()
-            return dict(g=g, costs=costs, keep=keeps, kinds=('pair',))
-        finally:
-            if forkable:
-                self.model.fork_now = False
-
-    def _iteration_pair(self, it):
-        """Ring mode, one graph per iteration, paired nets pass: this call runs CRITIC step `it` and GENERATOR step `it + 1` -- the
-        flattened step sequence d0 g1 d1 g2 d2 ... of the reference loop is unchanged, the grouping into replays is shifted by one
-        step (one stand-alone generator step on entry), because it is the critic step and the generator step BEHIND it that share
-        the Extractor's / Generator's weights."""
-        if not getattr(self, '_pair_entered', False):
-            self._calls['gen'] += 1
-            self._eager('gen')                # generator step `it`: from here on the sequence continues with (d_it, g_it+1)
-            self._pair_entered = True
-        for k in ('disc', 'gen'):
-            self._calls[k] += 1
-        lib.end_build_phase()
-        rec = getattr(self, '_iter_graph', None)
-        if rec is None or rec['kinds'] != ('pair',):
-            self.flush()
-            rec = self._iter_graph = self._capture_pair()
-        rec['g'].replay()
-        return dict(rec['costs'])
-
     def iteration(self, it, batches):
         """batches: iterator of device minibatches (or feed dicts when inject_noise); ignored in ring mode (use_ring)."""
         feed = getattr(self, 'feed', None)
@@ -694,9 +599,6 @@ class Trainer(object):
                      and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
         if not one_graph:
             return {k + '_cost': self.step(k) for k in kinds}
-        if (self.pair_nets and hasattr(self.model, 'pair_supported') and self.model.pair_supported(self.feed)
-                and getattr(self, '_feeder', None) is None):       # (a host-fed ring is filled one iteration ahead, not one step beyond it)
-            return self._iteration_pair(it)
         for k in kinds:
             self._calls[k] += 1
         if all(self._calls[k] >= 2 for k in set(kinds)):

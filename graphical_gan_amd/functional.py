@@ -132,7 +132,7 @@ def _wgrad_parts(x, gy, y, act, alpha, geom, with_bias):
         return None
     elems = k * k * Ci * Co
     stride = elems + (Co if with_bias else 0)
-    tiles = -(-Ci // 16) * -(-Co // 16)
+    tiles = -(-Ci // 16) * -(-Co // 32)                      # (conv_wgrad.hip: 16 ci x 32 co per workgroup, split-K to ~256 workgroups, <= 64 slabs)
     cap = min(64, max(1, -(-256 // tiles))) * stride
     if Ci <= 4 and stride <= 8192 and N * Ho >= 8192:        # thin layers at 512..1024 frames: up to 256 small slabs (conv_thin.hip)
         cap = 256 * stride
@@ -301,84 +301,6 @@ def _geom(t):
 
 
 # ---------------------------------------------------------------------------------------------------
-# Paired nets pass (round 4, models.GraphicalGAN.forward_nets_pair).  A critic step does not touch the Generator's / Extractor's
-# weights, so the Extractor / Generator passes of a critic step and of the generator step that follows it read the SAME weights: they
-# are evaluated together, once, on 2 x B rows (each launch carries twice the work of a launch that has trouble filling the chip at
-# batch 64).  The pass runs without a tape (`Replay.record`: every layer leaves its outputs in a list); the generator step then calls the
-# same layer code on ITS B rows under `Replay.attach`, where every layer takes its output -- a row range of the recorded one -- from the
-# list instead of launching anything and registers its ordinary backward for those rows.  Statistics layers (BatchNorm) are evaluated
-# per group of B rows, as the two session.runs of the reference would.
-# ---------------------------------------------------------------------------------------------------
-class Replay(object):
-    def __init__(self, group_rows, groups=2):
-        self.B, self.G = int(group_rows), int(groups)
-        self.items, self.pos, self.mode, self.group = [], 0, 'record', None
-
-    def put(self, op, *pairs):
-        """pairs: (tensor, kind) -- 'rows': leading dimension = G x (rows of one group); 'group': leading dimension = G"""
-        self.items.append((op, pairs))
-
-    def take(self, op):
-        if self.pos >= len(self.items) or self.items[self.pos][0] != op:
-            raise _lib.GganError('paired nets pass: layer sequence of the attached pass differs from the recorded one at #%d (%s vs %s)' % (
-                self.pos, op, self.items[self.pos][0] if self.pos < len(self.items) else 'end'))
-        pairs = self.items[self.pos][1]
-        self.pos += 1
-        g, out = self.group, []
-        for t, kind in pairs:
-            if t is None:
-                out.append(None)
-            elif kind == 'group':
-                out.append(t[g])
-            else:
-                n = t.shape[0] // self.G
-                out.append(t[g * n:(g + 1) * n])
-        return out
-
-
-_REPLAY = [None]
-
-
-class replay_record(object):
-    def __init__(self, rp):
-        self.rp = rp
-
-    def __enter__(self):
-        self.prev, _REPLAY[0] = _REPLAY[0], self.rp
-        self.rp.mode, self.rp.items, self.rp.pos = 'record', [], 0
-        return self.rp
-
-    def __exit__(self, *a):
-        _REPLAY[0] = self.prev
-
-
-class replay_attach(object):
-    def __init__(self, rp, group):
-        self.rp, self.group = rp, int(group)
-
-    def __enter__(self):
-        self.prev, _REPLAY[0] = _REPLAY[0], self.rp
-        self.rp.mode, self.rp.pos, self.rp.group = 'attach', 0, self.group
-        return self.rp
-
-    def __exit__(self, et, ev, tb):
-        _REPLAY[0] = self.prev
-        if et is None and self.rp.pos != len(self.rp.items):
-            raise _lib.GganError('paired nets pass: the attached pass used %d of %d recorded layers' % (self.rp.pos, len(self.rp.items)))
-        self.rp.mode = None
-
-
-def _recording():
-    rp = _REPLAY[0]
-    return rp if (rp is not None and rp.mode == 'record') else None
-
-
-def _attaching():
-    rp = _REPLAY[0]
-    return rp if (rp is not None and rp.mode == 'attach') else None
-
-
-# ---------------------------------------------------------------------------------------------------
 # convolution family
 # ---------------------------------------------------------------------------------------------------
 # tests: rows of a data-gradient that a grad_rows backward leaves unwritten are filled with NaN, so any consumer shows up
@@ -430,39 +352,32 @@ class ConvFwd(Function):
         pend = x if isinstance(x, PendingCast) else None
         if pend is not None:
             # the input is a minibatch still waiting in the device ring as int32: this layer scales it on the way in (one launch less at
-            # the head of the Extractor chain) unless the geometry -- or a recorded / attached pass -- needs the float tensor first
+            # the head of the Extractor chain) unless the geometry needs the float tensor first
             x = pend.out.view(N, Ci, H, W)
-            if pend.done or _attaching() is not None or _recording() is not None:
-                pend.materialize()
+            if pend.done:
                 pend = None
         x, w = _c(x), _c(w)
         assert tuple(x.shape) == (N, Ci, H, W) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (x.shape, w.shape, geom)
         ctx.grad_rows = int(grad_rows) if grad_rows else None
         ctx.target = _TARGET[0]
-        at = _attaching()
-        if at is not None:
-            (y,) = at.take('ConvFwd')
-        else:
-            y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
-            ws = workspace(x.device)
-            with _planned_for(ctx.target):
-                g = _geom(geom)
-                bp = _p(_c(bias)) if bias is not None else _p(None)
-                if pend is not None:
-                    rt, ca, cb, off = pend.ring
-                    nz = _p(_c(pend.noise)) if pend.noise is not None else _p(None)
-                    rc = _L().ggan_conv2d_fwd_cast_ring(C.byref(g), _p(rt), rt.shape[0], _p(ca), _p(cb), int(off), nz, pend.div, pend.mul,
-                                                        _p(x), _p(w), bp, _p(y), act, alpha, _stream())
-                    if rc == 1:
-                        pend.materialize()          # (geometry outside the thin-channel kernel: the two launches)
-                        pend = None
-                    else:
-                        check(rc, 'ggan_conv2d_fwd_cast_ring')
-                        pend.done = True
-                if pend is None:
-                    check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), bp, _p(y), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
-            if _recording() is not None:
-                _recording().put('ConvFwd', (y, 'rows'))
+        y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        ws = workspace(x.device)
+        with _planned_for(ctx.target):
+            g = _geom(geom)
+            bp = _p(_c(bias)) if bias is not None else _p(None)
+            if pend is not None:
+                rt, ca, cb, off = pend.ring
+                nz = _p(_c(pend.noise)) if pend.noise is not None else _p(None)
+                rc = _L().ggan_conv2d_fwd_cast_ring(C.byref(g), _p(rt), rt.shape[0], _p(ca), _p(cb), int(off), nz, pend.div, pend.mul,
+                                                    _p(x), _p(w), bp, _p(y), act, alpha, _stream())
+                if rc == 1:
+                    pend.materialize()          # (geometry outside the thin-channel kernel: the two launches)
+                    pend = None
+                else:
+                    check(rc, 'ggan_conv2d_fwd_cast_ring')
+                    pend.done = True
+            if pend is None:
+                check(_L().ggan_conv2d_fwd(C.byref(g), _p(x), _p(w), bp, _p(y), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_fwd')
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
         ctx.w_param, ctx.b_param = _is_param(w), _is_param(bias)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -545,19 +460,12 @@ class ConvDgrad(Function):
         N, Ci, H, W, Co, Ho, Wo = geom[:7]
         assert tuple(gy.shape) == (N, Co, Ho, Wo) and tuple(w.shape) == (geom[7], geom[7], Ci, Co), (gy.shape, w.shape, geom)
         ctx.target = _TARGET[0]
-        at = _attaching()
-        if at is not None:
-            (gx,) = at.take('ConvDgrad')
-            gx = gx.view(N, Ci, H, W)
-        else:
-            gx = _new_out(slot, (N, Ci, H, W), gy.device)
-            ws = workspace(gy.device)
-            with _planned_for(ctx.target):
-                g = _geom(geom)
-                check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
-                                                _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
-            if _recording() is not None:
-                _recording().put('ConvDgrad', (gx, 'rows'))
+        gx = _new_out(slot, (N, Ci, H, W), gy.device)
+        ws = workspace(gy.device)
+        with _planned_for(ctx.target):
+            g = _geom(geom)
+            check(_L().ggan_conv2d_bwd_data(C.byref(g), _p(gy), _p(w), _p(_c(bias)) if bias is not None else _p(None),
+                                            _p(gx), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_conv2d_bwd_data')
         ctx.geom, ctx.act, ctx.alpha, ctx.has_bias = geom, act, alpha, bias is not None
         ctx.save_for_backward(gy, w, gx if act != ACT_NONE else None)
         return gx
@@ -756,18 +664,10 @@ class Gemm(Function):
         M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
         K2, N = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
         assert K == K2, (a.shape, b.shape, ta, tb)
-        at = _attaching()
-        if at is not None:
-            (out,) = at.take('Gemm')
-            out = out.view(M, N)
-        else:
-            out = _new_out(slot, (M, N), a.device)
-            ws = workspace(a.device)
-            check(_L().ggan_gemm(int(ta), int(tb), M, N, K, _p(a), _p(b), _p(_c(bias)) if bias is not None else _p(None),
-                                 _p(out), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm')
-            if _recording() is not None:
-                assert not ta, 'paired nets pass: row-major left operand'
-                _recording().put('Gemm', (out, 'rows'))
+        out = _new_out(slot, (M, N), a.device)
+        ws = workspace(a.device)
+        check(_L().ggan_gemm(int(ta), int(tb), M, N, K, _p(a), _p(b), _p(_c(bias)) if bias is not None else _p(None),
+                             _p(out), act, alpha, _p(ws), ws.numel(), _stream()), 'ggan_gemm')
         ctx.ta, ctx.tb, ctx.act, ctx.alpha, ctx.has_bias = ta, tb, act, alpha, bias is not None
         ctx.b_param, ctx.bias_param = _is_param(b), _is_param(bias)
         ctx.save_for_backward(a, b, out if act != ACT_NONE else None)
@@ -1060,6 +960,8 @@ class CriticHead(Function):
         tail = rec.get('tail') if rec is not None else None
         if tail is not None:
             rec['tail'] = None
+            if tail.get('loss') is not None:
+                _PENDING_COSTS.pop(tail['loss'].data_ptr(), None)      # (the value is written below, one way or the other)
             if fused:
                 # hinted head: gh and g left with the forward's tail launch; the products' launch carries the cost, d_wout, d_bout
                 nt = len(tail['terms'])
@@ -1074,103 +976,14 @@ class CriticHead(Function):
                 return (d_a1 if need[0] else None, d_a2 if (a2 is not None and need[1]) else None, d_w if need[2] else None, d_b, d_wout,
                         d_bout, None)
             # (another upstream gradient than the unit seed reached this head: the cost's value is still owed -- by the head that carries it)
-            nt = len(tail['terms']) if tail['loss'] is not None else 0
-            lg = tail['logits']
-            ext = tail.get('ext') or [None] * nt
-            xs, o = [], 0
-            for (n, _, _), e in zip(tail['terms'], ext):
-                if e is not None:
-                    xs.append(e.data_ptr())
-                else:
-                    xs.append(lg.data_ptr() + 4 * o)
-                    o += n
-            pw, pn = (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]), (C.c_int * nt)(*[n for n, _, _ in tail['terms']])
-            if nt == 0:
-                pass
-            elif tail.get('kind') == 'mean':
-                check(_L().ggan_mean_multi_fwd_grad((C.c_void_p * nt)(*xs), pw, pn, nt, _p(tail['loss']), None, _stream()),
-                      'ggan_mean_multi_fwd_grad')
-            else:
-                check(_L().ggan_bce_logits_multi_fwd((C.c_void_p * nt)(*xs), (C.c_float * nt)(*[z for _, z, _ in tail['terms']]), pw, pn, nt,
-                                                     _p(tail['loss']), _stream()), 'ggan_bce_logits_multi_fwd')
+            if tail.get('loss') is not None:
+                _tail_value(tail)
         # (fused: gh, d_wout, d_bout left with the cost's launch -- ggan_bce_head_bwd; g = NULL launches the products only)
         check(_L().ggan_critic_head_bwd(M, K1, K2, H, _p(None if fused else g), _p(a1), _p(a2), _p(w), _p(h), _p(w_out), ctx.alpha, _p(gh), _p(d_a1),
                                         _p(d_a2), _p(d_w), _p(d_b), _p(d_wout), _p(d_bout), _p(ws), ws.numel(), _stream()),
               'ggan_critic_head_bwd')
         return (d_a1 if need[0] else None, d_a2 if (a2 is not None and need[1]) else None, d_w if need[2] else None, d_b, d_wout,
                 d_bout, None)
-
-
-@_skip_undefined
-class MlpChain(Function):
-    """logits[M] = Linear(H -> 1)(lrelu(Linear(H -> H)(lrelu(Linear(H -> H)(lrelu(Linear([x1 | x2] -> H))))))), H = 512: the mixture critic
-    on codes of the gmgan scripts (HyperDiscriminator, gmgan_inference_cifar10.py:255-271) as ONE launch per direction
-    (ggan_mlp_chain_fwd / _bwd: a workgroup carries 16 rows through the whole chain; backward = [head kernel, or riding in the cost
-    launch as for CriticHead] + chain kernel + one grouped launch for the three weight-gradient products).  x2 may be None.
-    Not differentiable twice (no script differentiates this critic twice)."""
-
-    @staticmethod
-    def usable(x1, x2, hidden):
-        if x1.dim() != 2 or (x2 is not None and (x2.dim() != 2 or x2.shape[0] != x1.shape[0])) or not x1.is_cuda:
-            return False
-        return bool(_L().ggan_mlp_chain_ok(x1.shape[0], x1.shape[1], x2.shape[1] if x2 is not None else 0, hidden))
-
-    @staticmethod
-    def forward(ctx, x1, x2, w1, b1, w2, b2, w3, b3, w_out, b_out, alpha):
-        x1, w1, b1, w2, b2, w3, b3, w_out, b_out = [_c(t) for t in (x1, w1, b1, w2, b2, w3, b3, w_out, b_out)]
-        x2 = _c(x2) if x2 is not None else None
-        M, K1 = x1.shape
-        K2 = x2.shape[1] if x2 is not None else 0
-        H = w2.shape[0]
-        assert w1.shape == (K1 + K2, H) and w2.shape == (H, H) and w3.shape == (H, H) and w_out.numel() == H, (x1.shape, w1.shape, w2.shape)
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x1.device)
-        h1, h2, h3, logits = new(M, H), new(M, H), new(M, H), new(M)
-        # (the backward launch reads the weights transposed: the forward launch's spare workgroups write them into wt)
-        wt = new(_L().ggan_mlp_chain_scratch(K1, K2) // 4) if any(ctx.needs_input_grad) else None
-        check(_L().ggan_mlp_chain_fwd(M, K1, K2, H, _p(x1), _p(x2), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(w_out), _p(b_out),
-                                      float(alpha), _p(h1), _p(h2), _p(h3), _p(logits), _p(wt), _stream()), 'ggan_mlp_chain_fwd')
-        ctx.alpha, ctx.has_x2 = float(alpha), x2 is not None
-        ctx.save_for_backward(x1, x2, wt, w_out, h1, h2, h3)
-        # (as CriticHead: a BCE cost on exactly these logits takes the head kernel of this op's backward into its own launch)
-        ctx.rec = None
-        if M <= _lib.HEAD_BCE_MAX_ROWS and any(ctx.needs_input_grad) and not os.environ.get('GGAN_NO_HEAD_BCE'):
-            ctx.rec = dict(ptr=logits.data_ptr(), M=M, H=H, h=weakref.ref(h3), w_out=weakref.ref(w_out), alpha=float(alpha),
-                           want_out=ctx.needs_input_grad[8], want_bout=ctx.needs_input_grad[9], g_ptr=None)
-            if len(HEAD_LOGITS) >= 8:
-                HEAD_LOGITS.clear()
-            HEAD_LOGITS[ctx.rec['ptr']] = ctx.rec
-        return logits
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g):
-        x1, x2, wt, w_out, h1, h2, h3 = ctx.saved_tensors
-        g = _c(g)
-        M, K1 = x1.shape
-        K2 = x2.shape[1] if x2 is not None else 0
-        H = h1.shape[1]
-        need = ctx.needs_input_grad
-        dev = g.device
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        rec = ctx.rec
-        fused = rec is not None and rec['g_ptr'] is not None and rec['g_ptr'] == g.data_ptr() and rec.get('g_version') == g._version
-        gh3 = rec['gh'] if fused else new(M, H)
-        want_w = any(need[2:8])
-        want_x = need[0] or (x2 is not None and need[1])
-        gh2 = new(M, H) if want_w else None
-        gh1 = new(M, H) if want_w else None
-        d_x1 = new(M, K1) if want_x else None
-        d_x2 = new(M, K2) if (want_x and x2 is not None) else None
-        d_w1, d_b1, d_w2, d_b2, d_w3, d_b3 = (new(K1 + K2, H), new(H), new(H, H), new(H), new(H, H), new(H)) if want_w else (None,) * 6
-        d_wout = (rec['d_wout'].view(w_out.shape) if fused else new(*w_out.shape)) if need[8] else None
-        d_bout = (rec['d_bout'] if fused else new(1)) if need[9] else None
-        ws = workspace(dev)
-        check(_L().ggan_mlp_chain_bwd(M, K1, K2, H, _p(None if fused else g), _p(x1), _p(x2), _p(wt), _p(w_out), _p(h1), _p(h2),
-                                      _p(h3), ctx.alpha, _p(gh3), _p(gh2), _p(gh1), _p(d_x1), _p(d_x2), _p(d_w1), _p(d_b1), _p(d_w2), _p(d_b2),
-                                      _p(d_w3), _p(d_b3), _p(d_wout), _p(d_bout), _p(ws), ws.numel(), _stream()), 'ggan_mlp_chain_bwd')
-        pick = lambda t, i: t if need[i] else None
-        return (pick(d_x1, 0), pick(d_x2, 1) if x2 is not None else None, pick(d_w1, 2), pick(d_b1, 3), pick(d_w2, 4), pick(d_b2, 5),
-                pick(d_w3, 6), pick(d_b3, 7), d_wout, d_bout, None)
 
 
 class DynScan(Function):
@@ -1316,27 +1129,11 @@ class BatchNormTrain(Function):
         N, Cc = x.shape[0], x.shape[1]
         HW = x.numel() // (N * Cc)
         sc, of = _c(scale).reshape(-1), _c(offset).reshape(-1)
-        at, rec = _attaching(), _recording()
-        if at is not None:
-            y, mean, invstd = at.take('BatchNormTrain')
-            y = y.view(x.shape)
-        elif rec is not None:
-            # paired nets pass: batch statistics per group of rows (each group is one session.run's minibatch)
-            G, n = rec.G, N // rec.G
-            assert n * G == N
-            y = torch.empty_like(x)
-            mean = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
-            invstd = torch.empty_like(mean)
-            for gi in range(G):
-                check(_L().ggan_bn_fwd_train(_p(x[gi * n:(gi + 1) * n]), _p(sc), _p(of), _p(y[gi * n:(gi + 1) * n]), _p(mean[gi]), _p(invstd[gi]),
-                                             n, Cc, HW, eps, act, alpha, _stream()), 'ggan_bn_fwd_train')
-            rec.put('BatchNormTrain', (y, 'rows'), (mean, 'group'), (invstd, 'group'))
-        else:
-            y = torch.empty_like(x)
-            mean = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-            invstd = torch.empty_like(mean)
-            check(_L().ggan_bn_fwd_train(_p(x), _p(sc), _p(of), _p(y), _p(mean), _p(invstd), N, Cc, HW, eps, act, alpha,
-                                         _stream()), 'ggan_bn_fwd_train')
+        y = torch.empty_like(x)
+        mean = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        check(_L().ggan_bn_fwd_train(_p(x), _p(sc), _p(of), _p(y), _p(mean), _p(invstd), N, Cc, HW, eps, act, alpha,
+                                     _stream()), 'ggan_bn_fwd_train')
         ctx.dims = (N, Cc, HW)
         ctx.act, ctx.alpha = act, alpha
         ctx.pshape = tuple(scale.shape)
@@ -1424,28 +1221,12 @@ class LinearBatchNormRows(Function):
         N = w.shape[1]
         sc, of = _c(scale).reshape(-1), _c(offset).reshape(-1)
         bp = _p(_c(b)) if b is not None else _p(None)
-        at, rec = _attaching(), _recording()
-        if at is not None:
-            h, y, mean, invstd = at.take('LinearBatchNormRows')
-        elif rec is not None:
-            G, n = rec.G, M // rec.G          # (statistics per group of rows, as for BatchNormTrain)
-            assert n * G == M
-            h = torch.empty((M, N), dtype=torch.float32, device=x.device)
-            y = torch.empty_like(h)
-            mean = torch.empty((G, N), dtype=torch.float32, device=x.device)
-            invstd = torch.empty_like(mean)
-            for gi in range(G):
-                sl = slice(gi * n, (gi + 1) * n)
-                check(_L().ggan_linear_bn_rows_fwd(_p(x[sl]), _p(w), bp, _p(sc), _p(of), _p(h[sl]), _p(y[sl]), _p(mean[gi]), _p(invstd[gi]),
-                                                   n, K, N, eps, act, alpha, _stream()), 'ggan_linear_bn_rows_fwd')
-            rec.put('LinearBatchNormRows', (h, 'rows'), (y, 'rows'), (mean, 'group'), (invstd, 'group'))
-        else:
-            h = torch.empty((M, N), dtype=torch.float32, device=x.device)
-            y = torch.empty_like(h)
-            mean = torch.empty((N,), dtype=torch.float32, device=x.device)
-            invstd = torch.empty_like(mean)
-            check(_L().ggan_linear_bn_rows_fwd(_p(x), _p(w), bp, _p(sc), _p(of), _p(h), _p(y), _p(mean),
-                                               _p(invstd), M, K, N, eps, act, alpha, _stream()), 'ggan_linear_bn_rows_fwd')
+        h = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(h)
+        mean = torch.empty((N,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        check(_L().ggan_linear_bn_rows_fwd(_p(x), _p(w), bp, _p(sc), _p(of), _p(h), _p(y), _p(mean),
+                                           _p(invstd), M, K, N, eps, act, alpha, _stream()), 'ggan_linear_bn_rows_fwd')
         ctx.act, ctx.alpha, ctx.has_bias, ctx.pshape = act, alpha, b is not None, tuple(scale.shape)
         ctx.save_for_backward(x, w, h, sc, mean, invstd, y if act != ACT_NONE else None)
         return y
@@ -1687,15 +1468,8 @@ class Axpby(Function):
     def forward(ctx, x, y, a, b, c, slot=None):
         x = _c(x)
         y = _c(y) if y is not None else None
-        at = _attaching()
-        if at is not None:
-            (out,) = at.take('Axpby')
-            out = out.view(x.shape)
-        else:
-            out = _new_out(slot, x.shape, x.device)
-            check(_L().ggan_axpby(_p(x), _p(y), _p(out), x.numel(), a, b, c, _stream()), 'ggan_axpby')
-            if _recording() is not None:
-                _recording().put('Axpby', (out, 'rows'))
+        out = _new_out(slot, x.shape, x.device)
+        check(_L().ggan_axpby(_p(x), _p(y), _p(out), x.numel(), a, b, c, _stream()), 'ggan_axpby')
         ctx.a, ctx.b, ctx.has_y = a, b, y is not None
         return out
 
@@ -1713,7 +1487,7 @@ class MixMean(Function):
 
     @staticmethod
     def usable(k, mu, noise):
-        return k.dim() == 2 and mu.dim() == 2 and mu.shape[1] % 4 == 0 and k.is_cuda and _attaching() is None and _recording() is None
+        return k.dim() == 2 and mu.dim() == 2 and mu.shape[1] % 4 == 0 and k.is_cuda
 
     @staticmethod
     def forward(ctx, k, mu, noise, slot=None):
@@ -1748,16 +1522,10 @@ class GmmLatent(Function):
         B, D = z.shape
         K = mu.shape[0]
         assert tuple(mu.shape) == (K, D) and tuple(gumbel_u.shape) == (B, K)
-        at = _attaching()
-        if at is not None:
-            logits, k = at.take('GmmLatent')
-        else:
-            logits = torch.empty((B, K), dtype=torch.float32, device=z.device)
-            k = _new_out(slot, (B, K), z.device)
-            check(_L().ggan_gmm_latent_fwd(_p(z), _p(mu), _p(gumbel_u), _p(logits), _p(k), B, K, D, float(log_pi), float(temp),
-                                           _stream()), 'ggan_gmm_latent_fwd')
-            if _recording() is not None:
-                _recording().put('GmmLatent', (logits, 'rows'), (k, 'rows'))
+        logits = torch.empty((B, K), dtype=torch.float32, device=z.device)
+        k = _new_out(slot, (B, K), z.device)
+        check(_L().ggan_gmm_latent_fwd(_p(z), _p(mu), _p(gumbel_u), _p(logits), _p(k), B, K, D, float(log_pi), float(temp),
+                                       _stream()), 'ggan_gmm_latent_fwd')
         ctx.temp = float(temp)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(z, mu, k)
@@ -2035,6 +1803,51 @@ class RowLerp(Function):
 # losses
 # ---------------------------------------------------------------------------------------------------
 HEAD_LOGITS = {}        # logits data pointer -> CriticHead record (CriticHead.forward registers, BceSum.forward consumes)
+
+# A hinted critic head (head_bce_hint) owes its cost's VALUE until its backward launch: the cost tensor BceSum / MeanSum return is
+# unwritten memory in between.  Whoever reads the value first settles the debt: the objectives call settle_cost() before any arithmetic
+# on a cost (cost + s_f, / n, + rec_penalty), the head's backward clears it, and a Trainer step checks that none is left over.
+_PENDING_COSTS = {}     # cost data pointer -> tail record (the head that carries the value)
+
+
+def _tail_value(tail):
+    """the cost launch a hinted head's tail record stands for (ggan_bce_logits_multi_fwd / ggan_mean_multi_fwd_grad), now"""
+    nt = len(tail['terms'])
+    lg = tail['logits']
+    ext = tail.get('ext') or [None] * nt
+    xs, o = [], 0
+    for (n, _, _), e in zip(tail['terms'], ext):
+        if e is not None:
+            xs.append(e.data_ptr())
+        else:
+            xs.append(lg.data_ptr() + 4 * o)
+            o += n
+    pw, pn = (C.c_float * nt)(*[wt for _, _, wt in tail['terms']]), (C.c_int * nt)(*[n for n, _, _ in tail['terms']])
+    if tail.get('kind') == 'mean':
+        check(_L().ggan_mean_multi_fwd_grad((C.c_void_p * nt)(*xs), pw, pn, nt, _p(tail['loss']), None, _stream()), 'ggan_mean_multi_fwd_grad')
+    else:
+        check(_L().ggan_bce_logits_multi_fwd((C.c_void_p * nt)(*xs), (C.c_float * nt)(*[z for _, z, _ in tail['terms']]), pw, pn, nt,
+                                             _p(tail['loss']), _stream()), 'ggan_bce_logits_multi_fwd')
+
+
+def settle_cost(cost):
+    """`cost` is about to be read by something else than the train op's backward: if a hinted critic head still owes its value, compute
+    it now (one small launch; the head's backward then no longer writes it).  Returns cost."""
+    if cost is None or not _PENDING_COSTS or not torch.is_tensor(cost):
+        return cost
+    tail = _PENDING_COSTS.pop(cost.data_ptr(), None)
+    if tail is not None and tail.get('loss') is not None:
+        _tail_value(tail)
+        tail['loss'] = None
+    return cost
+
+
+def pending_costs():
+    return len(_PENDING_COSTS)
+
+
+def drop_pending_costs():
+    _PENDING_COSTS.clear()
 UNIT_SEEDS = {}         # data pointer -> the all-ones tensor an optimizer seeds d(cost)/d(cost) with (kept alive here: an address
                         # in this table can never belong to another tensor); emptied by optim.reset_optimizers
 
@@ -2148,6 +1961,7 @@ class BceSum(Function):
                     if hi == len(heads) - 1:
                         rec['tail'] = dict(kind='bce', terms=all_terms, logits=logits[k0], g=hh['g'], loss=loss,
                                            ext=[logits[j] for j in range(k0)] + [None] * nt)
+                        _PENDING_COSTS[loss.data_ptr()] = rec['tail']
                     else:
                         rec['tail'] = dict(kind='bce', terms=hh['terms'], logits=logits[k0], g=hh['g'], loss=None, ext=None)
                     k0 += nt
@@ -2273,6 +2087,7 @@ class MeanSum(Function):
             hrec['g_ptr'], hrec['g_version'] = outs[0].data_ptr(), outs[0]._version
             hrec['tail'] = dict(kind='mean', terms=hh['terms'] + tuple((1, 0.0, 1.0) for _ in xs[nh:]), logits=xs[0], g=hh['g'], loss=loss,
                                 ext=[None] * nh + list(xs[nh:]))
+            _PENDING_COSTS[loss.data_ptr()] = hrec['tail']
             ctx.unit_grads = outs
             return loss.reshape(())
         if n <= _lib.BCE_MAX and not os.environ.get('GGAN_NO_BCE_FWD_GRAD'):
@@ -2396,25 +2211,6 @@ def noise_fill_(state, specs):
     b = (C.c_float * n)(*[float(x) for _, _, _, x in specs])
     widths = (C.c_int * n)(*[int(t.shape[-1]) if k == NOISE_ONEHOT else 0 for t, k, _, _ in specs])
     check(_L().ggan_noise_fill(dsts, sizes, kinds, a, b, widths, n, _p(state), _stream()), 'ggan_noise_fill')
-
-
-def noise_fill_steps_(state, steps):
-    """The noise of several consecutive steps in one launch.  steps: a list (one entry per step, in order) of spec lists as for
-    noise_fill_; every tensor receives what noise_fill_(state, steps[i]) issued as the i-th of len(steps) launches would have written."""
-    assert state.dtype == torch.int64 and state.numel() == 3 and state.is_cuda
-    flat = [(t, k, a, b, si, st) for st, specs in enumerate(steps) for si, (t, k, a, b) in enumerate(specs)]
-    n = len(flat)
-    for t, *_ in flat:
-        assert t.is_contiguous() and t.dtype == torch.float32 and t.device == state.device
-    dsts = (C.c_void_p * n)(*[f[0].data_ptr() for f in flat])
-    sizes = (C.c_size_t * n)(*[f[0].numel() for f in flat])
-    kinds = (C.c_int * n)(*[int(f[1]) for f in flat])
-    a = (C.c_float * n)(*[float(f[2]) for f in flat])
-    b = (C.c_float * n)(*[float(f[3]) for f in flat])
-    widths = (C.c_int * n)(*[int(f[0].shape[-1]) if f[1] == NOISE_ONEHOT else 0 for f in flat])
-    slots = (C.c_int * n)(*[int(f[4]) for f in flat])
-    stp = (C.c_int * n)(*[int(f[5]) for f in flat])
-    check(_L().ggan_noise_fill_steps(dsts, sizes, kinds, a, b, widths, slots, stp, n, len(steps), _p(state), _stream()), 'ggan_noise_fill_steps')
 
 
 def pack_(tensors, offsets, flat, bump=None, adam=None):

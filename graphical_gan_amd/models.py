@@ -196,117 +196,6 @@ class GraphicalGAN(object):
         return ring
 
 
-    # ---- paired nets pass (round 4) ------------------------------------------------------------------------------------
-    def pair_supported(self, feed):
-        """The Extractor / Generator passes of a critic step and of the generator step behind it can be evaluated together (the critic
-        step leaves their weights alone): image scripts with the batched joint critic and fused epilogues, one critic step per
-        iteration, int32 minibatches read from the device ring."""
-        c = self.cfg
-        return bool(c.batch_critic and 'z_pair' in feed and c.dataset != 'mnist' and not c.agg and not c.latent_critic and c.fuse
-                    and c.mode in ('ali', 'local_ep') and c.critic_iters == 1 and feed.get('ring') is not None
-                    and not os.environ.get('GGAN_NO_PAIR_NETS'))
-
-    def _pair_buffers(self, feed):
-        """4B-row buffers whose row ranges are, in this order, [generator step's fake half | critic step's fake half | critic step's
-        real half | generator step's real half]: the Generator pass writes rows [0, 2B) (its pair order is generator step first), the
-        Extractor pass reads / writes rows [2B, 4B) (critic step first), and the critic step's [fake; real] pair is rows [B, 3B) with
-        no copy.  Per-step noise buffers beside them."""
-        pb = getattr(self, '_pairbuf', None)
-        if pb is not None:
-            return pb
-        c, B, dev = self.cfg, self.cfg.B, feed['z_pair'].device
-        z = lambda *shape: torch.zeros(shape, device=dev)
-        pb = dict(X4=z(4 * B, c.output_dim), Z4=z(4 * B, c.dim_latent))
-        if c.K:
-            pb.update(K4=z(4 * B, c.K), PN=z(2 * B, c.dim_latent), GU=z(2 * B, c.K))
-        if c.dataset == 'face':
-            pb['DQ'] = z(2 * B, c.output_dim)          # (critic step, generator step)
-        self._pairbuf = pb
-        return pb
-
-    def forward_nets_pair(self, feed):
-        """-> (feed_d, nets_d, feed_g, nets_g): the nets pass of the NEXT critic step and of the generator step after it, evaluated
-        once on 2B rows (functional.Replay).  nets_d holds plain tensors (the critic step treats them as data); nets_g carries the tape
-        of the generator step's B rows.  Draws the noise of both steps (unless the Trainer injects it) exactly as two single-step
-        launches would, and reads the two minibatches from the device ring."""
-        c, B = self.cfg, self.cfg.B
-        pb = self._pair_buffers(feed)
-        X4, Z4 = pb['X4'], pb['Z4']
-        dev = X4.device
-        S = lambda t, i: t[i * B:(i + 1) * B]
-        # ---- noise of the two steps: step 0 = critic step, step 1 = generator step (the order they run in) ----
-        if not getattr(self, '_pair_inject', False):
-            if 'rng_state' not in feed:
-                feed['rng_state'] = F.noise_state(dev)
-            steps = []
-            for st in (0, 1):
-                g = st == 1
-                if c.K:
-                    specs = [(S(pb['PN'], 0 if g else 1), F.NOISE_NORMAL, 0., 1.), (S(pb['K4'], 0 if g else 1), F.NOISE_ONEHOT, 0., 0.),
-                             (S(pb['GU'], 1 if g else 0), F.NOISE_UNIFORM, 0., 1.)]
-                else:
-                    specs = [(S(Z4, 0 if g else 1), F.NOISE_NORMAL, 0., 1.)]
-                if c.dataset == 'face':
-                    specs.append((S(pb['DQ'], st), F.NOISE_UNIFORM, 0., 1. / 128))
-                steps.append(specs)
-            F.noise_fill_steps_(feed['rng_state'], steps)
-        else:       # tests: both steps read the Trainer's injected draws
-            if c.K:
-                for i in (0, 1):
-                    S(pb['PN'], i).copy_(feed['p_z_noise']); S(pb['K4'], i).copy_(feed['k_onehot']); S(pb['GU'], i).copy_(feed['gumbel_u'])
-            else:
-                for i in (0, 1):
-                    S(Z4, i).copy_(feed['p_z_noise'])
-            if c.dataset == 'face':
-                for i in (0, 1):
-                    S(pb['DQ'], i).copy_(feed['dequant_u'])
-        cur = torch.cuda.current_stream(dev)
-        if self._side is None:
-            self._side = F.shared_stream(dev, 'side')
-        side = self._side
-        nets_target = int(os.environ.get('GGAN_NETS_TARGET_WGS', '128'))
-        ring, ca, cb, off = feed['ring']
-        div = 256. if c.dataset == 'face' else 255.
-        rp_e, rp_g = F.Replay(B), F.Replay(B)
-        if os.environ.get('GGAN_PAIR_NOFORK'):          # (experiment: the two recorded passes one after the other on this stream)
-            side = cur
-        side.wait_stream(cur) if side is not cur else None
-        # (the 2B-row launches of the recorded pass plan for themselves: at 128 images a layer fills the chip at the default plan, and the
-        #  128-workgroup plan of the B-row passes would pick 64x64 tiles here -- 60 / 84 us per forward layer instead of ~35)
-        pair_target = int(os.environ.get('GGAN_PAIR_TARGET_WGS', '0'))
-        with torch.no_grad(), F.target_workgroups(pair_target):
-            # Extractor pass on the second stream: rows [2B, 4B) = (critic step's minibatch, generator step's minibatch)
-            with torch.cuda.stream(side):
-                for st, row in ((0, 2), (1, 3)):
-                    lib.ops.act.cast_scale(feed['real_x_int'], div, 2., noise=S(pb['DQ'], st) if c.dataset == 'face' else None,
-                                           out=F.RowSlot(X4, row * B, (row + 1) * B), ring=(ring, ca, cb, off + st))
-                with F.replay_record(rp_e):
-                    q_pair = self.Extractor(X4[2 * B:], F.RowSlot(Z4, 2 * B, 4 * B))
-                    if c.K:
-                        self.HyperExtractor(q_pair, pb['GU'], F.RowSlot(pb['K4'], 2 * B, 4 * B))
-            # Generator pass on this stream: rows [0, 2B) = (generator step, critic step)
-            with F.replay_record(rp_g):
-                p_pair = self.HyperGenerator(pb['K4'][:2 * B], pb['PN'], F.RowSlot(Z4, 0, 2 * B)) if c.K else Z4[:2 * B]
-                self.Generator(p_pair, F.RowSlot(X4, 0, 2 * B))
-        # ---- the generator step's rows again, now on the tape: every layer takes its output from the recorded pass ----
-        with F.target_workgroups(nets_target):
-            with torch.cuda.stream(self._side):   # (autograd runs a pass's backward on the stream of its forward: the two backward chains side by side)
-                with F.replay_attach(rp_e, 1):
-                    q_z_g = self.Extractor(S(X4, 3))
-                    q_k_g = self.HyperExtractor(q_z_g, S(pb['GU'], 1))[1] if c.K else None
-            with F.replay_attach(rp_g, 0):
-                p_z_g = self.HyperGenerator(S(pb['K4'], 0), S(pb['PN'], 0)) if c.K else S(Z4, 0)
-                fake_g = self.Generator(p_z_g)
-        cur.wait_stream(self._side)
-        self._pending_join, self._early = None, False
-        nets_d = dict(real_x=S(X4, 2), q_z=S(Z4, 2), p_z=S(Z4, 1), fake_x=S(X4, 1))
-        nets_g = dict(real_x=S(X4, 3), q_z=q_z_g, p_z=p_z_g, fake_x=fake_g)
-        feed_d, feed_g = dict(feed), dict(feed)
-        if c.K:
-            nets_d['q_k'], nets_g['q_k'] = S(pb['K4'], 2), q_k_g
-            feed_d['k_onehot'], feed_g['k_onehot'] = S(pb['K4'], 1), S(pb['K4'], 0)
-        return feed_d, nets_d, feed_g, nets_g
-
     # ---- small helpers: an op followed by its pointwise, fused or not -------------------------------------
     def _conv(self, name, cin, cout, x, act, grad_rows=None):
         if self.cfg.fuse:
@@ -472,12 +361,6 @@ class GraphicalGAN(object):
 
     def HyperDiscriminator(self, z, k):
         c = self.cfg
-        if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION') and os.environ.get('GGAN_MLP_CHAIN'):
-            # the whole net as one op (ggan_mlp_chain_*: one launch per direction).  OPT-IN: measured slower than the composed launches at
-            # the scripts' 128 rows (a row-local workgroup is bound by one CU's fp32 MFMA rate: 40 / 46 us against 29 / 49 us, gmgan
-            # iteration 1.22 against 1.14 ms; profiles/r04_notes.md)
-            return lib.ops.linear.MlpLReLUChain(['Discriminator.HyperInput', 'Discriminator.Hyper2', 'Discriminator.Hyper3'],
-                                                c.dim_latent + c.K, 512, 'Discriminator.HyperOutput', (z, k))
         out = self._lin('Discriminator.HyperInput', c.dim_latent + c.K, 512, (z, k), LRELU)     # Linear on concat([z, k], 1)
         out = self._lin('Discriminator.Hyper2', 512, 512, out, LRELU)
         if c.fuse and not os.environ.get('GGAN_NO_HEAD_FUSION'):

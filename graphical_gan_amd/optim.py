@@ -172,20 +172,6 @@ class AdamOptimizer(object):
         F.pack_(gs, self.slots[lo:hi], self.g, bump=self.step if bump else None)
         return gs
 
-    def pack_update_subset(self, grads, lo, hi, last):
-        """pack(fuse_update=True) for the parameters [lo, hi) alone: a step may apply the update of the parameters whose gradients
-        exist early (the critic's tail) beside the rest of its backward pass.  Every launch of a step takes step + 1 as the update's
-        ordinal; the LAST one (last=True) advances the counter -- it must be ordered behind the others."""
-        assert self.can_fuse_update()
-        _xlog('pack', int(lo), int(hi))
-        gs = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
-        if self._arrive is None:
-            self._arrive = torch.zeros(F._lib.PACK_ARRIVE_INTS, dtype=torch.int32, device=self.theta.device)
-        F.pack_(gs, self.slots[lo:hi], self.g, adam=(self.theta, self.m, self.v, self.step, self._arrive if last else None, self.lr,
-                                                      self.beta1, self.beta2, self.eps, self.bucket.scale))
-        self._updated = bool(last)
-        return gs
-
     def update(self):
         if self._updated:            # applied by the pack launch (pack(fuse_update=True))
             self._updated = False

@@ -10,6 +10,7 @@ from ...optim import TrainOp, get_optimizer
 
 
 ONLY = [None]   # 'gen' | 'disc': build just that cost (what one session.run fetches); None builds both
+_val = F.settle_cost      # a cost is READ here: a hinted critic head that still owes its value computes it first (functional.settle_cost)
 
 
 def _bce_costs(fakes, reals, ratios):
@@ -28,7 +29,7 @@ def _bce_costs(fakes, reals, ratios):
 def ali(disc_fake, disc_real, gen_params, disc_params, lr=2e-4, beta1=0.5, beta2=0.999, s_f=None):
     gen_cost, disc_cost = _bce_costs([disc_fake], [disc_real], [1.0])
     if s_f is not None and gen_cost is not None:
-        gen_cost = gen_cost + s_f
+        gen_cost = _val(gen_cost) + s_f
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
@@ -40,8 +41,8 @@ def local_ep(disc_fake_list, disc_real_list, gen_params, disc_params, lr=2e-4, b
         gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0 / n] * len(disc_fake_list))
     else:   # (sum + s_f) / n, as gan_inference.py:102-106
         gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0] * len(disc_fake_list))
-        gen_cost = (gen_cost + s_f) / n if gen_cost is not None else None
-        disc_cost = disc_cost / n if disc_cost is not None else None
+        gen_cost = (_val(gen_cost) + s_f) / n if gen_cost is not None else None
+        disc_cost = _val(disc_cost) / n if disc_cost is not None else None
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
@@ -50,7 +51,7 @@ def local_ep(disc_fake_list, disc_real_list, gen_params, disc_params, lr=2e-4, b
 def _plus(cost, *terms):
     for t in terms:
         if t is not None and cost is not None:
-            cost = cost + t
+            cost = _val(cost) + t
     return cost
 
 
@@ -61,8 +62,8 @@ def local_epce(disc_fake_list, disc_real_list, rec_penalty, gen_params, disc_par
         gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0 / n] * len(disc_fake_list))
     else:
         gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, [1.0] * len(disc_fake_list))
-        gen_cost = (gen_cost + s_f) / n if gen_cost is not None else None
-        disc_cost = disc_cost / n if disc_cost is not None else None
+        gen_cost = (_val(gen_cost) + s_f) / n if gen_cost is not None else None
+        disc_cost = _val(disc_cost) / n if disc_cost is not None else None
     gen_cost = _plus(gen_cost, rec_penalty)
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
@@ -83,7 +84,7 @@ def vegan(disc_fake, disc_real, rec_penalty, gen_params, disc_params, lamb, lr=2
     gen_cost = disc_cost = None
     if ONLY[0] != 'disc':
         gen_cost = F.BceSum.apply((1.0,), (1.0,), disc_fake)
-        gen_cost = _plus(gen_cost, s_f) * float(lamb)
+        gen_cost = _val(_plus(gen_cost, s_f)) * float(lamb)
         gen_cost = _plus(gen_cost, rec_penalty)
     if ONLY[0] != 'gen':
         disc_cost = F.BceSum.apply((0.0, 1.0), (float(lamb) / 2, float(lamb) / 2), disc_fake, disc_real)
@@ -114,7 +115,7 @@ def weighted_local_epce(disc_fake_list, disc_real_list, ratio_list, gen_params, 
     gen_cost, disc_cost = _bce_costs(disc_fake_list, disc_real_list, list(ratio_list))
     gen_debug_list, disc_debug_list = [], []   # per-factor terms are debug-only in the reference (:321-343)
     if rec_penalty is not None and gen_cost is not None:
-        gen_cost = gen_cost + rec_penalty
+        gen_cost = _val(gen_cost) + rec_penalty
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
     return (gen_cost, disc_cost, gen_debug_list, disc_debug_list,

@@ -115,27 +115,6 @@ def LinearLReLULinear(name1, input_dim, hidden_dim, name2, inputs, alpha=0.2, di
     return F.CriticHead.apply(x1, x2, w1, b1, w2, b2, float(alpha))
 
 
-def MlpLReLUChain(names, input_dim, hidden_dim, name_out, inputs, alpha=0.2):
-    """Extension: Linear(names[0], input_dim, hidden_dim) -> LeakyReLU -> Linear(names[1], hidden_dim, hidden_dim) -> LeakyReLU ->
-    Linear(names[2], hidden_dim, hidden_dim) -> LeakyReLU -> Linear(name_out, hidden_dim, 1): the mixture critic on codes of the gmgan
-    scripts (gmgan_inference_cifar10.py:255-271 'Discriminator.HyperInput' / 'Hyper2' / 'Hyper3' / 'HyperOutput') as ONE op
-    (functional.MlpChain) where the shapes allow; otherwise the composed layers.  Same registry keys, shapes and initial-value draws, in
-    the same order, as the four Linear calls.  inputs: a tensor or a pair standing for tf.concat([x1, x2], 1).  Returns the logits [rows]."""
-    pair = isinstance(inputs, (tuple, list))
-    x1, x2 = inputs if pair else (inputs, None)
-    if not F.MlpChain.usable(x1, x2, hidden_dim):
-        h = Linear(names[0], input_dim, hidden_dim, inputs, activation=F.ACT_LRELU, alpha=alpha)
-        h = Linear(names[1], hidden_dim, hidden_dim, h, activation=F.ACT_LRELU, alpha=alpha)
-        return LinearLReLULinear(names[2], hidden_dim, hidden_dim, name_out, h, alpha=alpha)
-    dims = [(names[0], input_dim, hidden_dim), (names[1], hidden_dim, hidden_dim), (names[2], hidden_dim, hidden_dim), (name_out, hidden_dim, 1)]
-    wb = []
-    for nm, nin, nout in dims:
-        wb.append(_param(nm + '.W', _initial(None, nin, nout) if _draw(nm + '.W') else None))
-        wb.append(_param(nm + '.b', np.zeros((nout,), dtype='float32')))
-    assert x1.shape[1] + (x2.shape[1] if x2 is not None else 0) == input_dim, (names[0], x1.shape, input_dim)
-    return F.MlpChain.apply(x1, x2, *wb, float(alpha))
-
-
 def linear_params(name, input_dim, output_dim):
     """(W, b) of Linear(name, input_dim, output_dim) without applying it: same registry keys, shapes and initial-value draws"""
     w = _param(name + '.W', _initial(None, input_dim, output_dim) if _draw(name + '.W') else None)

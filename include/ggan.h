@@ -172,33 +172,6 @@ int ggan_critic_head_bwd_tail(int M, int K1, int K2, int H, const float* a1, con
                               const float* labels, const float* weights, const float* const* ext, float* loss, void* ws, size_t ws_bytes,
                               ggan_stream_t stream);
 
-/* The mixture critic on codes as ONE launch per direction: Linear ([x1 | x2] -> 512) -> LeakyReLU -> Linear (512 -> 512) -> LeakyReLU ->
- * Linear (512 -> 512) -> LeakyReLU -> Linear (512 -> 1).  Replaces tf.concat([z, k], 1) + lib.ops.linear.Linear('Discriminator.HyperInput')
- * / 'Discriminator.Hyper2' / 'Discriminator.Hyper3' / 'Discriminator.HyperOutput' with their LeakyReLUs
- * (/root/reference/gmgan_inference_cifar10.py:255-271 HyperDiscriminator; gmgan_inference_mnist.py, gmgan_inference_face.py: the same
- * net; tf.layers.dropout without training=True is the identity).  Every layer is row-local, so a workgroup carries 16 rows through
- * the whole chain with the activations in LDS and the weights streamed into the MFMA operand (csrc/mlp_chain.hip).
- *   ggan_mlp_chain_ok: 1 when the shape is covered (H == 512, K1 + K2 <= 256, K1 a multiple of 64 when K2 > 0); the entry points
- *             return 1 without launching otherwise.
- *   forward:  x1 [M,K1], x2 [M,K2] (NULL when K2 == 0), w1 [K1+K2,H], w2, w3 [H,H], b1..b3 [H], w_out [H], b_out [1];
- *             h1, h2, h3 [M,H] are kept (the backward's activation references and weight-gradient operands), logits [M];
- *             wt: caller-owned scratch of ggan_mlp_chain_scratch(K1, K2) bytes (16-byte aligned) that receives the transposed weights the
- *             backward launch reads -- NULL when no backward follows.
- *   backward: from g[M] = d cost / d logits (NULL: gh3 -- and d_wout / d_bout, then ignored here -- came with the cost, ggan_bce_heads_bwd);
- *             wt as filled by the forward call on the same weights; gh3 [M,H] caller-owned; gh2, gh1 [M,H] (NULL allowed when no weight
- *             gradient is wanted); d_x1 [M,K1], d_x2 [M,K2] (NULL: the inputs are data); d_w1..3 / d_b1..3 all or none; d_wout [H],
- *             d_bout [1] may be NULL.
- *             Launches: [head kernel] + chain kernel + [one grouped launch for the three weight-gradient products]. */
-int ggan_mlp_chain_ok(int M, int K1, int K2, int H);
-size_t ggan_mlp_chain_scratch(int K1, int K2);
-int ggan_mlp_chain_fwd(int M, int K1, int K2, int H, const float* x1, const float* x2, const float* w1, const float* b1, const float* w2,
-                       const float* b2, const float* w3, const float* b3, const float* w_out, const float* b_out, float alpha, float* h1,
-                       float* h2, float* h3, float* logits, float* wt, ggan_stream_t stream);
-int ggan_mlp_chain_bwd(int M, int K1, int K2, int H, const float* g, const float* x1, const float* x2, const float* wt, const float* w_out,
-                       const float* h1, const float* h2, const float* h3, float alpha, float* gh3, float* gh2, float* gh1, float* d_x1,
-                       float* d_x2, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_wout,
-                       float* d_bout, void* ws, size_t ws_bytes, ggan_stream_t stream);
-
 /* ---- dense -------------------------------------------------------------------------------
  * C[M,N] = op(A) * op(B) (+ bias[N]) (+act), row-major, ta/tb = 1 reads the operand transposed
  * (A stored [K,M] / B stored [N,K]).  tf.matmul + bias_add of tflib/ops/linear.py:133-146 is

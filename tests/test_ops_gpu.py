@@ -5,6 +5,7 @@ Tolerance (fp32): per-op max |err| <= 2e-5 * max|ref| for K <= 320
 """
 import ctypes as C
 
+import contextlib
 import numpy as np
 import pytest
 
@@ -1200,6 +1201,49 @@ def test_critic_head_that_knows_its_cost(gpu, M, K1, K2, H, terms, need):
         assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
 
 
+@pytest.mark.parametrize('kind', ['bce', 'mean'])
+def test_hinted_head_cost_read_before_its_backward(gpu, kind):
+    """A hinted critic head owes its cost's value until its backward launch (functional._PENDING_COSTS).  Whatever reads the cost earlier
+    must see the unhinted value: the objectives settle it (functional.settle_cost) before `cost + s_f` / `/ n` / `+ rec_penalty`; a
+    non-unit seed takes the plain backward kernels; and nothing stays owed afterwards."""
+    import torch
+    from graphical_gan_amd import functional as F
+    rng = np.random.default_rng(5)
+    M, K1, H = 64, 96, 128
+    a1 = rng.standard_normal((M, K1)).astype(np.float32)
+    w = (rng.standard_normal((K1, H)) / np.sqrt(K1)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    wo = (rng.standard_normal((H, 1)) / np.sqrt(H) * 3).astype(np.float32)
+    bo = rng.standard_normal(1).astype(np.float32)
+    s_f = _t(np.float32([0.37]), gpu).reshape(())
+    terms = [(32, 1.0, 1.0), (32, 0.0, 1.0)] if kind == 'bce' else [(32, 0.0, -1.0), (32, 0.0, 1.0)]
+
+    def run(hinted, seed, add):
+        t = lambda v: _t(v, gpu).requires_grad_(True)
+        ta1, tw, tb, two, tbo = t(a1), t(w), t(b), t(wo), t(bo)
+        F.drop_pending_costs()
+        with (F.head_bce_hint(terms, kind) if hinted else contextlib.nullcontext()):
+            out = F.CriticHead.apply(ta1, None, tw, tb, two, tbo, 0.2)
+        parts = [out[:32], out[32:]]
+        if kind == 'bce':
+            cost = F.BceSum.apply(tuple(z for _, z, _ in terms), tuple(wt for _, _, wt in terms), *parts)
+        else:
+            cost = F.MeanSum.apply(tuple(wt for _, _, wt in terms), *parts)
+        owed = F.pending_costs()
+        total = (F.settle_cost(cost) + s_f) / 2.0 if add else cost
+        settled = F.pending_costs()
+        g = torch.autograd.grad(total, [ta1, tw, tb, two, tbo], grad_outputs=(F.unit_seed(total) if seed == 1.0 else torch.full_like(total, seed)))
+        torch.cuda.synchronize()
+        return float(total.detach()), float(cost.detach()), [x.cpu().numpy() for x in g], owed, settled, F.pending_costs()
+    for seed, add in ((1.0, True), (0.5, False), (1.0, False)):
+        v0, c0, g0, o0, _, _ = run(False, seed, add)
+        v1, c1, g1, o1, s1, left = run(True, seed, add)
+        assert o0 == 0 and o1 == 1 and left == 0 and (s1 == 0 if add else s1 == 1), (seed, add, o0, o1, s1, left)
+        assert v1 == v0 and c1 == c0, (kind, seed, add, v0, v1, c0, c1)
+        for x, y in zip(g0, g1):
+            assert _rel(y, x) < 1e-6, (kind, seed, add)
+
+
 @pytest.mark.parametrize('B,K,D,onehot', [(64, 30, 128, True), (50, 10, 128, True), (7, 100, 64, False)])
 def test_mix_mean(gpu, B, K, D, onehot):
     """ggan_mix_mean (functional.MixMean: HyperGenerator, gmgan_inference_cifar10.py:150-153, as one pointwise launch): k @ mu + noise
@@ -1269,101 +1313,6 @@ def test_first_layer_scales_the_ring_minibatch_itself(gpu, N, Ci, S, Co, noise):
     g1 = torch.autograd.grad(y, [w, b], grad_outputs=gy)
     g0 = torch.autograd.grad(y_ref, [w, b], grad_outputs=gy)
     assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1])
-
-
-@pytest.mark.parametrize('M,K1,K2,need', [(128, 128, 30, 'all'), (128, 128, 30, 'data'), (128, 128, 10, 'weights'), (100, 128, 30, 'all'),
-                                          (64, 128, 100, 'all'), (7, 64, 5, 'all'), (33, 250, 0, 'all'), (16, 8, 0, 'data')])
-def test_mlp_chain(gpu, M, K1, K2, need):
-    """ggan_mlp_chain_fwd/bwd (functional.MlpChain: the mixture critic on codes, gmgan_inference_cifar10.py:255-271, one launch per
-    direction): kept activations, logits and every gradient vs numpy float64 -- the critic-step case (all gradients), the
-    generator-step case (data gradients only, frozen weights), ragged row counts (last workgroup partly empty), K not on the
-    16-step grid, single source.  Also: a shape the kernels do not cover reports so (composed layers take it)."""
-    import torch
-    from graphical_gan_amd import functional as F
-    H = 512
-    rng = np.random.default_rng(M * 1000 + K1 + K2)
-    f64 = lambda a: a.astype(np.float64)
-    x1 = rng.standard_normal((M, K1)).astype(np.float32)
-    x2 = rng.standard_normal((M, K2)).astype(np.float32) if K2 else None
-    K = K1 + K2
-    ws = [(rng.standard_normal((K, H)) * np.sqrt(2. / K)).astype(np.float32), (rng.standard_normal((H, H)) * np.sqrt(2. / H)).astype(np.float32),
-          (rng.standard_normal((H, H)) * np.sqrt(2. / H)).astype(np.float32)]
-    bs = [(0.1 * rng.standard_normal(H)).astype(np.float32) for _ in range(3)]
-    wo = (rng.standard_normal((H, 1)) / np.sqrt(H)).astype(np.float32)
-    bo = rng.standard_normal(1).astype(np.float32)
-    g = rng.standard_normal(M).astype(np.float32)
-    X = f64(np.concatenate([x1, x2], 1)) if K2 else f64(x1)
-    acts, pres, a = [X], [], X
-    for w, b in zip(ws, bs):
-        pre = a @ f64(w) + f64(b)
-        a = np.maximum(0.2 * pre, pre)
-        pres.append(pre)
-        acts.append(a)
-    logits = (a @ f64(wo)).reshape(-1) + f64(bo)
-    gh = f64(g)[:, None] * f64(wo).reshape(1, -1) * np.where(pres[2] > 0, 1.0, 0.2)
-    ref = dict(wo=acts[3].T @ f64(g), bo=f64(g).sum())
-    for i in (2, 1, 0):
-        ref['w%d' % i], ref['b%d' % i] = acts[i].T @ gh, gh.sum(0)
-        gin = gh @ f64(ws[i]).T
-        gh = gin * np.where(pres[i - 1] > 0, 1.0, 0.2) if i else gin
-    ref['x'] = gh
-    assert F.MlpChain.usable(_t(x1, gpu), _t(x2, gpu) if K2 else None, H)
-    assert not F.MlpChain.usable(_t(x1, gpu), _t(x2, gpu) if K2 else None, 256)
-    wt_grad, in_grad = need in ('all', 'weights'), need in ('all', 'data')
-    t = lambda v, rg: None if v is None else _t(v, gpu).requires_grad_(rg)
-    tx1, tx2 = t(x1, in_grad), t(x2, in_grad)
-    tw, tb = [t(w, wt_grad) for w in ws], [t(b, wt_grad) for b in bs]
-    two, tbo = t(wo, wt_grad), t(bo, wt_grad)
-    out = F.MlpChain.apply(tx1, tx2, tw[0], tb[0], tw[1], tb[1], tw[2], tb[2], two, tbo, 0.2)
-    assert np.abs(out.detach().cpu().numpy() - logits).max() <= 2e-5 * max(1.0, np.abs(logits).max())
-    ins = [x for x in [tx1, tx2] + tw + tb + [two, tbo] if x is not None and x.requires_grad]
-    grads = dict(zip([id(x) for x in ins], torch.autograd.grad(out, ins, grad_outputs=_t(g, gpu))))
-    G = lambda x: grads[id(x)].cpu().numpy()
-    if in_grad:
-        assert _rel(G(tx1), ref['x'][:, :K1]) < 2e-5
-        if K2:
-            assert _rel(G(tx2), ref['x'][:, K1:]) < 2e-5
-    if wt_grad:
-        for i in range(3):
-            assert _rel(G(tw[i]), ref['w%d' % i]) < 2e-5, i
-            assert _rel(G(tb[i]), ref['b%d' % i]) < 2e-5, i
-        assert _rel(G(two).reshape(-1), ref['wo'].reshape(-1)) < 2e-5
-        assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
-
-
-def test_mlp_chain_matches_composed_layers_through_the_cost_launch(gpu):
-    """tflib.ops.linear.MlpLReLUChain under a BCE cost (the head kernel of its backward rides in the cost launch, as for CriticHead):
-    same registry keys as the four Linear calls; cost and every gradient agree with the composed layers (GGAN_NO_MLP_CHAIN path)."""
-    import torch
-    from graphical_gan_amd import tflib as lib, functional as F
-    rng = np.random.default_rng(5)
-    z = _t(rng.standard_normal((128, 128)), gpu)
-    k = _t(rng.random((128, 30)), gpu)
-    names = ['T.HyperInput', 'T.Hyper2', 'T.Hyper3']
-
-    def run(chain):
-        zz, kk = z.clone().requires_grad_(True), k.clone().requires_grad_(True)
-        if chain:
-            lg = lib.ops.linear.MlpLReLUChain(names, 158, 512, 'T.HyperOutput', (zz, kk))
-        else:
-            h = lib.ops.linear.Linear(names[0], 158, 512, (zz, kk), activation=F.ACT_LRELU)
-            h = lib.ops.linear.Linear(names[1], 512, 512, h, activation=F.ACT_LRELU)
-            lg = lib.ops.linear.LinearLReLULinear(names[2], 512, 512, 'T.HyperOutput', h)
-        hf, hr = F.SplitRows.apply(lg, 64)
-        cost = F.BceSum.apply([1.0, 0.0], [1.0, 1.0], hf, hr)
-        ps = lib.params_with_name('T.')
-        gs = torch.autograd.grad(cost, [zz, kk] + ps, grad_outputs=F.unit_seed(cost))
-        return float(cost), [x.detach().cpu().numpy().copy() for x in gs], sorted(p.param_name for p in ps)
-
-    lib.delete_all_params()
-    np.random.seed(11)
-    c0, g0, n0 = run(False)
-    c1, g1, n1 = run(True)          # (the parameters exist now: the same tensors)
-    lib.delete_all_params()
-    assert n0 == n1 and len(n0) == 8
-    assert abs(c0 - c1) <= 1e-6 * max(1.0, abs(c0))
-    for a, b in zip(g0, g1):
-        assert _rel(b, a) < 5e-5
 
 
 @pytest.mark.parametrize('res_w', [False, True], ids=['res', 'res_w'])

@@ -922,87 +922,3 @@ def test_head_that_knows_its_cost_is_bit_identical(gpu, monkeypatch, dataset, mo
     assert all(np.isfinite(v) for v in finals[1][1].values())
     for k in finals[0][0]:
         assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
-
-
-def test_paired_nets_pass_continues_the_same_step_sequence(gpu):
-    """engine.Trainer(pair_nets=True) (round 4, opt-in): the Extractor / Generator passes of critic step `it` and of generator step
-    `it + 1` -- which read the same weights -- evaluated once on 2B rows (functional.Replay: recorded without a tape, the generator
-    step's rows attached to it afterwards; BatchNorm statistics per group of B rows; the noise of both steps from one launch with each
-    step's own draw number).  The flattened step sequence d0 g1 d1 g2 ... is the unpaired one: the first paired critic step and the
-    generator step behind it reproduce the unpaired path's costs (same weights, same minibatches, same noise; different launch shapes,
-    so to fp32 rounding), and a few iterations on the weights have moved by the same updates."""
-    import torch
-    from graphical_gan_amd import tflib as lib, optim
-    from graphical_gan_amd.engine import Trainer
-    from graphical_gan_amd.models import Config
-
-    def run(pair):
-        optim.reset_optimizers(); lib.delete_all_params()
-        np.random.seed(0); torch.manual_seed(1234)
-        tr = Trainer(Config('cifar10', batch_size=16, dim=16, dim_latent=32), device=gpu, graph=True, seed=1234, pair_nets=pair)
-        ring = tr.model.synthetic_ring(gpu, n=8, seed=1234)
-        bi = iter(ring * 10)
-        tr.iteration(0, bi); tr.iteration(1, bi)
-        P1 = tr.get_params()
-        tr.use_ring(ring)
-        costs = [{k: float(v) for k, v in tr.iteration(it, None).items()} for it in (2, 3, 4)]
-        if not pair:
-            tr.step('gen')             # the paired grouping ends one generator step later in the sequence
-        torch.cuda.synchronize()
-        return P1, tr.get_params(), costs, tr
-
-    P1, Pa, ca, _ = run(False)
-    _, Pb, cb, trb = run(True)
-    assert trb._iter_graph['kinds'] == ('pair',)
-    # unpaired iteration it = (g_it, d_it); paired iteration it = (d_it, g_it+1)
-    assert abs(cb[0]['disc_cost'] - ca[0]['disc_cost']) <= 2e-6 * max(1.0, abs(ca[0]['disc_cost']))
-    assert abs(cb[0]['gen_cost'] - ca[1]['gen_cost']) <= 2e-5 * max(1.0, abs(ca[1]['gen_cost']))
-    assert abs(cb[1]['disc_cost'] - ca[1]['disc_cost']) <= 1e-4 * max(1.0, abs(ca[1]['disc_cost']))
-    for n in Pa:
-        if n.endswith('.moving_mean') or n.endswith('.moving_variance') or n.endswith('.b') or n.endswith('.Biases'):
-            continue
-        upd = np.linalg.norm(Pa[n] - P1[n])
-        assert np.linalg.norm(Pa[n] - Pb[n]) <= 0.05 * upd + 1e-6, (n, np.linalg.norm(Pa[n] - Pb[n]), upd)
-    optim.reset_optimizers(); lib.delete_all_params()
-
-
-@pytest.mark.parametrize('dataset,mode', [('cifar10', 'ali'), ('cifar10', 'local_ep')])
-def test_critic_tail_updated_beside_the_conv_backward_is_bit_identical(gpu, monkeypatch, dataset, mode):
-    """engine.Trainer._disc_early_tail: in a single-replica step graph the critic's tail parameters (most of the critic) take their
-    pack + Adam launch on the second stream as soon as the head's backward produced their gradients, the conv stack's follow at the
-    end of the step (AdamOptimizer.pack_update_subset: ggan_pack_adam with arrive = NULL leaves the step counter alone).  Same
-    arithmetic per parameter => bit-identical weights, Adam moments and step counts."""
-    import torch
-    from graphical_gan_amd import _lib
-    from graphical_gan_amd.models import Config
-    from graphical_gan_amd.engine import Trainer
-    finals, partial = [], []
-    for early in (False, True):
-        monkeypatch.setenv('GGAN_EARLY_TAIL_UPDATE', '1' if early else '0')
-        _fresh()
-        np.random.seed(0)
-        cfg = Config(dataset, batch_size=16, n_coms=10 if mode == 'local_ep' else 0, mode=mode, dim=16, dim_latent=32)
-        tr = Trainer(cfg, device=gpu, graph=True, seed=4321)
-        batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 40)
-        lib_, calls = _lib.load(), []
-        entry = lib_.ggan_pack_adam
-
-        def counted(*args):
-            calls.append(bool(args[14]))           # arrive pointer: None / 0 = a partial update
-            return entry(*args)
-        monkeypatch.setattr(lib_, 'ggan_pack_adam', counted)
-        for it in range(6):
-            res = tr.iteration(it, batches)
-        monkeypatch.setattr(lib_, 'ggan_pack_adam', entry)
-        tr.flush()
-        torch.cuda.synchronize()
-        partial.append(sum(1 for c in calls if not c))
-        opts = tr._optimizers()
-        finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()},
-                       [(o.m.cpu().numpy().copy(), o.v.cpu().numpy().copy(), int(o.step)) for o in opts]))
-    assert partial[0] == 0 and partial[1] > 0
-    assert finals[0][1] == finals[1][1]
-    for k in finals[0][0]:
-        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
-    for a, b in zip(finals[0][2], finals[1][2]):
-        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

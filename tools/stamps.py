@@ -22,6 +22,7 @@ st.zero_(); torch.cuda.synchronize()
 fn(); torch.cuda.synchronize()
 a = st.cpu().numpy().reshape(-1, 16)
 a = a[a[:, 0] != 0]
+a = a[np.abs(a[:, 0] - np.median(a[:, 0])) < 10_000_000]      # (rows left over from another launch's stamps)
 print(op, sys.argv[2:] , 'workgroups', len(a))
 t0 = a[:, 0].min()
 names = ['start', 'descr', 'commit0', 'bar0'] + ['chunk%d' % i for i in range(8)] + ['loop_end', 'reduced', 'stored', 'x15']
@@ -32,4 +33,12 @@ for i, nme in enumerate(names):
     if not ok.any() or i == 0: continue
     rel = col[ok] - a[ok, 0]
     print('%-9s since WG start: median %7d  max %7d' % (nme, np.median(rel), rel.max()))
-print('kernel span (last store - first start): %d ticks' % (a[:, 14].max() - t0))
+print('kernel span (last store - first start): %d ticks; WG duration median %d' % (a[:, 14].max() - t0, np.median(a[:, 14] - a[:, 0])))
+# wall-clock of the same launch (HIP events) -> shader clock during the kernel
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+os.environ['GGAN_DBG'] = '0'
+for _ in range(3): fn()
+torch.cuda.synchronize(); e0.record()
+for _ in range(20): fn()
+e1.record(); torch.cuda.synchronize()
+print('launch wall %.2f us (back to back, no stamps)' % (e0.elapsed_time(e1) * 1e3 / 20))
