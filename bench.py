@@ -1,14 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of the Graphical-GAN training iteration on N MI355X GPUs (one process per GPU).
 
-A "step" is one iteration of the reference loop (gmgan_inference_cifar10.py:480-494): one generator+extractor
-session.run followed by CRITIC_ITERS critic session.runs, each on a fresh synthetic minibatch + fresh noise,
-each including forward, backward and the TF-Adam update.  Headline workload: BASELINE.json configs[1],
-gan_inference_cifar10.py (32x32x3, BATCH_SIZE=64, MODE='ali' = "G+D"); per-GPU batch stays 64 as N grows (weak scaling).
+A "step" is one iteration of the reference loop (gan_inference_cifar10.py:480-494): one generator+extractor session.run followed by
+CRITIC_ITERS critic session.runs, each on a fresh synthetic minibatch + fresh noise, each including forward, backward and the TF-Adam
+update.  Headline workload = BASELINE.json's metric, "images/sec (G+D+GP step) CIFAR-10 32x32 bs=64": BASELINE configs[1],
+gan_inference_cifar10.py (32x32x3, BATCH_SIZE=64) with the one MODE of that script that has a gradient penalty, MODE='wali-gp'
+(CRITIC_ITERS=5, Adam 1e-4 / .5 / .9, LAMBDA=10: gan_inference_cifar10.py:57,351-366) -- so an iteration is 1 generator step + 5 critic
+steps, each critic step with the penalty's double backward, and consumes 6 minibatches; `value` counts BATCH_SIZE images per iteration
+as the reference's own iteration counter does.  Per-GPU batch stays 64 as N grows (weak scaling).
 
 The one JSON line also carries `variants`: the other BASELINE configurations measured in the same process, each with its
 own ms_per_step, algorithmic GFLOP, roofline (dominant kernel) and cpu_baseline:
-  wali-gp            gan_inference_cifar10.py MODE='wali-gp' ("G+D+GP", CRITIC_ITERS=5, gan_inference_cifar10.py:351-366)
+  ali                gan_inference_cifar10.py at the script's default MODE='ali' ("G+D", CRITIC_ITERS=1: the headline of rounds 1-4)
   gmgan-cifar10-K30  gmgan_inference_cifar10.py with the script's N_COMS=30;  gmgan-cifar10-K10: BASELINE configs[2] (K=10)
   gan-face           gan_inference_face.py 64x64x3 bs=64 (configs[3])
   ssgan-moving-mnist ssgan_inference_moving_mnist.py 64x64 T=16 bs=32 (configs[4])
@@ -30,7 +33,7 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 VARIANTS = [
-    dict(key='wali-gp', dataset='cifar10', mode='wali-gp'),
+    dict(key='ali', dataset='cifar10', mode='ali'),
     dict(key='gmgan-cifar10-K30', dataset='cifar10', mode='local_ep', n_coms=30),
     dict(key='gmgan-cifar10-K10', dataset='cifar10', mode='local_ep', n_coms=10),
     dict(key='gan-face', dataset='face', mode='ali'),
@@ -127,8 +130,9 @@ def ssgan_gflop_per_iteration(cfg):
 
 
 def _pmc_table(workload_key):
-    """HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same workload,
-    committed by tools/prof_round.sh; counters cannot be read from inside the process.  -> (kernel -> record, tag)"""
+    """Static figures that cannot be read from inside the process: per (kernel, grid) the duration inside the graph-replayed step
+    (rocprofv3 --kernel-trace) and the counters of separate rocprofv3 --pmc passes of the same workload, written by tools/prof_round.sh /
+    tools/collect_profiles.py into profiles/pmc_traffic.json.  -> (kernel -> {'by_grid': {grid: record}, ...}, tag)"""
     try:
         tab = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
     except (OSError, ValueError):
@@ -136,11 +140,8 @@ def _pmc_table(workload_key):
     tag = tab.get('_tag')
     if workload_key == 'gmgan-cifar10-K30' and workload_key not in tab:      # (profiled at K = 10: the same kernels and launch shapes but the mixture size)
         workload_key = 'gmgan-cifar10-K10'
-    if workload_key in tab and isinstance(tab[workload_key], dict) and 'traffic_bytes' not in tab[workload_key]:
-        return tab[workload_key], tag
-    if workload_key == 'headline' and '_tag' not in tab:      # round-1 layout: kernel -> record of the headline workload
-        return tab, 'r01l'
-    return {}, tag
+    w = tab.get(workload_key)
+    return (w, tag) if isinstance(w, dict) else ({}, tag)
 
 
 def cpu_baseline(spec, cfg, K, np, torch, budget_s=float(os.environ.get('GGAN_BENCH_CPU_BUDGET_S', '3'))):
@@ -344,51 +345,89 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
         recs = _lib.prof_report() if rank == 0 else []
         L.ggan_prof_reset()
     if rank == 0 and not args.no_kernel_profile:
-        recs.sort(key=lambda r: -r['total_ms'])
-        kernels = [dict(name=r['name'], launches_per_iter=r['launches'] / n_prof,
-                        ms_per_iter=round(r['total_ms'] / n_prof, 4),
-                        avg_us=round(1e3 * r['total_ms'] / r['launches'], 2),
-                        tflops=round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 2) if r['flops'] else None)
-                   for r in recs]
-        launches_per_iter = sum(r['launches'] for r in recs) / n_prof
-        dom = next((r for r in recs if r['flops'] > 0), None)
+        # libggan's profiler keeps one record per (kernel, grid): a kernel a step launches on two problem sizes is two rows, and the
+        # kernel-level figures below are SUMS over its rows -- flops, bytes and time of the same launches, so every ratio of them
+        # describes the same launch mix (the mix of the timed graph: eager replay on its launch plan)
+        byname = {}
+        for r in recs:
+            a = byname.setdefault(r['name'], dict(name=r['name'], total_ms=0.0, launches=0, flops=0.0, bytes=0.0, rows=[]))
+            for k in ('total_ms', 'launches', 'flops', 'bytes'):
+                a[k] += r[k]
+            a['rows'].append(r)
+        agg = sorted(byname.values(), key=lambda r: -r['total_ms'])
+        tab, tag = _pmc_table(spec.get('key', 'headline'))
+
+        def rows_of(a):
+            """per-grid rows of one kernel: live eager-bracket figures next to the static in-graph / counter figures of the same grid"""
+            st = (tab.get(a['name']) or {}).get('by_grid') or {}
+            out = []
+            for r in sorted(a['rows'], key=lambda r: r['grid']):
+                g = st.get(str(r['grid'])) or {}
+                out.append(dict(grid=r['grid'], launches_per_step=r['launches'] / n_prof,
+                                flop_per_launch=r['flops'] / r['launches'], algorithmic_bytes=round(r['bytes'] / r['launches']),
+                                avg_us=round(1e3 * r['total_ms'] / r['launches'], 2), avg_us_in_graph=g.get('avg_us_in_graph'),
+                                traffic=g.get('traffic_bytes'), mfma_util_pct=g.get('mfma_util_pct')))
+            return out
+
+        def mixed(rows, field, weight='launches_per_step'):
+            """a static per-grid figure weighted by the LIVE launch mix (None unless every launched grid has the figure)"""
+            if not rows or any(r[field] is None for r in rows):
+                return None
+            return sum(r[weight] * r[field] for r in rows) / sum(r[weight] for r in rows)
+        kernels = [dict(name=a['name'], launches_per_iter=a['launches'] / n_prof, ms_per_iter=round(a['total_ms'] / n_prof, 4),
+                        avg_us=round(1e3 * a['total_ms'] / a['launches'], 2),
+                        tflops=round(a['flops'] / (a['total_ms'] * 1e-3) / 1e12, 2) if a['flops'] else None,
+                        grids=[dict(grid=r['grid'], launches_per_iter=r['launches'] / n_prof, avg_us=round(1e3 * r['total_ms'] / r['launches'], 2))
+                               for r in sorted(a['rows'], key=lambda r: r['grid'])]) for a in agg]
+        launches_per_iter = sum(a['launches'] for a in agg) / n_prof
+        dom = next((a for a in agg if a['flops'] > 0), None)
         if dom is not None:
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-            tab, tag = _pmc_table(spec.get('key', 'headline'))
-            pmc = tab.get(dom['name'])
+            rows = rows_of(dom)
             avg_us = 1e3 * dom['total_ms'] / dom['launches']
             fpl = dom['flops'] / dom['launches']
-            ig_us = (pmc or {}).get('avg_us_in_graph')          # rocprofv3 --kernel-trace of the graph-replayed step, same workload
+            ig_us = mixed(rows, 'avg_us_in_graph')
+            traffic = mixed(rows, 'traffic')
+            # counter MFMA utilisation of the kernel = its rows weighted by the TIME each contributes
+            for r in rows:
+                r['_t'] = r['launches_per_step'] * (r['avg_us_in_graph'] or r['avg_us'])
+            util = mixed(rows, 'mfma_util_pct', '_t')
+            for r in rows:
+                del r['_t']
             roofline = dict(bound='mfma', kernel=dom['name'], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
                             unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                             frac_eager=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                             frac_in_graph=round(fpl / (ig_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if ig_us else None,
-                            avg_launch_us=round(avg_us, 2), avg_launch_us_in_graph=ig_us,
+                            avg_launch_us=round(avg_us, 2), avg_launch_us_in_graph=round(ig_us, 2) if ig_us else None,
                             flop_per_launch=fpl,
-                            traffic=pmc['traffic_bytes'] if pmc else None,
-                            algorithmic_bytes=round(dom['bytes'] / dom['launches']) if dom.get('bytes') else None,
-                            mfma_util_pct=(pmc or {}).get('mfma_util_pct'),
-                            static_tag=tag if pmc else None,
-                            source='achieved / frac / frac_eager: HIP-event bracket around every launch of this kernel on the stream it is launched '
-                                   'on, eager replay of the same step ON THE LAUNCH PLAN OF THE TIMED GRAPH (two-stream nets pass, 128-workgroup '
-                                   'plans of side-by-side chains) in this process (%d iterations); frac_in_graph, traffic, '
-                                   'mfma_util_pct: static, profiles/pmc_traffic.json @%s (rocprofv3 --kernel-trace of the graph-replayed '
-                                   'step and separate --pmc passes of this workload, per launch; FETCH_SIZE corrected per staging '
-                                   'path, tools/pmc_summary.py)' % (n_prof, tag),
-                            pmc=pmc,
+                            traffic=round(traffic) if traffic else None,
+                            algorithmic_bytes=round(dom['bytes'] / dom['launches']) if dom['bytes'] else None,
+                            mfma_util_pct=round(util, 2) if util is not None else None,
+                            launch_mix=rows,
+                            static_tag=tag if (tab.get(dom['name']) is not None) else None,
+                            source='achieved / frac / frac_eager / avg_launch_us: HIP-event bracket around every launch of this kernel on the stream it '
+                                   'is launched on, eager replay of the same step ON THE LAUNCH PLAN OF THE TIMED GRAPH (two-stream nets pass, '
+                                   '128-workgroup plans of side-by-side chains) in this process (%d iterations); flop_per_launch and '
+                                   'algorithmic_bytes: sums over the same launches / their number; launch_mix: one row per grid size (work-items); '
+                                   'avg_launch_us_in_graph, frac_in_graph, traffic, mfma_util_pct: per-grid figures of profiles/pmc_traffic.json @%s '
+                                   '(rocprofv3 --kernel-trace of the graph-replayed step, separate --pmc passes; FETCH_SIZE x 2, WRITE_SIZE as counted: '
+                                   'tools/pmc_summary.py) weighted by the launch mix measured HERE' % (n_prof, tag),
                             whole_step_tflops=round(step_tflops, 2),
                             whole_step_frac=round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                             libggan_launches_per_step=launches_per_iter)
             # the conv stack as a whole (north star: "MFMA utilisation on the Conv2D / Deconv2D stack"): counter MFMA utilisation of every
-            # MFMA conv kernel (static table, median per dispatch) weighted by the kernel time measured here
+            # MFMA conv kernel (static per-grid table, median per dispatch) weighted by the kernel time measured here
             cw = ca = 0.0
-            for r in recs:
-                if r['name'].startswith(('corr_kernel', 'wgrad_kernel', 'conv3d_igemm')) and (tab.get(r['name']) or {}).get('mfma_util_pct') is not None:
-                    cw += r['total_ms']
-                    ca += r['total_ms'] * tab[r['name']]['mfma_util_pct']
+            for a in agg:
+                if not a['name'].startswith(('corr_kernel', 'wgrad_kernel', 'wgrad4_kernel', 'dg16_kernel', 'conv3d_igemm')):
+                    continue
+                for r, row in zip(sorted(a['rows'], key=lambda r: r['grid']), rows_of(a)):
+                    if row['mfma_util_pct'] is not None:
+                        cw += r['total_ms']
+                        ca += r['total_ms'] * row['mfma_util_pct']
             if cw > 0:
                 roofline['conv_stack_mfma_util_pct'] = round(ca / cw, 1)
-                roofline['conv_stack_share_of_kernel_time'] = round(cw / sum(r['total_ms'] for r in recs), 3)
+                roofline['conv_stack_share_of_kernel_time'] = round(cw / sum(a['total_ms'] for a in agg), 3)
     if world > 1:
         dist.barrier()
 
@@ -495,13 +534,16 @@ def supervise():
     return 1
 
 
-DIAG_ENV = ('GGAN_SKIP_KERNELS', 'GGAN_SKIP_ALLREDUCE', 'GGAN_TARGET_WGS', 'GGAN_WGRAD_WGS', 'GGAN_DBG', 'GGAN_DG16', 'GGAN_DG16_KQ',
-            'GGAN_DG16_FORCE', 'GGAN_FWD_CFG', 'GGAN_DGRAD_CFG', 'GGAN_FWD_SK', 'GGAN_DGRAD_SK', 'GGAN_WGRAD_SK', 'GGAN_DGRAD_MODE')
+# environment switches that do NOT change what a step launches (bookkeeping of the benchmark itself, rendezvous, tracing to stderr);
+# every other GGAN_* variable that is set is a diagnostic switch of libggan / the engine and is stamped into the line
+BENIGN_ENV = ('GGAN_DIST_BACKEND', 'GGAN_DP_GRAPH', 'GGAN_NO_DIRECT_RCCL', 'GGAN_FORCE_ALLREDUCE', 'GGAN_TRACE_LAUNCHES', 'GGAN_TRACE_NAIVE',
+              'GGAN_TRACE_CONV', 'GGAN_BUILD_DIAG', 'GGAN_CAPTURE_MODE', 'GGAN_TEST_REPORT')
 
 
 def diag_env():
     """diagnostic switches of libggan / the engine that change what is launched: a line measured with any of them set says so"""
-    return sorted(k for k in DIAG_ENV if os.environ.get(k) not in (None, ''))
+    return sorted(k for k, v in os.environ.items()
+                  if k.startswith('GGAN_') and not k.startswith('GGAN_BENCH_') and k not in BENIGN_ENV and v not in (None, ''))
 
 
 def self_launch(args):
@@ -510,10 +552,16 @@ def self_launch(args):
     arguments -- pass their output through and keep the contract line the last line of stdout."""
     import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    port = max(20000, min(port, 60000))                  # (bench children use MASTER_PORT + 1 + attempt)
+    def free(p):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            try:
+                sk.bind(('127.0.0.1', p))
+            except OSError:
+                return None
+            return sk.getsockname()[1]
+    port = free(0)
+    if not (20000 <= port <= 60000 and free(port + 1) and free(port + 2)):      # (bench children use MASTER_PORT + 1 + attempt)
+        port = next((p for p in range(29600, 60000, 7) if free(p) and free(p + 1) and free(p + 2)), port)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), GGAN_BENCH_SELF_LAUNCHED='1')
@@ -569,9 +617,9 @@ def compact_line(full):
                        frac_in_graph=r.get('frac_in_graph'), conv_mfma_util=r.get('conv_stack_mfma_util_pct'), cpu=(v.get('cpu_baseline') or {}).get('value'),
                        finite=(v.get('config') or {}).get('finite_costs')))
     line['variants'] = vs
-    gp = next((v for v in vs if v['key'] == 'wali-gp'), None)
-    if gp is not None:          # BASELINE.json's metric string names the "G+D+GP step": the same script with MODE wali-gp (CRITIC_ITERS 5)
-        line['g_d_gp_step'] = dict(value=gp['value'], unit=gp['unit'], ms_per_step=gp['ms_per_step'], whole_step_frac=gp['whole_step_frac'])
+    gd = next((v for v in vs if v['key'] == 'ali'), None)
+    if gd is not None:          # the same script at its default MODE='ali' (CRITIC_ITERS 1, no penalty): the "G+D step", headline of rounds 1-4
+        line['g_d_step'] = dict(value=gd['value'], unit=gd['unit'], ms_per_step=gd['ms_per_step'], whole_step_frac=gd['whole_step_frac'])
     line['full_record'] = full.get('_full_path')
     if full.get('diag_env'):
         line['diag_env'] = full['diag_env']
@@ -583,7 +631,7 @@ def compact_line(full):
         if line.get('roofline'):
             line['roofline'].pop('source', None)
         txt = json.dumps(line, separators=(',', ':'))
-    for drop in ('variants', 'data_parallel', 'g_d_gp_step', 'cpu_baseline', 'roofline', 'config'):
+    for drop in ('variants', 'data_parallel', 'g_d_step', 'cpu_baseline', 'roofline', 'config'):
         if len(txt) < LINE_LIMIT:
             break
         if drop == 'cpu_baseline' and line.get(drop):
@@ -629,7 +677,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--dataset', default='cifar10')
-    ap.add_argument('--mode', default='ali', help="ali | wali-gp | local_ep (gmgan, N_COMS=30)")
+    ap.add_argument('--mode', default='wali-gp', help="wali-gp (the BASELINE metric's G+D+GP step) | ali | local_ep (gmgan, N_COMS=30) | ...")
     ap.add_argument('--ssgan-mode', default='local_ep', help="moving_mnist / chairs: local_ep | local_epce-z | ali | alice-z, optionally "
                     "':concat_x' | ':concat_z' | ':3dcnn' (the sequence critic of ali / alice-z)")
     ap.add_argument('--n-coms', type=int, default=None, help='mixture components of the gmgan prior (default: the script value, 30 / 50 / 100)')
@@ -689,7 +737,7 @@ def main():
     out = run_workload(head_spec, args, env, args.steps, args.warmup)
 
     # the other BASELINE configurations, same process, same measurement (only next to the default headline workload)
-    default_head = args.dataset == 'cifar10' and args.mode == 'ali' and args.batch_size is None and not args.host_feed
+    default_head = args.dataset == 'cifar10' and args.mode == 'wali-gp' and args.batch_size is None and not args.host_feed
     variants = []
     if not args.no_variants and (default_head or args.variants):
         want = [k.strip() for k in args.variants.split(',')] if args.variants else [v['key'] for v in VARIANTS]

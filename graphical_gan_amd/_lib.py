@@ -14,6 +14,7 @@ HEAD_BCE_MAX_ROWS = 2048             # include/ggan.h: GGAN_HEAD_BCE_MAX_ROWS
 BCE_HEADS = 2                        # include/ggan.h: GGAN_BCE_HEADS
 PACK_ARRIVE_INTS = 33 * 1024          # include/ggan.h: GGAN_PACK_ARRIVE_INTS (arrival counters of ggan_pack_adam)
 BCE_MAX = 16
+ABI_VERSION = 500                    # include/ggan.h: GGAN_ABI_VERSION (struct layouts and entry points this module binds)
 
 
 class ConvGeom(C.Structure):
@@ -26,7 +27,7 @@ PLAN_PLAIN = 1
 
 class ProfRec(C.Structure):
     _fields_ = [('name', C.c_char * 48), ('total_ms', C.c_double), ('launches', C.c_long),
-                ('flops', C.c_double), ('bytes', C.c_double)]
+                ('flops', C.c_double), ('bytes', C.c_double), ('grid', C.c_long)]
 
 
 class GganError(RuntimeError):
@@ -158,6 +159,9 @@ def load():
             raise GganError('libggan.so does not export %s' % name)
         fn.restype = res
         fn.argtypes = args
+    if lib.ggan_version() != ABI_VERSION:
+        raise GganError('libggan.so speaks ABI version %d, this binding %d: a stale build -- run `python -c "import __graft_entry__ as g; g.build()"`'
+                        % (lib.ggan_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -176,5 +180,5 @@ def prof_report(cap=256):
     for i in range(n):
         r = recs[i]
         out.append(dict(name=r.name.decode(), total_ms=r.total_ms, launches=int(r.launches),
-                        flops=r.flops, bytes=r.bytes))
+                        flops=r.flops, bytes=r.bytes, grid=int(r.grid)))
     return out

@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...);
 
 // ---- per-kernel profiling ---------------------------------------------------------------------
 struct ProfScope {
-    ProfScope(const char* name, hipStream_t s, double flops, double bytes);
+    ProfScope(const char* name, hipStream_t s, double flops, double bytes, long grid);
     ~ProfScope();
     hipStream_t s_;
     int idx_;
@@ -46,12 +46,14 @@ void trace_launch(const char* name, dim3 grid, dim3 block, size_t shmem, double 
     do {                                                                                    \
         if (GGAN_LAUNCH_SKIPPED(name)) break;                                               \
         ggan::trace_launch(name, grid, block, shmem, (double)(flops));                      \
-        ggan::ProfScope _ps(name, stream, (double)(flops), (double)(bytes));              \
+        ggan::ProfScope _ps(name, stream, (double)(flops), (double)(bytes), ggan::grid_wgs(grid) * ggan::grid_wgs(block)); \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
     } while (0);                                                                            \
     if (ggan::check_launch(name)) return -2
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long grid_wgs(dim3 g) { return (long)g.x * g.y * g.z; }
+static inline long grid_wgs(long g) { return g; }
 
 // Workspace convention (include/ggan.h): the first GGAN_WS_RESERVED bytes of every caller workspace are arrival counters
 // for in-kernel split-K combines.  They must be zero before the first call and every kernel leaves them zero.

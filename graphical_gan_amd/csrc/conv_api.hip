@@ -15,6 +15,12 @@ int check_geom(const ggan_conv_geom* g) {
                   g->W, g->Co, g->Ho, g->Wo, g->k, g->stride, g->pad_t, g->pad_l);
         return -1;
     }
+    // the launch plan travels in the struct (ABI 500): a caller that hands over the shorter pre-plan struct leaves garbage here
+    if ((g->plan_flags & ~GGAN_PLAN_PLAIN) || g->plan_wgs < 0 || g->plan_wgs > 65536 || g->plan_wgs_filter < 0 || g->plan_wgs_filter > 65536) {
+        set_error("conv geometry: launch plan fields out of range (plan_wgs=%d plan_wgs_filter=%d plan_flags=%d): struct built against "
+                  "an older ggan.h? (GGAN_ABI_VERSION %d)", g->plan_wgs, g->plan_wgs_filter, g->plan_flags, GGAN_ABI_VERSION);
+        return -1;
+    }
     // the last window must start inside the padded input
     if ((g->Ho - 1) * g->stride - g->pad_t >= g->H || (g->Wo - 1) * g->stride - g->pad_l >= g->W) {
         set_error("conv geometry: output grid larger than the input allows");

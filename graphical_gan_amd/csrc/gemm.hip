@@ -761,7 +761,12 @@ size_t ggan_gemm_workspace(int M, int N, int K) {
 
 // Fill the parameter block of one product (operand views, float4 legality, split-K choice, FAST path); no launch.
 // mode 0: normal (split-K result reduced by the caller)   1: no split-K (grouped launches, fused column sums)
-int g_split_target = 256;      // workgroups a split-K product aims at (the critic head's forward may ask for more)
+constexpr int kSplitTarget = 256;     // workgroups a split-K product aims at (the critic head's forward asks for more: split_target)
+
+static int head_split_target() {
+    static const int v = [] { const char* e = getenv("GGAN_HEAD_WGS"); return e ? atoi(e) : 512; }();
+    return v;
+}
 
 struct GemmPlan {
     GemmParams P;
@@ -772,7 +777,7 @@ struct GemmPlan {
 static int gemm_plan(GemmPlan& G, int mode, int ta, int tb, int M, int N, int K, const float* A, const float* B, const float* bias,
                      float* C, float* colsum, int act, float alpha, void* ws, size_t ws_bytes, const float* a_ref = nullptr,
                      const float* b_ref = nullptr, int ref_act = 0, float ref_alpha = 0.f, const float* A2 = nullptr,
-                     int a_split = 0, float* C2 = nullptr, int c_split = 0) {
+                     int a_split = 0, float* C2 = nullptr, int c_split = 0, int split_target = kSplitTarget) {
     GemmParams& P = G.P;
     memset(&P, 0, sizeof(P));
     P.a_ref = a_ref; P.b_ref = b_ref; P.ref_act = ref_act; P.ref_alpha = ref_alpha;
@@ -811,10 +816,10 @@ static int gemm_plan(GemmPlan& G, int mode, int ta, int tb, int M, int N, int K,
             // (long reductions -- the Conv3D patch-matrix filter gradients, K = 10^4..10^6 rows: four workgroups per CU and up to
             // 256 slabs, so each workgroup's serial chain stays ~10^3 rows)
             const bool tall = K >= 16384;
-            sk = (tall ? 1024 : g_split_target) / base;
+            sk = (tall ? 1024 : split_target) / base;
             const int max_sk = K / BK;
             if (sk > max_sk) sk = max_sk;
-            if (sk > (tall ? 256 : g_split_target / 4)) sk = tall ? 256 : g_split_target / 4;
+            if (sk > (tall ? 256 : split_target / 4)) sk = tall ? 256 : split_target / 4;
             // short reductions over a grid that already covers a good part of the chip (the weight gradients of the batch-64
             // layers): the extra reduce launch costs more than it spreads (5.4 vs 8.4 us measured at 512x512x64)
             if (K <= 128 && base >= 32) sk = 1;
@@ -950,10 +955,8 @@ int ggan_critic_head_fwd(int M, int K1, int K2, int H, const float* a1, const fl
     GemmPlan G;
     // (twice the workgroups of the other split products: the tail kernel below sums the slabs anyway, and this product sits alone on
     //  the step's critical chain -- 9 serial k-steps per workgroup at 256, 5 at 512: 1.127 -> 1.122 ms; 1024: slower again)
-    { const char* e = getenv("GGAN_HEAD_WGS"); g_split_target = e ? atoi(e) : 512; }
     int rc = gemm_plan(G, 0, 0, 0, M, H, K1 + K2, a1, w, nullptr, h, nullptr, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
-                       K2 ? a2 : nullptr, K2 ? K1 : 0);
-    g_split_target = 256;
+                       K2 ? a2 : nullptr, K2 ? K1 : 0, nullptr, 0, head_split_target());
     if (rc) return rc;
     rc = gemm_launch_planned(G, 0, 0, s);
     if (rc) return rc;
@@ -993,10 +996,8 @@ int ggan_critic_head_fwd_bce(int M, int K1, int K2, int H, const float* a1, cons
     GGAN_CHECK_ARG(head_terms(T, M, kind, nterms, term_rows, labels, weights, nullptr) == 0, "terms must be 1..4 row ranges covering the M rows");
     hipStream_t s = (hipStream_t)stream;
     GemmPlan G;
-    { const char* e = getenv("GGAN_HEAD_WGS"); g_split_target = e ? atoi(e) : 512; }
     int rc = gemm_plan(G, 0, 0, 0, M, H, K1 + K2, a1, w, nullptr, h, nullptr, GGAN_ACT_NONE, 0.f, ws, ws_bytes, nullptr, nullptr, 0, 0.f,
-                       K2 ? a2 : nullptr, K2 ? K1 : 0);
-    g_split_target = 256;
+                       K2 ? a2 : nullptr, K2 ? K1 : 0, nullptr, 0, head_split_target());
     if (rc) return rc;
     rc = gemm_launch_planned(G, 0, 0, s);
     if (rc) return rc;

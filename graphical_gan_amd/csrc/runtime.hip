@@ -69,17 +69,19 @@ struct ProfEntry {
     const char* name;
     hipEvent_t a, b;
     double flops, bytes;
+    long grid;
 };
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
 static std::vector<ProfEntry> g_prof;
 
-ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes) : s_(s), idx_(-1) {
+ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes, long grid) : s_(s), idx_(-1) {
     if (!g_prof_on) return;
     ProfEntry e;
     e.name = name;
     e.flops = flops;
     e.bytes = bytes;
+    e.grid = grid;
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
     (void)hipEventRecord(e.a, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -99,7 +101,7 @@ using namespace ggan;
 
 extern "C" {
 
-int ggan_version(void) { return 100; }
+int ggan_version(void) { return GGAN_ABI_VERSION; }
 const char* ggan_last_error(void) { return t_err; }
 int ggan_prof_enable(int on) {
     g_prof_on = on != 0;
@@ -125,11 +127,12 @@ int ggan_prof_report(ggan_prof_rec* out, int cap) {
         if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
         int j = 0;
         for (; j < n; ++j)
-            if (strncmp(out[j].name, e.name, sizeof(out[j].name) - 1) == 0) break;
+            if (out[j].grid == e.grid && strncmp(out[j].name, e.name, sizeof(out[j].name) - 1) == 0) break;
         if (j == n) {
             if (n >= cap) continue;
             memset(&out[n], 0, sizeof(out[n]));
             strncpy(out[n].name, e.name, sizeof(out[n].name) - 1);
+            out[n].grid = e.grid;
             ++n;
         }
         out[j].total_ms += ms;

@@ -121,7 +121,7 @@ class Trainer(object):
         if self.sync_bn:
             lib.ops.batchnorm.set_sync_group(True)
             if self.comm is not None:
-                rccl.get_stats(self.device)   # (collective: the statistics exchange's own communicator, functional._all_gather_rows)
+                rccl.get_stats(self.device)   # (the communicator goes serial: statistics gathers and gradient buckets in one order, functional._all_gather_rows)
             if self.comm is None:       # the statistics exchange is a host-issued collective inside the passes: eager steps.  With the
                 self.graph_enabled = False   # direct communicator it is an enqueue on the step's stream and is captured like a kernel
             if hasattr(self.model, 'fork_nets'):

@@ -1271,8 +1271,8 @@ def _all_gather_rows(t, group):
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     from . import rccl
-    # (the statistics travel on a communicator of their own, created by Trainer(sync_bn=True): the gradient buckets may be in flight on
-    #  the first one's stream at the same time, and one communicator's operations must stay on one stream)
+    # (rccl.get_stats, called by Trainer(sync_bn=True): the gradient buckets' communicator in serial mode -- this gather waits for a bucket
+    #  that is still on the wire on the communicator's stream, and the next bucket waits for it)
     comm = rccl._STATS[0] if (t.is_cuda and (group is None or group is dist.group.WORLD)) else None
     if comm is not None:             # an enqueue on the current stream (capturable: cross-replica BatchNorm inside a step graph)
         return comm.all_gather(out, t.contiguous())
@@ -1387,6 +1387,7 @@ class Fanout(Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)      # (an alias nobody differentiates contributes None, not a zero tensor + an addition launch)
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod

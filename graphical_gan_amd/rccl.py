@@ -101,6 +101,7 @@ class Communicator(object):
         # the exchanges run on a stream of their own: forked from the issuing stream, joined by Work.wait() -- inside a capture this is
         # a parallel branch of the step graph, so the backward pass that follows the pack keeps running while the bucket is on the wire
         self.stream = torch.cuda.Stream(device=self.device)
+        self.serial = False          # get_stats(): every operation goes through self.stream, an in-order queue
 
     def _enqueue(self, fn, stream):
         with torch.cuda.device(self.device):
@@ -131,9 +132,17 @@ class Communicator(object):
         assert out.is_cuda and row.is_cuda and out.dtype == row.dtype == torch.float32 and out.is_contiguous() and row.is_contiguous()
         assert out.numel() == self.world * row.numel()
         L = _lib()
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        # serial mode (cross-replica BatchNorm): through the communicator's own stream, forked from and joined to the current one -- behind
+        # whatever bucket is still on the wire there, and the next bucket behind it: ONE in-order queue for the communicator
+        s = stream if stream is not None else (self.stream if self.serial else cur)
+        via = s.cuda_stream != cur.cuda_stream
+        if via:
+            s.wait_stream(cur)
         self._enqueue(lambda st: L.ncclAllGather(C.c_void_p(row.data_ptr()), C.c_void_p(out.data_ptr()), row.numel(), ncclFloat32,
                                                  self._comm, st), s)
+        if via:
+            cur.wait_stream(s)
         return out
 
     def count(self):
@@ -154,26 +163,18 @@ _FAILED = [False]      # creation was tried and refused: do not retry (every ret
 
 
 def get_stats(device=None):
-    """A SECOND communicator for the cross-replica BatchNorm statistics (all-gathers on the step's own stream): the gradient buckets
-    travel on the first one's stream at the same time (two-bucket steps), and operations of ONE communicator must not be in flight from
-    two streams.  Created on first use (a collective call: every rank enables sync_bn at the same point); None where get() is None."""
+    """The communicator for the cross-replica BatchNorm statistics (all-gathers on the step's own stream): the SAME communicator as the
+    gradient buckets', switched to serial mode -- from here on its all-gathers go through the communicator's own stream too (forked from and
+    joined to the issuing stream: Communicator.all_gather), so all its operations form one in-order queue.  The buckets travel on the communicator's stream while the backward pass
+    (whose BatchNorm layers gather statistics) runs on the step's: operations of one communicator must not be in flight from two
+    streams, and two communicators whose kernels the ranks may start in different orders can deadlock (rounds 3-4 used a second
+    communicator).  Cross-replica BatchNorm is the parity mode, not the throughput mode: the lost overlap is its price.  None where
+    get() is None (the statistics then go through torch.distributed.all_gather between eager launches)."""
     base = get(device)
-    if base is None:
-        return None
-    if _STATS[0] is None:
-        comm, err = None, None
-        try:
-            comm = Communicator(base.rank, base.world, base.device)
-        except (RcclError, OSError, AttributeError) as e:
-            err = e
-        flag = torch.tensor([0.0 if comm is None else 1.0], device=base.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag[0]) < 0.5:
-            if comm is not None:
-                comm.destroy()
-            raise RcclError('no second communicator for the BatchNorm statistics (%s)' % (err if err is not None else 'another rank failed'))
-        _STATS[0] = comm
-    return _STATS[0]
+    if base is not None:
+        base.serial = True
+    _STATS[0] = base
+    return base
 
 
 def get(device=None, create=True):
@@ -206,8 +207,8 @@ def get(device=None, create=True):
 
 
 def reset():
-    for slot in (_STATS, _COMM):
-        if slot[0] is not None:
-            slot[0].destroy()
-            slot[0] = None
+    _STATS[0] = None
+    if _COMM[0] is not None:
+        _COMM[0].destroy()
+        _COMM[0] = None
     _FAILED[0] = False

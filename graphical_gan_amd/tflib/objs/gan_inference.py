@@ -1,4 +1,4 @@
-"""Objectives of tflib/objs/gan_inference.py: ali (:47-79), local_ep (:81-119), weighted_local_epce (:307-358),
+"""Objectives of tflib/objs/gan_inference.py: ali (:47-79), local_ep (:81-119), local_ep_dynamic (:246-305), weighted_local_epce (:307-358),
 wali_gp (:28-45), and the reconstruction variants local_epce (:121-160), alice (:162-195), vegan (:197-225),
 vegan_wgan_gp (:227-244).  wali (:4-26, RMSProp + weight clipping).  Same signatures and return tuples; `*_train_op` are
 callables (TrainOp) that run backward + one TF-flavoured Adam step, the costs are 0-dim device tensors.
@@ -105,6 +105,21 @@ def vegan_wgan_gp(disc_fake, disc_real, rec_penalty, gradient_penalty, gen_param
             disc_cost = F.MeanSum.apply((float(lamb), -float(lamb)), disc_fake, disc_real)
     gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=0.999)
     disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=0.999)
+    return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
+
+
+def local_ep_dynamic(disc_fake_zz, disc_real_zz, disc_fake_xz, disc_real_xz, gen_params, disc_params, lr=2e-4, beta1=0.5, beta2=.999,
+                     rec_penalty=None):
+    """tflib/objs/gan_inference.py:246-305: the transition factors' BCE pairs summed and divided by (their number + 1) -- not by their
+    number: the reference's own normalisation -- plus the observation factor's pair at weight 1 (+ rec_penalty on the generator side).
+    All terms of a cost are ONE launch: the division is folded into the terms' weights."""
+    n = len(disc_fake_zz)
+    assert n == len(disc_real_zz)
+    w = 1.0 / (n + 1) if n > 0 else 1.0
+    gen_cost, disc_cost = _bce_costs(list(disc_fake_zz) + [disc_fake_xz], list(disc_real_zz) + [disc_real_xz], [w] * n + [1.0])
+    gen_cost = _plus(gen_cost, rec_penalty)
+    gen_opt = get_optimizer('gen', gen_params, lr=lr, beta1=beta1, beta2=beta2)
+    disc_opt = get_optimizer('disc', disc_params, lr=lr, beta1=beta1, beta2=beta2)
     return gen_cost, disc_cost, TrainOp(gen_opt, gen_cost), TrainOp(disc_opt, disc_cost)
 
 

@@ -34,6 +34,9 @@ typedef void* ggan_stream_t; /* hipStream_t */
 /* activation codes for fused epilogues and ggan_act_* */
 enum { GGAN_ACT_NONE = 0, GGAN_ACT_LRELU = 1, GGAN_ACT_RELU = 2, GGAN_ACT_TANH = 3, GGAN_ACT_SIGMOID = 4 };
 
+/* The ABI's version: changes whenever a struct layout or an entry point's meaning changes (500: ggan_conv_geom carries the launch plan,
+ * ggan_prof_rec the grid).  A binding compares it with the header it was written against before the first call. */
+#define GGAN_ABI_VERSION 500
 int ggan_version(void);
 const char* ggan_last_error(void);
 /* ---- convolution geometry ------------------------------------------------------------------
@@ -491,8 +494,9 @@ int ggan_pack_adam(const float* const* srcs, const size_t* sizes, const size_t* 
 
 /* ---- per-kernel timing (bench.py roofline leg) -----------------------------------------------
  * When enabled every launch is bracketed by hipEvents on its own stream.  ggan_prof_report
- * synchronises, then writes up to `cap` records; returns the number of distinct kernels. */
-typedef struct { char name[48]; double total_ms; long launches; double flops; double bytes; } ggan_prof_rec;
+ * synchronises, then writes up to `cap` records -- one per (kernel, work-items per launch): a kernel launched on two grid sizes is two
+ * records, so that per-launch figures are not averages over different problems -- and returns their number. */
+typedef struct { char name[48]; double total_ms; long launches; double flops; double bytes; long grid; } ggan_prof_rec;   /* one record per (kernel, grid = work-items per launch, rocprofv3's Grid_Size) */
 int ggan_prof_enable(int on);
 int ggan_prof_reset(void);
 int ggan_prof_report(ggan_prof_rec* out, int cap);

@@ -37,6 +37,23 @@ def weighted_local_epce_costs(disc_fake_list, disc_real_list, ratio_list):
     return gen, disc
 
 
+def local_ep_dynamic_costs(disc_fake_zz, disc_real_zz, disc_fake_xz, disc_real_xz, rec_penalty=None):
+    """tflib/objs/gan_inference.py:246-296: literally -- accumulate the transition factors' pairs, divide by (n + 1) when there are
+    any, add the observation factor's pair, add rec_penalty to the generator side."""
+    gen, disc = 0.0, 0.0
+    for f, r in zip(disc_fake_zz, disc_real_zz):
+        gen = tp.add(tp.add(_bce_mean(f, 1.0), _bce_mean(r, 0.0)), gen)
+        disc = tp.add(tp.add(_bce_mean(f, 0.0), _bce_mean(r, 1.0)), disc)
+    if len(disc_fake_zz) > 0:
+        gen = tp.scale(gen, 1.0 / (len(disc_fake_zz) + 1))
+        disc = tp.scale(disc, 1.0 / (len(disc_fake_zz) + 1))
+    gen = tp.add(tp.add(_bce_mean(disc_fake_xz, 1.0), _bce_mean(disc_real_xz, 0.0)), gen)
+    disc = tp.add(tp.add(_bce_mean(disc_fake_xz, 0.0), _bce_mean(disc_real_xz, 1.0)), disc)
+    if rec_penalty is not None:
+        gen = tp.add(gen, rec_penalty)
+    return gen, disc
+
+
 def distance(x, y, d_type):
     """tflib/utils/distance.py:3-17"""
     d = tp.add(x, tp.neg(y))

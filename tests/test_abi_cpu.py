@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound(lib_built):
         assert hasattr(lib, n), 'libggan.so does not export %s' % n
     assert sorted(_lib.SIGNATURES) == names, set(names) ^ set(_lib.SIGNATURES)
     L = _lib.load()
-    assert L.ggan_version() >= 100
+    assert L.ggan_version() == _lib.ABI_VERSION == int(re.search(r'#define GGAN_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'ggan.h')).read()).group(1))
     assert L.ggan_last_error() is not None
 
 

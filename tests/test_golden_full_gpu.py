@@ -15,12 +15,18 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
 
 
-def _check_grads(z, which, names, grads, tol, allow_flip=False):
+OBSERVED = {}        # (fixture, configuration, step) -> (worst entry error / scale, worst L2 error / norm), filled by _check_grads
+
+
+def _check_grads(z, which, names, grads, tol, allow_flip=False, tag=None):
     """per tensor: the 64 fixture entries within tol * scale and the L2 norm within tol/3 (scale = max |g| of the tensor, floored at
-    1e-2 of the largest gradient of the step for the mathematically-zero ones, e.g. a bias that feeds a BatchNorm)"""
+    1e-2 of the largest gradient of the step for the mathematically-zero ones, e.g. a bias that feeds a BatchNorm).  Every failure
+    message carries the observed error; the worst observed ratios of a passing check go to OBSERVED[tag] (and to stdout with
+    GGAN_TEST_REPORT=1: that is where the table OBS below comes from)."""
     import make_golden_full as MG
     refs = {n: z['%s/g/%s' % (which, n)] for n in names if '%s/g/%s' % (which, n) in z.files}
     gmax = max(r[1] for r in refs.values())
+    worst_e, worst_l, flips, n_all, n_over = 0.0, 0.0, 0, 0, [0, 0, 0]
     for n, g in zip(names, grads):
         if n not in refs:
             assert g is None or float(g.abs().max()) == 0.0, n
@@ -42,8 +48,41 @@ def _check_grads(z, which, names, grads, tol, allow_flip=False):
             bad = sorted(set(int(i) for i in idx[e > tol * scale]))
             assert len(bad) == 1 and err <= 1e-2 * scale, (which, n, 'entries', err, scale, bad)
             err = 0.0
-        assert err <= tol * scale, (which, n, 'entries', err, scale)
-        assert abs(np.linalg.norm(f) - ref[0]) <= tol / 3 * max(ref[0], 1e-2 * gmax * np.sqrt(f.size)), (which, n, 'l2', np.linalg.norm(f), ref[0])
+            flips += 1
+        assert err <= tol * scale, (which, n, 'entries: observed %.3g of the scale, tolerance %.3g' % (err / scale, tol))
+        l2den = max(ref[0], 1e-2 * gmax * np.sqrt(f.size))
+        l2 = abs(np.linalg.norm(f) - ref[0])
+        assert l2 <= tol / 3 * l2den, (which, n, 'l2: observed %.3g relative, tolerance %.3g' % (l2 / l2den, tol / 3))
+        worst_e, worst_l = max(worst_e, err / scale), max(worst_l, l2 / l2den)
+        n_all += e.size
+        for k_, th in enumerate((1e-5, 5e-5, 2e-4)):
+            n_over[k_] += int((e > th * scale).sum())
+    if tag is not None:
+        OBSERVED[tag + (which,)] = (worst_e, worst_l, flips)
+        if os.environ.get('GGAN_TEST_REPORT'):
+            print('OBSERVED %s entries %.3g l2 %.3g flips %d (tolerance %.3g); of %d sampled entries %d / %d / %d above 1e-5 / 5e-5 / 2e-4 of the scale'
+                  % ('/'.join(tag + (which,)), worst_e, worst_l, flips, tol, n_all, n_over[0], n_over[1], n_over[2]))
+
+
+# Gradient tolerances at full size = 3 x the worst error OBSERVED on MI355X (round 5: GGAN_TEST_REPORT=1, max over the eager and the timed
+# configuration), per fixture and step, floored at 2e-5 and capped at SURVEY.md 8(c)'s ceilings (1e-3; 2e-3 through the gradient penalty /
+# the mixture prior) -- not one blanket figure.  The observed errors are BIMODAL: a step whose ~7e6 ReLU / LeakyReLU units all land on the
+# float64 side of their kinks agrees to 1e-6 .. 5e-5 (largest entry error over the tensor's max |g|; the wali-gp critic step WITH its
+# double backward: 1e-6); a step in which one conv-layer unit sits within fp32 rounding of its kink and lands on the other side
+# carries that flip into every gradient upstream of it (a third of the sampled entries move by 1e-5 .. 1e-3: PyTorch-CPU float32
+# against float64 does the same, up to 1.4e-3 on unscreened feeds).  Which steps flip is a property of the fixture's feed and of the
+# summation order of the kernels that produce that activation, and it is deterministic: a kernel change that moves a clean step
+# above its tolerance shows here, is re-measured with GGAN_TEST_REPORT=1 and the table updated with the reason.
+CEIL = {'full_cifar_wali_gp': 2e-3, 'full_cifar_gmgan_k30': 2e-3, 'full_cifar_gmgan_k10': 2e-3, 'full_face_gmgan_k100': 2e-3, 'full_mnist_gmgan': 2e-3}
+OBS = {     # fixture -> (generator step, critic step): worst entry error / scale observed (r05, either configuration)
+    'full_cifar_ali': (5.8e-6, 5.3e-4), 'full_cifar_wali_gp': (4.6e-6, 1.1e-6), 'full_cifar_gmgan_k30': (1.6e-3, 7.8e-4),
+    'full_cifar_gmgan_k10': (2.8e-5, 7.9e-7), 'full_face_ali': (4.8e-5, 1.5e-4), 'full_face_gmgan_k100': (1.2e-3, 2.7e-4),
+    'full_mnist_ali': (3.4e-4, 2.4e-4), 'full_mnist_gmgan': (1.2e-5, 1.1e-6), 'full_ssgan_b32_t16': (3.2e-4, 2.4e-5),
+}
+
+
+def tol_of(name, which):
+    return min(CEIL.get(name, 1e-3), max(2e-5, 3.0 * OBS[name][0 if which == 'gen' else 1]))
 
 
 @pytest.mark.parametrize('name', ['full_cifar_ali', 'full_cifar_wali_gp', 'full_cifar_gmgan_k30', 'full_cifar_gmgan_k10',
@@ -88,22 +127,24 @@ def test_full_size_first_step_vs_fixture(gpu, name):
         # of the same kernel, or PyTorch-CPU float32 vs float64: up to 1.4e-3 on unscreened feeds) do not agree tighter than that.
         # The fixture feeds are screened so that the Linear-layer activations are clear of their kinks and a float32 CPU
         # evaluation reproduces float64 to 3e-5; at the small sizes of tests/test_step_gpu.py the tolerance is 1e-4.
-        loose = (mode == 'wali-gp' and which == 'disc') or K
         # (the one-flip allowance only where BatchNorm sits INSIDE the critic: the gan/gmgan_inference_mnist fixtures)
-        _check_grads(z, which, names, grads, 2e-3 if loose else 1e-3, allow_flip=dataset == 'mnist')
+        _check_grads(z, which, names, grads, tol_of(name, which), allow_flip=dataset == 'mnist', tag=(name, 'eager'))
     optim.reset_optimizers()
     lib.delete_all_params()
 
 
-@pytest.mark.parametrize('name', ['full_cifar_ali', 'full_face_ali', 'full_cifar_gmgan_k30', 'full_cifar_wali_gp'])
+@pytest.mark.parametrize('name', ['full_cifar_ali', 'full_face_ali', 'full_cifar_gmgan_k30', 'full_cifar_wali_gp', 'full_cifar_gmgan_k10',
+                                  'full_face_gmgan_k100', 'full_mnist_ali', 'full_mnist_gmgan'])
 def test_full_size_timed_configuration_vs_fixture(gpu, name):
     """The configuration bench.py TIMES, against the float64 fixture (round-3 review: the full-size fixtures ran graph=False on the default
-    launch plan, the graph path was only compared with itself): batch 64, minibatches read in place from the device ring, generator
-    step + critic step(s) captured as ONE HIP graph with the Generator / Extractor passes forked onto two streams and their conv
-    launches planned for 128 workgroups (models.launch_hint / functional.target_workgroups), gradients packed and the Adam update
-    applied by the pack launch.  The noise launch is replaced by the fixture's draws (inject_noise) and the learning rates are zero, so
-    that every step of the replayed graph is evaluated at the fixture's weights: costs, critic logits, and every parameter's gradient as
-    the pack launch left it in the optimizer's flat bucket."""
+    launch plan, the graph path was only compared with itself; round-4 review: every fixture, not four of them): the steps captured as
+    HIP graphs with the Generator / Extractor passes forked onto two streams and their conv launches planned for 128 workgroups
+    (models.launch_hint / functional.target_workgroups), gradients packed and the Adam update applied by the pack launch; for the int32
+    image scripts the minibatches are read in place from the device ring and generator step + critic step(s) are ONE graph, the MNIST
+    scripts (float minibatches) go through the staging buffer and one graph per step -- exactly what bench.py runs for each.  The
+    noise launch is replaced by the fixture's draws (inject_noise) and the learning rates are zero, so that every step of the replayed
+    graph is evaluated at the fixture's weights: costs, critic logits, and every parameter's gradient as the pack launch left it in
+    the optimizer's flat bucket."""
     import torch
     import make_golden_full as MG
     from oracle import nets as N, step as S
@@ -130,13 +171,20 @@ def test_full_size_timed_configuration_vs_fixture(gpu, name):
         o.lr = 0.0                           # (baked into the captured update launches: the weights stay the fixture's)
     tr.load_params(P0)
     tr.set_feed(feed)
-    x = torch.as_tensor(np.ascontiguousarray(feed['real_x_int'])).to(gpu)
-    tr.use_ring([x] * 4)                     # every ring slot holds the fixture's minibatch
+    tr.flush()
+    tr._graphs, tr._iter_graph = {}, None    # (the critic step's second call captured its graph with the learning rate it had then)
+    ring = dataset != 'mnist'
+    if ring:
+        x = torch.as_tensor(np.ascontiguousarray(feed['real_x_int'])).to(gpu)
+        tr.use_ring([x] * 4)                 # every ring slot holds the fixture's minibatch
     res = None
     for it in (2, 3, 4):                     # capture (with its warm-up steps), then replays
-        res = tr.iteration(it, None)
-    assert getattr(tr, '_iter_graph', None) is not None and tr._iter_graph['kinds'] == ('gen',) + ('disc',) * cfg.critic_iters
-    assert tr.model.fork_nets                # (the two-stream nets pass and its 128-workgroup plans were on while the graph was built)
+        res = tr.iteration(it, None if ring else feeds)
+    if ring:
+        assert getattr(tr, '_iter_graph', None) is not None and tr._iter_graph['kinds'] == ('gen',) + ('disc',) * cfg.critic_iters
+        assert tr.model.fork_nets            # (the two-stream nets pass and its 128-workgroup plans were on while the graph was built)
+    else:
+        assert set(tr._graphs) == {'gen', 'disc'}        # (one captured graph per step kind, replayed by the last iterations)
     torch.cuda.synchronize()
     for which in ('gen', 'disc'):
         ref = float(z[which + '/cost'])
@@ -150,8 +198,7 @@ def test_full_size_timed_configuration_vs_fixture(gpu, name):
         opt = next(o for k, o in _optimizers.items() if k[0] == which)
         names = [p.param_name for p in opt.params]
         grads = [opt.g[o:o + n].view(p.shape) for p, (o, n) in zip(opt.params, opt.slots)]
-        loose = (mode == 'wali-gp' and which == 'disc') or K
-        _check_grads(z, which, names, grads, 2e-3 if loose else 1e-3)
+        _check_grads(z, which, names, grads, tol_of(name, which), allow_flip=dataset == 'mnist', tag=(name, 'timed'))
     # the weights did not move (lr 0) and match the fixture's
     got = tr.get_params()
     for n_, v in P0.items():
@@ -161,8 +208,12 @@ def test_full_size_timed_configuration_vs_fixture(gpu, name):
     lib.delete_all_params()
 
 
-def test_full_size_ssgan_first_step_vs_fixture(gpu):
-    """ssgan_inference_moving_mnist.py at BASELINE configs[4]: 32 sequences x 16 frames of 64x64"""
+@pytest.mark.parametrize('timed', [False, True], ids=['eager', 'timed'])
+def test_full_size_ssgan_first_step_vs_fixture(gpu, timed):
+    """ssgan_inference_moving_mnist.py at BASELINE configs[4]: 32 sequences x 16 frames of 64x64.  `timed`: the configuration bench.py
+    times for the state-space scripts -- one captured HIP graph per step kind, minibatch through the staging buffer (an 8 MB device
+    copy per 9 ms step; the int32 ring of the image scripts does not exist for float frames + labels), pack + Adam in one launch --
+    with the fixture's noise and zero learning rates; gradients as the pack launch left them in the flat bucket."""
     import torch
     import make_golden_full as MG
     from oracle import ssgan as O
@@ -178,12 +229,38 @@ def test_full_size_ssgan_first_step_vs_fixture(gpu):
     optim.reset_optimizers()
     lib.delete_all_params()
     cfg = SSConfig(**MG.SSGAN[name])
-    tr = Trainer(cfg, device=gpu, graph=False, inject_noise=True, model=StateSpaceGAN(cfg))
+    tr = Trainer(cfg, device=gpu, graph=timed, inject_noise=True, model=StateSpaceGAN(cfg))
     tr.load_params(P0)
     tr.set_feed(feed)
     fx = tr.model.forward_nets(tr.feed)['fake_x'].detach().cpu().numpy().astype(np.float64).reshape(-1)
     ref = z['fake_x_digest']
     assert np.abs(fx[MG.sample_index('fake_x', fx.size)] - ref[2:]).max() <= 2e-5 and abs(np.linalg.norm(fx) - ref[0]) <= 1e-5 * ref[0]
+    if timed:
+        from graphical_gan_amd.optim import _optimizers
+        feeds = iter([feed] * 64)
+        tr.iteration(0, feeds)
+        tr.iteration(1, feeds)
+        for o in _optimizers.values():
+            o.lr = 0.0
+        tr.load_params(P0)
+        tr.flush()
+        tr._graphs, tr._iter_graph = {}, None
+        res = None
+        for it in (2, 3, 4):
+            res = tr.iteration(it, feeds)
+        assert set(tr._graphs) == {'gen', 'disc'}
+        torch.cuda.synchronize()
+        for which in ('gen', 'disc'):
+            refc = float(z[which + '/cost'])
+            c = float(res[which + '_cost'])
+            assert abs(c - refc) <= 1e-5 * max(1.0, abs(refc)), (which, c, refc)
+            opt = next(o for k, o in _optimizers.items() if k[0] == which)
+            names = [p.param_name for p in opt.params]
+            grads = [opt.g[o:o + n].view(p.shape) for p, (o, n) in zip(opt.params, opt.slots)]
+            _check_grads(z, which, names, grads, tol_of(name, which), tag=(name, 'timed'))
+        optim.reset_optimizers()
+        lib.delete_all_params()
+        return
     for which in ('gen', 'disc'):
         out = tr.model.forward(tr.feed, which)
         refc = float(z[which + '/cost'])
@@ -192,6 +269,6 @@ def test_full_size_ssgan_first_step_vs_fixture(gpu):
         opt = out[which + '_train_op'].optimizer
         names = [p.param_name for p in opt.params]
         grads = torch.autograd.grad(out[which + '_cost'], opt.params, allow_unused=True)
-        _check_grads(z, which, names, grads, 1e-3)       # (as above; filter gradients here are fp32 sums over up to 5e5 pixels)
+        _check_grads(z, which, names, grads, tol_of(name, which), tag=(name, 'eager'))       # (filter gradients here are fp32 sums over up to 5e5 pixels)
     optim.reset_optimizers()
     lib.delete_all_params()

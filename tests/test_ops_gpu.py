@@ -1,7 +1,9 @@
 """-m gpu: every C-ABI op (through graphical_gan_amd.functional) against the float64 oracle.
 
-Tolerance (fp32): per-op max |err| <= 2e-5 * max|ref| for K <= 3200-term fp32 dot products
-(observed ~1e-6); second-order (GP) <= 1e-4 relative.
+Tolerance (fp32): per-op max |err| <= TOL = 5e-6 of max |ref| -- 3 x the worst error observed on MI355X over every op test below
+(round 5, GGAN_TEST_REPORT=<file>: 1.5e-6; the typical op sits at 1e-7 .. 6e-7) -- and TOL_LONG = 1e-5, SURVEY.md 8(c)'s per-op
+figure, where the reference value is an fp32 sum over 4e3 .. 8e3 pixels or a softmax over squared distances (observed 4.0e-6 /
+8.8e-6: test_conv_family's filter gradients, test_gmm_latent_fused_op); second-order (GP) <= 1e-4 relative.
 """
 import ctypes as C
 
@@ -10,6 +12,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+TOL, TOL_LONG = 5e-6, 1e-5
 
 CONV_CASES = [  # (N, Ci, H, Co) 5x5 stride 2 SAME
     (4, 8, 16, 64),
@@ -27,7 +31,16 @@ CONV_CASES = [  # (N, Ci, H, Co) 5x5 stride 2 SAME
 
 
 def _rel(a, ref):
-    return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
+    v = float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30))
+    if _REPORT is not None:             # GGAN_TEST_REPORT=<file>: every observed relative error with the test that measured it
+        import os
+        with open(_REPORT, 'a') as f:
+            f.write('%s %.3e\n' % (os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0], v))
+    return v
+
+
+import os as _os
+_REPORT = _os.environ.get('GGAN_TEST_REPORT') if _os.environ.get('GGAN_TEST_REPORT', '1') not in ('', '1') else None
 
 
 def _t(a, dev):
@@ -61,15 +74,15 @@ def test_conv_family(gpu, naive, case):
     y = F.ConvFwd.apply(_t(x, gpu), _t(w, gpu), _t(b, gpu), geom, F.ACT_NONE, 0.0).cpu().numpy()
     ref = O.conv2d(x64, w64, 2, 'SAME') + b.reshape(1, -1, 1, 1)
     assert y.shape == ref.shape
-    assert _rel(y, ref) < 2e-5, ('fwd', _rel(y, ref))
+    assert _rel(y, ref) < TOL_LONG, ('fwd', _rel(y, ref))
 
     gx = F.ConvDgrad.apply(_t(gy, gpu), _t(w, gpu), _t(bi, gpu), geom, F.ACT_NONE, 0.0).cpu().numpy()
     ref = O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME') + bi.reshape(1, -1, 1, 1)
-    assert _rel(gx, ref) < 2e-5, ('dgrad', _rel(gx, ref))
+    assert _rel(gx, ref) < TOL_LONG, ('dgrad', _rel(gx, ref))
 
     gw = F.ConvWgrad.apply(_t(x, gpu), _t(gy, gpu), geom).cpu().numpy()
     ref = O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')
-    assert _rel(gw, ref) < 2e-5, ('wgrad', _rel(gw, ref))
+    assert _rel(gw, ref) < TOL_LONG, ('wgrad', _rel(gw, ref))
 
 
 def test_conv_fused_epilogue(gpu):
@@ -82,7 +95,7 @@ def test_conv_fused_epilogue(gpu):
     geom = F.conv_geom(8, 16, 16, 16, 32, 5, 2)
     y = F.ConvFwd.apply(_t(x, gpu), _t(w, gpu), _t(b, gpu), geom, F.ACT_LRELU, 0.2).cpu().numpy()
     ref = O.leaky_relu(O.conv2d(x.astype(np.float64), w.astype(np.float64), 2) + b.reshape(1, -1, 1, 1))
-    assert _rel(y, ref) < 2e-5
+    assert _rel(y, ref) < TOL
 
 
 def test_conv_other_geometry_uses_plain_kernels(gpu):
@@ -96,12 +109,12 @@ def test_conv_other_geometry_uses_plain_kernels(gpu):
         geom = F.conv_geom(2, 5, H, H, 7, k, s, pad)
         y = F.ConvFwd.apply(_t(x, gpu), _t(w, gpu), None, geom, F.ACT_NONE, 0.0).cpu().numpy()
         ref = O.conv2d(x.astype(np.float64), w.astype(np.float64), s, pad)
-        assert _rel(y, ref) < 2e-5
+        assert _rel(y, ref) < TOL
         gy = rng.standard_normal(ref.shape).astype(np.float32)
         gx = F.ConvDgrad.apply(_t(gy, gpu), _t(w, gpu), None, geom, F.ACT_NONE, 0.0).cpu().numpy()
-        assert _rel(gx, O.conv2d_bwd_data(gy.astype(np.float64), w.astype(np.float64), (H, H), s, pad)) < 2e-5
+        assert _rel(gx, O.conv2d_bwd_data(gy.astype(np.float64), w.astype(np.float64), (H, H), s, pad)) < TOL
         gw = F.ConvWgrad.apply(_t(x, gpu), _t(gy, gpu), geom).cpu().numpy()
-        assert _rel(gw, O.conv2d_bwd_filter(x.astype(np.float64), gy.astype(np.float64), k, s, pad)) < 2e-5
+        assert _rel(gw, O.conv2d_bwd_filter(x.astype(np.float64), gy.astype(np.float64), k, s, pad)) < TOL
 
 
 def test_deconv_delta_alignment(gpu):
@@ -142,7 +155,7 @@ def test_gemm(gpu, mnk, ta, tb):
     b64 = B.astype(np.float64).T if tb else B.astype(np.float64)
     ref = a64 @ b64 + bias
     assert out.shape == ref.shape
-    assert _rel(out, ref) < 2e-5
+    assert _rel(out, ref) < TOL
 
 
 @pytest.mark.parametrize('shape', [(64, 128, 8, 8), (64, 64, 16, 16), (64, 256, 4, 4), (50, 128, 7, 7), (64, 4096), (7, 130)])
@@ -167,9 +180,9 @@ def test_batchnorm(gpu, shape):
     y = F.BatchNormTrain.apply(xd, sd, od, 1e-5, F.ACT_NONE, 0.0)
     assert _rel(y.detach().cpu().numpy(), yt.v) < 1e-5
     gx, gsd, god = torch.autograd.grad(y, [xd, sd, od], grad_outputs=_t(gy, gpu))
-    assert _rel(gx.cpu().numpy(), gs[0].v) < 2e-5
-    assert _rel(gsd.cpu().numpy().reshape(-1), gs[1].v) < 2e-5
-    assert _rel(god.cpu().numpy().reshape(-1), gs[2].v) < 2e-5
+    assert _rel(gx.cpu().numpy(), gs[0].v) < TOL
+    assert _rel(gsd.cpu().numpy().reshape(-1), gs[1].v) < TOL
+    assert _rel(god.cpu().numpy().reshape(-1), gs[2].v) < TOL
     # known answer: per-channel mean 0, variance 1 - eps-correction
     yn = F.BatchNormTrain.apply(xd, torch.ones_like(sd), torch.zeros_like(od), 1e-5, F.ACT_NONE, 0.0).detach().cpu().numpy()
     red = tuple(axes)
@@ -220,6 +233,42 @@ def test_losses(gpu):
     (gg,) = torch.autograd.grad(pen, [gd])
     ggref = (10 * 2 * (s - 1) / 64 / s)[:, None] * g
     assert _rel(gg.cpu().numpy(), ggref) < 1e-5
+
+
+@pytest.mark.parametrize('n_zz,rec', [(3, False), (3, True), (0, False), (1, True)])
+def test_local_ep_dynamic_objective(gpu, n_zz, rec):
+    """tflib.objs.gan_inference.local_ep_dynamic (reference :246-305): both costs and the gradient of each w.r.t. every logit tensor
+    against the oracle's literal restatement (sum of the transition pairs / (n + 1) + the observation pair + rec_penalty)."""
+    import torch
+    from graphical_gan_amd import functional as F, tflib as lib, optim
+    from oracle import objs as OJ, tape as tp
+    J = lib.objs.gan_inference
+    rng = np.random.default_rng(7 + n_zz)
+    mk = lambda n: (rng.standard_normal(n) * 3).astype(np.float32)
+    fz, rz = [mk(48) for _ in range(n_zz)], [mk(48) for _ in range(n_zz)]
+    fx, rx = mk(64), mk(64)
+    pen = np.float32(0.731)
+    T = lambda a: tp.T(a.astype(np.float64))
+    ofz, orz, ofx, orx = [T(a) for a in fz], [T(a) for a in rz], T(fx), T(rx)
+    open_ = tp.T(np.float64(pen)) if rec else None
+    og, od = OJ.local_ep_dynamic_costs(ofz, orz, ofx, orx, open_)
+    leaves = ofz + orz + [ofx, orx]
+    ogg, odg = tp.grad(og, leaves), tp.grad(od, leaves)
+    optim.reset_optimizers(); lib.delete_all_params()
+    t = lambda a: _t(a, gpu).requires_grad_(True)
+    tfz, trz, tfx, trx = [t(a) for a in fz], [t(a) for a in rz], t(fx), t(rx)
+    tpen = _t(np.float32([pen]), gpu).reshape(()) if rec else None
+    pg, pd = lib.param('Generator.x', np.zeros(3, np.float32)), lib.param('Discriminator.x', np.zeros(3, np.float32))
+    gen_cost, disc_cost, gop, dop = J.local_ep_dynamic(tfz, trz, tfx, trx, [pg], [pd], rec_penalty=tpen)
+    assert abs(float(gen_cost.detach()) - float(og.v)) <= 2e-6 * max(1.0, abs(float(og.v)))
+    assert abs(float(disc_cost.detach()) - float(od.v)) <= 2e-6 * max(1.0, abs(float(od.v)))
+    tl = tfz + trz + [tfx, trx]
+    for cost, refs in ((gen_cost, ogg), (disc_cost, odg)):
+        gs = torch.autograd.grad(cost, tl, retain_graph=True)
+        for g, r in zip(gs, refs):
+            assert np.abs(g.cpu().numpy() - r.v).max() <= 1e-7
+    assert gop.optimizer.beta2 == 0.999 and dop.optimizer.lr == 2e-4
+    optim.reset_optimizers(); lib.delete_all_params()
 
 
 def test_adam_known_answer_and_trajectory(gpu):
@@ -291,12 +340,12 @@ def test_gemm_colsum_and_splitk_is_deterministic(gpu):
     x = rng.standard_normal((64, 4608)).astype(np.float32)
     gy = rng.standard_normal((64, 512)).astype(np.float32)
     dw, db = F.gemm_colsum_(_t(x, gpu), _t(gy, gpu), True)
-    assert _rel(dw.cpu().numpy(), x.astype(np.float64).T @ gy.astype(np.float64)) < 2e-5
+    assert _rel(dw.cpu().numpy(), x.astype(np.float64).T @ gy.astype(np.float64)) < TOL
     assert _rel(db.cpu().numpy(), gy.astype(np.float64).sum(0)) < 1e-5
     w = rng.standard_normal((4608, 512)).astype(np.float32)
     outs = [F.Gemm.apply(_t(x, gpu), _t(w, gpu), None, False, False, 0, 0.0).cpu().numpy() for _ in range(5)]
     assert all(np.array_equal(outs[0], o) for o in outs[1:])          # bitwise reproducible
-    assert _rel(outs[0], x.astype(np.float64) @ w.astype(np.float64)) < 2e-5
+    assert _rel(outs[0], x.astype(np.float64) @ w.astype(np.float64)) < TOL
     ws = F.workspace(gpu)
     assert int(ws[:16384].view(torch.int32).abs().sum()) == 0             # arrival counters left at zero
 
@@ -387,9 +436,9 @@ def test_linear_backward_with_fused_activation_mask(gpu, mnk):
                                         _stream()) == 0
     f64 = lambda a: np.asarray(a, np.float32).astype(np.float64)
     gm = f64(g) * np.where(f64(y) > 0, 1.0, 0.2)
-    assert _rel(dx.cpu().numpy(), gm @ f64(w).T) < 2e-5
-    assert _rel(dw.cpu().numpy(), f64(x).T @ gm) < 2e-5
-    assert _rel(db.cpu().numpy(), gm.sum(0)) < 2e-5
+    assert _rel(dx.cpu().numpy(), gm @ f64(w).T) < TOL
+    assert _rel(dw.cpu().numpy(), f64(x).T @ gm) < TOL
+    assert _rel(db.cpu().numpy(), gm.sum(0)) < TOL
 
 
 def test_bn_backward_with_mask_and_channel_sums(gpu):
@@ -407,8 +456,8 @@ def test_bn_backward_with_mask_and_channel_sums(gpu):
     tx = _t(x, gpu).requires_grad_(True); ts = _t(sc, gpu).requires_grad_(True); to = _t(of, gpu).requires_grad_(True)
     y = F.BatchNormTrain.apply(tx, ts, to, 1e-5, 2, 0.0)
     gx, gs, go = torch.autograd.grad(y, [tx, ts, to], grad_outputs=_t(gy, gpu))
-    assert _rel(gx.cpu().numpy(), gxo.v) < 2e-5 and _rel(gs.cpu().numpy().reshape(-1), gso.v.reshape(-1)) < 2e-5
-    assert _rel(go.cpu().numpy().reshape(-1), goo.v.reshape(-1)) < 2e-5
+    assert _rel(gx.cpu().numpy(), gxo.v) < TOL and _rel(gs.cpu().numpy().reshape(-1), gso.v.reshape(-1)) < TOL
+    assert _rel(go.cpu().numpy().reshape(-1), goo.v.reshape(-1)) < TOL
     cs = getattr(gx, '_ggan_chansum', None)
     assert cs is not None
     assert np.abs(cs.cpu().numpy() - gx.cpu().numpy().astype(np.float64).sum((0, 2, 3))).max() <= 1e-4
@@ -438,7 +487,7 @@ def test_filter_gradient_parts_and_widened_paths(gpu, case):
     gw, gb = torch.empty(5, 5, Ci, Co, device=gpu), torch.empty(Co, device=gpu)
     rc = L.ggan_conv2d_bwd_filter_act(C.byref(G), _ptr(tx), _ptr(tg), _ptr(ty), 1, 0.2, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
     assert rc == 0
-    assert _rel(gw.cpu().numpy(), ref_w) < 3e-5 and _rel(gb.cpu().numpy(), ref_b) < 3e-5
+    assert _rel(gw.cpu().numpy(), ref_w) < TOL and _rel(gb.cpu().numpy(), ref_b) < TOL
     elems = 25 * Ci * Co
     cap = 64 * (elems + Co)
     part = torch.empty(cap, device=gpu)
@@ -449,7 +498,7 @@ def test_filter_gradient_parts_and_widened_paths(gpu, case):
         return
     assert rc == 0 and n.value >= 1 and st.value == elems + Co
     slabs = part[:n.value * st.value].cpu().numpy().astype(np.float64).reshape(n.value, st.value).sum(0)
-    assert _rel(slabs[:elems].reshape(5, 5, Ci, Co), ref_w) < 3e-5 and _rel(slabs[elems:], ref_b) < 3e-5
+    assert _rel(slabs[:elems].reshape(5, 5, Ci, Co), ref_w) < TOL and _rel(slabs[elems:], ref_b) < TOL
 
 
 def test_rmsprop_with_clipping_and_wali_costs(gpu):
@@ -528,9 +577,9 @@ def test_sync_batchnorm_entry_points(gpu, shape, world, act):
         check(L.ggan_bn_sync_bwd_apply(_p(xs[r]), _p(gys[r]), _p(ys[r]) if act else _p(None), act, 0.2, _p(tsc), _p(means[r]),
                                        _p(invs[r]), _p(sums), world, r, _p(gx), _p(gs), _p(go), n, Cc, HW, _stream()), 'bwd_apply')
         gxs.append(gx); gss.append(gs); gos.append(go)
-    assert _rel(torch.cat(gxs).cpu().numpy(), gxo.v) < 2e-5
-    assert _rel(sum(g.cpu().numpy().astype(np.float64) for g in gss), gso.v.reshape(-1)) < 2e-5
-    assert _rel(sum(g.cpu().numpy().astype(np.float64) for g in gos), goo.v.reshape(-1)) < 2e-5
+    assert _rel(torch.cat(gxs).cpu().numpy(), gxo.v) < TOL
+    assert _rel(sum(g.cpu().numpy().astype(np.float64) for g in gss), gso.v.reshape(-1)) < TOL
+    assert _rel(sum(g.cpu().numpy().astype(np.float64) for g in gos), goo.v.reshape(-1)) < TOL
 
 
 @pytest.mark.parametrize('case', [(5, 3, 32, 64), (3, 1, 28, 64), (2, 3, 64, 32), (4, 2, 16, 12), (3, 4, 8, 8)])
@@ -554,7 +603,7 @@ def test_thin_channel_data_gradient(gpu, case):
     # Deconv2D forward: bias + tanh epilogue
     out = F.ConvDgrad.apply(_t(gy, gpu), _t(w, gpu), _t(bi, gpu), geom, F.ACT_TANH, 0.0).cpu().numpy()
     ref = np.tanh(O.conv2d_bwd_data(gy.astype(np.float64), w.astype(np.float64), (H, H), 2, 'SAME') + bi.reshape(1, -1, 1, 1))
-    assert _rel(out, ref) < 2e-5
+    assert _rel(out, ref) < TOL
     # data gradient with the activation derivative of the producing layer folded in
     L = _lib.load()
     g = F._geom(geom)
@@ -573,7 +622,7 @@ def test_thin_channel_data_gradient(gpu, case):
             res[tag] = gx.cpu().numpy()
         finally:
             os.environ.pop('GGAN_NO_THIN', None)
-        assert _rel(res[tag], ref) < 2e-5, tag
+        assert _rel(res[tag], ref) < TOL, tag
     assert _rel(res['thin'], res['general']) < 1e-5
 
 
@@ -610,16 +659,16 @@ def test_thin_channel_filter_gradient_slabs(gpu, case):
         slabs = part[:n.value * st.value].cpu().numpy().astype(np.float64).reshape(n.value, st.value)
         assert np.isfinite(slabs).all()
         tot = slabs.sum(0)
-        assert _rel(tot[:elems].reshape(5, 5, Ci, Co), ref_w) < 3e-5
+        assert _rel(tot[:elems].reshape(5, 5, Ci, Co), ref_w) < TOL
         if with_bias:
-            assert _rel(tot[elems:], ref_b) < 3e-5
+            assert _rel(tot[elems:], ref_b) < TOL
     # non-deferred entry point (slabs in the workspace + reduce launch), no mask
     ws = F.workspace(tx.device)
     gw, gb = torch.empty(5, 5, Ci, Co, device=gpu), torch.empty(Co, device=gpu)
     rc = L.ggan_conv2d_bwd_filter(C.byref(G), _ptr(tx), _ptr(tg), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
     assert rc == 0
-    assert _rel(gw.cpu().numpy(), O.conv2d_bwd_filter(x.astype(np.float64), gy.astype(np.float64), 5, 2)) < 3e-5
-    assert _rel(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3))) < 3e-5
+    assert _rel(gw.cpu().numpy(), O.conv2d_bwd_filter(x.astype(np.float64), gy.astype(np.float64), 5, 2)) < TOL
+    assert _rel(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3))) < TOL
 
 
 def test_row_slots_make_the_critic_concatenation_free(gpu):
@@ -683,7 +732,7 @@ def test_batchnorm_second_derivative(gpu, shape, act):
     tg = _t(g0, gpu).requires_grad_(True)
     y = F.BatchNormTrain.apply(tx, ts, to, 1e-5, act, 0.2)
     (gx,) = torch.autograd.grad(y, [tx], grad_outputs=tg, create_graph=True)
-    assert _rel(gx.detach().cpu().numpy(), gxo.v) < 2e-5
+    assert _rel(gx.detach().cpu().numpy(), gxo.v) < TOL
     L = (gx * _t(w, gpu)).sum()
     dx, dg, ds = torch.autograd.grad(L, [tx, tg, ts])
     assert _rel(dx.cpu().numpy(), rx.v) < 5e-5, _rel(dx.cpu().numpy(), rx.v)
@@ -709,15 +758,15 @@ def test_linear_on_a_pair_of_inputs_equals_linear_on_their_concatenation(gpu, M,
     tw, tb = _t(w, gpu).requires_grad_(True), _t(b, gpu).requires_grad_(True)
     assert F.Gemm2.usable(t1, t2)
     y = F.Gemm2.apply(t1, t2, tw, tb, F.ACT_LRELU, 0.2)
-    assert _rel(y.detach().cpu().numpy(), ref) < 2e-5
+    assert _rel(y.detach().cpu().numpy(), ref) < TOL
     d1, d2, dw, db = torch.autograd.grad(y, [t1, t2, tw, tb], grad_outputs=_t(g, gpu))
     da = gm @ w.T
-    assert _rel(d1.cpu().numpy(), da[:, :K1]) < 3e-5 and _rel(d2.cpu().numpy(), da[:, K1:]) < 3e-5
-    assert _rel(dw.cpu().numpy(), a.T @ gm) < 3e-5 and _rel(db.cpu().numpy(), gm.sum(0)) < 3e-5
+    assert _rel(d1.cpu().numpy(), da[:, :K1]) < TOL and _rel(d2.cpu().numpy(), da[:, K1:]) < TOL
+    assert _rel(dw.cpu().numpy(), a.T @ gm) < TOL and _rel(db.cpu().numpy(), gm.sum(0)) < TOL
     # while a double backward is recorded the differentiable composition takes over: same first derivatives
     y2 = F.Gemm2.apply(t1, t2, tw, tb, F.ACT_LRELU, 0.2)
     e1, e2 = torch.autograd.grad(y2, [t1, t2], grad_outputs=_t(g, gpu), create_graph=True)
-    assert _rel(e1.detach().cpu().numpy(), da[:, :K1]) < 3e-5 and _rel(e2.detach().cpu().numpy(), da[:, K1:]) < 3e-5
+    assert _rel(e1.detach().cpu().numpy(), da[:, :K1]) < TOL and _rel(e2.detach().cpu().numpy(), da[:, K1:]) < TOL
     (hw,) = torch.autograd.grad((e1 * e1).sum() + (e2 * e2).sum(), [tw])
     assert np.isfinite(hw.cpu().numpy()).all() and float(hw.abs().max()) > 0
 
@@ -741,7 +790,7 @@ def test_gmm_latent_fused_op(gpu, B, K, D):
     rz, rmu = tp.grad(L, [Z, MU])
     tz, tmu = _t(z, gpu).requires_grad_(True), _t(mu, gpu).requires_grad_(True)
     lg, kk = F.GmmLatent.apply(tz, tmu, _t(u, gpu), float(np.log(np.float32(1.0) / np.float32(K))), 0.5)
-    assert _rel(lg.detach().cpu().numpy(), lo.v) < 2e-5 and np.abs(kk.detach().cpu().numpy() - ko.v).max() < 2e-5
+    assert _rel(lg.detach().cpu().numpy(), lo.v) < TOL_LONG and np.abs(kk.detach().cpu().numpy() - ko.v).max() < 2e-5
     assert np.abs(kk.detach().cpu().numpy().sum(1) - 1).max() < 1e-5
     dz, dmu = torch.autograd.grad([lg, kk], [tz, tmu], grad_outputs=[_t(gl, gpu), _t(gk, gpu)])
     assert _rel(dz.cpu().numpy(), rz.v) < 1e-4 and _rel(dmu.cpu().numpy(), rmu.v) < 1e-4
@@ -939,21 +988,21 @@ def test_conv3d_entry_points(gpu, case):
     tx, tw, tb = (_t(a, gpu).requires_grad_() for a in (x, w, b.reshape(1, 1, 1, 1, Co)))
     y = F.conv3d(tx, tw, tb, sl, st)
     assert tuple(y.shape) == ref.shape
-    assert _rel(y.detach().cpu().numpy(), ref) <= 2e-5
+    assert _rel(y.detach().cpu().numpy(), ref) <= TOL
     gx, gw, gb = torch.autograd.grad(y, (tx, tw, tb), _t(gy, gpu))
-    assert _rel(gx.cpu().numpy(), O.conv3d_bwd_data(gy, w, x.shape, sl, st)) <= 2e-5
-    assert _rel(gw.cpu().numpy(), O.conv3d_bwd_filter(x, gy, fl, fs, sl, st)) <= 2e-5
-    assert gb.shape == tb.shape and _rel(gb.cpu().numpy().reshape(-1), gy.reshape(-1, Co).sum(0)) <= 2e-5
+    assert _rel(gx.cpu().numpy(), O.conv3d_bwd_data(gy, w, x.shape, sl, st)) <= TOL
+    assert _rel(gw.cpu().numpy(), O.conv3d_bwd_filter(x, gy, fl, fs, sl, st)) <= TOL
+    assert gb.shape == tb.shape and _rel(gb.cpu().numpy().reshape(-1), gy.reshape(-1, Co).sum(0)) <= TOL
     # no bias, no input gradient
     y2 = F.conv3d(_t(x, gpu), tw, None, sl, st)
-    assert _rel(y2.detach().cpu().numpy(), ref - b) <= 2e-5
+    assert _rel(y2.detach().cpu().numpy(), ref - b) <= TOL
     (gw2,) = torch.autograd.grad(y2, (tw,), _t(gy, gpu))
     assert _rel(gw2.cpu().numpy(), gw.cpu().numpy()) <= 1e-5      # (a different split of the same reduction)
     # fused activation epilogue and its backward
     y3 = F.conv3d(tx, tw, tb, sl, st, F.ACT_LRELU, 0.2)
-    assert _rel(y3.detach().cpu().numpy(), np.where(ref > 0, ref, 0.2 * ref)) <= 2e-5
+    assert _rel(y3.detach().cpu().numpy(), np.where(ref > 0, ref, 0.2 * ref)) <= TOL
     (gx3,) = torch.autograd.grad(y3, (tx,), _t(gy, gpu))
-    assert _rel(gx3.cpu().numpy(), O.conv3d_bwd_data(gy * np.where(ref > 0, 1.0, 0.2), w, x.shape, sl, st)) <= 2e-5
+    assert _rel(gx3.cpu().numpy(), O.conv3d_bwd_data(gy * np.where(ref > 0, 1.0, 0.2), w, x.shape, sl, st)) <= TOL
     # the two routes against each other, and the implicit route under double differentiation
     import ctypes as C
     from graphical_gan_amd import _lib
@@ -1132,13 +1181,13 @@ def test_critic_head(gpu, M, K1, K2, H, need):
     ins = [x for x in (ta1, ta2, tw, tb, two, tbo) if x is not None and x.requires_grad]
     grads = dict(zip([id(x) for x in ins], torch.autograd.grad(out, ins, grad_outputs=_t(g, gpu))))
     if in_grad:
-        assert _rel(grads[id(ta1)].cpu().numpy(), ref['a'][:, :K1]) < 2e-5
+        assert _rel(grads[id(ta1)].cpu().numpy(), ref['a'][:, :K1]) < TOL
         if K2:
-            assert _rel(grads[id(ta2)].cpu().numpy(), ref['a'][:, K1:]) < 2e-5
+            assert _rel(grads[id(ta2)].cpu().numpy(), ref['a'][:, K1:]) < TOL
     if wt_grad:
-        assert _rel(grads[id(tw)].cpu().numpy(), ref['w']) < 2e-5
-        assert _rel(grads[id(tb)].cpu().numpy(), ref['b']) < 2e-5
-        assert _rel(grads[id(two)].cpu().numpy().reshape(-1), ref['wo'].reshape(-1)) < 2e-5
+        assert _rel(grads[id(tw)].cpu().numpy(), ref['w']) < TOL
+        assert _rel(grads[id(tb)].cpu().numpy(), ref['b']) < TOL
+        assert _rel(grads[id(two)].cpu().numpy().reshape(-1), ref['wo'].reshape(-1)) < TOL
         assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
 
 
@@ -1191,13 +1240,13 @@ def test_critic_head_that_knows_its_cost(gpu, M, K1, K2, H, terms, need):
     assert abs(float(loss.detach()) - cost) <= 1e-5 * max(1.0, abs(cost))
     plain = F.BceSum.apply(tuple(z for _, z, _ in terms), tuple(wt for _, _, wt in terms), *[p.detach() for p in parts])
     assert float(plain) == float(loss.detach())
-    assert _rel(grads[id(ta1)].cpu().numpy(), ref['a'][:, :K1]) < 2e-5
+    assert _rel(grads[id(ta1)].cpu().numpy(), ref['a'][:, :K1]) < TOL
     if K2:
-        assert _rel(grads[id(ta2)].cpu().numpy(), ref['a'][:, K1:]) < 2e-5
+        assert _rel(grads[id(ta2)].cpu().numpy(), ref['a'][:, K1:]) < TOL
     if wt_grad:
-        assert _rel(grads[id(tw)].cpu().numpy(), ref['w']) < 2e-5
-        assert _rel(grads[id(tb)].cpu().numpy(), ref['b']) < 2e-5
-        assert _rel(grads[id(two)].cpu().numpy().reshape(-1), ref['wo'].reshape(-1)) < 2e-5
+        assert _rel(grads[id(tw)].cpu().numpy(), ref['w']) < TOL
+        assert _rel(grads[id(tb)].cpu().numpy(), ref['b']) < TOL
+        assert _rel(grads[id(two)].cpu().numpy().reshape(-1), ref['wo'].reshape(-1)) < TOL
         assert abs(float(grads[id(tbo)]) - ref['bo']) < 2e-5 * max(1.0, abs(ref['bo']))
 
 
@@ -1269,8 +1318,8 @@ def test_mix_mean(gpu, B, K, D, onehot):
     comp = F.Axpby.apply(F.Gemm.apply(_t(k, gpu), _t(mu, gpu), None, False, False, F.ACT_NONE, 0.0), _t(nz, gpu), 1.0, 1.0, 0.0)
     assert torch.equal(out.detach(), comp) if onehot else _rel(out.detach().cpu().numpy(), comp.cpu().numpy()) < 1e-6
     dk, dm, dn = torch.autograd.grad(out, [tk, tm, tn], grad_outputs=_t(g, gpu))
-    assert _rel(dm.cpu().numpy(), k.astype(np.float64).T @ g) < 2e-5
-    assert _rel(dk.cpu().numpy(), g.astype(np.float64) @ mu.astype(np.float64).T) < 2e-5
+    assert _rel(dm.cpu().numpy(), k.astype(np.float64).T @ g) < TOL
+    assert _rel(dk.cpu().numpy(), g.astype(np.float64) @ mu.astype(np.float64).T) < TOL
     assert torch.equal(dn, _t(g, gpu))
 
 
@@ -1348,7 +1397,7 @@ def test_dyn_scan(gpu, B, T, dl, dt, res_w):
     dev = [_t(v, gpu).requires_grad_(True) for v in vals]
     d = dict(zip(names, dev))
     out = F.DynScan.apply(d['z0'], d['eps'], d['w_in'], d['b_in'], d['w_1'], d['b_1'], d['w_out'], d['b_out'], d.get('zw'), d.get('b_zw'), T, 0.2)
-    assert _rel(out.detach().cpu().numpy(), zs.detach().numpy()) < 2e-5
+    assert _rel(out.detach().cpu().numpy(), zs.detach().numpy()) < TOL
     g = torch.autograd.grad(out, dev, grad_outputs=_t(gz, gpu))
     for n, a, b in zip(names, g, gref):
         assert _rel(a.cpu().numpy(), b.numpy()) < 5e-5, n
@@ -1429,12 +1478,12 @@ def test_masked_data_gradient_and_its_backward(gpu, case, act):
     tg, tw = _t(gy, gpu).requires_grad_(True), _t(w, gpu).requires_grad_(True)
     gx = F.ConvDgradMasked.apply(tg, _t(yref, gpu), tw, geom, a, alpha)
     ref = O.conv2d_bwd_data(gm64, w64, (H, H), 2, 'SAME')
-    assert _rel(gx.detach().cpu().numpy(), ref) < 2e-5
+    assert _rel(gx.detach().cpu().numpy(), ref) < TOL
     d_gy, d_w = torch.autograd.grad(gx, [tg, tw], grad_outputs=_t(h, gpu))
     ref_gy = O.conv2d(h64, w64, 2, 'SAME') * slope
     ref_w = O.conv2d_bwd_filter(h64, gm64, 5, 2, 'SAME')
-    assert _rel(d_gy.cpu().numpy(), ref_gy) < 2e-5, _rel(d_gy.cpu().numpy(), ref_gy)
-    assert _rel(d_w.cpu().numpy(), ref_w) < 2e-5, _rel(d_w.cpu().numpy(), ref_w)
+    assert _rel(d_gy.cpu().numpy(), ref_gy) < TOL, _rel(d_gy.cpu().numpy(), ref_gy)
+    assert _rel(d_w.cpu().numpy(), ref_w) < TOL, _rel(d_w.cpu().numpy(), ref_w)
     # the composition it replaces
     ug, uw = _t(gy, gpu).requires_grad_(True), _t(w, gpu).requires_grad_(True)
     gx2 = F.ConvDgrad.apply(F.ActBwd.apply(ug, _t(yref, gpu), a, alpha), uw, None, geom, F.ACT_NONE, 0.0)
@@ -1490,12 +1539,12 @@ def test_gradient_penalty_one_launch_forward_and_unit_gradient(gpu, B, D):
         assert abs(float(pen) - pen_ref) <= 2e-5 * max(1.0, pen_ref), (rep, float(pen), pen_ref)
         ref_cost = float(d_fake.mean() - d_real.mean()) + pen_ref
         assert abs(float(cost) - ref_cost) <= 2e-5 * max(1.0, abs(ref_cost))
-        assert _rel(gg.cpu().numpy(), gg_ref) < 2e-5
+        assert _rel(gg.cpu().numpy(), gg_ref) < TOL
         assert np.allclose(gf.cpu().numpy(), 1.0 / B) and np.allclose(gr.cpu().numpy(), -1.0 / B)
     # the generic path (an upstream gradient that is not the unit seed) and the two-launch entry points
     pen = F.GradPenalty.apply(tg, 10.0)
     (gg2,) = torch.autograd.grad(pen, [tg], grad_outputs=torch.full((), 0.5, device=gpu))
-    assert _rel(gg2.cpu().numpy(), 0.5 * gg_ref) < 2e-5
+    assert _rel(gg2.cpu().numpy(), 0.5 * gg_ref) < TOL
     assert int(F.GradPenalty._ARRIVE[(gpu.type, gpu.index)][0]) == 0
 
 
@@ -1524,16 +1573,16 @@ def test_conv_family_planned_for_fewer_workgroups(gpu, case, target):
         tw2 = _t(w, gpu).requires_grad_(True)
         dx = F.ConvDgrad.apply(tg, tw2, None, geom, F.ACT_NONE, 0.0)          # Deconv2D forward
     assert F._geom(geom).plan_wgs == 0 and F._geom(geom).plan_wgs_filter == 0      # nothing left set outside the context
-    assert _rel(y.detach().cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < 2e-5
-    assert _rel(dx.detach().cpu().numpy(), O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME')) < 2e-5
+    assert _rel(y.detach().cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < TOL
+    assert _rel(dx.detach().cpu().numpy(), O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME')) < TOL
     with torch.no_grad():
         pass
     gx, gw = torch.autograd.grad(y, [tx, tw], grad_outputs=_t(gy, gpu))        # backward launches: the remembered plan
-    assert _rel(gx.cpu().numpy(), O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME')) < 2e-5
-    assert _rel(gw.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < 2e-5
+    assert _rel(gx.cpu().numpy(), O.conv2d_bwd_data(gy64, w64, (H, H), 2, 'SAME')) < TOL
+    assert _rel(gw.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < TOL
     dg, dw2 = torch.autograd.grad(dx, [tg, tw2], grad_outputs=_t(x, gpu))      # Deconv2D backward: forward conv + filter gradient
-    assert _rel(dg.cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < 2e-5
-    assert _rel(dw2.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < 2e-5
+    assert _rel(dg.cpu().numpy(), O.conv2d(x64, w64, 2, 'SAME')) < TOL
+    assert _rel(dw2.cpu().numpy(), O.conv2d_bwd_filter(x64, gy64, 5, 2, 'SAME')) < TOL
     assert F._geom(geom).plan_wgs == 0 and F._geom(geom).plan_wgs_filter == 0
 
 
@@ -1587,7 +1636,7 @@ def test_dg16_data_gradient(gpu, case, kq, variant, monkeypatch):
     names = [r['name'] for r in _lib.prof_report()]
     L.ggan_prof_reset()
     assert any(n.startswith('dg16_kernel<') for n in names), names
-    assert _rel(gx.cpu().numpy(), ref) < 2e-5
+    assert _rel(gx.cpu().numpy(), ref) < TOL
 
 
 @pytest.mark.parametrize('case', [(64, 64, 16, 128), (128, 64, 16, 128), (128, 128, 8, 256), (64, 256, 8, 256), (64, 32, 32, 64)])

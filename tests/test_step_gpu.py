@@ -444,7 +444,9 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
     assert 'workload' in d['config'] and 'model' not in d['config']
     # every BASELINE configuration rides along as a SHORT record; the long form is the full record next to it
-    assert [v['key'] for v in d['variants']] == ['wali-gp', 'gmgan-cifar10-K30', 'gmgan-cifar10-K10', 'gan-face', 'ssgan-moving-mnist',
+    assert 'G+D+GP' in d['metric'] and 'MODE=wali-gp' in d['config']['workload'] and d['config']['minibatches_per_step'] == 6
+    assert d['g_d_step']['value'] > d['value']           # (the script's default MODE='ali': one critic step, no penalty)
+    assert [v['key'] for v in d['variants']] == ['ali', 'gmgan-cifar10-K30', 'gmgan-cifar10-K10', 'gan-face', 'ssgan-moving-mnist',
                                                  'ssgan-moving-mnist-3dcnn']
     for v in d['variants']:
         assert v['value'] > 0 and v['ms_per_step'] > 0 and v['frac'] > 0 and v['cpu'] > 0 and v['finite'], v['key']
@@ -452,7 +454,14 @@ def test_bench_contract_line_single_and_two_ranks(gpu):
     assert full['value'] == d['value'] and len(full['variants']) == 6
     for v in full['variants']:
         assert v['algorithmic_gflop_per_step'] > 0 and v['roofline']['frac'] > 0 and v['cpu_baseline']['value'] > 0, v['key']
-    assert 'G+D+GP' in full['variants'][0]['metric'] and 'N_COMS=10' in full['variants'][2]['config']['workload']
+    assert 'G+D step' in full['variants'][0]['metric'] and 'N_COMS=10' in full['variants'][2]['config']['workload']
+    # the roofline object is one record: the kernel-level figures are sums / launch-mix averages of its per-grid rows
+    rf = full['roofline']
+    mix = rf['launch_mix']
+    n = sum(r['launches_per_step'] for r in mix)
+    assert n > 0 and abs(sum(r['launches_per_step'] * r['flop_per_launch'] for r in mix) / n - rf['flop_per_launch']) <= 1e-6 * rf['flop_per_launch']
+    assert abs(sum(r['launches_per_step'] * r['algorithmic_bytes'] for r in mix) / n - rf['algorithmic_bytes']) <= 2 + 1e-6 * rf['algorithmic_bytes']
+    assert abs(sum(r['launches_per_step'] * r['avg_us'] for r in mix) / n - rf['avg_launch_us']) <= 0.02 * rf['avg_launch_us']
     port = 29700 + (os.getpid() % 200)
     env2 = dict(env, GGAN_DIST_BACKEND='gloo')
     # exactly as the driver invokes it: no launcher around it -- bench.py starts its own ranks (round-3 review: this form used to exit)
@@ -507,7 +516,7 @@ def test_rccl_exchange_inside_the_step_graph_one_rank_rehearsal(gpu):
     port = 29400 + (os.getpid() % 200)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                         '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '6', '--warmup', '2',
-                        '--variants', 'wali-gp', '--variant-steps', '3', '--no-cpu-baseline', '--repeats', '0'],
+                        '--variants', 'ali', '--variant-steps', '3', '--no-cpu-baseline', '--repeats', '0'],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])

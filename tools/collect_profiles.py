@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-WORK = {'': 'headline', '_face': 'gan-face', '_waligp': 'wali-gp', '_ssgan': 'ssgan-moving-mnist', '_gmgan': 'gmgan-cifar10-K10',
+WORK = {'': 'headline', '_face': 'gan-face', '_ali': 'ali', '_ssgan': 'ssgan-moving-mnist', '_gmgan': 'gmgan-cifar10-K10',
         '_ssgan3d': 'ssgan-moving-mnist-3dcnn'}
 table = {'_tag': tag}
 for suffix, key in WORK.items():

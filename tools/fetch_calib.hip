@@ -64,6 +64,46 @@ __global__ __launch_bounds__(256) void dma_k(const float* src, size_t n, float* 
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// Partial lines: every second SEG-byte segment of the buffer is read (dword loads, a wave covers 256 useful bytes per instruction), so
+// the useful bytes are HALF the buffer while every 128-byte line (SEG <= 64) or every second one (SEG = 128) is touched.  What FETCH_SIZE
+// reports for these tells whether a 64-byte row of a 16-wide image (the x slab rows of the 16x16 layers) is counted as 64 or 128 bytes.
+template <int SEG>
+__global__ __launch_bounds__(256) void seg_k(const float* src, size_t n, float* out) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, (short)0, 0x7FFFFFF0, 0x00020000);
+    constexpr int SF = SEG / 4;                    // floats per segment
+    float acc = 0.f;
+    for (size_t base = (size_t)blockIdx.x * 262144; base < n; base += (size_t)gridDim.x * 262144)
+        for (int i = threadIdx.x; i < 131072; i += 256) {      // useful float i of this stripe -> segment i / SF, every second segment
+            const int e = (i / SF) * (2 * SF) + (i % SF);
+            acc += __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((base + e) * 4), 0, 0));
+        }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+// WRITE_SIZE: the same question for the store paths (round-4 review: the counter read half of a forward kernel's output tensor).
+//   st_dword_k    global store, 4 B per lane, coalesced           (pointwise kernels, scalar epilogues)
+//   st_b128_k     global store, 16 B per lane                     (the conv / GEMM epilogues: float4 rows through LDS)
+//   st_b128_buf_k raw buffer store, 16 B per lane
+__global__ __launch_bounds__(256) void st_dword_k(float* dst, size_t n) {
+    for (size_t base = (size_t)blockIdx.x * 262144; base < n; base += (size_t)gridDim.x * 262144)
+        for (int i = threadIdx.x; i < 262144; i += 256) dst[base + i] = (float)i;
+}
+
+__global__ __launch_bounds__(256) void st_b128_k(float* dst, size_t n) {
+    for (size_t base = (size_t)blockIdx.x * 262144; base < n; base += (size_t)gridDim.x * 262144)
+        for (int i = threadIdx.x * 4; i < 262144; i += 256 * 4)
+            *reinterpret_cast<float4*>(dst + base + i) = make_float4((float)i, 1.f, 2.f, 3.f);
+}
+
+__global__ __launch_bounds__(256) void st_b128_buf_k(float* dst, size_t n) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, (short)0, 0x7FFFFFF0, 0x00020000);
+    for (size_t base = (size_t)blockIdx.x * 262144; base < n; base += (size_t)gridDim.x * 262144)
+        for (int i = threadIdx.x * 4; i < 262144; i += 256 * 4) {
+            u32x4 v = {(unsigned)i, 1u, 2u, 3u};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)((base + i) * 4), 0, 0);
+        }
+}
+
 int main(int argc, char** argv) {
     const size_t bytes = (size_t)1 << 30;          // 1 GiB: four times L2 + Infinity Cache
     const size_t n = bytes / 4;
@@ -76,6 +116,12 @@ int main(int argc, char** argv) {
         if (which < 0 || which == 1) hipLaunchKernelGGL(b128_k, dim3(1024), dim3(256), 0, 0, d, n, o);
         if (which < 0 || which == 2) hipLaunchKernelGGL(dma_k<4>, dim3(1024), dim3(256), 0, 0, d, n, o);
         if (which < 0 || which == 3) hipLaunchKernelGGL(dma_k<16>, dim3(1024), dim3(256), 0, 0, d, n, o);
+        if (which < 0 || which == 7) hipLaunchKernelGGL(seg_k<32>, dim3(1024), dim3(256), 0, 0, d, n, o);
+        if (which < 0 || which == 8) hipLaunchKernelGGL(seg_k<64>, dim3(1024), dim3(256), 0, 0, d, n, o);
+        if (which < 0 || which == 9) hipLaunchKernelGGL(seg_k<128>, dim3(1024), dim3(256), 0, 0, d, n, o);
+        if (which < 0 || which == 4) hipLaunchKernelGGL(st_dword_k, dim3(1024), dim3(256), 0, 0, d, n);
+        if (which < 0 || which == 5) hipLaunchKernelGGL(st_b128_k, dim3(1024), dim3(256), 0, 0, d, n);
+        if (which < 0 || which == 6) hipLaunchKernelGGL(st_b128_buf_k, dim3(1024), dim3(256), 0, 0, d, n);
     }
     if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "kernel failed\n"); return 1; }
     printf("bytes_per_launch %zu\n", bytes);

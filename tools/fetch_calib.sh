@@ -21,9 +21,13 @@ for ctr in ('fetch', 'write'):
         v = sorted(d.values())[len(d) // 2] * 1024.0       # median dispatch, KiB -> bytes
         res.setdefault(k, {})[ctr.upper() + '_SIZE_bytes'] = v
 for k, d in res.items():
-    if 'FETCH_SIZE_bytes' in d and d['FETCH_SIZE_bytes'] > 0:
+    store = k.strip().startswith('st_')
+    key = 'WRITE_SIZE_bytes' if store else 'FETCH_SIZE_bytes'
+    if d.get(key, 0) > 0:
+        if 'seg_k' in k:
+            d['useful_bytes'] = bytes_per_launch / 2
         d['true_bytes'] = bytes_per_launch
-        d['bytes_per_counted_byte'] = round(bytes_per_launch / d['FETCH_SIZE_bytes'], 4)
+        d['bytes_per_counted_byte'] = round(bytes_per_launch / d[key], 4)
 json.dump(res, open(os.path.join(os.path.dirname(O), 'fetch_calib.json'), 'w'), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 P

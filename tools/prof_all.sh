@@ -1,8 +1,9 @@
 cd $GRAFT_REPO_ROOT
-T=${T:-r04}
-bash tools/prof_round.sh ${T}
-bash tools/prof_round.sh ${T}_face --dataset face
-SPI=6 bash tools/prof_round.sh ${T}_waligp --mode wali-gp
+T=${T:-r05}
+# the headline is the BASELINE metric's G+D+GP step (bench.py default: --mode wali-gp, 1 generator + 5 critic steps per iteration)
+SPI=6 bash tools/prof_round.sh ${T}
+bash tools/prof_round.sh ${T}_face --dataset face --mode ali
+SPI=2 bash tools/prof_round.sh ${T}_ali --mode ali
 bash tools/prof_round.sh ${T}_gmgan --mode local_ep --n-coms 10
 SPI=2 bash tools/prof_round.sh ${T}_ssgan --dataset moving_mnist
 SPI=2 bash tools/prof_round.sh ${T}_ssgan3d --dataset moving_mnist --ssgan-mode ali:3dcnn
