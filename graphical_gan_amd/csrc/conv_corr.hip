@@ -71,6 +71,11 @@ struct CorrParams {
     int dma;                      // forward kinds: stage the slab and the filter slice by LDS-DMA (buffer_load ... lds)
     int xq;                       // 4: the slab is staged in 16-byte units of image rows (forward DMA path, see plan_and_launch), else 1
     int plan_wgs;                 // ggan_conv_geom.plan_wgs of the call (0: default)
+    // XCD-aware tile order (round 5): workgroup id % 8 is the XCD it runs on and every XCD has its own L2.  The eight XCDs are dealt out as
+    // xcd_p pixel-tile groups x (8 / xcd_p) channel-tile groups, so that an XCD's L2 fetches 1 / xcd_p of the input tensor and
+    // xcd_p / 8 of the filter instead of (with the plain order: pixel tiles fastest) 1/8 of the input and ALL of the filter -- 26 of the
+    // 29 MB the 128->256 layer fetched for a 6.4 MB problem.  0: plain order.
+    int xcd_p;
     int nstg;                     // forward DMA path: LDS staging buffers (3: ring fetched two chunks ahead, round 4; 2: the round-2 scheme)
     const unsigned* xtab;         // forward DMA path: plan-time slab offsets [tile position][XE][NTHR] (relative to the tile's first image), or NULL
     unsigned long long* stamps;   // debug: per-workgroup s_memtime stamps (GGAN_DBG & 4)
@@ -222,7 +227,7 @@ template <> struct ClassList<3> { static constexpr int NC = 4; static constexpr 
                                   static constexpr int th(int i) { return i < 2 ? 3 : 2; } static constexpr int tw(int i) { return (i & 1) ? 2 : 3; } };
 
 template <int KIND, int SU, int DI, int WM, int WN, int KS, int PW, bool X4 = false>
-__device__ __forceinline__ void corr_body(const CorrParams& P, const int split, float* smem) {
+__device__ __forceinline__ void corr_body(const CorrParams& P, const int split, float* smem, const int bx, const int by) {
     using CL = ClassList<KIND>;
     constexpr int NC = CL::NC;
     constexpr int CK = 2 * KS * PW;
@@ -259,11 +264,11 @@ __device__ __forceinline__ void corr_body(const CorrParams& P, const int split, 
 
     // ---- which tile ---------------------------------------------------------------------------------
     const int tiles_per_img = P.tiles_r * P.tiles_c;
-    const int ig = blockIdx.x / tiles_per_img;
-    const int tt = blockIdx.x - ig * tiles_per_img;
+    const int ig = bx / tiles_per_img;
+    const int tt = bx - ig * tiles_per_img;
     const int tr = tt / P.tiles_c, tc = tt - tr * P.tiles_c;
     const int n0 = ig * P.TI, u0 = tr * P.TR, v0 = tc * P.TC;
-    const int cn0 = blockIdx.y * TNW;
+    const int cn0 = by * TNW;
     const int ck_begin = split * P.cps;
     const int ck_end = min(ck_begin + P.cps, P.CKtot);
     const int in_row0 = SU * u0 + P.row0, in_col0 = SU * v0 + P.col0;
@@ -873,14 +878,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void corr_kernel(const CorrParam
     extern __shared__ __attribute__((aligned(16))) float smem[];
     warm_kernarg(P);
     const int grp = blockIdx.z / P.SK, split = blockIdx.z - grp * P.SK;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (P.xcd_p > 0) {
+        // (gridDim.x % xcd_p == 0, gridDim.y % (8 / xcd_p) == 0 and gridDim.x * gridDim.y % 8 == 0: checked by the launcher)
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        const int pg = xcd % P.xcd_p, cg = xcd / P.xcd_p;
+        const int npx = gridDim.x / P.xcd_p, nch = gridDim.y / (8 / P.xcd_p);
+        bx = pg * npx + slot % npx;
+        by = cg * nch + slot / npx;
+    }
     if constexpr (MODE == 0) {
-        corr_body<0, 2, 1, WM, WN, KS, PW, X4>(P, split, smem);
+        corr_body<0, 2, 1, WM, WN, KS, PW, X4>(P, split, smem, bx, by);
     } else if constexpr (MODE == 2) {
-        corr_body<3, 1, -1, WM, WN, KS, PW, X4>(P, split, smem);
+        corr_body<3, 1, -1, WM, WN, KS, PW, X4>(P, split, smem, bx, by);
     } else if (grp == 0) {
-        corr_body<1, 1, -1, WM, WN, KS, PW, X4>(P, split, smem);
+        corr_body<1, 1, -1, WM, WN, KS, PW, X4>(P, split, smem, bx, by);
     } else {
-        corr_body<2, 1, -1, WM, WN, KS, PW, X4>(P, split, smem);
+        corr_body<2, 1, -1, WM, WN, KS, PW, X4>(P, split, smem, bx, by);
     }
 }
 
@@ -1236,6 +1250,18 @@ int plan_and_launch(CorrParams& P, int Hu, int Wv, int su, int ext_r, int ext_c,
     }
     if (MODE == 0 && P.dma && env_int("GGAN_CORR_XTAB", 1)) P.xtab = fwd_slab_table(P, CK, 64 * wc.WM * wc.WN * wc.KS, su, s);
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
+    {   // XCD-aware tile order: what the eight L2s fetch together is 8 * input / p + filter * p for p pixel-tile groups
+        P.xcd_p = 0;
+        const int force = env_int("GGAN_CORR_XCD", -1);
+        if (force != 0 && (gx * gy) % 8 == 0) {
+            double best = (gx % 8 == 0) ? (double)P.in_bytes + 8.0 * P.w_bytes : 8.0 * ((double)P.in_bytes + P.w_bytes);    // plain order
+            for (int p = 1; p <= 8; p *= 2) {
+                if (gx % p || gy % (8 / p) || (force > 0 && p != force)) continue;
+                const double cost = 8.0 * P.in_bytes / p + (double)P.w_bytes * p;
+                if (cost < 0.9 * best || force > 0) { best = cost; P.xcd_p = p; }
+            }
+        }
+    }
     int rc = launch_cfg<MODE>(cfg, P, dim3(gx, gy, groups * P.SK), shmem, s, name, fl);
     if (rc) return rc;
     if (P.SK > 1)

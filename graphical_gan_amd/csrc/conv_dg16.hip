@@ -61,6 +61,7 @@ struct Dg16Params {
     int ahead;             // chunks the DMA runs ahead: 1 (2: experiment)
     int nstage;            // staging buffers: 2, or 3 when something runs two chunks ahead (the MASKED slab's register loads, ahead == 2)
     unsigned in_bytes, w_bytes;
+    int xcd_p;                    // XCD-aware tile order (conv_corr.hip, CorrParams::xcd_p): pixel-tile groups among the 8 XCDs; 0 = plain order
     int act;
     float alpha;
     float in_slope;        // MASKED: slope of the negative side (lrelu alpha, relu 0)
@@ -123,10 +124,17 @@ __device__ __forceinline__ void dg16_body(const Dg16Params& P, float* smem) {
     // ---- which tile ---------------------------------------------------------------------------------------------------------
     const int lTC = P.lTC, lTR = P.lTR, TC = 1 << lTC, TR = 1 << lTR, TI = 64 >> (lTC + lTR);
     const int tpi = P.tiles_r * P.tiles_c;
-    const int ig = blockIdx.x / tpi, tpos = blockIdx.x - ig * tpi;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (P.xcd_p > 0) {
+        const int xcd = wg_lin & 7, slot = wg_lin >> 3;
+        const int npx = gridDim.x / P.xcd_p, nch = gridDim.y / (8 / P.xcd_p);
+        bx = (xcd % P.xcd_p) * npx + slot % npx;
+        by = (xcd / P.xcd_p) * nch + slot / npx;
+    }
+    const int ig = bx / tpi, tpos = bx - ig * tpi;
     const int tr = tpos / P.tiles_c, tc = tpos - tr * P.tiles_c;
     const int n0 = ig * TI, u0 = tr * TR, v0 = tc * TC;
-    const int cn0 = blockIdx.y * CHT;
+    const int cn0 = by * CHT;
     const int HWin = P.Hin * P.Win;
     const int XREG = P.xinstr * 256;                      // slab region of a stage: whole wave-instructions (64 lanes x 4 floats)
     const int STAGE = WREG + XREG;
@@ -535,6 +543,18 @@ int conv_dgrad_dg16(const ggan_conv_geom& g, const float* gy, GyMask m, const fl
     ws = ws_scratch(ws, ws_bytes);
     if ((P.dbg & 4) && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     const dim3 grid(ptiles, CN / (kq == 2 ? 32 : 16));
+    {   // XCD-aware tile order: what the eight L2s fetch together is 8 * input / p + filter * p for p pixel-tile groups
+        const int gx = (int)grid.x, gy = (int)grid.y, force = env_int("GGAN_CORR_XCD", -1);
+        P.xcd_p = 0;
+        if (force != 0 && (gx * gy) % 8 == 0) {
+            double best = (gx % 8 == 0) ? (double)in_bytes + 8.0 * w_bytes : 8.0 * ((double)in_bytes + w_bytes);
+            for (int p = 1; p <= 8; p *= 2) {
+                if (gx % p || gy % (8 / p) || (force > 0 && p != force)) continue;
+                const double cost = 8.0 * in_bytes / p + (double)w_bytes * p;
+                if (cost < 0.9 * best || force > 0) { best = cost; P.xcd_p = p; }
+            }
+        }
+    }
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
     const double ab = (double)in_bytes + (double)w_bytes + 4.0 * (double)g.N * CN * g.H * g.W;
     return launch_dg16(SCP, kq, P, masked, grid, shmem, s, fl, ab);
