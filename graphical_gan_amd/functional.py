@@ -224,6 +224,7 @@ class target_workgroups(object):
 # no process-wide plan (round 3 review: set / launch / restore sequences on C globals interleaved between threads).
 import threading as _threading
 _PLAN = _threading.local()
+_HINT_FILTER = _os.environ.get('GGAN_HINT_FILTER', '1') != '0'
 _PLAIN = [False]       # force_plain(): debug cross-check on the plain kernels (process-wide on purpose: a test switch)
 
 
@@ -234,8 +235,8 @@ def force_plain(on):
 
 
 class launch_hint(object):
-    """with launch_hint(n): forward / data-gradient launches of conv calls made inside (and not under target_workgroups) plan for n
-    workgroups; filter gradients keep their default (engine.Trainer._launch_hint: the wali-gp critic step)"""
+    """with launch_hint(n): the launches of conv calls made inside (and not under target_workgroups) plan for n workgroups
+    (engine.Trainer._launch_hint: the wali-gp critic step, whose penalty pass runs beside the main pass)"""
 
     def __init__(self, n):
         self.n = int(n or 0)
@@ -295,8 +296,10 @@ def conv_geom(N, Ci, H, W, Co, k, stride, padding='SAME'):
 
 
 def _geom(t):
-    both = getattr(_PLAN, 'both', 0)
-    return ConvGeom(*(tuple(t[:11]) + ((both or getattr(_PLAN, 'hint', 0)), both, _lib.PLAN_PLAIN if _PLAIN[0] else 0)))
+    both, hint = getattr(_PLAN, 'both', 0), getattr(_PLAN, 'hint', 0)
+    # (the hint plans the filter gradient too since round 5: with the four-wave kernel 128 workgroups x 4 chunks beat 256 x 2 beside a
+    #  second chain -- headline 4.29 -> 4.17 ms; GGAN_HINT_FILTER=0: filter gradients keep their default, as in rounds 3-4)
+    return ConvGeom(*(tuple(t[:11]) + ((both or hint), (both or (hint if _HINT_FILTER else 0)), _lib.PLAN_PLAIN if _PLAIN[0] else 0)))
 
 
 
