@@ -425,6 +425,21 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
                     if row['mfma_util_pct'] is not None:
                         cw += r['total_ms']
                         ca += r['total_ms'] * row['mfma_util_pct']
+            # the chip's matrix pipes over the WHOLE step: MFMA-busy SIMD-cycles of every launch of an iteration (static per-(kernel, grid)
+            # mean of SQ_VALU_MFMA_BUSY_CYCLES x the launches counted here) / (1024 SIMDs x 2.4 GHz x the measured iteration time).
+            # Unlike a per-kernel figure it does not care how many kernels share the chip at a time
+            busy = fl_cov = fl_all = 0.0
+            for a in agg:
+                st = (tab.get(a['name']) or {}).get('by_grid') or {}
+                for r in a['rows']:
+                    g = st.get(str(r['grid'])) or {}
+                    fl_all += r['flops']
+                    if g.get('mfma_busy_cycles') is not None:
+                        busy += g['mfma_busy_cycles'] * r['launches'] / n_prof
+                        fl_cov += r['flops']
+            if busy > 0 and fl_cov >= 0.9 * fl_all:       # (rows without a counter sample: the Linear products, whose symbols differ between the two profilers)
+                roofline['whole_step_mfma_util_pct'] = round(100.0 * busy / (ms_per_step * 1e-3 * 2.4e9 * 1024), 1)
+                roofline['whole_step_mfma_util_flop_coverage'] = round(fl_cov / fl_all, 3)
             if cw > 0:
                 roofline['conv_stack_mfma_util_pct'] = round(ca / cw, 1)
                 roofline['conv_stack_share_of_kernel_time'] = round(cw / sum(a['total_ms'] for a in agg), 3)
@@ -588,7 +603,7 @@ def _short_roofline(r):
     if not r:
         return None
     keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_eager', 'frac_in_graph', 'avg_launch_us',
-            'avg_launch_us_in_graph', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'conv_stack_mfma_util_pct', 'static_tag')
+            'avg_launch_us_in_graph', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'conv_stack_mfma_util_pct', 'whole_step_mfma_util_pct', 'static_tag')
     d = {k: r.get(k) for k in keep}
     d['source'] = 'frac=frac_eager: live HIP-event bracket, eager replay on the timed graph\'s launch plan; frac_in_graph/traffic/mfma_util_pct/conv_stack_mfma_util_pct (all MFMA conv kernels, time-weighted): profiles/pmc_traffic.json'
     return d

@@ -116,6 +116,7 @@ def main(argv):
                        write_bytes=round(1024.0 * w) if w is not None else None,
                        traffic_bytes=round(1024.0 * (f * FETCH_CORRECTION + w)) if (f is not None and w is not None) else None,
                        mfma_util_pct=round(median(util[key]), 2) if util.get(key) else None,
+                       mfma_busy_cycles=round(mean(c['SQ_VALU_MFMA_BUSY_CYCLES'])) if c.get('SQ_VALU_MFMA_BUSY_CYCLES') else None,
                        pmc_dispatches=max([len(v) for v in c.values()] or [0]))
             by_grid[str(g)] = rec
             if rec['launches_in_window'] and rec['traffic_bytes'] is None:
