@@ -63,7 +63,7 @@ def test_launch_plan_travels_in_the_geometry_struct(lib_built):
     g = F._geom(t)
     assert (g.plan_wgs, g.plan_wgs_filter, g.plan_flags) == (0, 0, 0)
     with F.launch_hint(128):
-        assert (F._geom(t).plan_wgs, F._geom(t).plan_wgs_filter) == (128, 0)
+        assert (F._geom(t).plan_wgs, F._geom(t).plan_wgs_filter) == (128, 128)       # (round 5: the hint plans the filter gradient too)
         with F._planned_for(96):
             assert (F._geom(t).plan_wgs, F._geom(t).plan_wgs_filter) == (96, 96)
         seen = []
