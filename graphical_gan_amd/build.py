@@ -12,8 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libggan.so')
 STAMP = os.path.join(HERE, '.libggan.stamp')
-SOURCES = ['runtime.hip', 'pointwise.hip', 'bn.hip', 'linear_bn.hip', 'gemm.hip', 'conv_naive.hip', 'conv_corr.hip', 'conv_dg16.hip', 'conv_wgrad.hip', 'conv_thin.hip', 'conv_api.hip', 'conv3d.hip', 'dynscan.hip']
+SOURCES = ['runtime.hip', 'pointwise.hip', 'bn.hip', 'linear_bn.hip', 'gemm.hip', 'conv_naive.hip', 'conv_corr.hip', 'conv_dg16.hip', 'conv_wgrad.hip', 'conv_wgrad_split.hip', 'conv_thin.hip', 'conv_api.hip', 'conv3d.hip', 'dynscan.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-Wall', '-Wno-unused-function']
+EXTRA_FLAGS = {'conv_wgrad_split.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 if os.environ.get('GGAN_BUILD_DIAG'):       # timing experiments only (tools/criticality*.sh): compiles GGAN_SKIP_KERNELS in
     FLAGS.append('-DGGAN_DIAG')
 
@@ -26,6 +27,7 @@ def _digest():
                 h.update(fn.encode())
                 h.update(f.read())
     h.update(' '.join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -51,7 +53,7 @@ def _build_locked(force, verbose):
     for src in SOURCES:
         obj = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
         os.makedirs(os.path.dirname(obj), exist_ok=True)
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

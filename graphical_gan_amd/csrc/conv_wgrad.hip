@@ -16,6 +16,7 @@
 #include "common.h"
 #include "conv.h"
 #include <stdlib.h>
+#include <string.h>
 using namespace ggan;
 
 namespace {
@@ -25,6 +26,20 @@ namespace {
 // instead of LDS fragments.  0 in the product build: the branches fold away.
 #ifndef GGAN_ABL
 #define GGAN_ABL 0
+#endif
+// conv_wgrad_split.hip includes this file with GGAN_WGRAD_SPLIT_TU set and is compiled with -mllvm -amdgpu-mfma-vgpr-form: the
+// role-split kernel's 256-register waves keep all 200 accumulators in architectural VGPRs (with AGPRs in play the allocator splits
+// the budget 128 / 128 and spills hundreds of registers), so the epilogue's parked quads are "v" operands there.
+#ifndef GGAN_WGRAD_SPLIT_TU
+#define GGAN_WGRAD_SPLIT_TU 0
+#endif
+#ifndef GGAN_SPLIT_SCHED
+#define GGAN_SPLIT_SCHED 1
+#endif
+#if GGAN_WGRAD_SPLIT_TU
+#define GGAN_ACC_REG(q) "v"(q)
+#else
+#define GGAN_ACC_REG(q) "a"(q)
 #endif
 constexpr int TCI = 16, TCO = 16;
 constexpr int NW = 8;                      // waves per workgroup: two per SIMD, pixel quads dealt round-robin
@@ -417,22 +432,28 @@ template <int W_> struct W4Geom {
 
 template <int W> struct WaveTag { static constexpr int value = W; };
 
-template <int GW>
-__global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
+// SPLIT (round 5, experiment GGAN_WGRAD_SPLIT=1): eight waves with the roles split -- waves 0-3 (one per SIMD) only read fragments and
+// multiply, waves 4-7 (their SIMD partners) only stage the next chunk -- so that no staging instruction sits in an MFMA stream.
+template <int GW, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 2 * W4_NTHR : W4_NTHR) void wgrad4_kernel(const WgradParams P) {
     using G = W4Geom<GW>;
     warm_kernarg(P);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 5, NT = 25, NA = 2 * NT, NQ = G::NQ;
     constexpr int XU = G::XU, GU = G::GU, NTHR = W4_NTHR, NITEM = XU + 2 * GU;
     constexpr int HW = G::H * G::W, HoWo = G::Ho * G::Wo;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid_all = threadIdx.x, lane = tid_all & 63, wave_all = tid_all >> 6;
+    const bool prod = !SPLIT || wave_all >= 4, cons = !SPLIT || wave_all < 4;
+    const int tid = SPLIT ? (tid_all & (NTHR - 1)) : tid_all;        // staging thread id (producers) / thread id among the multiplying waves
+    const int wave = wave_all & 3;                                   // pixel-quad owner index of a multiplying wave
+    constexpr int NALL = SPLIT ? 2 * NTHR : NTHR;
     const int l15 = lane & 15, qq = lane >> 4;
     // split-fastest numbering (XCD = id % 8): the tiles of one image range share an L2
     const int split = blockIdx.x % P.SK, tile = blockIdx.x / P.SK;
     const int gxt = (P.Ci + TCI - 1) / TCI;
     const int ci0 = (tile % gxt) * TCI, co0 = (tile / gxt) * W4_TCO;
 
-    const bool stamping = P.stamps != nullptr && tid == 0;
+    const bool stamping = P.stamps != nullptr && tid_all == 0;
     auto stamp = [&](int i) { if (stamping) P.stamps[(size_t)blockIdx.x * 16 + i] = __builtin_readcyclecounter(); };
     stamp(0);
 
@@ -484,10 +505,6 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
         gvo[j] = (unsigned)((gimg * P.Co + col) * HoWo + gr * G::Wo + gc) * 4u | (co0 + col < P.Co ? 0u : DEAD);
     }
     const int gl = TCI * G::CS + gcol0 * G::PCp + gp4 * 4;      // LDS float index of unit 0 in staging buffer 0 (unit j: + j*GSTEP*PCp)
-
-    f32x4 acc[NA];
-#pragma unroll
-    for (int t = 0; t < NA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // fragment lane bases (floats): x (ci = lane & 15, pixel = lane >> 4) + this wave's first quad; gy (co = lane & 15, pixel) likewise
     const int wrow = ((4 * wave) % (G::TR * G::Wo)) / G::Wo, wcol = (4 * wave) % G::Wo;
@@ -546,7 +563,57 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
     const int c_end = min(c_begin + P.chunks_per_split, P.chunks_total);
     stamp(1);
     if (c_begin >= c_end) return;        // (the host plans no empty split)
-    {
+    if constexpr (SPLIT) {
+        // The staging waves' whole program: nothing of it is reachable from the multiplying waves' code and the reverse, so neither
+        // role carries the other's registers (200 accumulators here would leave the staging set in scratch).  Both roles pass the
+        // same number of workgroup barriers: two in the prologue, one per chunk, one in the epilogue.
+        if (wave_all >= 4) {
+            {
+                const ChunkBase b0 = chunk_base(c_begin, true);
+#pragma unroll
+                for (int i = 0; i < NITEM; ++i) pf_item(b0, i);
+            }
+            {
+                constexpr int n4 = (TCI * G::CS) >> 2;
+                float4* z0 = reinterpret_cast<float4*>(smem);
+                float4* z1 = reinterpret_cast<float4*>(smem + G::STG);
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = tid_all; e < n4; e += NALL) { z0[e] = z; z1[e] = z; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NITEM; ++i) commit_item(0, i);
+            __syncthreads();
+            for (int ch = c_begin; ch < c_end; ++ch) {
+                const int obo = (((ch - c_begin) & 1) ^ 1) * G::STG;
+                const ChunkBase nb = chunk_base(min(ch + 1, c_end - 1), ch + 1 < c_end);
+#pragma unroll
+                for (int i = 0; i < NITEM; ++i) pf_item(nb, i);
+#pragma unroll
+                for (int i = 0; i < NITEM; ++i) commit_item(obo, i);
+                __syncthreads();
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < GU; ++j) {
+                    float b = bsum[j];
+#pragma unroll
+                    for (int o = G::PC4 >> 1; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+                    const int co = co0 + gcol0 + j * G::GSTEP;
+                    if (gp4 == 0 && co < P.Co) {
+                        if (P.SK == 1) P.gbias[co] = b;
+                        else P.out[(size_t)split * P.slab_stride + P.out_elems + co] = b;
+                    }
+                }
+            }
+            __syncthreads();
+            return;
+        }
+    }
+    f32x4 acc[NA];
+#pragma unroll
+    for (int t = 0; t < NA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (prod) {
         const ChunkBase b0 = chunk_base(c_begin, true);
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) pf_item(b0, i);
@@ -556,11 +623,13 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
         float4* z0 = reinterpret_cast<float4*>(smem);
         float4* z1 = reinterpret_cast<float4*>(smem + G::STG);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = tid; e < n4; e += NTHR) { z0[e] = z; z1[e] = z; }
+        for (int e = tid_all; e < n4; e += NALL) { z0[e] = z; z1[e] = z; }
     }
     __syncthreads();
+    if (prod) {
 #pragma unroll
-    for (int i = 0; i < NITEM; ++i) commit_item(0, i);
+        for (int i = 0; i < NITEM; ++i) commit_item(0, i);
+    }
     __syncthreads();
     stamp(2);
 
@@ -574,6 +643,35 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
         const float* xq = smem + buf * G::STG + xa;        // + q_off(q) + tap offset: immediates
         const float* gq = smem + buf * G::STG + gb;        // + 16 q (+ 16 * PCp for the second channel tile)
         const int obo = (buf ^ 1) * G::STG;
+        if constexpr (SPLIT) {
+            {
+                // multiplying waves: ONE set of fragment registers, a fragment refilled for the next quad right behind its two MFMAs
+                // (200 accumulators + 27 fragments have to fit the 256 registers of a wave that shares its SIMD)
+                float a[NT], b0, b1;
+                auto tap = [&](int q, int t) { return xq[G::q_off(q) + (t / KS) * G::SCp + (((t % KS) + 3) & 1) * G::SCh + (((t % KS) + 3) >> 1)]; };
+                b0 = gq[0]; b1 = gq[16 * G::PCp];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a[t] = tap(0, t);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    float nb0 = 0.f, nb1 = 0.f;
+                    if (q + 1 < NQ) { nb0 = gq[16 * (q + 1)]; nb1 = gq[16 * (q + 1) + 16 * G::PCp]; }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, a[t], acc[t], 0, 0, 0);
+                        acc[NT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, a[t], acc[NT + t], 0, 0, 0);
+                        if (q + 1 < NQ) a[t] = tap(q + 1, t);
+                        // keep each refill where it is written (the scheduler otherwise sinks the read to just above its use a quad
+                        // later and the wave waits out the LDS latency with the matrix pipe idle)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    b0 = nb0; b1 = nb1;
+                }
+            }
+            __syncthreads();
+            if (ch - c_begin < 8) stamp(4 + ch - c_begin);
+            continue;
+        }
         float av[2][NT], bv[2][2];
         auto load_quad = [&](int q, float* a, float* b) {
             if (GGAN_ABL & 4) { b[0] = __int_as_float(gb + q); b[1] = b[0]; for (int t = 0; t < NT; ++t) a[t] = __int_as_float(xa + t); return; }
@@ -619,7 +717,7 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
     }
 
     stamp(12);
-    if (do_bias) {
+    if (do_bias && prod) {
         // lanes gcol*PC4 .. +PC4-1 hold the partial sums of one channel: xor-shuffle within that lane group (PC4 = 32 / 16)
 #pragma unroll
         for (int j = 0; j < GU; ++j) {
@@ -650,7 +748,7 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
 #pragma unroll
             for (int j = o; j < NA; j += 4) {
                 const f32x4 q = acc[j];         // (an asm operand cannot name a captured variable)
-                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "a"(q), "n"((((W - o) & 3) - 1) * REGION + (j >> 2) * 1024) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), GGAN_ACC_REG(q), "n"((((W - o) & 3) - 1) * REGION + (j >> 2) * 1024) : "memory");
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -684,7 +782,7 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
             }
         }
     };
-    switch (wave) {
+    if (cons) switch (wave) {
         case 0: park(WaveTag<0>{}); break;
         case 1: park(WaveTag<1>{}); break;
         case 2: park(WaveTag<2>{}); break;
@@ -692,7 +790,7 @@ __global__ __launch_bounds__(W4_NTHR) void wgrad4_kernel(const WgradParams P) {
     }
     __syncthreads();
     stamp(13);
-    switch (wave) {
+    if (cons) switch (wave) {
         case 0: sum_store(WaveTag<0>{}); break;
         case 1: sum_store(WaveTag<1>{}); break;
         case 2: sum_store(WaveTag<2>{}); break;
@@ -708,7 +806,31 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
+#if GGAN_WGRAD_SPLIT_TU
 namespace ggan {
+int wgrad4_split_launch(int W, unsigned grid, size_t shmem, hipStream_t s, const void* params, double fl, double ab) {
+    WgradParams P;
+    memcpy(&P, params, sizeof(P));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid4(grid);
+    if (W == 16) { GGAN_LAUNCH("wgrad4_kernel<16, true>", fl, ab, (wgrad4_kernel<16, true>), grid4, dim3(2 * W4_NTHR), shmem, s, P); }
+    else if (W == 8) { GGAN_LAUNCH("wgrad4_kernel<8, true>", fl, ab, (wgrad4_kernel<8, true>), grid4, dim3(2 * W4_NTHR), shmem, s, P); }
+    else if (W == 32) { GGAN_LAUNCH("wgrad4_kernel<32, true>", fl, ab, (wgrad4_kernel<32, true>), grid4, dim3(2 * W4_NTHR), shmem, s, P); }
+    else { GGAN_LAUNCH("wgrad4_kernel<64, true>", fl, ab, (wgrad4_kernel<64, true>), grid4, dim3(2 * W4_NTHR), shmem, s, P); }
+    return 0;
+}
+}  // namespace ggan
+#else
+namespace ggan {
+
+int wgrad4_split_launch(int W, unsigned grid, size_t shmem, hipStream_t s, const void* params, double fl, double ab);
 
 int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
                     size_t ws_bytes, hipStream_t s, WgradParts* parts) {
@@ -817,7 +939,10 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     if (parts && ws_bytes < P.slab_stride * sizeof(float)) { set_error("conv_wgrad: partial-slab buffer too small"); return -1; }
     if (want_stamps && !parts && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     const dim3 grid4(gx * gy_ * P.SK);       // split-fastest workgroup numbering (decoded in the kernel)
-    if (four == 16) { GGAN_LAUNCH("wgrad4_kernel<16>", fl, ab, wgrad4_kernel<16>, grid4, dim3(W4_NTHR), shmem, s, P); }
+    static const bool split_roles = env_int("GGAN_WGRAD_SPLIT", 1) != 0;
+    static const int split_roles_mask = env_int("GGAN_WGRAD_SPLIT_W", 8 | 16 | 32 | 64);
+    if (split_roles && four > 0 && (split_roles_mask & four)) { const int rc = wgrad4_split_launch(four, grid4.x, shmem, s, &P, fl, ab); if (rc) return rc; }
+    else if (four == 16) { GGAN_LAUNCH("wgrad4_kernel<16>", fl, ab, wgrad4_kernel<16>, grid4, dim3(W4_NTHR), shmem, s, P); }
     else if (four == 8) { GGAN_LAUNCH("wgrad4_kernel<8>", fl, ab, wgrad4_kernel<8>, grid4, dim3(W4_NTHR), shmem, s, P); }
     else if (four == 32) { GGAN_LAUNCH("wgrad4_kernel<32>", fl, ab, wgrad4_kernel<32>, grid4, dim3(W4_NTHR), shmem, s, P); }
     else if (four == 64) { GGAN_LAUNCH("wgrad4_kernel<64>", fl, ab, wgrad4_kernel<64>, grid4, dim3(W4_NTHR), shmem, s, P); }
@@ -836,3 +961,4 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
 }
 
 }  // namespace ggan
+#endif  // GGAN_WGRAD_SPLIT_TU
