@@ -550,6 +550,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * W4_NTHR : W4_NTHR) void wgrad4_kernel(c
             const int j = i - XU - GU;
             const u32x4 g = sreg[XU + j], rf = sreg[i];
             float4 gv = make_float4(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z), __uint_as_float(g.w));
+            if (GGAN_ABL & 2) { *reinterpret_cast<float4*>(smem + bo + gl + j * G::GSTEP * G::PCp) = gv; return; }
             gv.x = __uint_as_float(rf.x) > 0.f ? gv.x : gv.x * mslope;
             gv.y = __uint_as_float(rf.y) > 0.f ? gv.y : gv.y * mslope;
             gv.z = __uint_as_float(rf.z) > 0.f ? gv.z : gv.z * mslope;
@@ -568,11 +569,48 @@ __global__ __launch_bounds__(SPLIT ? 2 * W4_NTHR : W4_NTHR) void wgrad4_kernel(c
         // role carries the other's registers (200 accumulators here would leave the staging set in scratch).  Both roles pass the
         // same number of workgroup barriers: two in the prologue, one per chunk, one in the epilogue.
         if (wave_all >= 4) {
-            {
-                const ChunkBase b0 = chunk_base(c_begin, true);
+            // What a staging instruction costs the partner wave's MFMA stream (tools/scratch/mfma_filler.hip, profiles/r05_notes.md): LDS and
+            // scalar instructions nothing, a VALU instruction ~10 cycles.  So this loop has next to no VALU: LDS byte addresses of both
+            // buffers sit in registers (the loop is unrolled over the buffer parity), an x unit leaves as two ds_write2_b32 straight out
+            // of the loaded registers (the compiler's ds_write2_b64 first shuffled them into pairs: 3 v_mov per unit), the activation mask
+            // and the bias sums are wave-uniform branches, and an unmasked launch does not issue the reference loads at all.
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+            unsigned xaddr[2][XU];
 #pragma unroll
-                for (int i = 0; i < NITEM; ++i) pf_item(b0, i);
-            }
+            for (int j = 0; j < XU; ++j) { xaddr[0][j] = lds0 + 4u * (unsigned)xl[j]; xaddr[1][j] = xaddr[0][j] + 4u * G::STG; }
+            auto fetch = [&](const ChunkBase& b) {
+#pragma unroll
+                for (int i = 0; i < XU + GU; ++i) pf_item(b, i);
+                if (masked) {
+#pragma unroll
+                    for (int i = XU + GU; i < NITEM; ++i) pf_item(b, i);
+                }
+            };
+            auto commit = [&](auto par) {
+                constexpr int B = decltype(par)::value;
+#pragma unroll
+                for (int i = 0; i < XU; ++i) {
+                    const unsigned x0 = sreg[i].x, x1 = sreg[i].y, x2 = sreg[i].z, x3 = sreg[i].w;
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(xaddr[B][i]), "v"(x0), "v"(x2) : "memory");
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(xaddr[B][i]), "v"(x1), "v"(x3), "n"(G::SCh), "n"(G::SCh + 1) : "memory");
+                }
+#pragma unroll
+                for (int j = 0; j < GU; ++j) {
+                    const u32x4 g = sreg[XU + j];
+                    float4 gv = make_float4(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z), __uint_as_float(g.w));
+                    if (masked && !(GGAN_ABL & 2)) {
+                        const u32x4 rf = sreg[XU + GU + j];
+                        gv.x = __uint_as_float(rf.x) > 0.f ? gv.x : gv.x * mslope;
+                        gv.y = __uint_as_float(rf.y) > 0.f ? gv.y : gv.y * mslope;
+                        gv.z = __uint_as_float(rf.z) > 0.f ? gv.z : gv.z * mslope;
+                        gv.w = __uint_as_float(rf.w) > 0.f ? gv.w : gv.w * mslope;
+                    }
+                    *reinterpret_cast<float4*>(smem + B * G::STG + gl + j * G::GSTEP * G::PCp) = gv;
+                    if (do_bias) bsum[j] += (gv.x + gv.y) + (gv.z + gv.w);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the x stores above are not the compiler's to wait for)
+            };
+            fetch(chunk_base(c_begin, true));
             {
                 constexpr int n4 = (TCI * G::CS) >> 2;
                 float4* z0 = reinterpret_cast<float4*>(smem);
@@ -581,16 +619,19 @@ __global__ __launch_bounds__(SPLIT ? 2 * W4_NTHR : W4_NTHR) void wgrad4_kernel(c
                 for (int e = tid_all; e < n4; e += NALL) { z0[e] = z; z1[e] = z; }
             }
             __syncthreads();
-#pragma unroll
-            for (int i = 0; i < NITEM; ++i) commit_item(0, i);
+            commit(WaveTag<0>{});
             __syncthreads();
-            for (int ch = c_begin; ch < c_end; ++ch) {
-                const int obo = (((ch - c_begin) & 1) ^ 1) * G::STG;
-                const ChunkBase nb = chunk_base(min(ch + 1, c_end - 1), ch + 1 < c_end);
-#pragma unroll
-                for (int i = 0; i < NITEM; ++i) pf_item(nb, i);
-#pragma unroll
-                for (int i = 0; i < NITEM; ++i) commit_item(obo, i);
+            for (int ch = c_begin; ch < c_end; ch += 2) {
+                if (!(GGAN_ABL & 1) && ch + 1 < c_end) {        // (behind the last chunk there is nothing to stage)
+                    fetch(chunk_base(ch + 1, true));
+                    commit(WaveTag<1>{});
+                }
+                __syncthreads();
+                if (ch + 1 >= c_end) break;
+                if (!(GGAN_ABL & 1) && ch + 2 < c_end) {
+                    fetch(chunk_base(ch + 2, true));
+                    commit(WaveTag<0>{});
+                }
                 __syncthreads();
             }
             if (do_bias) {
@@ -648,7 +689,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * W4_NTHR : W4_NTHR) void wgrad4_kernel(c
                 // multiplying waves: ONE set of fragment registers, a fragment refilled for the next quad right behind its two MFMAs
                 // (200 accumulators + 27 fragments have to fit the 256 registers of a wave that shares its SIMD)
                 float a[NT], b0, b1;
-                auto tap = [&](int q, int t) { return xq[G::q_off(q) + (t / KS) * G::SCp + (((t % KS) + 3) & 1) * G::SCh + (((t % KS) + 3) >> 1)]; };
+                auto tap = [&](int q, int t) { if (GGAN_ABL & 4) return __int_as_float(xa + t + q); return xq[G::q_off(q) + (t / KS) * G::SCp + (((t % KS) + 3) & 1) * G::SCh + (((t % KS) + 3) >> 1)]; };
                 b0 = gq[0]; b1 = gq[16 * G::PCp];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) a[t] = tap(0, t);
