@@ -1,7 +1,7 @@
 """graphical_gan_amd -- MI355X-native hot path of zhenxuan00/graphical-gan.
 
   csrc/ + libggan.so   hand-written gfx950 HIP kernels behind the C ABI of include/ggan.h
-  functional.py        torch.autograd bindings (torch = memory / streams / tape only)
+  functional/          torch.autograd bindings, one module per op family (torch = memory / streams / tape only)
   tflib/               host-side mirror of the reference's `tflib` operator API (drop-in module paths)
   optim.py             TF-flavoured Adam on flat buffers + RCCL gradient exchange
   engine.py            step scheduler: gen step / critic steps, HIP-graph capture
