@@ -1701,3 +1701,18 @@ def test_linear_batchnorm_rows_layer_falls_back_where_the_kernel_cannot(gpu, M, 
     ref = np.maximum(O.batchnorm_train(x.astype(np.float64) @ w, np.ones(N), np.zeros(N), (0,)), 0.0)
     assert np.abs(y.detach().cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     lib.delete_all_params()
+
+
+@pytest.mark.parametrize('env', [{'GGAN_WGRAD_SPLIT': '0'}, {'GGAN_WGRAD_SPLIT': '0', 'GGAN_WGRAD_W4': '0'}], ids=['four-waves', 'eight-waves-r4'])
+def test_earlier_filter_gradient_kernels_stay_correct(gpu, env):
+    """The filter gradient runs on the role-split kernel (round 5, conv_wgrad_split.hip); the four-wave kernel it replaced and round 4's
+    eight-wave kernel stay in the library as run-time selections (the switches are read once per process, hence the subprocess): the
+    filter-gradient and conv-family cases against the oracle on each of them."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-k',
+                        'test_conv_family or test_filter_gradient_parts_and_widened_paths'], capture_output=True, text=True, timeout=900, env=e, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
