@@ -542,17 +542,12 @@ class Trainer(object):
             torch.cuda.current_stream(self.device).wait_stream(s)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            dot = os.environ.get('GGAN_GRAPH_DOT')               # debugging: the captured graph's nodes and edges (tools/graph_dot.py)
-            if dot:
-                g.enable_debug_mode()
             costs, keeps = {}, []
             with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
                 for k in kinds:
                     cost, opt, keep = self._step_body(k)          # (with the in-graph gradient exchange when there are replicas)
                     costs[k + '_cost'] = cost
                     keeps.append((opt, keep))
-            if dot:
-                g.debug_dump('%s.%s.dot' % (dot, '_'.join(kinds)))
             return dict(g=g, costs=costs, keep=keeps, kinds=tuple(kinds))
         finally:
             if forkable:
