@@ -618,6 +618,8 @@ def compact_line(full):
     line['config'] = {k: c[k] for k in ('workload', 'parallelism', 'global_batch', 'hip_graph', 'minibatch_feed', 'minibatches_per_step',
                                          'algorithmic_gflop_per_step', 'finite_costs') if k in c}
     line['whole_step_frac'] = full.get('whole_step_frac')
+    if full.get('repeat_ms_per_step'):      # the K-step window repeated after the timed one: the spread a reader of `value` should see
+        line['repeat_ms_per_step'] = full['repeat_ms_per_step']
     if full.get('roofline'):
         line['launches_per_step'] = full['roofline'].get('libggan_launches_per_step')
     line['roofline'] = _short_roofline(full.get('roofline'))
@@ -646,7 +648,7 @@ def compact_line(full):
         if line.get('roofline'):
             line['roofline'].pop('source', None)
         txt = json.dumps(line, separators=(',', ':'))
-    for drop in ('variants', 'data_parallel', 'g_d_step', 'cpu_baseline', 'roofline', 'config'):
+    for drop in ('repeat_ms_per_step', 'variants', 'data_parallel', 'g_d_step', 'cpu_baseline', 'roofline', 'config'):
         if len(txt) < LINE_LIMIT:
             break
         if drop == 'cpu_baseline' and line.get(drop):
