@@ -144,6 +144,17 @@ class Trainer(object):
                 self.feed['k_onehot'].copy_(torch.as_tensor(oh))
             else:
                 self.feed[k].copy_(torch.as_tensor(np.asarray(v)))
+        self._ahead_sync_feeds()
+
+    def _ahead_sync_feeds(self):
+        """injected inputs (inject_noise: tests) reach the per-step feeds of the ahead-of-time nets passes too"""
+        st = getattr(self, '_ahead', None)
+        if st is None or not self.inject_noise:
+            return
+        for f in st['feeds']:
+            for k, v in self.feed.items():
+                if torch.is_tensor(v) and k != 'rng_state' and torch.is_tensor(f.get(k)) and f[k].data_ptr() != v.data_ptr():
+                    f[k].copy_(v)
 
     def set_batch(self, batch):
         self.model.set_batch(self.feed, batch)
@@ -193,13 +204,80 @@ class Trainer(object):
         self.model.sample_noise(self.feed)
 
     # ---- one session.run ------------------------------------------------------------------------------
-    def _nets(self):
+    def _nets(self, feed=None):
+        feed = self.feed if feed is None else feed
         self._sl0 = lib.second_leaf_count()          # (see _no_second_leaves)
         if hasattr(self.model, 'begin_nets'):
-            self.model.begin_nets(self.feed)
+            self.model.begin_nets(feed)
         if not self.inject_noise:
-            self._sample_noise()
-        return self.model.forward_nets(self.feed)
+            self.model.sample_noise(feed)
+        return self.model.forward_nets(feed)
+
+    # ---- the critic steps' nets passes ahead of time (round 5) ---------------------------------------------------------------------
+    # An iteration of the WGAN scripts is one generator step and CRITIC_ITERS critic steps (gan_inference_cifar10.py:351-366), and
+    # every critic step starts with a Generator and an Extractor pass on a fresh minibatch and fresh noise that read no critic weight:
+    # inside the iteration graph the passes of critic steps 2.. are issued as ONE chain on a stream of their own as soon as step 1's
+    # passes are, and run beside critic step 1 (~110 us each of a chain that otherwise stands in front of its critic step; headline
+    # -2.9 %; the bound with those passes removed altogether is -11 %: profiles/r05_notes.md).  What that needs: a feed of its own per
+    # step (noise, [fake; real] pair buffers), the noise launches in the order of the steps (they share the generator state: the chain
+    # is forked behind step 1's launch and joined before the iteration ends), and a ring slot that does not depend on WHEN a pass
+    # runs -- the passes read the critic's step count from a snapshot taken in front of critic step 1 plus their distance from it.
+    def _ahead_ok(self, kinds):
+        c = self.cfg
+        return (not os.environ.get('GGAN_NO_NETS_AHEAD') and list(kinds).count('disc') >= 2 and self.world == 1 and not self.dp_graph
+                and not self.split_graph and not self.sync_bn
+                and hasattr(self.model, 'fork_now') and hasattr(self.model, 'feed_buffers')
+                and not getattr(c, 'K', 0) and not getattr(c, 'agg', None) and getattr(c, 'dataset', '') != 'mnist'
+                and isinstance(self.feed, dict) and self.feed.get('ring') is not None and self.feed['ring'][2] is not None)
+
+    def _ahead_prepare(self, kinds):
+        """outside the capture: the per-step feeds, the snapshot of the critic's step count, the stream and its workspace"""
+        n = list(kinds).count('disc') - 1
+        st = getattr(self, '_ahead', None)
+        if st is None or len(st['feeds']) != n or st['ring'] is not self.feed['ring']:
+            ring, gen_ctr, disc_ctr, off = self.feed['ring']
+            snap = torch.zeros_like(disc_ctr)
+            feeds = []
+            for j in range(n):
+                f = self.model.feed_buffers(self.device)
+                if 'rng_state' in self.feed:
+                    f['rng_state'] = self.feed['rng_state']               # ONE generator state: the draws come in the order of the steps
+                f['ring'] = (ring, gen_ctr, snap, off + j + 1)
+                feeds.append(f)
+            st = self._ahead = dict(feeds=feeds, snap=snap, ring=self.feed['ring'], stream=F.shared_stream(self.device, 'nets'))
+            with torch.cuda.stream(st['stream']):
+                F.workspace(self.device)
+            torch.cuda.synchronize(self.device)
+        self._ahead_sync_feeds()
+        st.update(i=0, nets=[], events=[])
+        return st
+
+    def _ahead_step(self):
+        """(nets, feed) of the next critic step of the iteration being captured"""
+        st, m = self._ahead_run, self.model
+        i = st['i']
+        st['i'] += 1
+        cur = torch.cuda.current_stream(self.device)
+        if i == 0:
+            st['snap'].copy_(self.feed['ring'][2])                        # the critic's step count in front of critic step 1
+            nets = self._nets()
+            ns = st['stream']
+            ns.wait_stream(cur)                                           # (behind step 1's noise launch and the snapshot)
+            saved = (m._pending_join, getattr(m, '_noise_event', None), m._early, m.fork_now)
+            m.fork_now = False                                            # one chain: Generator then Extractor, nothing forked off it
+            try:
+                with torch.cuda.stream(ns), F.launch_hint(int(os.environ.get('GGAN_AHEAD_WGS', '128'))):
+                    for f in st['feeds']:
+                        st['nets'].append(self._nets(f))
+                        ev = torch.cuda.Event()
+                        ev.record(ns)
+                        st['events'].append(ev)
+            finally:
+                m._pending_join, m._noise_event, m._early, m.fork_now = saved
+            return nets, self.feed
+        cur.wait_event(st['events'][i - 1])
+        self._sl0 = lib.second_leaf_count()
+        return st['nets'][i - 1], st['feeds'][i - 1]
 
     def _forward(self, feed, which, nets):
         """model.forward for a step whose backward follows at once: the critic head may then leave its cost's gradient behind with
@@ -220,9 +298,9 @@ class Trainer(object):
             raise RuntimeError('a hinted critic head still owes its cost value after the backward pass (functional.head_bce_hint): '
                                'the cost was not differentiated through that head')
 
-    def _fwd_bwd(self, which, nets=None, fuse_update=False):
+    def _fwd_bwd(self, which, nets=None, fuse_update=False, feed=None):
         """fuse_update: the caller applies the update next with nothing but a (single-replica: empty) exchange in between"""
-        out = self._forward(self.feed, which, nets if nets is not None else self._nets())
+        out = self._forward(self.feed if feed is None else feed, which, nets if nets is not None else self._nets())
         if self.keep_outputs:        # (tests: the critic logits of a captured step -- static graph memory, valid after every replay)
             det = lambda v: [t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()    # (no tape kept alive across steps)
             self.last_out[which] = {k: det(v) for k, v in out.items() if k in ('disc_fake', 'disc_real')}
@@ -362,7 +440,12 @@ class Trainer(object):
         elif self.dp_graph and which == 'disc' and hasattr(self.model, 'critic_cut') and not os.environ.get('GGAN_ONE_BUCKET'):
             cost, opt, keep = self._disc_two_buckets(nets)
         else:
-            cost, opt, keep = self._fwd_bwd(which, nets, fuse_update=not self.dp_graph)
+            feed = None
+            if which == 'disc' and getattr(self, '_ahead_run', None) is not None:
+                nets, feed = self._ahead_step()
+            cost, opt, keep = self._fwd_bwd(which, nets, fuse_update=not self.dp_graph, feed=feed)
+            if feed is not None:
+                keep = (keep, nets)
             if self.dp_graph:
                 opt.all_reduce()
         opt.update()
@@ -541,13 +624,21 @@ class Trainer(object):
                     rng.copy_(rng_snap)
             torch.cuda.current_stream(self.device).wait_stream(s)
             torch.cuda.synchronize(self.device)
+            ahead = self._ahead_prepare(kinds) if self._ahead_ok(kinds) else None
             g = torch.cuda.CUDAGraph()
             costs, keeps = {}, []
             with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
-                for k in kinds:
-                    cost, opt, keep = self._step_body(k)          # (with the in-graph gradient exchange when there are replicas)
-                    costs[k + '_cost'] = cost
-                    keeps.append((opt, keep))
+                self._ahead_run = ahead
+                try:
+                    for k in kinds:
+                        cost, opt, keep = self._step_body(k)          # (with the in-graph gradient exchange when there are replicas)
+                        costs[k + '_cost'] = cost
+                        keeps.append((opt, keep))
+                finally:
+                    self._ahead_run = None
+                if ahead is not None:
+                    torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
+                    keeps.append((None, (ahead['nets'], ahead['events'])))
             return dict(g=g, costs=costs, keep=keeps, kinds=tuple(kinds))
         finally:
             if forkable:

@@ -783,6 +783,9 @@ def test_ring_feed_one_graph_per_iteration_matches_staging_buffer(gpu, mode, cri
             res = tr.iteration(it, batches)
         if use_ring:
             assert tr._iter_graph is not None and not tr._graphs, 'one graph per iteration expected'
+            # (round 5: with CRITIC_ITERS > 1 the nets passes of critic steps 2.. run ahead of time on a stream of their own inside that
+            #  graph -- per-step feeds, ring slots from a snapshot of the critic's step count, noise launches in step order)
+            assert (getattr(tr, '_ahead', None) is not None) == (crit > 1)
         tr.flush()
         torch.cuda.synchronize()
         assert all(np.isfinite(float(v)) for v in res.values())
