@@ -217,8 +217,8 @@ class Trainer(object):
     # An iteration of the WGAN scripts is one generator step and CRITIC_ITERS critic steps (gan_inference_cifar10.py:351-366), and
     # every critic step starts with a Generator and an Extractor pass on a fresh minibatch and fresh noise that read no critic weight:
     # inside the iteration graph the passes of critic steps 2.. are issued as ONE chain on a stream of their own as soon as step 1's
-    # passes are, and run beside critic step 1 (~110 us each of a chain that otherwise stands in front of its critic step; headline
-    # -2.9 %; the bound with those passes removed altogether is -11 %: profiles/r05_notes.md).  What that needs: a feed of its own per
+    # passes are, and run beside the critic steps before theirs (~110 us each of a chain that otherwise stands in front of its critic
+    # step; headline -4.4 %; the bound with those passes removed altogether is -11 %: profiles/r05_notes.md).  What that needs: a feed of its own per
     # step (noise, [fake; real] pair buffers), the noise launches in the order of the steps (they share the generator state: the chain
     # is forked behind step 1's launch and joined before the iteration ends), and a ring slot that does not depend on WHEN a pass
     # runs -- the passes read the critic's step count from a snapshot taken in front of critic step 1 plus their distance from it.
@@ -252,29 +252,41 @@ class Trainer(object):
         st.update(i=0, nets=[], events=[])
         return st
 
+    def _ahead_issue(self, st, k):
+        """the nets pass of critic step k + 2 on the chain's stream: one chain (Generator, then Extractor), nothing forked off it"""
+        m, ns = self.model, st['stream']
+        saved = (m._pending_join, getattr(m, '_noise_event', None), m._early, m.fork_now)
+        m.fork_now = False
+        try:
+            with torch.cuda.stream(ns), F.launch_hint(int(os.environ.get('GGAN_AHEAD_WGS', '128'))):
+                st['nets'].append(self._nets(st['feeds'][k]))
+                ev = torch.cuda.Event()
+                ev.record(ns)
+                st['events'].append(ev)
+        finally:
+            m._pending_join, m._noise_event, m._early, m.fork_now = saved
+
     def _ahead_step(self):
-        """(nets, feed) of the next critic step of the iteration being captured"""
-        st, m = self._ahead_run, self.model
-        i = st['i']
+        """(nets, feed) of the next critic step of the iteration being captured.  The chain is forked behind critic step 1's own nets
+        pass (its noise launch, the snapshot); the pass of step i + 2 is held back until critic step i + 1 begins, so that one pass runs
+        beside each critic step instead of all of them beside the first (3.886 -> 3.836 ms; GGAN_AHEAD_BUNCH=1: all at once)."""
+        st = self._ahead_run
+        i, n = st['i'], len(st['feeds'])
         st['i'] += 1
         cur = torch.cuda.current_stream(self.device)
+        bunch = bool(os.environ.get('GGAN_AHEAD_BUNCH'))
         if i == 0:
             st['snap'].copy_(self.feed['ring'][2])                        # the critic's step count in front of critic step 1
             nets = self._nets()
-            ns = st['stream']
-            ns.wait_stream(cur)                                           # (behind step 1's noise launch and the snapshot)
-            saved = (m._pending_join, getattr(m, '_noise_event', None), m._early, m.fork_now)
-            m.fork_now = False                                            # one chain: Generator then Extractor, nothing forked off it
-            try:
-                with torch.cuda.stream(ns), F.launch_hint(int(os.environ.get('GGAN_AHEAD_WGS', '128'))):
-                    for f in st['feeds']:
-                        st['nets'].append(self._nets(f))
-                        ev = torch.cuda.Event()
-                        ev.record(ns)
-                        st['events'].append(ev)
-            finally:
-                m._pending_join, m._noise_event, m._early, m.fork_now = saved
+            st['stream'].wait_stream(cur)                                 # (behind step 1's noise launch and the snapshot)
+            for k in range(n if bunch else 1):
+                self._ahead_issue(st, k)
             return nets, self.feed
+        if not bunch and i < n:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            st['stream'].wait_event(ev)
+            self._ahead_issue(st, i)
         cur.wait_event(st['events'][i - 1])
         self._sl0 = lib.second_leaf_count()
         return st['nets'][i - 1], st['feeds'][i - 1]
