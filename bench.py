@@ -77,6 +77,11 @@ def algorithmic_gflop_per_iteration(cfg):
     return total / 1e9
 
 
+def _build_id():
+    from graphical_gan_amd import build
+    return build.build_id()
+
+
 def host_cores():
     """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota (the GPU boxes expose 256 logical
     CPUs but grant 16; running the CPU baseline on 256 threads measured 0.6 img/s instead of 670)."""
@@ -129,6 +134,9 @@ def ssgan_gflop_per_iteration(cfg):
     return ((fwd + gen_bwd) + cfg.critic_iters * (fwd + disc_bwd)) / 1e9
 
 
+_STATIC_BUILD = None
+
+
 def _pmc_table(workload_key):
     """Static figures that cannot be read from inside the process: per (kernel, grid) the duration inside the graph-replayed step
     (rocprofv3 --kernel-trace) and the counters of separate rocprofv3 --pmc passes of the same workload, written by tools/prof_round.sh /
@@ -138,6 +146,8 @@ def _pmc_table(workload_key):
     except (OSError, ValueError):
         return {}, None
     tag = tab.get('_tag')
+    global _STATIC_BUILD
+    _STATIC_BUILD = tab.get('_build')
     if workload_key == 'gmgan-cifar10-K30' and workload_key not in tab:      # (profiled at K = 10: the same kernels and launch shapes but the mixture size)
         workload_key = 'gmgan-cifar10-K10'
     w = tab.get(workload_key)
@@ -358,35 +368,56 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
         tab, tag = _pmc_table(spec.get('key', 'headline'))
 
         def rows_of(a):
-            """per-grid rows of one kernel: live eager-bracket figures next to the static in-graph / counter figures of the same grid"""
+            """per-SHAPE rows of one kernel -- (grid, flop per launch): live eager-bracket figures next to the static in-graph / counter figures
+            of the same grid.  The static table is keyed by (kernel, grid) -- what rocprofv3 sees --, so a grid that two shapes of this
+            kernel share has no static figures here (`grid_shared`): a row is ONE problem shape or carries nothing."""
             st = (tab.get(a['name']) or {}).get('by_grid') or {}
+            per_grid = {}
+            for r in a['rows']:
+                per_grid[r['grid']] = per_grid.get(r['grid'], 0) + 1
             out = []
-            for r in sorted(a['rows'], key=lambda r: r['grid']):
-                g = st.get(str(r['grid'])) or {}
+            for r in sorted(a['rows'], key=lambda r: (r['grid'], r['flops'] / r['launches'])):
+                shared = per_grid[r['grid']] > 1
+                g = {} if shared else (st.get(str(r['grid'])) or {})
                 out.append(dict(grid=r['grid'], launches_per_step=r['launches'] / n_prof,
                                 flop_per_launch=r['flops'] / r['launches'], algorithmic_bytes=round(r['bytes'] / r['launches']),
                                 avg_us=round(1e3 * r['total_ms'] / r['launches'], 2), avg_us_in_graph=g.get('avg_us_in_graph'),
-                                traffic=g.get('traffic_bytes'), mfma_util_pct=g.get('mfma_util_pct')))
+                                traffic=g.get('traffic_bytes'), mfma_util_pct=g.get('mfma_util_pct'),
+                                **({'grid_shared': True} if shared else {})))
             return out
 
         def mixed(rows, field, weight='launches_per_step'):
-            """a static per-grid figure weighted by the LIVE launch mix (None unless every launched grid has the figure)"""
+            """a static per-grid figure weighted by the LIVE launch mix (None unless every launched shape has the figure)"""
             if not rows or any(r[field] is None for r in rows):
                 return None
             return sum(r[weight] * r[field] for r in rows) / sum(r[weight] for r in rows)
         kernels = [dict(name=a['name'], launches_per_iter=a['launches'] / n_prof, ms_per_iter=round(a['total_ms'] / n_prof, 4),
                         avg_us=round(1e3 * a['total_ms'] / a['launches'], 2),
                         tflops=round(a['flops'] / (a['total_ms'] * 1e-3) / 1e12, 2) if a['flops'] else None,
-                        grids=[dict(grid=r['grid'], launches_per_iter=r['launches'] / n_prof, avg_us=round(1e3 * r['total_ms'] / r['launches'], 2))
-                               for r in sorted(a['rows'], key=lambda r: r['grid'])]) for a in agg]
+                        grids=[dict(grid=r['grid'], flop_per_launch=r['flops'] / r['launches'], launches_per_iter=r['launches'] / n_prof,
+                                    avg_us=round(1e3 * r['total_ms'] / r['launches'], 2))
+                               for r in sorted(a['rows'], key=lambda r: (r['grid'], r['flops'] / r['launches']))]) for a in agg]
         launches_per_iter = sum(a['launches'] for a in agg) / n_prof
-        dom = next((a for a in agg if a['flops'] > 0), None)
+        # The dominant kernel = the one with the most time INSIDE THE TIMED GRAPH: per-shape duration of the rocprofv3 kernel trace of the
+        # graph replay (profiles/pmc_traffic.json, the rows of profiles/<tag>_kernel_trace.md) x the launches counted here.  The live
+        # eager bracket ranks kernels differently from run to run (its events sit around launches on two streams, so a launch's bracket
+        # includes what it waited for on the other stream); it is kept as `frac_eager` / `avg_launch_us_eager`.
+        for a in agg:
+            rws = rows_of(a)
+            a['_rows'] = rws
+            a['_ig_ms'] = (sum(r['launches_per_step'] * r['avg_us_in_graph'] for r in rws) * 1e-3
+                           if rws and all(r['avg_us_in_graph'] is not None for r in rws) else None)
+        flop_k = [a for a in agg if a['flops'] > 0]
+        static_ok = bool(flop_k) and all(a['_ig_ms'] is not None for a in flop_k[:6])       # (the eager top six all have in-graph figures)
+        dom = (max((a for a in flop_k if a['_ig_ms'] is not None), key=lambda a: a['_ig_ms']) if static_ok
+               else next(iter(flop_k), None))
         if dom is not None:
-            ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-            rows = rows_of(dom)
+            ach_e = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            rows = dom['_rows']
             avg_us = 1e3 * dom['total_ms'] / dom['launches']
             fpl = dom['flops'] / dom['launches']
             ig_us = mixed(rows, 'avg_us_in_graph')
+            ach = fpl / (ig_us * 1e-6) / 1e12 if ig_us else ach_e
             traffic = mixed(rows, 'traffic')
             # counter MFMA utilisation of the kernel = its rows weighted by the TIME each contributes
             for r in rows:
@@ -396,22 +427,28 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
                 del r['_t']
             roofline = dict(bound='mfma', kernel=dom['name'], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
                             unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                            frac_eager=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                            frac_basis='in_graph' if ig_us else 'eager_bracket',
+                            frac_eager=round(ach_e / MFMA_F32_PEAK_TFLOPS, 4),
                             frac_in_graph=round(fpl / (ig_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if ig_us else None,
-                            avg_launch_us=round(avg_us, 2), avg_launch_us_in_graph=round(ig_us, 2) if ig_us else None,
+                            avg_launch_us=round(ig_us, 2) if ig_us else round(avg_us, 2),
+                            avg_launch_us_eager=round(avg_us, 2), avg_launch_us_in_graph=round(ig_us, 2) if ig_us else None,
+                            time_in_graph_ms_per_step=round(dom['_ig_ms'], 4) if dom['_ig_ms'] is not None else None,
                             flop_per_launch=fpl,
                             traffic=round(traffic) if traffic else None,
                             algorithmic_bytes=round(dom['bytes'] / dom['launches']) if dom['bytes'] else None,
                             mfma_util_pct=round(util, 2) if util is not None else None,
                             launch_mix=rows,
                             static_tag=tag if (tab.get(dom['name']) is not None) else None,
-                            source='achieved / frac / frac_eager / avg_launch_us: HIP-event bracket around every launch of this kernel on the stream it '
-                                   'is launched on, eager replay of the same step ON THE LAUNCH PLAN OF THE TIMED GRAPH (two-stream nets pass, '
-                                   '128-workgroup plans of side-by-side chains) in this process (%d iterations); flop_per_launch and '
-                                   'algorithmic_bytes: sums over the same launches / their number; launch_mix: one row per grid size (work-items); '
-                                   'avg_launch_us_in_graph, frac_in_graph, traffic, mfma_util_pct: per-grid figures of profiles/pmc_traffic.json @%s '
-                                   '(rocprofv3 --kernel-trace of the graph-replayed step, separate --pmc passes; FETCH_SIZE x 2, WRITE_SIZE as counted: '
-                                   'tools/pmc_summary.py) weighted by the launch mix measured HERE' % (n_prof, tag),
+                            static_matches_build=(_STATIC_BUILD == _build_id()) if _STATIC_BUILD else None,
+                            source='kernel: the one with the most time inside the timed graph (per-shape duration of profiles/%s_kernel_trace.md x the launches '
+                                   'counted here); achieved / frac / avg_launch_us: flop_per_launch / that trace\'s average duration of the kernel, weighted by the '
+                                   'launch mix measured HERE (rocprofv3 --kernel-trace of the graph-replayed step; a trace of the same command is '
+                                   'committed per round); frac_eager / avg_launch_us_eager: HIP-event bracket around every launch of this kernel on the stream '
+                                   'it is launched on, eager replay of the same step ON THE LAUNCH PLAN OF THE TIMED GRAPH in this process (%d iterations: the '
+                                   'bracket of a launch includes what it waited for on the other stream); flop_per_launch and algorithmic_bytes: sums over the '
+                                   'same launches / their number; launch_mix: one row per problem shape (grid = work-items, flop per launch); traffic, '
+                                   'mfma_util_pct: separate rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE as counted: tools/pmc_summary.py), '
+                                   'profiles/pmc_traffic.json @%s' % (tag, n_prof, tag),
                             whole_step_tflops=round(step_tflops, 2),
                             whole_step_frac=round(step_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                             libggan_launches_per_step=launches_per_iter)
@@ -421,7 +458,7 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
             for a in agg:
                 if not a['name'].startswith(('corr_kernel', 'wgrad_kernel', 'wgrad4_kernel', 'dg16_kernel', 'conv3d_igemm')):
                     continue
-                for r, row in zip(sorted(a['rows'], key=lambda r: r['grid']), rows_of(a)):
+                for r, row in zip(sorted(a['rows'], key=lambda r: (r['grid'], r['flops'] / r['launches'])), a['_rows']):
                     if row['mfma_util_pct'] is not None:
                         cw += r['total_ms']
                         ca += r['total_ms'] * row['mfma_util_pct']
@@ -431,8 +468,9 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
             busy = fl_cov = fl_all = 0.0
             for a in agg:
                 st = (tab.get(a['name']) or {}).get('by_grid') or {}
+                shared = set(g for g in (r['grid'] for r in a['rows']) if sum(1 for q in a['rows'] if q['grid'] == g) > 1)
                 for r in a['rows']:
-                    g = st.get(str(r['grid'])) or {}
+                    g = {} if r['grid'] in shared else (st.get(str(r['grid'])) or {})
                     fl_all += r['flops']
                     if g.get('mfma_busy_cycles') is not None:
                         busy += g['mfma_busy_cycles'] * r['launches'] / n_prof
@@ -602,10 +640,13 @@ def _short_cpu(c):
 def _short_roofline(r):
     if not r:
         return None
-    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_eager', 'frac_in_graph', 'avg_launch_us',
-            'avg_launch_us_in_graph', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'conv_stack_mfma_util_pct', 'whole_step_mfma_util_pct', 'static_tag')
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_basis', 'frac_eager', 'frac_in_graph', 'avg_launch_us', 'avg_launch_us_eager',
+            'flop_per_launch', 'traffic', 'algorithmic_bytes', 'mfma_util_pct', 'conv_stack_mfma_util_pct', 'whole_step_mfma_util_pct', 'static_tag',
+            'static_matches_build')
     d = {k: r.get(k) for k in keep}
-    d['source'] = 'frac=frac_eager: live HIP-event bracket, eager replay on the timed graph\'s launch plan; frac_in_graph/traffic/mfma_util_pct/conv_stack_mfma_util_pct (all MFMA conv kernels, time-weighted): profiles/pmc_traffic.json'
+    d['source'] = ('kernel = most time inside the timed graph; frac = flop_per_launch / avg_launch_us / peak, avg_launch_us = its average duration in profiles/'
+                   '%s_kernel_trace.md (rocprofv3 trace of the graph replay) on the launch mix counted live; frac_eager: live HIP-event bracket; traffic / '
+                   'mfma_util: --pmc passes, profiles/pmc_traffic.json' % r.get('static_tag'))
     return d
 
 

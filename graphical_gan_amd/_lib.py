@@ -14,7 +14,7 @@ HEAD_BCE_MAX_ROWS = 2048             # include/ggan.h: GGAN_HEAD_BCE_MAX_ROWS
 BCE_HEADS = 2                        # include/ggan.h: GGAN_BCE_HEADS
 PACK_ARRIVE_INTS = 33 * 1024          # include/ggan.h: GGAN_PACK_ARRIVE_INTS (arrival counters of ggan_pack_adam)
 BCE_MAX = 16
-ABI_VERSION = 500                    # include/ggan.h: GGAN_ABI_VERSION (struct layouts and entry points this module binds)
+ABI_VERSION = 600                    # include/ggan.h: GGAN_ABI_VERSION (struct layouts and entry points this module binds)
 
 
 class ConvGeom(C.Structure):
@@ -70,7 +70,6 @@ SIGNATURES = {
     'ggan_mix_rbf_mmd2_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'ggan_mix_rbf_mmd2_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'ggan_noise_fill': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    'ggan_noise_fill_steps': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     'ggan_gmm_latent_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     'ggan_gmm_latent_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'ggan_gemm_split': (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _F, _P, _Z, _P]),

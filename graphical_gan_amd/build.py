@@ -31,6 +31,18 @@ def _digest():
     return h.hexdigest()
 
 
+def build_id():
+    """what a profile of the timed step depends on: the digest of csrc/ + include/ + flags, and the committed launch-site plans
+    (profiles/pmc_traffic.json carries it as `_build`; bench.py says whether its static figures belong to the build it runs)"""
+    h = hashlib.sha256()
+    try:
+        with open(os.path.join(HERE, 'site_plans.json'), 'rb') as f:
+            h.update(f.read())
+    except OSError:
+        pass
+    return _digest()[:16] + '/' + h.hexdigest()[:8]
+
+
 def build(force=False, verbose=False):
     """Compile every .hip translation unit and link libggan.so.  Returns the library path.  Safe to call from several
     processes at once (one rank per GPU does): an exclusive file lock serialises them and the later ones find the stamp."""

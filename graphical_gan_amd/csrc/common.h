@@ -1,5 +1,6 @@
 // Internal helpers shared by the libggan translation units (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -52,6 +53,14 @@ void trace_launch(const char* name, dim3 grid, dim3 block, size_t shmem, double 
     if (ggan::check_launch(name)) return -2
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// true the first time it is called with `seen` on the current device: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device,
+// a process-wide "once" flag would leave a second device of the same process on the 64 KB default
+static inline bool first_on_device(std::atomic<unsigned long long>& seen) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return !(seen.fetch_or(bit) & bit);
+}
 static inline long grid_wgs(dim3 g) { return (long)g.x * g.y * g.z; }
 static inline long grid_wgs(long g) { return g; }
 

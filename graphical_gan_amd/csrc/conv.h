@@ -51,10 +51,6 @@ struct ThinCastSrc {
     int nslots, offset;
     float div, mul;
 };
-int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
-                  hipStream_t s, const ThinCastSrc* cast = nullptr);
-int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
-                    size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
 // Output mask of a forward launch (conv_corr.hip epilogue): while *g_out_mask is set, conv_fwd_mfma stores act_grad(value, ref[i]) instead of
 // the value -- or returns 1 before launching anything when the planned launch cannot (split-K: the epilogue does not see final values).
 struct OutMask {
@@ -64,6 +60,11 @@ struct OutMask {
     bool applied;
 };
 extern thread_local OutMask* g_out_mask;
+// mask (optional): the thin-channel forward stores act_grad(value, mask->ref[i]) (the masked forward of a first layer)
+int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
+                  hipStream_t s, const ThinCastSrc* cast = nullptr, const OutMask* mask = nullptr);
+int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, GyMask m, float* gw, float* gbias, void* ws,
+                    size_t ws_bytes, hipStream_t s, WgradParts* parts = nullptr);
 size_t conv_workspace_bytes(const ggan_conv_geom& g);
 // out[i] = act(sum_s partial[s][i] + bias[(i/HW)%C]) -- deterministic split-K combine (conv + gemm)
 int launch_splitk_reduce(const float* partial, int SK, size_t elems, float* out, const float* bias, int C, int HW, int act,

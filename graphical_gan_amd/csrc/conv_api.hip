@@ -203,10 +203,18 @@ int ggan_conv2d_fwd_masked(const ggan_conv_geom* g, const float* x, const float*
     GGAN_CHECK_ARG(x && w && y && yref, "null pointer");
     if ((g->plan_flags & GGAN_PLAN_PLAIN) || getenv("GGAN_NAIVE_FWD") || getenv("GGAN_NO_FWD_MASK")) return 1;
     if ((((uintptr_t)yref) & 15) != 0) return 1;
-    // (thin first layers too: the padded-channel MFMA launch with the mask measured 1 % of a wali-gp iteration shorter than
-    //  conv_thin.hip + act_bwd; GGAN_NO_FWD_MASK_THIN selects that pair)
+    // (thin first layers: the thin-channel forward kernel with the mask in its epilogue since round 6 -- K = 25 * Ci instead of 25 x a padded
+    //  16-channel chunk; rounds 3-5 ran the padded-channel MFMA launch with the mask.  GGAN_FWD_MASK_THIN=0 selects that one,
+    //  GGAN_NO_FWD_MASK_THIN the unfused pair conv_thin.hip + act_bwd)
     if (g->Ci <= 4 && getenv("GGAN_NO_FWD_MASK_THIN")) return 1;
     OutMask M{yref, ref_act, ref_alpha, false};
+    if (g->Ci <= 4 && (ref_act == GGAN_ACT_LRELU || ref_act == GGAN_ACT_RELU)) {
+        const char* e = getenv("GGAN_FWD_MASK_THIN");
+        if (!e || atoi(e) != 0) {
+            const int r = conv_fwd_thin(*g, x, w, nullptr, y, GGAN_ACT_NONE, 0.f, (hipStream_t)stream, nullptr, &M);
+            if (r <= 0) return r;
+        }
+    }
     g_out_mask = &M;
     const int rc = conv_fwd_mfma(*g, x, w, nullptr, y, GGAN_ACT_NONE, 0.f, ws, ws ? ws_bytes : 0, (hipStream_t)stream);
     g_out_mask = nullptr;

@@ -992,8 +992,8 @@ template <int MODE>
 int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_t s, const char* name, double fl) {
     // algorithmic bytes of the launch: input + filter + output, one pass each (SURVEY.md App. B "bytes")
     const double ab = (double)P.in_bytes + (double)P.w_bytes + 4.0 * (double)P.out_elems;
-    static bool once = false;
-    if (!once) {   // double-buffered staging can exceed the 64 KiB default dynamic-LDS limit
+    static std::atomic<unsigned long long> once{0};
+    if (first_on_device(once)) {   // double-buffered staging can exceed the 64 KiB default dynamic-LDS limit
         allow_big_lds(corr_kernel<0, 2, 2, 1, 2>); allow_big_lds(corr_kernel<0, 2, 1, 2, 2>); allow_big_lds(corr_kernel<0, 1, 1, 4, 1>);
         allow_big_lds(corr_kernel<1, 2, 2, 1, 4>); allow_big_lds(corr_kernel<1, 2, 1, 2, 4>); allow_big_lds(corr_kernel<1, 1, 1, 4, 2>);
         allow_big_lds(corr_kernel<0, 1, 1, 4, 2>); allow_big_lds(corr_kernel<1, 1, 1, 4, 4>);
@@ -1008,7 +1008,6 @@ int launch_cfg(int cfg, const CorrParams& P, dim3 grid, size_t shmem, hipStream_
         allow_big_lds(corr_kernel<0, 2, 1, 4, 2, true>); allow_big_lds(corr_kernel<0, 4, 1, 2, 2, true>);
         allow_big_lds(corr_kernel<1, 2, 1, 4, 2, true>); allow_big_lds(corr_kernel<1, 1, 1, 8, 1, true>); allow_big_lds(corr_kernel<1, 1, 1, 8, 2, true>);
         allow_big_lds(corr_kernel<2, 1, 1, 8, 1, true>); allow_big_lds(corr_kernel<2, 2, 1, 4, 2, true>); allow_big_lds(corr_kernel<2, 2, 2, 2, 1, true>);
-        once = true;
     }
     if (shmem > 160 * 1024) { set_error("%s: LDS request %zu too large", name, shmem); return -3; }
     if constexpr (MODE == 0) {

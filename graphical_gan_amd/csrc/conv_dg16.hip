@@ -446,15 +446,14 @@ int env_int(const char* name, int dflt) {
 }
 
 int launch_dg16(int scp, int kq, const Dg16Params& P, bool masked, dim3 grid, size_t shmem, hipStream_t s, double fl, double ab) {
-    static bool once = false;
+    static std::atomic<unsigned long long> once{0};
 #define DG16_EACH(X) X(12, 4) X(16, 4) X(24, 4) X(12, 2) X(16, 2) X(24, 2)
-    if (!once) {
+    if (first_on_device(once)) {
 #define DG16_ATTR(SCP, KQ)                                                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dg16_kernel<SCP, KQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dg16_kernel<SCP, KQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         DG16_EACH(DG16_ATTR)
 #undef DG16_ATTR
-        once = true;
     }
     // (names as rocprofv3 prints the instantiations)
 #define DG16_CASE(SCP, KQ)                                                                                                                        \

@@ -418,6 +418,11 @@ struct ThinFwdParams {
     FastDiv d_Wo, d_W4, d_SR, d_Ci, d_5, d_c4;
     unsigned x_bytes;
     int dbg;
+    // optional output mask (ggan_conv2d_fwd_masked: the backward of a masked data gradient, the gradient-penalty pass's second derivative
+    // through the critic's first layer): y = act_grad(conv, mref, mask_act, mask_alpha) -- mref has y's layout
+    const float* mref;
+    int mask_act;
+    float mask_alpha;
     // optional: the input is an int32 minibatch in a device-resident ring, scaled on the way into LDS (the reference's
     // real_x = 2*((tf.cast(real_x_int, tf.float32)/255.)-.5), gan_inference_cifar10.py:342, in front of Extractor.1): x = mul*(float(v)/div - .5)
     // (+ noise), written to x_out as well (every input row by the one band that owns it) -- no cast launch, no float read of the images
@@ -582,12 +587,18 @@ __global__ __launch_bounds__(64 * NWV) void thin_fwd_kernel(const ThinFwdParams 
             for (int t = 0; t < NTW; ++t) {
                 const int co = (half * NTW + t) * 16 + l15;
                 const float bs = P.bias ? P.bias[co] : 0.f;
+                const size_t o = ((size_t)n * P.Co + co) * HoWo + pp;
                 float4 v;
                 v.x = act_apply(acc[i][t][0] + bs, P.act, P.alpha);
                 v.y = act_apply(acc[i][t][1] + bs, P.act, P.alpha);
                 v.z = act_apply(acc[i][t][2] + bs, P.act, P.alpha);
                 v.w = act_apply(acc[i][t][3] + bs, P.act, P.alpha);
-                *reinterpret_cast<float4*>(P.y + ((size_t)n * P.Co + co) * HoWo + pp) = v;
+                if (P.mref) {                            // (uniform)
+                    const float4 rf = *reinterpret_cast<const float4*>(P.mref + o);
+                    v.x = act_grad(v.x, rf.x, P.mask_act, P.mask_alpha); v.y = act_grad(v.y, rf.y, P.mask_act, P.mask_alpha);
+                    v.z = act_grad(v.z, rf.z, P.mask_act, P.mask_alpha); v.w = act_grad(v.w, rf.w, P.mask_act, P.mask_alpha);
+                }
+                *reinterpret_cast<float4*>(P.y + o) = v;
             }
         }
     }
@@ -718,11 +729,10 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     const dim3 grid(SK, g.Co / 16);
 #define THIN_WGRAD(MPW_)                                                                                                    \
     do {                                                                                                                    \
-        static bool attr_set = false;                                                                                       \
-        if (!attr_set) {                                                                                                    \
+        static std::atomic<unsigned long long> attr_set{0};                                                                 \
+        if (first_on_device(attr_set)) {                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(thin_wgrad_kernel<MPW_, NG>),                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
-            attr_set = true;                                                                                                \
         }                                                                                                                   \
     } while (0);                                                                                                            \
     GGAN_LAUNCH("thin_wgrad_kernel", fl, 0, (thin_wgrad_kernel<MPW_, NG>), grid, dim3(NTHR * NG), shmem, s, P)
@@ -741,7 +751,7 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
 }
 
 int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const float* bias, float* y, int act, float alpha,
-                  hipStream_t s, const ThinCastSrc* cast) {
+                  hipStream_t s, const ThinCastSrc* cast, const OutMask* mask) {
     if (g.k != 5 || g.stride != 2 || g.pad_l < 1 || g.pad_l > 2 || g.Ci > 4 || (g.W & 3)) return 1;
     if ((g.Co != 32 && g.Co != 64) || ((g.Ho * g.Wo) & 3) || getenv("GGAN_NO_THIN")) return 1;
     if (cast) {
@@ -755,6 +765,10 @@ int conv_fwd_thin(const ggan_conv_geom& g, const float* x, const float* w, const
     memset(&P, 0, sizeof(P));
     P.x = x; P.w = w; P.bias = bias; P.y = y; P.act = act; P.alpha = alpha; P.x_bytes = (unsigned)xb;
     if (cast) P.cast = *cast;
+    if (mask) {
+        if ((((uintptr_t)mask->ref) & 15) || !mask->ref) return 1;
+        P.mref = mask->ref; P.mask_act = mask->act; P.mask_alpha = mask->alpha;
+    }
     { const char* d = getenv("GGAN_THIN_DBG"); P.dbg = d ? atoi(d) : 0; }
     P.N = g.N; P.Ci = g.Ci; P.H = g.H; P.W = g.W; P.Co = g.Co; P.Ho = g.Ho; P.Wo = g.Wo; P.pad_t = g.pad_t; P.pad_l = g.pad_l;
     P.d_c4 = make_fastdiv((uint32_t)(g.Co / 4 > 0 ? g.Co / 4 : 1));

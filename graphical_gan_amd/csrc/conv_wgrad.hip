@@ -852,13 +852,12 @@ namespace ggan {
 int wgrad4_split_launch(int W, unsigned grid, size_t shmem, hipStream_t s, const void* params, double fl, double ab) {
     WgradParams P;
     memcpy(&P, params, sizeof(P));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const dim3 grid4(grid);
     if (W == 16) { GGAN_LAUNCH("wgrad4_kernel<16, true>", fl, ab, (wgrad4_kernel<16, true>), grid4, dim3(2 * W4_NTHR), shmem, s, P); }
@@ -963,8 +962,8 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     size_t red = four ? (size_t)W4_RED_BYTES / sizeof(float) : (size_t)(NW / 2) * 100 * 64;
     const size_t shmem = (stage > red ? stage : red) * sizeof(float);
     if (shmem > 160 * 1024) return 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -972,7 +971,6 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad4_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const int nit = env_int("GGAN_WGRAD_DEAL", 1) ? (P.PC == 128 ? 2 : (P.PC == 64 ? 1 : 0)) : 0;
     const double fl = 2.0 * g.N * g.Co * g.Ho * g.Wo * (double)g.Ci * 25.0;
@@ -980,8 +978,8 @@ int conv_wgrad_mfma(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     if (parts && ws_bytes < P.slab_stride * sizeof(float)) { set_error("conv_wgrad: partial-slab buffer too small"); return -1; }
     if (want_stamps && !parts && ws && ws_bytes > (64u << 20)) P.stamps = (unsigned long long*)((char*)ws + ws_bytes - (32u << 20));
     const dim3 grid4(gx * gy_ * P.SK);       // split-fastest workgroup numbering (decoded in the kernel)
-    static const bool split_roles = env_int("GGAN_WGRAD_SPLIT", 1) != 0;
-    static const int split_roles_mask = env_int("GGAN_WGRAD_SPLIT_W", 8 | 16 | 32 | 64);
+    const bool split_roles = env_int("GGAN_WGRAD_SPLIT", 1) != 0;          // (read per call, like GGAN_WGRAD_W4 / _SK / _WGS / _PC)
+    const int split_roles_mask = env_int("GGAN_WGRAD_SPLIT_W", 8 | 16 | 32 | 64);
     if (split_roles && four > 0 && (split_roles_mask & four)) { const int rc = wgrad4_split_launch(four, grid4.x, shmem, s, &P, fl, ab); if (rc) return rc; }
     else if (four == 16) { GGAN_LAUNCH("wgrad4_kernel<16>", fl, ab, wgrad4_kernel<16>, grid4, dim3(W4_NTHR), shmem, s, P); }
     else if (four == 8) { GGAN_LAUNCH("wgrad4_kernel<8>", fl, ab, wgrad4_kernel<8>, grid4, dim3(W4_NTHR), shmem, s, P); }

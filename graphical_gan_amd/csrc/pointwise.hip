@@ -1036,8 +1036,8 @@ struct NoiseTable {
     int kind[GGAN_NOISE_MAX];      // 0 normal(a, b) = a + b*N(0,1); 1 uniform [a, b); 2 one-hot rows of width K (n = rows * K)
     float a[GGAN_NOISE_MAX], b[GGAN_NOISE_MAX];
     int K[GGAN_NOISE_MAX];
-    int slot[GGAN_NOISE_MAX];      // the tensor's ordinal within ITS step's draw (part of the counter), ggan_noise_fill_steps; else the index
-    int step[GGAN_NOISE_MAX];      // which of the launch's `advance` steps the tensor belongs to: draw number = state + step
+    int slot[GGAN_NOISE_MAX];      // the tensor's ordinal within the step's draw (part of the counter): its index
+    int step[GGAN_NOISE_MAX];      // draw number = state + step (always 0: one session.run per launch)
     int count, advance;
 };
 
@@ -1604,13 +1604,7 @@ int ggan_gmm_latent_bwd(const float* z, const float* mu, const float* k, const f
 
 int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
                     int count, uint64_t* state, ggan_stream_t stream) {
-    return ggan_noise_fill_steps(dsts, sizes, kinds, a, b, widths, nullptr, nullptr, count, 1, state, stream);
-}
-
-int ggan_noise_fill_steps(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
-                          const int* slots, const int* steps, int count, int advance, uint64_t* state, ggan_stream_t stream) {
     GGAN_CHECK_ARG(dsts && sizes && kinds && a && b && widths && state, "null pointer");
-    GGAN_CHECK_ARG(advance >= 1 && (advance == 1 || (slots && steps)), "several steps need the per-tensor slot / step tables");
     GGAN_CHECK_ARG(count > 0 && count <= GGAN_NOISE_MAX, "count out of range");
     NoiseTable t;
     size_t mx = 0, tot = 0;
@@ -1618,14 +1612,13 @@ int ggan_noise_fill_steps(float* const* dsts, const size_t* sizes, const int* ki
         GGAN_CHECK_ARG(dsts[i] && sizes[i] > 0 && sizes[i] < 0x7FFFFFFFull && kinds[i] >= 0 && kinds[i] <= 2, "bad noise spec");
         GGAN_CHECK_ARG(kinds[i] != 2 || (widths[i] > 0 && sizes[i] % (size_t)widths[i] == 0), "one-hot rows need a width dividing the size");
         t.dst[i] = dsts[i]; t.n[i] = (unsigned)sizes[i]; t.kind[i] = kinds[i]; t.a[i] = a[i]; t.b[i] = b[i]; t.K[i] = widths[i];
-        t.slot[i] = slots ? slots[i] : i;
-        t.step[i] = steps ? steps[i] : 0;
-        GGAN_CHECK_ARG(t.slot[i] >= 0 && t.step[i] >= 0 && t.step[i] < advance, "bad slot / step");
+        t.slot[i] = i;
+        t.step[i] = 0;
         if (sizes[i] > mx) mx = sizes[i];
         tot += sizes[i];
     }
     t.count = count;
-    t.advance = advance;
+    t.advance = 1;
     int gx = (int)cdivz(mx, (size_t)1024);
     if (gx < 1) gx = 1;
     if (gx > 256) gx = 256;

@@ -121,18 +121,20 @@ int ggan_prof_reset(void) {
 int ggan_prof_report(ggan_prof_rec* out, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0;
+    std::vector<double> fpl;          // flop per launch of record j (part of its key)
     for (auto& e : g_prof) {
         if (hipEventSynchronize(e.b) != hipSuccess) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
         int j = 0;
-        for (; j < n; ++j)
-            if (out[j].grid == e.grid && strncmp(out[j].name, e.name, sizeof(out[j].name) - 1) == 0) break;
+        for (; j < n; ++j)        // one record per problem shape: (kernel, grid, flop per launch)
+            if (out[j].grid == e.grid && fpl[j] == e.flops && strncmp(out[j].name, e.name, sizeof(out[j].name) - 1) == 0) break;
         if (j == n) {
             if (n >= cap) continue;
             memset(&out[n], 0, sizeof(out[n]));
             strncpy(out[n].name, e.name, sizeof(out[n].name) - 1);
             out[n].grid = e.grid;
+            fpl.push_back(e.flops);
             ++n;
         }
         out[j].total_ms += ms;

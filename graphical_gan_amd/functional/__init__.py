@@ -15,7 +15,7 @@ from ._core import (  # noqa: F401
     check, _WS, _WS_BYTES, _L, _p, _stream, _dev, _c, _os, FUSED_CONV_BWD, _DEFER, _DATA_ONLY, _is_param, data_grad_only,
     _skip_undefined, defer_wgrad_reduce, _wgrad_parts, _STREAMS, shared_stream, workspace, _TARGET, _SERIAL_BWD, serial_backward,
     _bwd_target, target_workgroups, _threading, _PLAN, _HINT_FILTER, _PLAIN, force_plain, launch_hint, _carries_hint, _planned_for,
-    same_geometry, conv_geom, _geom, RowSlot, _new_out, _adjacent, HEAD_LOGITS, _PENDING_COSTS, _tail_value, settle_cost,
+    same_geometry, conv_geom, _geom, _SITE, site_scope, set_site_plan, record_sites, site_log, site_mismatches, RowSlot, _new_out, _adjacent, HEAD_LOGITS, _PENDING_COSTS, _tail_value, settle_cost,
     pending_costs, drop_pending_costs, UNIT_SEEDS, unit_seed, is_unit_seed)
 from .pointwise import ActFwd, ActBwd, leaky_relu, relu, tanh, sigmoid  # noqa: F401
 from .conv import (  # noqa: F401

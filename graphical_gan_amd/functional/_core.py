@@ -287,14 +287,69 @@ def conv_geom(N, Ci, H, W, Co, k, stride, padding='SAME'):
     return (N, Ci, H, W, Co, Ho, Wo, k, stride, pt, pl)
 
 
+# ---- launch plans per launch SITE (round 6) ------------------------------------------------------------------------------------------
+# target_workgroups / launch_hint plan a whole pass or step: every conv launch of a chain that runs beside another chain asks for ~128
+# workgroups.  But a captured step graph is a fixed schedule, and in it some of those launches turn out to run ALONE (the head of the
+# penalty chain, the tail of the longer backward pass: a third of the G+D+GP iteration had ONE half-chip kernel in flight, profiles/
+# r05d_timeline.md).  A launch SITE is (scope, ordinal): the scope names the step of the iteration being built (engine.Trainer:
+# 'gen0', 'disc0' .. 'disc4'), the ordinal counts the conv geometries built inside it in issue order -- forward launches on the
+# recording thread, backward launches on autograd's worker thread for the device; the two never run at the same time and autograd's
+# order is a function of the recorded graph, so the numbering is the same in the eager rehearsal, in the capture and in the next process.
+# A site plan maps site -> (plan_wgs, plan_wgs_filter) and overrides whatever the pass-level settings say (-1 = leave that field);
+# entries carry the geometry they were made for and are ignored (counted in site_mismatches) when the site holds another one.
+_SITE = dict(scope=None, n=0, table={}, log=None, mismatches=0)
+
+
+class site_scope(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = (_SITE['scope'], _SITE['n'])
+        _SITE['scope'], _SITE['n'] = self.name, 0
+
+    def __exit__(self, *a):
+        _SITE['scope'], _SITE['n'] = self.prev
+
+
+def set_site_plan(table):
+    """table: {'disc2:17': dict(geom=[N, Ci, H, W, Co], wgs=0, wgs_filter=-1), ...} or None"""
+    _SITE['table'] = dict(table or {})
+    _SITE['mismatches'] = 0
+
+
+def record_sites(on=True):
+    """start (or stop) logging every site passed: site_log() -> [(site, (N, Ci, H, W, Co, Ho, Wo), plan_wgs, plan_wgs_filter)]"""
+    _SITE['log'] = [] if on else None
+
+
+def site_log():
+    return list(_SITE['log'] or [])
+
+
+def site_mismatches():
+    return _SITE['mismatches']
+
+
 def _geom(t):
     both, hint = getattr(_PLAN, 'both', 0), getattr(_PLAN, 'hint', 0)
     # (the hint plans the filter gradient too since round 5: with the four-wave kernel 128 workgroups x 4 chunks beat 256 x 2 beside a
     #  second chain -- headline 4.29 -> 4.17 ms; GGAN_HINT_FILTER=0: filter gradients keep their default, as in rounds 3-4)
-    return ConvGeom(*(tuple(t[:11]) + ((both or hint), (both or (hint if _HINT_FILTER else 0)), _lib.PLAN_PLAIN if _PLAIN[0] else 0)))
-
-
-
+    wgs, wgs_f = (both or hint), (both or (hint if _HINT_FILTER else 0))
+    scope = _SITE['scope']
+    if scope is not None:
+        site = '%s:%d' % (scope, _SITE['n'])
+        _SITE['n'] += 1
+        ov = _SITE['table'].get(site)
+        if ov is not None:
+            if list(ov.get('geom', t[:5])) != [int(v) for v in t[:5]]:
+                _SITE['mismatches'] += 1
+            else:
+                wgs = ov['wgs'] if ov.get('wgs', -1) >= 0 else wgs
+                wgs_f = ov['wgs_filter'] if ov.get('wgs_filter', -1) >= 0 else wgs_f
+        if _SITE['log'] is not None:
+            _SITE['log'].append((site, tuple(int(v) for v in t[:7]), int(wgs), int(wgs_f)))
+    return ConvGeom(*(tuple(t[:11]) + (wgs, wgs_f, _lib.PLAN_PLAIN if _PLAIN[0] else 0)))
 
 
 class RowSlot(object):

@@ -177,6 +177,16 @@ def get_stats(device=None):
     return base
 
 
+def release_stats():
+    """Leave serial mode: the communicator's all-gathers go back to the issuing stream and nothing joins the gradient buckets' stream any
+    more (a Trainer without cross-replica BatchNorm, tflib.ops.batchnorm.set_sync_group(None)).  ADVICE r5: serial mode used to stick to
+    the shared communicator for the rest of the process, and every later Trainer lost the bucket / backward overlap."""
+    base = _STATS[0]
+    if base is not None:
+        base.serial = False
+    _STATS[0] = None
+
+
 def get(device=None, create=True):
     """The process's communicator for captured (and eager) exchanges: created on first use when torch.distributed runs on the nccl
     backend (a collective call: every rank reaches it at Trainer construction); None on other backends -- gloo stages device

@@ -14,6 +14,22 @@ import torch
 _params = {}
 _param_aliases = {}
 _device = [None]
+# activation taps (off unless a list is put here): every layer whose epilogue is a ReLU / LeakyReLU on an image-shaped tensor appends
+# (layer name, output) in call order -- tests read the sign pattern of the units nearest their kink (tests/test_golden_full_gpu.py)
+TAPS = [None]
+
+
+def tap(name, out):
+    if TAPS[0] is not None and out.dim() == 4:
+        from ..functional import _SITE
+        TAPS[0].append((_SITE['scope'], name, out.detach()))       # (scope: the step being built -- 'gen0', 'disc3', ... -- or None)
+    return out
+
+
+def drop_taps(prefixes):
+    """forget the taps of steps about to be built again (engine.Trainer: the eager rehearsal's tensors in front of the capture's)"""
+    if TAPS[0] is not None:
+        TAPS[0][:] = [t for t in TAPS[0] if not (t[0] or '').startswith(tuple(prefixes))]
 
 
 def set_device(device):

@@ -6,6 +6,7 @@ import numpy as np
 
 from ... import functional as F
 from .. import param as _param
+from .. import tap as _tap
 
 _SYNC_GROUP = None      # False/None: per-replica statistics (the reference's single-GPU behaviour); else a process group
 
@@ -15,6 +16,9 @@ def set_sync_group(group):
     now on; None switches back.  SURVEY.md 8(e): the mode in which N GPUs x B/N reproduce 1 GPU x B.  Returns the old value."""
     global _SYNC_GROUP
     old, _SYNC_GROUP = _SYNC_GROUP, group
+    if group is None or group is False:
+        from ... import rccl
+        rccl.release_stats()         # (the shared communicator leaves serial mode with the statistics exchange)
     return old
 
 
@@ -40,6 +44,8 @@ def Batchnorm(name, axes, inputs, is_training=None, stats_iter=None, update_movi
         _param(name + '.moving_mean', np.zeros(c, dtype='float32'), trainable=False)
         _param(name + '.moving_variance', np.ones(c, dtype='float32'), trainable=False)
         out = _bn(x, scale, offset, act, alpha)
+        if act in (F.ACT_LRELU, F.ACT_RELU):
+            _tap(name, out)
         return out[:, :, :, 0] if axes == [0, 2] else out
     if axes == [0] and inputs.dim() == 2:
         shape = [1, inputs.shape[1]]

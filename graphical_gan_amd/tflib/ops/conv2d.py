@@ -4,6 +4,7 @@ import numpy as np
 
 from ... import functional as F
 from .. import param as _param
+from .. import tap as _tap
 from .. import initial_values_needed as _draw
 
 _default_weightnorm = False
@@ -78,4 +79,5 @@ def Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, mask_
     assert C == input_dim, (name, inputs.shape, input_dim)
     geom = F.conv_geom(N, input_dim, H, W, output_dim, filter_size, stride, padding)
     act = F.ACT_NONE if activation is None else activation
-    return F.ConvFwd.apply(inputs, filters, b, geom, act, float(alpha), grad_rows)
+    out = F.ConvFwd.apply(inputs, filters, b, geom, act, float(alpha), grad_rows)
+    return _tap(name, out) if act in (F.ACT_LRELU, F.ACT_RELU) else out

@@ -5,6 +5,7 @@ import numpy as np
 
 from ... import functional as F
 from .. import param as _param
+from .. import tap as _tap
 from .. import initial_values_needed as _draw
 
 _default_weightnorm = False
@@ -66,4 +67,5 @@ def Deconv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, wei
     geom = F.conv_geom(N, output_dim, H, W, input_dim, filter_size, stride, padding)
     assert geom[5] == h and geom[6] == w, (geom, h, w)
     act = F.ACT_NONE if activation is None else activation
-    return F.ConvDgrad.apply(inputs, filters, b, geom, act, float(alpha), out)
+    y = F.ConvDgrad.apply(inputs, filters, b, geom, act, float(alpha), out)
+    return _tap(name, y) if act in (F.ACT_LRELU, F.ACT_RELU) else y

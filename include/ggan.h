@@ -35,8 +35,9 @@ typedef void* ggan_stream_t; /* hipStream_t */
 enum { GGAN_ACT_NONE = 0, GGAN_ACT_LRELU = 1, GGAN_ACT_RELU = 2, GGAN_ACT_TANH = 3, GGAN_ACT_SIGMOID = 4 };
 
 /* The ABI's version: changes whenever a struct layout or an entry point's meaning changes (500: ggan_conv_geom carries the launch plan,
- * ggan_prof_rec the grid).  A binding compares it with the header it was written against before the first call. */
-#define GGAN_ABI_VERSION 500
+ * ggan_prof_rec the grid; 600: a profiler record is one problem SHAPE -- (kernel, grid, flop per launch) --, ggan_noise_fill_steps is
+ * gone).  A binding compares it with the header it was written against before the first call. */
+#define GGAN_ABI_VERSION 600
 int ggan_version(void);
 const char* ggan_last_error(void);
 /* ---- convolution geometry ------------------------------------------------------------------
@@ -409,13 +410,6 @@ int ggan_agg_div_bwd(int kind, const float* mu, const float* sd, const float* k_
 #define GGAN_NOISE_MAX 16
 int ggan_noise_fill(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
                     int count, uint64_t* state, ggan_stream_t stream);
-/* The same launch drawing the noise of SEVERAL consecutive session.runs at once (round 4: the Extractor / Generator passes of a critic
- * step and of the generator step behind it are evaluated together, models.GraphicalGAN.forward_nets_pair): tensor i belongs to step
- * steps[i] in [0, advance) and is tensor number slots[i] of that step's draw, i.e. it receives exactly the values a single-step launch
- * of that step would have written; the draw number advances by `advance`. */
-int ggan_noise_fill_steps(float* const* dsts, const size_t* sizes, const int* kinds, const float* a, const float* b, const int* widths,
-                          const int* slots, const int* steps, int count, int advance, uint64_t* state, ggan_stream_t stream);
-
 /* Mixture-of-Gaussians latent glue of the gmgan scripts (HyperExtractor, gmgan_inference_cifar10.py:156-173 with MODE_K =
  * 'CONCRETE'): logits[b,j] = -.5*||z_b - mu_j||^2 + log_pi and k[b,:] = softmax((logits[b,:] + gumbel(u[b,:])) / temp), gumbel(u) =
  * -log(-log(u + 1e-20) + 1e-20) (:117-120).  One launch instead of the dozen [B,K] / [B,K,D] pointwise ops of the TF graph.
@@ -494,9 +488,10 @@ int ggan_pack_adam(const float* const* srcs, const size_t* sizes, const size_t* 
 
 /* ---- per-kernel timing (bench.py roofline leg) -----------------------------------------------
  * When enabled every launch is bracketed by hipEvents on its own stream.  ggan_prof_report
- * synchronises, then writes up to `cap` records -- one per (kernel, work-items per launch): a kernel launched on two grid sizes is two
- * records, so that per-launch figures are not averages over different problems -- and returns their number. */
-typedef struct { char name[48]; double total_ms; long launches; double flops; double bytes; long grid; } ggan_prof_rec;   /* one record per (kernel, grid = work-items per launch, rocprofv3's Grid_Size) */
+ * synchronises, then writes up to `cap` records -- one per (kernel, work-items per launch, algorithmic flop per launch): a kernel launched
+ * on two problem shapes is two records even where the two launches have the same grid, so that per-launch figures are never averages
+ * over different problems -- and returns their number.  `flops` / `launches` is the record's flop per launch (its key). */
+typedef struct { char name[48]; double total_ms; long launches; double flops; double bytes; long grid; } ggan_prof_rec;   /* one record per (kernel, grid = work-items per launch = rocprofv3's Grid_Size, flop per launch) */
 int ggan_prof_enable(int on);
 int ggan_prof_reset(void);
 int ggan_prof_report(ggan_prof_rec* out, int cap);

@@ -38,6 +38,34 @@ class Step(object):
         # margins: set to [] to record, per ReLU / LeakyReLU on a Linear-layer output, (kind, min |pre-activation| / rms(row)): how far the
         # forward pass stays from a kink where fp32 rounding could pick the other branch (tests/golden/make_golden_full.py)
         self.margins = None
+        # kinks: set to {} to record, per ReLU / LeakyReLU on an image-shaped tensor, the KINK_K units nearest their kink (flat positions,
+        # float64 pre-activations, the layer's rms); force: key -> (flat positions, bool "take the positive branch"): those units take the
+        # given branch whatever the sign of their pre-activation -- the float64 evaluation a float32 run agrees with when rounding put
+        # exactly those units on the other side of zero (tests/golden/make_golden_full.py, tests/test_golden_full_gpu.py)
+        self.kinks = None
+        self.force = None
+        self._tag = ''
+
+    KINK_K = 48
+
+    def _act(self, key, x, slope):
+        if self.kinks is not None and x.dim() == 4:
+            with torch.no_grad():
+                f = x.detach().reshape(-1).double()
+                k = min(self.KINK_K, f.numel())
+                _, idx = torch.topk(f.abs(), k, largest=False)
+                idx = idx.sort().values
+                self.kinks[key + self._tag] = dict(idx=idx.numpy().astype(np.int64), val=f[idx].numpy(), rms=float(f.pow(2).mean().sqrt()),
+                                                    shape=tuple(x.shape))
+        y = torch.maximum(slope * x, x) if slope else torch.relu(x)
+        f = self.force.get(key + self._tag) if self.force else None
+        if f is None:
+            return y
+        idx, pos = f
+        m = (x.detach() > 0).reshape(-1).clone()
+        m[torch.as_tensor(np.asarray(idx, dtype=np.int64))] = torch.as_tensor(np.asarray(pos, dtype=bool))
+        m = m.view_as(x).to(x.dtype)
+        return x * (m + slope * (1 - m))
 
     # ---- layers -----------------------------------------------------------------------------------------------------
     def conv(self, x, name):
@@ -68,8 +96,10 @@ class Step(object):
                 rms = x.pow(2).mean(1, keepdim=True).sqrt() + 1e-30
                 self.margins.append((tag, float((x.abs() / rms).min())))
 
-    def lrelu(self, x):
+    def lrelu(self, x, key=None):
         self._margin('lrelu', x)
+        if key is not None:
+            return self._act(key, x, 0.2)
         return torch.maximum(0.2 * x, x)
 
     def Extractor(self, x):
@@ -77,9 +107,11 @@ class Step(object):
         e = x.reshape(-1, c.C, c.S, c.S)
         for i in range(c.nl):
             e = self.conv(e, 'Extractor.%d' % (i + 1))
+            key = 'Extractor.%d' % (i + 1)
             if c.bn and i > 0:
                 e = self.bn(e, 'Extractor.BN%d' % (i + 1), (0, 2, 3))
-            e = self.lrelu(e)
+                key = 'Extractor.BN%d' % (i + 1)
+            e = self.lrelu(e, key)
         return self.lin(e.reshape(-1, c.flat), 'Extractor.Output')
 
     def Generator(self, z):
@@ -95,7 +127,7 @@ class Step(object):
             if i < len(names) - 1:
                 if c.bn:
                     g = self.bn(g, 'Generator.BN' + nm, (0, 2, 3))
-                g = torch.relu(g)
+                g = self._act('Generator.' + ('BN' if c.bn else '') + nm, g, 0.0)
                 if c.dataset == 'mnist' and nm == '2':
                     g = g[:, :, :7, :7]
         g = torch.tanh(g) if c.out_act == 'tanh' else torch.sigmoid(g)
@@ -107,9 +139,11 @@ class Step(object):
         deep = getattr(c, 'critic_deep', False)          # gan_inference_mnist.py:215-250 (oracle/nets.py Discriminator)
         for i in range(c.nl):
             o = self.conv(o, 'Discriminator.%d' % (i + 1))
+            key = 'Discriminator.%d' % (i + 1)
             if deep and c.bn and i > 0:
                 o = self.bn(o, 'Discriminator.BN%d' % (i + 1), (0, 2, 3))
-            o = self.lrelu(o)
+                key = 'Discriminator.BN%d' % (i + 1)
+            o = self.lrelu(o, key)
         zo = self.lrelu(self.lin(z, 'Discriminator.z1'))
         if deep:
             zo = self.lrelu(self.lin(zo, 'Discriminator.2'))
@@ -159,13 +193,19 @@ class Step(object):
         fake = self.Generator(p_z)
         out.update(p_z=p_z, fake_x=fake)
         bce = F.binary_cross_entropy_with_logits
+        def D(tag, x, z):
+            self._tag = '@' + tag
+            try:
+                return self.Discriminator(x, z)
+            finally:
+                self._tag = ''
         if c.K:
-            d_fake = [self.HyperDiscriminator(p_z, onehot), self.Discriminator(fake, p_z)]
-            d_real = [self.HyperDiscriminator(q_z, q_k), self.Discriminator(real, q_z)]
+            d_fake = [self.HyperDiscriminator(p_z, onehot), D('fake', fake, p_z)]
+            d_real = [self.HyperDiscriminator(q_z, q_k), D('real', real, q_z)]
             gen = sum(bce(f, torch.ones_like(f)) + bce(r, torch.zeros_like(r)) for f, r in zip(d_fake, d_real)) / len(d_fake)
             disc = sum(bce(f, torch.zeros_like(f)) + bce(r, torch.ones_like(r)) for f, r in zip(d_fake, d_real)) / len(d_fake)
         else:
-            d_fake, d_real = self.Discriminator(fake, p_z), self.Discriminator(real, q_z)
+            d_fake, d_real = D('fake', fake, p_z), D('real', real, q_z)
             if mode == 'ali':
                 gen = bce(d_fake, torch.ones_like(d_fake)) + bce(d_real, torch.zeros_like(d_real))
                 disc = bce(d_fake, torch.zeros_like(d_fake)) + bce(d_real, torch.ones_like(d_real))
@@ -176,7 +216,7 @@ class Step(object):
                     a = torch.as_tensor(np.asarray(feed['alpha']), dtype=self.dtype).view(-1, 1)
                     x_hat = real + a * (fake - real)
                     z_hat = q_z + a * (p_z - q_z)
-                    d_hat = self.Discriminator(x_hat, z_hat)
+                    d_hat = D('hat', x_hat, z_hat)
                     (g,) = torch.autograd.grad(d_hat.sum(), [x_hat], create_graph=True)
                     gp = 10.0 * ((torch.sqrt((g ** 2).sum(1)) - 1.0) ** 2).mean()
                     disc = disc + gp

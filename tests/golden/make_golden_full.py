@@ -11,8 +11,20 @@ guards that.  The feed seed of each fixture is the first one whose forward pass 
 Linear layers at least MARGIN, and every ReLU input of the Generator's first Linear layer at least MARGIN_RELU (relative to
 the row's rms), away from zero, so that fp32 rounding cannot take the other branch of a unit that carries a macroscopic share
 of a weight-gradient entry: the -m gpu test then needs no "kink" allowance.
+
+Kinks (round 6).  The nets hold ~7e6 ReLU / LeakyReLU units per pass; a few of the conv-layer units sit within float32 rounding of zero
+in ANY evaluation order, and a float32 run that lands one of them on the other side of its kink carries the other slope into every
+gradient behind it (1e-5 .. 1e-3 of a tensor's scale).  So that the -m gpu test can tell such a flip from an error, a fixture also holds
+  <step>/kink/<layer>@<pass>/{idx,val,rms}   the 48 units of every image-shaped activation nearest their kink: flat positions, float64
+                                             pre-activations, the layer's rms -- the GPU's sign at those positions identifies its flips;
+  <step>/flipsets                            JSON list of the flip sets observed on the MI355X (tests/golden/full_flips.json, written by the
+                                             test's report mode), each with
+  <step>/flip<i>/cost, <step>/flip<i>/g/...  the float64 cost and gradient digests with EXACTLY those units forced onto the branch the
+                                             GPU took (oracle.torch_cpu.Step.force).  The test gates the gradients at 5e-5 against the
+                                             variant whose flip set the run shows (the plain digests when it shows none).
     python tests/golden/make_golden_full.py [name ...]      (rewrites tests/golden/full_*.npz; deterministic)
 """
+import json
 import os
 import sys
 import zlib
@@ -80,6 +92,14 @@ def digest(name, g):
     return np.concatenate([[np.linalg.norm(f), np.abs(f).max()], f[sample_index(name, f.size)]])
 
 
+def load_flips():
+    """tests/golden/full_flips.json: fixture -> step -> list of flip sets, a flip set = sorted [[kink key, flat position], ...]"""
+    try:
+        return json.load(open(os.path.join(HERE, 'full_flips.json')))
+    except OSError:
+        return {}
+
+
 def omode_of(mode):
     return 'wali-gp' if mode == 'wali-gp' else 'ali'
 
@@ -122,8 +142,11 @@ def make_image(name):
         seed += 1
     out = {'feed_seed': np.asarray(seed), 'feed_crc': np.asarray(feed_checksum(feed)), 'margin': np.asarray(margin),
            'margin_relu': np.asarray(margin_relu), 'fp32_agree': np.asarray(agree)}
+    flips = load_flips().get(name, {})
     for which in ('gen', 'disc'):
+        ts.kinks = {}
         o, cost, grads = ts.grads(feed, which)
+        kinks, ts.kinks = ts.kinks, None
         out[which + '/cost'] = np.asarray(float(cost))
         df, dr = (o['disc_fake'], o['disc_real']) if not K else (o['disc_fake'][1], o['disc_real'][1])
         out[which + '/disc_fake'] = df.detach().numpy()
@@ -134,6 +157,27 @@ def make_image(name):
         for n, g in grads.items():
             if g is not None:
                 out['%s/g/%s' % (which, n)] = digest(n, g.numpy())
+        for key, kk in kinks.items():
+            out['%s/kink/%s/idx' % (which, key)] = kk['idx']
+            out['%s/kink/%s/val' % (which, key)] = kk['val']
+            out['%s/kink/%s/rms' % (which, key)] = np.asarray(kk['rms'])
+        # the flip sets the MI355X showed on this step: the same evaluation with exactly those units on the other branch
+        sets = flips.get(which, [])
+        out[which + '/flipsets'] = np.asarray(json.dumps(sets))
+        for i, fs in enumerate(sets):
+            force = {}
+            for key, idx in fs:
+                kk = kinks[key]
+                j = int(np.where(kk['idx'] == idx)[0][0])            # (must be one of the recorded units)
+                f = force.setdefault(key, ([], []))
+                f[0].append(int(idx)); f[1].append(not (kk['val'][j] > 0))
+            ts.force = force
+            o2, cost2, grads2 = ts.grads(feed, which)
+            ts.force = None
+            out['%s/flip%d/cost' % (which, i)] = np.asarray(float(cost2))
+            for n, g in grads2.items():
+                if g is not None:
+                    out['%s/flip%d/g/%s' % (which, i, n)] = digest(n, g.numpy())
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     print(name, 'feed seed', seed, 'margin %.2e / %.2e fp32-agree %.1e' % (margin, margin_relu, agree), 'gen %.6f disc %.6f' % (out['gen/cost'], out['disc/cost']))
 

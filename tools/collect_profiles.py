@@ -12,6 +12,9 @@ tag = sys.argv[1]
 WORK = {'': 'headline', '_face': 'gan-face', '_ali': 'ali', '_ssgan': 'ssgan-moving-mnist', '_gmgan': 'gmgan-cifar10-K10',
         '_ssgan3d': 'ssgan-moving-mnist-3dcnn'}
 table = {'_tag': tag}
+bid = os.path.join(ROOT, 'gpurun_out', tag, 'build_id.txt')
+if os.path.exists(bid):
+    table['_build'] = open(bid).read().strip()       # (graphical_gan_amd.build.build_id() on the box that profiled)
 for suffix, key in WORK.items():
     src = os.path.join(ROOT, 'gpurun_out', tag + suffix)
     if not os.path.isdir(src):

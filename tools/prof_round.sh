@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+python -c "from graphical_gan_amd import build; print(build.build_id())" > $O/build_id.txt
 SPI=${SPI:-2}
 B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-profile --no-variants $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $B > $O/trace.log 2>&1

@@ -51,7 +51,39 @@ def main(argv):
             r.get('LDS_Block_Size', ''), short(r['Kernel_Name'])))
         busy += (e - s) / 1e3
         prev_end = max(prev_end, e)
-    print('\n%d kernels, span %.2f us, sum of kernel durations %.2f us' % (len(seg), (prev_end - t0) / 1e3, busy))
+    span = (prev_end - t0) / 1e3
+    print('\n%d kernels, span %.2f us, sum of kernel durations %.2f us' % (len(seg), span, busy))
+    # kernels in flight over the iteration, and how much of it ONE conv kernel on a half-chip plan (<= 160 workgroups) has the chip to itself
+    ev = []
+    for r in seg:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        grid = int(r.get('Grid_Size_X', 0) or 0) * int(r.get('Grid_Size_Y', 1) or 1) * int(r.get('Grid_Size_Z', 1) or 1)
+        wg = int(r.get('Workgroup_Size_X', 0) or 0) * int(r.get('Workgroup_Size_Y', 1) or 1) * int(r.get('Workgroup_Size_Z', 1) or 1)
+        nm = short(r['Kernel_Name'])
+        half = nm.startswith(('corr_kernel', 'dg16_kernel', 'wgrad4_kernel', 'wgrad_kernel')) and grid // max(wg, 1) <= 160
+        ev.append((s, 1, half, nm))
+        ev.append((e, -1, half, nm))
+    ev.sort(key=lambda x: (x[0], x[1]))
+    hist, alone_half, alone_by = {}, 0.0, {}
+    live, live_half, names, prev = 0, 0, [], ev[0][0]
+    for t, d, half, nm in ev:
+        dt = (t - prev) / 1e3
+        hist[min(live, 3)] = hist.get(min(live, 3), 0.0) + dt
+        if live == 1 and live_half == 1:
+            alone_half += dt
+            alone_by[names[0]] = alone_by.get(names[0], 0.0) + dt
+        prev = t
+        live += d
+        live_half += d if half else 0
+        if d > 0:
+            names.append(nm)
+        else:
+            names.remove(nm)
+    tot = sum(hist.values()) or 1.0
+    print('kernels in flight (share of the span): ' + ', '.join('%s: %.1f %%' % ('3+' if k == 3 else k, 100 * v / tot) for k, v in sorted(hist.items())))
+    print('ONE conv kernel on a half-chip plan (<= 160 workgroups) alone on the chip: %.1f us = %.1f %% of the span' % (alone_half, 100 * alone_half / tot))
+    for nm, v in sorted(alone_by.items(), key=lambda kv: -kv[1])[:8]:
+        print('    %-44s %.1f us' % (nm, v))
 
 
 if __name__ == '__main__':
