@@ -667,6 +667,9 @@ def compact_line(full):
     line['cpu_baseline'] = _short_cpu(full.get('cpu_baseline'))
     if full.get('data_parallel'):
         line['data_parallel'] = full['data_parallel']
+    if full.get('dp_schedule_n1'):
+        line['dp_schedule_n1'] = {k: full['dp_schedule_n1'].get(k) for k in ('ms_per_step', 'value', 'vs_single_replica_schedule_pct', 'error')
+                                  if full['dp_schedule_n1'].get(k) is not None}
     vs = []
     for v in full.get('variants') or []:
         r = v.get('roofline') or {}
@@ -689,7 +692,7 @@ def compact_line(full):
         if line.get('roofline'):
             line['roofline'].pop('source', None)
         txt = json.dumps(line, separators=(',', ':'))
-    for drop in ('repeat_ms_per_step', 'variants', 'data_parallel', 'g_d_step', 'cpu_baseline', 'roofline', 'config'):
+    for drop in ('repeat_ms_per_step', 'dp_schedule_n1', 'variants', 'data_parallel', 'g_d_step', 'cpu_baseline', 'roofline', 'config'):
         if len(txt) < LINE_LIMIT:
             break
         if drop == 'cpu_baseline' and line.get(drop):
@@ -727,6 +730,38 @@ def emit(full):
     _flush_c_stdio()
     print(compact_line(full))
     sys.stdout.flush()
+
+
+def dp_schedule_leg(args, head_ms):
+    import subprocess
+    import tempfile
+    port = 29600 + (os.getpid() % 300)
+    tmp = tempfile.NamedTemporaryFile(prefix='ggan_dp_n1_', suffix='.json', delete=False)
+    tmp.close()
+    env = dict(os.environ, GGAN_FORCE_ALLREDUCE='1', GGAN_BENCH_NO_DP_LEG='1', GGAN_BENCH_FULL=tmp.name, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = {k: v for k, v in env.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
+           str(port), os.path.abspath(__file__), '--gpus', '1', '--steps', str(min(args.steps, 100)), '--warmup', str(min(args.warmup, 5)),
+           '--no-variants', '--no-cpu-baseline', '--no-kernel-profile', '--repeats', '0']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get('GGAN_BENCH_DP_LEG_TIMEOUT_S', '240')), env=env, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return dict(error='child exited %d: %s' % (r.returncode, (r.stderr or '')[-300:]))
+        d = json.loads(lines[-1])
+        rec = dict(ms_per_step=d['ms_per_step'], value=d['value'], unit=d['unit'], steps=d['steps'], ranks=1,
+                   exchange='one-rank RCCL all-reduce captured in the iteration graph (GGAN_FORCE_ALLREDUCE=1), child process',
+                   minibatch_feed=(d.get('config') or {}).get('minibatch_feed'), finite=(d.get('config') or {}).get('finite_costs'))
+        if head_ms:
+            rec['vs_single_replica_schedule_pct'] = round(100.0 * (d['ms_per_step'] / head_ms - 1.0), 2)
+        return rec
+    except Exception as e:                                 # noqa: BLE001  (a leg that fails must not take the contract line with it)
+        return dict(error='%s: %s' % (type(e).__name__, str(e)[:200]))
+    finally:
+        try:
+            os.unlink(tmp.name)
+        except OSError:
+            pass
 
 
 def main():
@@ -834,6 +869,14 @@ def main():
             if rank == 0:
                 dp_extra['strong_scaling'] = {'global_batch': 64, 'per_gpu_batch': 64 // world, 'images_per_sec': r1['value'],
                                               'ms_per_step': r1['ms_per_step']}
+    # N = 1: the same headline iteration on the DATA-PARALLEL schedule -- one rank over RCCL, the gradient exchange captured inside the
+    # iteration graph (pack -> all-reduce on the communicator's stream -> Adam, instead of the update riding in the pack launch), the
+    # critic steps' nets passes ahead of time as in the single-replica graph -- measured in a child process of its own, so that nothing
+    # of RCCL lives in the process whose line the driver parses.  What a replica of an N > 1 run executes, minus the wire.
+    dp_n1 = None
+    if world == 1 and default_head and not args.no_variants and not args.no_graph and not os.environ.get('GGAN_BENCH_NO_DP_LEG') \
+            and not os.environ.get('GGAN_FORCE_ALLREDUCE'):
+        dp_n1 = dp_schedule_leg(args, out['ms_per_step'] if out else None)
     # the contract line must be the LAST thing on stdout: librccl writes its version banner to stdout through C stdio (block-buffered on a
     # pipe, so it would surface at exit, behind the line) -- tear the process groups down first, flush C stdio, then print
     if dist.is_available() and dist.is_initialized():
@@ -855,6 +898,8 @@ def main():
                                         exchange='captured in the step graph' if os.environ.get('GGAN_DP_GRAPH', '1') != '0'
                                         else 'host-issued between cut graphs', weak_scaling_per_gpu_batch=64)
         out['variants'] = variants
+        if dp_n1 is not None:
+            out['dp_schedule_n1'] = dp_n1
         emit(out)
 
 

@@ -259,7 +259,7 @@ class Trainer(object):
                 F.workspace(self.device)
             torch.cuda.synchronize(self.device)
         self._ahead_sync_feeds()
-        st.update(i=0, nets=[], events=[])
+        st.update(i=0, nets=[], events=[], pending=None)
         return st
 
     def _ahead_issue(self, st, k):
@@ -278,28 +278,56 @@ class Trainer(object):
 
     def _ahead_step(self):
         """(nets, feed) of the next critic step of the iteration being captured.  The chain is forked behind critic step 1's own nets
-        pass (its noise launch, the snapshot); the pass of step i + 2 is held back until critic step i + 1 begins, so that one pass runs
-        beside each critic step instead of all of them beside the first (3.886 -> 3.836 ms; GGAN_AHEAD_BUNCH=1: all at once)."""
+        pass (its noise launch, the snapshot); the pass of step i + 2 is held back until critic step i + 1 has begun, so that one pass runs
+        beside each critic step instead of all of them beside the first (3.886 -> 3.836 ms; GGAN_AHEAD_BUNCH=1: all at once).  WHERE in
+        step i + 1 it is released is GGAN_AHEAD_AT: 'begin' (in front of its critic pass), 'bwd' (behind its forward: the pass then runs
+        beside the backward pass and the step's tail -- the last data gradient, the thin filter gradient, the pack launch -- where a
+        profiled iteration has one kernel in flight), 'pack' (behind its backward launches)."""
         st = self._ahead_run
         i, n = st['i'], len(st['feeds'])
         st['i'] += 1
         cur = torch.cuda.current_stream(self.device)
         bunch = bool(os.environ.get('GGAN_AHEAD_BUNCH'))
+        at = self._ahead_at()
         if i == 0:
             st['snap'].copy_(self.feed['ring'][2])                        # the critic's step count in front of critic step 1
             nets = self._nets()
             st['stream'].wait_stream(cur)                                 # (behind step 1's noise launch and the snapshot)
-            for k in range(n if bunch else 1):
-                self._ahead_issue(st, k)
+            if bunch or at == 'begin':
+                for k in range(n if bunch else 1):
+                    self._ahead_issue(st, k)
+            else:
+                st['pending'] = 0
             return nets, self.feed
         if not bunch and i < n:
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            st['stream'].wait_event(ev)
-            self._ahead_issue(st, i)
+            if at == 'begin':
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                st['stream'].wait_event(ev)
+                self._ahead_issue(st, i)
+            else:
+                st['pending'] = i
         cur.wait_event(st['events'][i - 1])
         self._sl0 = lib.second_leaf_count()
         return st['nets'][i - 1], st['feeds'][i - 1]
+
+    @staticmethod
+    def _ahead_at():
+        at = os.environ.get('GGAN_AHEAD_AT', 'begin')
+        assert at in ('begin', 'bwd', 'pack'), at
+        return at
+
+    def _ahead_release(self, point):
+        """issue the nets pass a critic step holds back, if `point` is where GGAN_AHEAD_AT releases it (engine._fwd_bwd calls this behind the
+        step's forward and behind its backward launches)"""
+        st = getattr(self, '_ahead_run', None)
+        if st is None or st.get('pending') is None or self._ahead_at() != point:
+            return
+        k, st['pending'] = st['pending'], None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        st['stream'].wait_event(ev)
+        self._ahead_issue(st, k)
 
     def _forward(self, feed, which, nets):
         """model.forward for a step whose backward follows at once: the critic head may then leave its cost's gradient behind with
@@ -323,6 +351,7 @@ class Trainer(object):
     def _fwd_bwd(self, which, nets=None, fuse_update=False, feed=None):
         """fuse_update: the caller applies the update next with nothing but a (single-replica: empty) exchange in between"""
         out = self._forward(self.feed if feed is None else feed, which, nets if nets is not None else self._nets())
+        self._ahead_release('bwd')
         if self.keep_outputs:        # (tests: the critic logits of a captured step -- static graph memory, valid after every replay)
             det = lambda v: [t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()    # (no tape kept alive across steps)
             self.last_out[which] = {k: det(v) for k, v in out.items() if k in ('disc_fake', 'disc_real')}
@@ -331,6 +360,7 @@ class Trainer(object):
         # (the filter-gradient slabs are summed by the pack kernel: legal under the same one-contribution condition)
         with F.defer_wgrad_reduce(self.single_contrib):
             grads = opt.compute_gradients(op.cost)
+            self._ahead_release('pack')
             keep = opt.pack(grads, fuse_update=fuse_update)
         self._costs_settled()
         return out[which + '_cost'].detach(), opt, keep
@@ -429,7 +459,8 @@ class Trainer(object):
         conv launches depends on"""
         c = self.cfg
         return '%s/%s/B%d/K%d/%s%s%s' % (getattr(c, 'dataset', '?'), getattr(c, 'mode', '?'), getattr(c, 'B', 0), getattr(c, 'K', 0) or 0,
-                                        '+'.join(kinds), '/ahead' if ahead else '', '/dp' if self.dp_graph else '')
+                                        '+'.join(kinds), ('/ahead' + ('' if self._ahead_at() == 'begin' else '-' + self._ahead_at())) if ahead else '',
+                                        '/dp' if self.dp_graph else '')
 
     def _site_plan(self, kinds, ahead):
         """the site plan of the graph about to be captured: GGAN_SITE_PLAN=0 none, =<file> that table, else the committed one"""
@@ -507,6 +538,7 @@ class Trainer(object):
         are (Discriminator.zx1: 2.6 M of the 4.1 M parameters) -- its bucket is exchanged while the conv stack's backward pass
         (two thirds of the critic's backward time) still runs; the conv stack's bucket follows.  Same sums as one bucket."""
         out = self._forward(self.feed if feed is None else feed, 'disc', nets if nets is not None else self._nets())
+        self._ahead_release('bwd')
         op = out['disc_train_op']
         opt = op.optimizer
         cutinfo = self.model.critic_cut()
@@ -518,7 +550,9 @@ class Trainer(object):
             opt._one = F.unit_seed(op.cost)
         if sp is None:
             with F.defer_wgrad_reduce(self.single_contrib):
-                keep = opt.pack(opt.compute_gradients(op.cost))
+                grads = opt.compute_gradients(op.cost)
+                self._ahead_release('pack')
+                keep = opt.pack(grads)
             opt.all_reduce()
             self._costs_settled()
             return out['disc_cost'].detach(), opt, (keep, out)
@@ -531,6 +565,7 @@ class Trainer(object):
             w1 = opt.all_reduce(async_op=True, lo=off, hi=None)
             _optim._xlog('backward', 'critic conv stack')
             g2 = torch.autograd.grad([cut], opt.params[:k], grad_outputs=[g[-1]], allow_unused=True)
+            self._ahead_release('pack')
             keep_b = opt.pack_subset(g2, 0, k, bump=False)
             w2 = opt.all_reduce(async_op=True, lo=0, hi=off)
         for w in (w1, w2):

@@ -2,7 +2,10 @@
 costs, critic logits and per-parameter gradient digests of every BASELINE configuration, generated offline by
 tests/golden/make_golden_full.py).  Nothing of the oracle's arithmetic runs here: only its deterministic initial-weight and
 feed generators, checked against the checksums in the fixture.  The fixtures' feeds keep every LeakyReLU input of the critics'
-MLP layers clear of its kink (margin stored in the fixture), so the tolerances below carry no allowance for branch flips."""
+MLP layers clear of its kink (margin stored in the fixture); the conv-layer units that float32 rounding can put on the other side of
+their kink are IDENTIFIED (kink tables, below) and the gradients gated at 5e-5 against the float64 evaluation with exactly those units
+on the GPU's branch -- for every image fixture, eager and timed.  The state-space fixture (numpy tape, per-time-step restatement) has no
+kink table yet and keeps a tolerance from the observed-error table."""
 import os
 import sys
 
@@ -24,13 +27,9 @@ OBSERVED = {}        # (fixture, configuration, step) -> (worst entry error / sc
 # (|float64 pre-activation| <= KINK_BOUND x the layer's rms), and the table must reach beyond that bound (else a flip could hide
 # outside it).  The step's gradients are then gated at TOL_KINK against the float64 evaluation with EXACTLY those units forced onto
 # the GPU's branch (fixture: <step>/flip<i>/...; the plain digests when there is no flip) -- a bound, not a regression pin.
-KINK_BOUND = 2e-5
+KINK_BOUND = 2e-6        # (worst flipped unit observed on MI355X, all fixtures, eager and timed: 6.7e-7 of its layer's rms)
 TOL_KINK = 5e-5
 FLIP_REPORT = os.environ.get('GGAN_FLIP_REPORT')       # discovery mode: append every observed flip set to this JSON-lines file
-
-
-def _has_kinks(z, which):
-    return (which + '/flipsets') in z.files
 
 
 def _gpu_flips(z, which, taps, B, last):
@@ -87,7 +86,7 @@ def _grad_reference(z, name, config, which, flips, worst):
                          % (name, config, which, flips, sets))
 
 
-def _check_grads(z, which, names, grads, tol, allow_flip=False, tag=None):
+def _check_grads(z, which, names, grads, tol, tag=None):
     """per tensor: the 64 fixture entries within tol * scale and the L2 norm within tol/3 (scale = max |g| of the tensor, floored at
     1e-2 of the largest gradient of the step for the mathematically-zero ones, e.g. a bias that feeds a BatchNorm).  Every failure
     message carries the observed error; the worst observed ratios of a passing check go to OBSERVED[tag] (and to stdout with
@@ -95,7 +94,7 @@ def _check_grads(z, which, names, grads, tol, allow_flip=False, tag=None):
     import make_golden_full as MG
     refs = {n: z['%s/g/%s' % (which, n)] for n in names if '%s/g/%s' % (which, n) in z.files}
     gmax = max(r[1] for r in refs.values())
-    worst_e, worst_l, flips, n_all, n_over = 0.0, 0.0, 0, 0, [0, 0, 0]
+    worst_e, worst_l, n_all, n_over = 0.0, 0.0, 0, [0, 0, 0]
     for n, g in zip(names, grads):
         if n not in refs:
             assert g is None or float(g.abs().max()) == 0.0, n
@@ -107,17 +106,6 @@ def _check_grads(z, which, names, grads, tol, allow_flip=False, tag=None):
         idx = MG.sample_index(n, f.size)
         e = np.abs(f[idx] - ref[2:])
         err = e.max()
-        if err > tol * scale and f.size <= 1024 and allow_flip:
-            # A per-channel tensor (bias, BatchNorm offset / scale) shows ONE unit's activation-derivative flip in one entry: the
-            # configurations with BatchNorm inside the critic (gan_inference_mnist.py) put ~6e6 ReLU / LeakyReLU units per step
-            # behind fp32 batch statistics, the closest of them sits ~1e-6 (relative) from its kink, and which side single-precision
-            # rounding takes there depends on the summation order of the statistics -- the fixture's CPU float32 screen cannot
-            # predict the GPU's.  Granted only if it IS that: at most one distinct position off, by less than 1e-2 of the scale,
-            # and the tensor's L2 norm (checked below, tol / 3) unaffected.
-            bad = sorted(set(int(i) for i in idx[e > tol * scale]))
-            assert len(bad) == 1 and err <= 1e-2 * scale, (which, n, 'entries', err, scale, bad)
-            err = 0.0
-            flips += 1
         assert err <= tol * scale, (which, n, 'entries: observed %.3g of the scale, tolerance %.3g' % (err / scale, tol))
         l2den = max(ref[0], 1e-2 * gmax * np.sqrt(f.size))
         l2 = abs(np.linalg.norm(f) - ref[0])
@@ -127,26 +115,21 @@ def _check_grads(z, which, names, grads, tol, allow_flip=False, tag=None):
         for k_, th in enumerate((1e-5, 5e-5, 2e-4)):
             n_over[k_] += int((e > th * scale).sum())
     if tag is not None:
-        OBSERVED[tag + (which,)] = (worst_e, worst_l, flips)
+        OBSERVED[tag + (which,)] = (worst_e, worst_l)
         if os.environ.get('GGAN_TEST_REPORT'):
-            print('OBSERVED %s entries %.3g l2 %.3g flips %d (tolerance %.3g); of %d sampled entries %d / %d / %d above 1e-5 / 5e-5 / 2e-4 of the scale'
-                  % ('/'.join(tag + (which,)), worst_e, worst_l, flips, tol, n_all, n_over[0], n_over[1], n_over[2]))
+            print('OBSERVED %s entries %.3g l2 %.3g (tolerance %.3g); of %d sampled entries %d / %d / %d above 1e-5 / 5e-5 / 2e-4 of the scale'
+                  % ('/'.join(tag + (which,)), worst_e, worst_l, tol, n_all, n_over[0], n_over[1], n_over[2]))
 
 
-# Gradient tolerances at full size = 3 x the worst error OBSERVED on MI355X (round 5: GGAN_TEST_REPORT=1, max over the eager and the timed
-# configuration), per fixture and step, floored at 2e-5 and capped at SURVEY.md 8(c)'s ceilings (1e-3; 2e-3 through the gradient penalty /
-# the mixture prior) -- not one blanket figure.  The observed errors are BIMODAL: a step whose ~7e6 ReLU / LeakyReLU units all land on the
-# float64 side of their kinks agrees to 1e-6 .. 5e-5 (largest entry error over the tensor's max |g|; the wali-gp critic step WITH its
-# double backward: 1e-6); a step in which one conv-layer unit sits within fp32 rounding of its kink and lands on the other side
-# carries that flip into every gradient upstream of it (a third of the sampled entries move by 1e-5 .. 1e-3: PyTorch-CPU float32
-# against float64 does the same, up to 1.4e-3 on unscreened feeds).  Which steps flip is a property of the fixture's feed and of the
-# summation order of the kernels that produce that activation, and it is deterministic: a kernel change that moves a clean step
-# above its tolerance shows here, is re-measured with GGAN_TEST_REPORT=1 and the table updated with the reason.
-CEIL = {'full_cifar_wali_gp': 2e-3, 'full_cifar_gmgan_k30': 2e-3, 'full_cifar_gmgan_k10': 2e-3, 'full_face_gmgan_k100': 2e-3, 'full_mnist_gmgan': 2e-3}
-OBS = {     # fixture -> (generator step, critic step): worst entry error / scale observed (r05, either configuration)
-    'full_cifar_ali': (5.8e-6, 5.3e-4), 'full_cifar_wali_gp': (4.6e-6, 1.1e-6), 'full_cifar_gmgan_k30': (1.6e-3, 7.8e-4),
-    'full_cifar_gmgan_k10': (2.8e-5, 7.9e-7), 'full_face_ali': (4.8e-5, 1.5e-4), 'full_face_gmgan_k100': (1.2e-3, 2.7e-4),
-    'full_mnist_ali': (3.4e-4, 2.4e-4), 'full_mnist_gmgan': (1.2e-5, 1.1e-6), 'full_ssgan_b32_t16': (3.2e-4, 2.4e-5),
+# Round 5 gated every fixture at 3 x the error the same implementation had shown (up to 2e-3): the errors were bimodal -- 1e-6 .. 5e-5 for a
+# step whose ~7e6 ReLU / LeakyReLU units all land on the float64 side of their kinks, 1e-5 .. 1.6e-3 for a step with a flipped conv-layer
+# unit -- and the explanation was asserted, not shown.  Round 6 shows it: every (fixture, configuration, step) with an error above 5e-5
+# has 1-3 flipped units, each within 7e-7 of its layer's rms of zero, and against the float64 evaluation with exactly those units forced
+# the worst error of ANY image fixture is 2.9e-5 (profiles/r06_notes.md; full_cifar_gmgan_k30: 1.6e-3 -> 2.9e-5 eager, no flip and 1.4e-5
+# timed).  What is left of the observed-error table is the state-space fixture, whose oracle (the numpy tape) has no kink table:
+CEIL = {}
+OBS = {     # fixture -> (generator step, critic step): worst entry error / scale observed (r05 / r06, either configuration)
+    'full_ssgan_b32_t16': (3.2e-4, 2.4e-5),
 }
 
 
@@ -190,21 +173,11 @@ def test_full_size_first_step_vs_fixture(gpu, name):
         names = [p.param_name for p in opt.params]
         # (through the optimizer: a weight that two passes of the step reach comes back as a pair of contributions)
         grads = [(g[0] + g[1]) if isinstance(g, tuple) else g for g in opt.compute_gradients(out[which + '_cost'])]
-        # Gradient tolerance at this size: 1e-3 of the tensor's max |g| per entry (3e-4 on its L2 norm); 2e-3 for the double backward
-        # of the gradient penalty and with the mixture prior (its Gumbel-softmax divides 128-term squared distances by TEMP = 0.1
-        # before exponentiating them).  Costs and logits stay at 1e-5 / 2e-5.  The nets hold ~7e6 ReLU / LeakyReLU units per pass;
-        # a handful of them sit within fp32 rounding of their kink in ANY evaluation order, and each flip is a sparse O(1e-4..1e-3)
-        # perturbation of some gradient tensor: two float32 evaluations that differ only in summation order (e.g. two tile shapes
-        # of the same kernel, or PyTorch-CPU float32 vs float64: up to 1.4e-3 on unscreened feeds) do not agree tighter than that.
-        # The fixture feeds are screened so that the Linear-layer activations are clear of their kinks and a float32 CPU
-        # evaluation reproduces float64 to 3e-5; at the small sizes of tests/test_step_gpu.py the tolerance is 1e-4.
-        # (the one-flip allowance only where BatchNorm sits INSIDE the critic: the gan/gmgan_inference_mnist fixtures)
-        if _has_kinks(z, which):
-            flips, worst = _gpu_flips(z, which, taps, B, last=False)
-            prefix, tol = _grad_reference(z, name, 'eager', which, flips, worst)
-            _check_grads(z, prefix, names, grads, tol if tol is not None else tol_of(name, which), tag=(name, 'eager'))
-        else:
-            _check_grads(z, which, names, grads, tol_of(name, which), allow_flip=dataset == 'mnist', tag=(name, 'eager'))
+        # (the gradient gate: TOL_KINK = 5e-5 of the tensor's max |g| per entry, a third of it on its L2 norm, against the float64 digests of
+        #  the flip set this run shows -- see the kink section at the top; costs and logits stay at 1e-5 / 2e-5)
+        flips, worst = _gpu_flips(z, which, taps, B, last=False)
+        prefix, tol = _grad_reference(z, name, 'eager', which, flips, worst)
+        _check_grads(z, prefix, names, grads, tol if tol is not None else 2e-3, tag=(name, 'eager'))
     optim.reset_optimizers()
     lib.delete_all_params()
 
@@ -258,6 +231,10 @@ def test_full_size_timed_configuration_vs_fixture(gpu, name):
     for it in (2, 3, 4):                     # capture (with its warm-up steps), then replays
         res = tr.iteration(it, None if ring else feeds)
     all_taps, lib.TAPS[0] = lib.TAPS[0], None     # (the captured graphs' activations: static graph memory, rewritten by every replay)
+    if os.environ.get('GGAN_EXPECT_DP_GRAPH'):           # (test_full_size_dp_schedule_vs_fixture: this process runs the data-parallel schedule)
+        assert tr.dp_graph and tr.comm is not None
+        if cfg.critic_iters > 1:
+            assert getattr(tr, '_ahead', None) is not None and len(tr._ahead['feeds']) == cfg.critic_iters - 1
     if ring:
         assert getattr(tr, '_iter_graph', None) is not None and tr._iter_graph['kinds'] == ('gen',) + ('disc',) * cfg.critic_iters
         assert tr.model.fork_nets            # (the two-stream nets pass and its 128-workgroup plans were on while the graph was built)
@@ -276,15 +253,12 @@ def test_full_size_timed_configuration_vs_fixture(gpu, name):
         opt = next(o for k, o in _optimizers.items() if k[0] == which)
         names = [p.param_name for p in opt.params]
         grads = [opt.g[o:o + n].view(p.shape) for p, (o, n) in zip(opt.params, opt.slots)]
-        if _has_kinks(z, which):
-            # a critic step's gradients in the bucket are those of the iteration's LAST critic step: its critic pass, and the nets pass
-            # issued for it (ahead of time, one step earlier) -- the last call of each layer among the critic steps' scopes
-            taps = [(n_, t_) for sc, n_, t_ in all_taps if sc is not None and sc.startswith(which)]
-            flips, worst = _gpu_flips(z, which, taps, B, last=which == 'disc')
-            prefix, tol = _grad_reference(z, name, 'timed', which, flips, worst)
-            _check_grads(z, prefix, names, grads, tol if tol is not None else tol_of(name, which), tag=(name, 'timed'))
-        else:
-            _check_grads(z, which, names, grads, tol_of(name, which), allow_flip=dataset == 'mnist', tag=(name, 'timed'))
+        # a critic step's gradients in the bucket are those of the iteration's LAST critic step: its critic pass, and the nets pass
+        # issued for it (ahead of time, one step earlier) -- the last call of each layer among the critic steps' scopes
+        taps = [(n_, t_) for sc, n_, t_ in all_taps if sc is not None and sc.startswith(which)]
+        flips, worst = _gpu_flips(z, which, taps, B, last=which == 'disc')
+        prefix, tol = _grad_reference(z, name, 'timed', which, flips, worst)
+        _check_grads(z, prefix, names, grads, tol if tol is not None else 2e-3, tag=(name, 'timed'))
     # the weights did not move (lr 0) and match the fixture's
     got = tr.get_params()
     for n_, v in P0.items():
@@ -292,6 +266,22 @@ def test_full_size_timed_configuration_vs_fixture(gpu, name):
             assert np.array_equal(got[n_].reshape(-1), np.asarray(v, np.float32).reshape(-1)), n_
     optim.reset_optimizers()
     lib.delete_all_params()
+
+
+def test_full_size_dp_schedule_vs_fixture(gpu):
+    """The DATA-PARALLEL schedule at full size against the float64 fixtures (round-5 review: the schedule a replica of an N > 1 run executes
+    was never the one a full-size fixture ran): the timed-configuration test above for BASELINE configs[2] (gmgan_inference_cifar10, K = 10)
+    and for the headline (wali-gp: the critic steps' nets passes ahead of time INSIDE the data-parallel iteration graph) in a process
+    with a one-rank RCCL communicator and GGAN_FORCE_ALLREDUCE=1 -- gradient exchange captured inside the iteration graph on the
+    communicator's stream, pack -> all-reduce -> Adam instead of the update riding in the pack launch.  Same tolerances."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GGAN_FORCE_ALLREDUCE='1', GGAN_TEST_DP_ONE_RANK='1', GGAN_EXPECT_DP_GRAPH='1')
+    env = {k: v for k, v in env.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_golden_full_gpu.py'), '-q', '-x', '-m', 'gpu', '-k',
+                        'test_full_size_timed_configuration_vs_fixture and (full_cifar_gmgan_k10 or full_cifar_wali_gp)'],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0 and '2 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
 
 
 @pytest.mark.parametrize('timed', [False, True], ids=['eager', 'timed'])
