@@ -15,7 +15,7 @@ STAMP = os.path.join(HERE, '.libggan.stamp')
 SOURCES = ['runtime.hip', 'pointwise.hip', 'bn.hip', 'linear_bn.hip', 'gemm.hip', 'conv_naive.hip', 'conv_corr.hip', 'conv_dg16.hip', 'conv_wgrad.hip', 'conv_wgrad_split.hip', 'conv_thin.hip', 'conv_api.hip', 'conv3d.hip', 'dynscan.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-Wall', '-Wno-unused-function']
 EXTRA_FLAGS = {'conv_wgrad_split.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
-if os.environ.get('GGAN_BUILD_DIAG'):       # timing experiments only (tools/criticality*.sh): compiles GGAN_SKIP_KERNELS in
+if os.environ.get('GGAN_BUILD_DIAG'):       # timing experiments only: compiles GGAN_SKIP_KERNELS in
     FLAGS.append('-DGGAN_DIAG')
 
 

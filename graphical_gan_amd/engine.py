@@ -415,6 +415,16 @@ class Trainer(object):
         opt.update()
         return cost
 
+    def _step_as_captured(self, which):
+        """eager_as_captured for the one-graph-per-step workloads: the step as its graph launches it (site plan of a [which] graph)"""
+        self.flush()
+        F.set_site_plan(self._site_plan([which], False))
+        try:
+            cost, _, _ = self._step_body(which)
+        finally:
+            F.set_site_plan(None)
+        return cost
+
     def _optimizers(self):
         from .optim import _optimizers
         return list(_optimizers.values())
@@ -438,12 +448,14 @@ class Trainer(object):
         the kernels of such steps with HIP events, so that its per-kernel table is the timed graph's kernel mix."""
         forkable = hasattr(self.model, 'fork_now') and not self.split_graph and not self.sync_bn
         prev_graph, self.graph_enabled = self.graph_enabled, False
+        self._as_captured = True
         if forkable:
             self.model.fork_now = True
         try:
             yield
         finally:
             self.graph_enabled = prev_graph
+            self._as_captured = False
             if forkable:
                 self.model.fork_now = False
 
@@ -656,6 +668,8 @@ class Trainer(object):
             lib.end_build_phase()        # both step kinds have been built once (critic-free modes: the generator step): from here on
                                          # the layer calls draw no initial values
         if not self.graph_enabled:
+            if getattr(self, '_as_captured', False) and self._calls[which] > 1 and not self.split_graph:
+                return self._step_as_captured(which)
             return self._eager(which)
         rec = self._graphs.get(which)
         if rec is None:
@@ -700,6 +714,45 @@ class Trainer(object):
             self.set_feed(feed)
         return self.step('disc')
 
+    def _iteration_body(self, kinds, ahead):
+        """the steps of one iteration as they are captured into ONE graph (and rehearsed eagerly in front of the capture): each step under
+        its site scope, the critic steps' nets passes ahead of time when `ahead` is the state _ahead_prepare made"""
+        costs, keeps, seen = {}, [], {}
+        self._ahead_run = ahead
+        try:
+            for k in kinds:
+                cost, opt, keep = self._step_body(k, seen.get(k, 0))    # (with the in-graph gradient exchange when there are replicas)
+                seen[k] = seen.get(k, 0) + 1
+                costs[k + '_cost'] = cost
+                keeps.append((opt, keep))
+        finally:
+            self._ahead_run = None
+        if ahead is not None:
+            torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
+            keeps.append((None, (ahead['nets'], ahead['events'])))
+        return costs, keeps
+
+    def _iteration_as_captured(self, kinds):
+        """eager_as_captured: one iteration launched eagerly exactly as the iteration graph launches it -- site plans, ahead-of-time passes --
+        on the capture stream (whose per-stream workspaces exist); the steps DO update the weights"""
+        forkable = hasattr(self.model, 'fork_now') and not self.sync_bn
+        s = self._cap_stream if getattr(self, '_cap_stream', None) is not None else F.shared_stream(self.device, 'capture')
+        self._cap_stream = s
+        use_ahead = self._ahead_ok(kinds)
+        F.set_site_plan(self._site_plan(kinds, use_ahead))
+        if forkable:
+            self.model.fork_now = True
+        try:
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                costs, _ = self._iteration_body(kinds, self._ahead_prepare(kinds) if use_ahead else None)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            return costs
+        finally:
+            F.set_site_plan(None)
+            if forkable:
+                self.model.fork_now = False
+
     def _capture_iteration(self, kinds):
         """one HIP graph for a whole iteration (ring mode, one GPU): [generator step, critic step x CRITIC_ITERS], each
         forward + backward + pack + Adam -- no graph-launch gap between the steps"""
@@ -728,21 +781,6 @@ class Trainer(object):
             use_ahead = self._ahead_ok(kinds)
             F.set_site_plan(self._site_plan(kinds, use_ahead))
 
-            def body(ahead):
-                costs, keeps, seen = {}, [], {}
-                self._ahead_run = ahead
-                try:
-                    for k in kinds:
-                        cost, opt, keep = self._step_body(k, seen.get(k, 0))    # (with the in-graph gradient exchange when there are replicas)
-                        seen[k] = seen.get(k, 0) + 1
-                        costs[k + '_cost'] = cost
-                        keeps.append((opt, keep))
-                finally:
-                    self._ahead_run = None
-                if ahead is not None:
-                    torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
-                    keeps.append((None, (ahead['nets'], ahead['events'])))
-                return costs, keeps
             try:
                 # dress rehearsal: the body exactly as it will be captured -- ahead-of-time passes, site plans -- run once eagerly, so that
                 # every plan-time cache (slab tables: a launch that finds none under capture bakes the slower in-kernel descriptors into
@@ -750,7 +788,7 @@ class Trainer(object):
                 with torch.cuda.stream(s):
                     snap = [(o, o.theta.clone(), o.m.clone(), o.v.clone(), o.step.clone()) for o in self._optimizers()]
                     rng_snap = rng.clone() if torch.is_tensor(rng) else None
-                    body(self._ahead_prepare(kinds) if use_ahead else None)
+                    self._iteration_body(kinds, self._ahead_prepare(kinds) if use_ahead else None)
                     for o, th, m, v, st in snap:
                         o.theta.copy_(th); o.m.copy_(m); o.v.copy_(v); o.step.copy_(st)
                     if rng_snap is not None:
@@ -763,7 +801,7 @@ class Trainer(object):
                 lib.drop_taps(set(kinds))                  # (tests: only the captured graph's activations are of interest)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
-                    costs, keeps = body(ahead)
+                    costs, keeps = self._iteration_body(kinds, ahead)
                 self.site_mismatches = F.site_mismatches()
             finally:
                 F.set_site_plan(None)
@@ -817,6 +855,11 @@ class Trainer(object):
         """ring mode: the steps of an iteration with nothing issued between them -- as ONE graph replay where that is possible"""
         one_graph = (self.graph_enabled and it > 0 and (self.world == 1 or self.dp_graph) and not self.split_graph
                      and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH'))
+        if (not one_graph and getattr(self, '_as_captured', False) and it > 0 and (self.world == 1 or self.dp_graph) and not self.split_graph
+                and all(self._calls[k] >= 1 for k in set(kinds)) and not os.environ.get('GGAN_NO_ITER_GRAPH')):
+            for k in kinds:
+                self._calls[k] += 1
+            return self._iteration_as_captured(kinds)       # (the iteration graph's launches, issued eagerly: site plans, ahead-of-time passes)
         if not one_graph:
             return {k + '_cost': self.step(k) for k in kinds}
         for k in kinds:

@@ -131,8 +131,8 @@ def used_names(cfg):
 
 
 # ---- nets ------------------------------------------------------------------------------------------------------------
-def _lrelu(x):
-    return tp.leaky_relu(x, 0.2)
+def _lrelu(x, key=None):
+    return tp.leaky_relu(x, 0.2, key)
 
 
 def expand_labels(cfg, y):
@@ -208,7 +208,7 @@ def Generator(cfg, P, z_g, z_l, labels):                     # :171-204
     out = tp.relu(N.Linear(P, 'Generator.Input', _z_rows(cfg, z_g, z_l, labels)))
     out = tp.reshape(out, (cfg.B * cfg.LEN, 8 * cfg.dim, 4, 4))
     for nm in ('2', '3', '4'):
-        out = tp.relu(N.Deconv2D(P, 'Generator.' + nm, out))
+        out = tp.relu(N.Deconv2D(P, 'Generator.' + nm, out), 'Generator.' + nm)
     out = tp.tanh(N.Deconv2D(P, 'Generator.5', out))
     return tp.reshape(out, (cfg.B, cfg.LEN, cfg.output_dim))
 
@@ -216,7 +216,7 @@ def Generator(cfg, P, z_g, z_l, labels):                     # :171-204
 def _conv_stack(cfg, P, pre, x):
     out = x
     for i in range(4):
-        out = _lrelu(N.Conv2D(P, '%s.%d' % (pre, i + 1), out))   # (dropout == identity; BN flags off)
+        out = _lrelu(N.Conv2D(P, '%s.%d' % (pre, i + 1), out), '%s.%d' % (pre, i + 1))   # (dropout == identity; BN flags off)
     return out
 
 
@@ -334,8 +334,11 @@ def forward(cfg, P, feed):
         disc_real.append(DynamicDiscriminator(cfg, P, _step(cfg, q_z_l, i), _step(cfg, q_z_l, i + 1)))
     disc_fake.append(ZGDiscriminator(cfg, P, p_z_g))
     disc_real.append(ZGDiscriminator(cfg, P, q_z_g))
+    tp.KINK_TAG[0] = '@fake'                 # (kink tables: the frame critic is called twice with the same layer names)
     disc_fake.append(Discriminator(cfg, P, fake_x, p_z_g, p_z_l, p_y))
+    tp.KINK_TAG[0] = '@real'
     disc_real.append(Discriminator(cfg, P, real_x, q_z_g, q_z_l, real_y))
+    tp.KINK_TAG[0] = ''
     gen_cost, disc_cost = J.weighted_local_epce_costs(disc_fake, disc_real, list(cfg.ratio()))
     if getattr(cfg, 'mode', 'local_ep') == 'local_epce-z':
         rec_x = Generator(cfg, P, q_z_g, q_z_l, real_y)

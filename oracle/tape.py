@@ -119,25 +119,54 @@ def absolute(a):
 
 
 KINK_LOG = None      # tests: set to [] to collect the 2-D (Linear-layer) ReLU / LeakyReLU inputs of a forward pass
+# Kink tables / forced branches of the image-shaped activations (tests/golden/make_golden_full.py, the state-space fixture; the image
+# scripts' fixtures use the same scheme in oracle/torch_cpu.py): with KINKS a dict, every keyed ReLU / LeakyReLU on a 4-D tensor records the
+# KINK_K units nearest zero (flat positions, float64 values, the layer's rms) under key + KINK_TAG[0]; with FORCE a dict key -> (positions,
+# take-the-positive-branch flags) those units take the given branch whatever the sign of their input.
+KINKS = None
+FORCE = None
+KINK_TAG = ['']
+KINK_K = 48
 
 
-def relu(a):
-    """tf.nn.relu; gradient g*(x>0)."""
+def _kink(a, key, slope):
+    """-> the 0/1 (or slope/1) derivative mask of the activation, with forced units, and records the kink table"""
+    x = a.v
+    pos = x > 0
+    if key is not None and x.ndim == 4:
+        k = key + KINK_TAG[0]
+        if KINKS is not None:
+            f = x.reshape(-1).astype(np.float64)
+            n = min(KINK_K, f.size)
+            idx = np.sort(np.argpartition(np.abs(f), n - 1)[:n])
+            KINKS[k] = dict(idx=idx.astype(np.int64), val=f[idx], rms=float(np.sqrt(np.mean(f * f))), shape=tuple(x.shape))
+        if FORCE and k in FORCE:
+            idx, p = FORCE[k]
+            pos = pos.copy().reshape(-1)
+            pos[np.asarray(idx, dtype=np.int64)] = np.asarray(p, dtype=bool)
+            pos = pos.reshape(x.shape)
+    return np.where(pos, 1.0, slope).astype(x.dtype)
+
+
+def relu(a, key=None):
+    """tf.nn.relu; gradient g*(x>0).  key: see KINKS / FORCE (a forced unit's value is x * its branch's slope, |x| ~ 1e-7 rms there)."""
     if KINK_LOG is not None and a.v.ndim == 2:
         KINK_LOG.append(a.v)
-    m = T((a.v > 0).astype(a.v.dtype))
-    return T(np.maximum(a.v, 0), (a,), lambda g: (mul(g, m),))
+    mv = _kink(a, key, 0.0)
+    m = T(mv)
+    forced = key is not None and FORCE and (key + KINK_TAG[0]) in FORCE
+    return T(a.v * mv if forced else np.maximum(a.v, 0), (a,), lambda g: (mul(g, m),))
 
 
-
-
-def leaky_relu(a, alpha=0.2):
+def leaky_relu(a, alpha=0.2, key=None):
     """tf.maximum(alpha*x, x) (gmgan_inference_cifar10.py:122-123).  Piecewise linear:
     slope 1 for x>0 else alpha; second derivative zero a.e."""
     if KINK_LOG is not None and a.v.ndim == 2:
         KINK_LOG.append(a.v)
-    m = T(np.where(a.v > 0, 1.0, alpha).astype(a.v.dtype))
-    return T(O.leaky_relu(a.v, alpha), (a,), lambda g: (mul(g, m),))
+    mv = _kink(a, key, alpha)
+    m = T(mv)
+    forced = key is not None and FORCE and (key + KINK_TAG[0]) in FORCE
+    return T(a.v * mv if forced else O.leaky_relu(a.v, alpha), (a,), lambda g: (mul(g, m),))
 
 
 def tanh(a):

@@ -187,19 +187,55 @@ def make_ssgan(name):
     ocfg = O.Cfg(**SSGAN[name])
     P0 = ssgan_params(ocfg)
     feed = O.make_feed(ocfg, np.random.default_rng(1000))
-    Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
-    oout = O.forward(ocfg, Pt, feed)
-    out = {'feed_seed': np.asarray(1000), 'feed_crc': np.asarray(feed_checksum(feed)), 'fake_x_digest': digest('fake_x', oout['fake_x'].v)}
     gen_names = [n for n in P0 if 'Generator' in n or 'Extractor' in n]
     disc_names = [n for n in P0 if 'Discriminator' in n]
-    for which, names in (('gen', gen_names), ('disc', disc_names)):
-        out[which + '/cost'] = np.asarray(float(oout[which + '_cost'].v))
-        gs = tp.grad(oout[which + '_cost'], [Pt[n] for n in names])
-        for n, g in zip(names, gs):
-            if g is not None:
-                out['%s/g/%s' % (which, n)] = digest(n, g.v)
+
+    def evaluate(force):
+        """one forward pass (it builds both costs) + the two gradient sets; force: kink key -> (positions, branches) or None"""
+        Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
+        tp.KINKS, tp.FORCE = ({} if force is None else None), force
+        try:
+            oout = O.forward(ocfg, Pt, feed)
+            kinks = tp.KINKS
+        finally:
+            tp.KINKS, tp.FORCE = None, None
+        res = {}
+        for which, names in (('gen', gen_names), ('disc', disc_names)):
+            gs = tp.grad(oout[which + '_cost'], [Pt[n] for n in names])
+            res[which] = (float(oout[which + '_cost'].v), {n: g.v for n, g in zip(names, gs) if g is not None})
+        return oout, kinks, res
+    oout, kinks, res = evaluate(None)
+    out = {'feed_seed': np.asarray(1000), 'feed_crc': np.asarray(feed_checksum(feed)), 'fake_x_digest': digest('fake_x', oout['fake_x'].v)}
+    for key, kk in kinks.items():            # (one forward pass serves both steps: the table is stored once, under 'fwd')
+        out['fwd/kink/%s/idx' % key] = kk['idx']
+        out['fwd/kink/%s/val' % key] = kk['val']
+        out['fwd/kink/%s/rms' % key] = np.asarray(kk['rms'])
+        out['fwd/kink/%s/rows' % key] = np.asarray(kk['shape'][0])
+    for which in ('gen', 'disc'):
+        out[which + '/cost'] = np.asarray(res[which][0])
+        for n, g in res[which][1].items():
+            out['%s/g/%s' % (which, n)] = digest(n, g)
+    flips = load_flips().get(name, {})
+    sets = []
+    for which in ('gen', 'disc'):
+        for fs in flips.get(which, []):
+            if fs not in sets:
+                sets.append(fs)
+    out['fwd/flipsets'] = np.asarray(json.dumps(sets))
+    for i, fs in enumerate(sets):
+        force = {}
+        for key, idx in fs:
+            kk = kinks[key]
+            j = int(np.where(kk['idx'] == idx)[0][0])
+            f = force.setdefault(key, ([], []))
+            f[0].append(int(idx)); f[1].append(not (kk['val'][j] > 0))
+        _, _, res2 = evaluate(force)
+        for which in ('gen', 'disc'):
+            out['%s/flip%d/cost' % (which, i)] = np.asarray(res2[which][0])
+            for n, g in res2[which][1].items():
+                out['%s/flip%d/g/%s' % (which, i, n)] = digest(n, g)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
-    print(name, 'gen %.6f disc %.6f' % (out['gen/cost'], out['disc/cost']))
+    print(name, 'gen %.6f disc %.6f' % (out['gen/cost'], out['disc/cost']), '%d kink tables, %d flip set(s)' % (len(kinks), len(sets)))
 
 
 if __name__ == '__main__':

@@ -32,31 +32,35 @@ TOL_KINK = 5e-5
 FLIP_REPORT = os.environ.get('GGAN_FLIP_REPORT')       # discovery mode: append every observed flip set to this JSON-lines file
 
 
-def _gpu_flips(z, which, taps, B, last):
+def _gpu_flips(z, which, taps, B, last, table=None):
     """taps: [(layer name, output tensor)] of this step in call order; last: take the LAST call of a layer (a critic step of an iteration
-    graph: the step whose gradients the bucket holds) instead of the first.  -> sorted [[kink key, flat position], ...], worst |pre| / rms"""
+    graph: the step whose gradients the bucket holds) instead of the first; table: the fixture prefix the kink table sits under (default:
+    the step's own; the state-space fixture has ONE table, 'fwd', for both steps, with the row count of every activation stored).
+    -> sorted [[kink key, flat position], ...], worst |pre| / rms"""
+    table = table or which
     by = {}
     for name, t in taps:
         by.setdefault((name, int(t.shape[0])), []).append(t)
     pick = (lambda v: v[-1]) if last else (lambda v: v[0])
     flips, worst = [], 0.0
-    keys = sorted(set(k.split('/')[2] for k in z.files if k.startswith(which + '/kink/') and k.endswith('/idx')))
+    keys = sorted(set(k.split('/')[2] for k in z.files if k.startswith(table + '/kink/') and k.endswith('/idx')))
     assert keys, 'fixture without a kink table'
     for key in keys:
         layer, _, tag = key.partition('@')
-        idx = z['%s/kink/%s/idx' % (which, key)].astype(np.int64)
-        val = z['%s/kink/%s/val' % (which, key)]
-        rms = float(z['%s/kink/%s/rms' % (which, key)])
-        if tag in ('fake', 'real') and (layer, 2 * B) in by:          # the critic evaluated once on [fake; real]
-            t = pick(by[(layer, 2 * B)])
+        idx = z['%s/kink/%s/idx' % (table, key)].astype(np.int64)
+        val = z['%s/kink/%s/val' % (table, key)]
+        rms = float(z['%s/kink/%s/rms' % (table, key)])
+        rows = int(z['%s/kink/%s/rows' % (table, key)]) if ('%s/kink/%s/rows' % (table, key)) in z.files else B
+        if tag in ('fake', 'real') and (layer, 2 * rows) in by:       # the critic evaluated once on [fake; real]
+            t = pick(by[(layer, 2 * rows)])
             off = 0 if tag == 'fake' else t.numel() // 2
         elif tag in ('fake', 'real'):                                 # (BatchNorm inside the critic: two calls, fake then real)
-            calls = by.get((layer, B), [])
+            calls = by.get((layer, rows), [])
             assert len(calls) >= 2, ('no critic taps for', key, sorted(by))
             t, off = (calls[-2:] if last else calls[:2])[0 if tag == 'fake' else 1], 0
         else:
-            assert (layer, B) in by, ('no tap for', key, sorted(by))
-            t, off = pick(by[(layer, B)]), 0
+            assert (layer, rows) in by, ('no tap for', key, sorted(by))
+            t, off = pick(by[(layer, rows)]), 0
         y = t.reshape(-1)[(idx + off).tolist()].cpu().numpy()
         gpu_pos, ref_pos = y > 0, val > 0
         assert np.abs(val).max() >= KINK_BOUND * rms, (key, 'kink table does not reach the rounding bound', np.abs(val).max() / rms)
@@ -68,10 +72,10 @@ def _gpu_flips(z, which, taps, B, last):
     return sorted(flips), worst
 
 
-def _grad_reference(z, name, config, which, flips, worst):
+def _grad_reference(z, name, config, which, flips, worst, table=None):
     """which digests the step's gradients are gated against: -> (prefix in the fixture, tolerance)"""
     import json
-    sets = json.loads(str(z[which + '/flipsets']))
+    sets = json.loads(str(z[(table or which) + '/flipsets']))
     if FLIP_REPORT:
         with open(FLIP_REPORT, 'a') as f:
             f.write(json.dumps(dict(fixture=name, config=config, step=which, flips=flips, worst_rms=worst, known=(not flips) or flips in sets)) + '\n')
@@ -322,8 +326,10 @@ def test_full_size_ssgan_first_step_vs_fixture(gpu, timed):
         tr.flush()
         tr._graphs, tr._iter_graph = {}, None
         res = None
+        lib.TAPS[0] = []
         for it in (2, 3, 4):
             res = tr.iteration(it, feeds)
+        all_taps, lib.TAPS[0] = lib.TAPS[0], None
         assert set(tr._graphs) == {'gen', 'disc'}
         torch.cuda.synchronize()
         for which in ('gen', 'disc'):
@@ -333,18 +339,25 @@ def test_full_size_ssgan_first_step_vs_fixture(gpu, timed):
             opt = next(o for k, o in _optimizers.items() if k[0] == which)
             names = [p.param_name for p in opt.params]
             grads = [opt.g[o:o + n].view(p.shape) for p, (o, n) in zip(opt.params, opt.slots)]
-            _check_grads(z, which, names, grads, tol_of(name, which), tag=(name, 'timed'))
+            taps = [(n_, t_) for sc, n_, t_ in all_taps if sc is not None and sc.startswith(which)]
+            flips, worst = _gpu_flips(z, which, taps, cfg.B, last=False, table='fwd')
+            prefix, tol = _grad_reference(z, name, 'timed', which, flips, worst, table='fwd')
+            _check_grads(z, prefix, names, grads, tol if tol is not None else tol_of(name, which), tag=(name, 'timed'))
         optim.reset_optimizers()
         lib.delete_all_params()
         return
     for which in ('gen', 'disc'):
+        lib.TAPS[0] = []
         out = tr.model.forward(tr.feed, which)
+        taps, lib.TAPS[0] = [(n_, t_) for _, n_, t_ in lib.TAPS[0]], None
         refc = float(z[which + '/cost'])
         c = float(out[which + '_cost'].detach())
         assert abs(c - refc) <= 1e-5 * max(1.0, abs(refc)), (which, c, refc)
         opt = out[which + '_train_op'].optimizer
         names = [p.param_name for p in opt.params]
         grads = torch.autograd.grad(out[which + '_cost'], opt.params, allow_unused=True)
-        _check_grads(z, which, names, grads, tol_of(name, which), tag=(name, 'eager'))       # (filter gradients here are fp32 sums over up to 5e5 pixels)
+        flips, worst = _gpu_flips(z, which, taps, cfg.B, last=False, table='fwd')
+        prefix, tol = _grad_reference(z, name, 'eager', which, flips, worst, table='fwd')
+        _check_grads(z, prefix, names, grads, tol if tol is not None else tol_of(name, which), tag=(name, 'eager'))       # (filter gradients here are fp32 sums over up to 5e5 pixels)
     optim.reset_optimizers()
     lib.delete_all_params()
