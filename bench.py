@@ -368,22 +368,27 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
         tab, tag = _pmc_table(spec.get('key', 'headline'))
 
         def rows_of(a):
-            """per-SHAPE rows of one kernel -- (grid, flop per launch): live eager-bracket figures next to the static in-graph / counter figures
-            of the same grid.  The static table is keyed by (kernel, grid) -- what rocprofv3 sees --, so a grid that two shapes of this
-            kernel share has no static figures here (`grid_shared`): a row is ONE problem shape or carries nothing."""
+            """rows of one kernel, one per GRID (what rocprofv3 can tell apart): live eager-bracket figures next to the static in-graph / counter
+            figures of the same grid.  The profiler's records are per problem SHAPE (grid, flop per launch); where several shapes of a kernel
+            share a grid (two layers whose tile counts multiply to the same number; 1-D split-K launches of a fixed workgroup count) the row
+            is their launch-weighted mix and lists them under `shapes` -- its flop_per_launch, launches and durations are still sums over the
+            same launches, so every kernel-level ratio stays exact; only a per-shape in-graph duration cannot be read from a trace."""
             st = (tab.get(a['name']) or {}).get('by_grid') or {}
-            per_grid = {}
+            by_grid = {}
             for r in a['rows']:
-                per_grid[r['grid']] = per_grid.get(r['grid'], 0) + 1
+                by_grid.setdefault(r['grid'], []).append(r)
             out = []
-            for r in sorted(a['rows'], key=lambda r: (r['grid'], r['flops'] / r['launches'])):
-                shared = per_grid[r['grid']] > 1
-                g = {} if shared else (st.get(str(r['grid'])) or {})
-                out.append(dict(grid=r['grid'], launches_per_step=r['launches'] / n_prof,
-                                flop_per_launch=r['flops'] / r['launches'], algorithmic_bytes=round(r['bytes'] / r['launches']),
-                                avg_us=round(1e3 * r['total_ms'] / r['launches'], 2), avg_us_in_graph=g.get('avg_us_in_graph'),
-                                traffic=g.get('traffic_bytes'), mfma_util_pct=g.get('mfma_util_pct'),
-                                **({'grid_shared': True} if shared else {})))
+            for grid in sorted(by_grid):
+                rs = sorted(by_grid[grid], key=lambda r: r['flops'] / r['launches'])
+                n = sum(r['launches'] for r in rs)
+                g = st.get(str(grid)) or {}
+                row = dict(grid=grid, launches_per_step=n / n_prof, flop_per_launch=sum(r['flops'] for r in rs) / n,
+                           algorithmic_bytes=round(sum(r['bytes'] for r in rs) / n), avg_us=round(1e3 * sum(r['total_ms'] for r in rs) / n, 2),
+                           avg_us_in_graph=g.get('avg_us_in_graph'), traffic=g.get('traffic_bytes'), mfma_util_pct=g.get('mfma_util_pct'))
+                if len(rs) > 1:
+                    row['shapes'] = [dict(flop_per_launch=r['flops'] / r['launches'], launches_per_step=r['launches'] / n_prof,
+                                          avg_us=round(1e3 * r['total_ms'] / r['launches'], 2)) for r in rs]
+                out.append(row)
             return out
 
         def mixed(rows, field, weight='launches_per_step'):
@@ -458,19 +463,19 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
             for a in agg:
                 if not a['name'].startswith(('corr_kernel', 'wgrad_kernel', 'wgrad4_kernel', 'dg16_kernel', 'conv3d_igemm')):
                     continue
-                for r, row in zip(sorted(a['rows'], key=lambda r: (r['grid'], r['flops'] / r['launches'])), a['_rows']):
+                for row in a['_rows']:
                     if row['mfma_util_pct'] is not None:
-                        cw += r['total_ms']
-                        ca += r['total_ms'] * row['mfma_util_pct']
+                        t_ms = sum(r['total_ms'] for r in a['rows'] if r['grid'] == row['grid'])
+                        cw += t_ms
+                        ca += t_ms * row['mfma_util_pct']
             # the chip's matrix pipes over the WHOLE step: MFMA-busy SIMD-cycles of every launch of an iteration (static per-(kernel, grid)
             # mean of SQ_VALU_MFMA_BUSY_CYCLES x the launches counted here) / (1024 SIMDs x 2.4 GHz x the measured iteration time).
             # Unlike a per-kernel figure it does not care how many kernels share the chip at a time
             busy = fl_cov = fl_all = 0.0
             for a in agg:
                 st = (tab.get(a['name']) or {}).get('by_grid') or {}
-                shared = set(g for g in (r['grid'] for r in a['rows']) if sum(1 for q in a['rows'] if q['grid'] == g) > 1)
                 for r in a['rows']:
-                    g = {} if r['grid'] in shared else (st.get(str(r['grid'])) or {})
+                    g = st.get(str(r['grid'])) or {}       # (busy cycles of a grid's launches: a mean over the shapes that share it, times their launches)
                     fl_all += r['flops']
                     if g.get('mfma_busy_cycles') is not None:
                         busy += g['mfma_busy_cycles'] * r['launches'] / n_prof

@@ -31,6 +31,20 @@ _CAPTURE_MODE = os.environ.get('GGAN_CAPTURE_MODE', 'thread_local')
 _DP_GRAPH_OK = {}
 
 
+def _dump_graph_dot(g, path):
+    """GGAN_GRAPH_DOT=<file>: the captured iteration graph (nodes = kernel launches, edges = stream order and event waits) as Graphviz text,
+    through hipGraphDebugDotPrint on the graph torch keeps (CUDAGraph(keep_graph=True)); torch's own debug_dump writes nothing on this build.
+    Diagnostic only (tools/graph_edges.py reads it): which launches a replay may run side by side is decided by these edges."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(g.raw_cuda_graph()), str(path).encode(), ctypes.c_uint(int(os.environ.get('GGAN_GRAPH_DOT_FLAGS', '0'))))
+        if rc != 0:
+            print('[engine] hipGraphDebugDotPrint returned %d' % rc)
+    except (OSError, AttributeError, RuntimeError) as e:
+        print('[engine] graph dump failed: %s' % e)
+
+
 def dp_graph_selftest(device, comm):
     """Can an all-reduce on the directly bound RCCL communicator (rccl.py) be captured in a HIP graph and replayed here?  Two rounds,
     each closed by an ordinary (eager, torch.distributed) MIN all-reduce so that every replica takes the same path and no rank ever
@@ -799,9 +813,12 @@ class Trainer(object):
                 F.record_sites(False)
                 ahead = self._ahead_prepare(kinds) if use_ahead else None
                 lib.drop_taps(set(kinds))                  # (tests: only the captured graph's activations are of interest)
-                g = torch.cuda.CUDAGraph()
+                dot = os.environ.get('GGAN_GRAPH_DOT')
+                g = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s, capture_error_mode=_CAPTURE_MODE):
                     costs, keeps = self._iteration_body(kinds, ahead)
+                if dot:
+                    _dump_graph_dot(g, dot)
                 self.site_mismatches = F.site_mismatches()
             finally:
                 F.set_site_plan(None)
