@@ -163,6 +163,30 @@ def cpu_baseline(spec, cfg, K, np, torch, budget_s=float(os.environ.get('GGAN_BE
         threadpool_limits(limits=host_cores())
     except ImportError:
         pass
+    if spec['dataset'] in ('moving_mnist', 'chairs') and cfg.mode in ('local_ep', 'ali') and cfg.pos_mode == 'naive_mean_field' \
+            and (not cfg.seq_critic or cfg.ali_mode in ('concat_x', '3dcnn')):
+        # the SAME iteration at the SAME size (all cfg.B sequences) on the PyTorch-CPU restatement of the state-space step (oneDNN convolutions,
+        # every granted core) -- round-5 review: the numpy tape only managed a 2-sequence sample
+        from oracle import ssgan as OSS, torch_cpu_ssgan
+        torch.set_num_threads(host_cores())
+        ocfg = OSS.Cfg(batch_size=cfg.B, length=cfg.LEN, n_c=cfg.n_c, channels=cfg.C, op_dyn_mode=cfg.op_dyn_mode, mode=cfg.mode,
+                       ali_mode=cfg.ali_mode)
+        ts = torch_cpu_ssgan.Step(ocfg, OSS.init_params(ocfg, 0), torch.float32)
+        rng = np.random.default_rng(0)
+
+        def feeds():
+            while True:
+                yield OSS.make_feed(ocfg, rng)
+        fi = feeds()
+        ts.iteration(1, fi)                            # warm-up (thread pool, oneDNN primitive cache)
+        n_cpu, t1 = 0, time.perf_counter()
+        while n_cpu < 1 or (time.perf_counter() - t1 < budget_s and n_cpu < 100):
+            ts.iteration(2 + n_cpu, fi)
+            n_cpu += 1
+        cdt = time.perf_counter() - t1
+        return dict(value=round(cfg.B * n_cpu / cdt, 3), unit='sequences/sec', cores=torch.get_num_threads(), kind='port',
+                    sample='%d iteration(s) (gen step + critic step) of the same script at the same size (%d sequences x %d frames) in %.1f s, '
+                           'PyTorch-CPU fp32 restatement (oneDNN convolutions, TF-SAME padding and TF-Adam emulated)' % (n_cpu, cfg.B, cfg.LEN, cdt))
     if spec['dataset'] in ('moving_mnist', 'chairs'):
         from oracle import ssgan as OSS
         ob = 2                                         # bounded sample: 2 sequences per minibatch instead of cfg.B

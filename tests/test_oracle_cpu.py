@@ -429,3 +429,45 @@ def test_full_size_fixture_kink_table_and_flip_variant():
         assert np.abs(d - z['disc/flip0/g/' + n]).max() <= 1e-11 * max(1.0, np.abs(d).max()), n
         worst = max(worst, np.abs(d[2:] - plain[n][2:]).max() / plain[n][1])
     assert worst > 2e-4, worst       # (observed on the GPU against the plain digests: 5.3e-4)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(mode='ali', ali_mode='3dcnn'), dict(mode='ali', ali_mode='concat_x'),
+                                dict(channels=3, n_c=0, length=5, op_dyn_mode='res_w')], ids=['local_ep', 'ali-3dcnn', 'ali-concat_x', 'chairs'])
+def test_torch_ssgan_restatement_matches_numpy_tape(kw):
+    """oracle/torch_cpu_ssgan.py (the state-space scripts' step on PyTorch-CPU primitives: bench.py's CPU baseline for BASELINE configs[4])
+    against the numpy tape (oracle/ssgan.py) in float64: both costs and every gradient of both steps, incl. the Conv3D sequence critic and
+    the chairs shapes (RGB, no labels, res_w operator)."""
+    import torch
+    from oracle import ssgan as O, tape as tp, torch_cpu_ssgan as TS
+    base = dict(batch_size=2, length=4, dim=4, dim_op=16, dim_g=8, dim_l=4)
+    base.update(kw)
+    cfg = O.Cfg(**base)
+    P0 = O.init_params(cfg, 0)
+    rng = np.random.default_rng(3)
+    for k in P0:
+        if k.endswith('.b') or k.endswith('.Biases'):
+            P0[k] = (0.1 * rng.standard_normal(P0[k].shape)).astype(np.float32)
+    feed = O.make_feed(cfg, np.random.default_rng(1))
+    Pt = {k: tp.T(v.astype(np.float64)) for k, v in P0.items()}
+    out = O.forward(cfg, Pt, feed)
+    ts = TS.Step(cfg, P0, torch.float64)
+    assert sorted(ts.gen_names + ts.disc_names) == sorted(P0)
+    for which in ('gen', 'disc'):
+        names = ts.gen_names if which == 'gen' else ts.disc_names
+        gs = tp.grad(out[which + '_cost'], [Pt[n] for n in names])
+        _, c, g = ts.grads(feed, which)
+        assert abs(float(c) - float(out[which + '_cost'].v)) <= 1e-12
+        for n, a in zip(names, gs):
+            if a is None:
+                assert g[n] is None or float(g[n].abs().max()) == 0.0, n
+            else:
+                assert np.abs(g[n].numpy() - a.v).max() <= 1e-10 * max(np.abs(a.v).max(), 1e-30), n
+    # and the update rule: one generator + one critic step leave the same weights as oracle.ssgan.Trainer
+    otr = O.Trainer(cfg, P0, np.float64)
+    feeds = [O.make_feed(cfg, np.random.default_rng(10 + i)) for i in range(3)]
+    otr.iteration(0, iter(feeds[:1]))
+    otr.iteration(1, iter(feeds[1:]))
+    ts.iteration(0, iter(feeds[:1]))
+    ts.iteration(1, iter(feeds[1:]))
+    for n in P0:
+        assert np.abs(ts.T[n].detach().numpy() - otr.P[n]).max() <= 1e-9, n
