@@ -488,10 +488,6 @@ class GraphicalGAN(object):
             ev_noise = torch.cuda.Event()
             ev_noise.record(cur)                      # (p_z exists on this stream from here on: the critic's z path reads it there)
             self._noise_event = ev_noise
-            # GGAN_NETS_G_FIRST: the Generator's forward nodes are recorded BEFORE the Extractor's -- autograd issues the backward nodes of
-            # the later-recorded pass first, and the order in which a capture sees the two chains' launches decides how the replayed
-            # graph's branches queue (profiles/r06_notes.md)
-            g_first = self.Generator(p_z_gen, xs[0]) if (os.environ.get('GGAN_NETS_G_FIRST', '') not in ('', '0')) else None
             with torch.cuda.stream(self._side):
                 if c.dataset == 'face' or c.K:
                     self._side.wait_event(ev_noise)       # (dequantisation noise of the 64x64 scripts / Gumbel noise of the mixture scripts)
@@ -508,7 +504,7 @@ class GraphicalGAN(object):
                 ev_end = torch.cuda.Event()
                 ev_end.record(self._side)
             self._pending_join = [cur, ev_x, ev_end]
-            out['fake_x'] = g_first if g_first is not None else self.Generator(p_z_gen, xs[0])
+            out['fake_x'] = self.Generator(p_z_gen, xs[0])
             return out
         if fork:
             cur = torch.cuda.current_stream(p_z.device)
