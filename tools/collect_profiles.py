@@ -19,7 +19,7 @@ for suffix, key in WORK.items():
     src = os.path.join(ROOT, 'gpurun_out', tag + suffix)
     if not os.path.isdir(src):
         continue
-    for f in ('kernel_trace.md', 'pmc.md', 'timeline.md', 'bench.json'):
+    for f in ('kernel_trace.md', 'pmc.md', 'timeline.md', 'critical_path.md', 'bench.json'):
         p = os.path.join(src, f)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(ROOT, 'profiles', '%s%s_%s' % (tag, suffix, f)))

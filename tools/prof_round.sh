@@ -14,6 +14,9 @@ B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-profile -
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $B > $O/trace.log 2>&1
 python tools/stats_md.py $O/trace > $O/kernel_trace.md
 python tools/timeline.py $O/trace --steps-per-iter $SPI --skip 5 > $O/timeline.md
+# the captured iteration graph's own critical path at the durations of this trace (image scripts: one graph per iteration)
+GGAN_GRAPH_DOT=$O/graph.dot python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-variants --repeats 0 $* > $O/dot.log 2>&1
+[ -s $O/graph.dot ] && python tools/graph_critical_path.py $O/graph.dot $O/kernel_trace.md > $O/critical_path.md 2>> $O/dot.log
 if [ -z "$NOPMC" ]; then
 S="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile --no-variants --no-graph $*"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $S > $O/pmc_fetch.log 2>&1
