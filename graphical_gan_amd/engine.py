@@ -347,6 +347,7 @@ class Trainer(object):
         """model.forward for a step whose backward follows at once: the critic head may then leave its cost's gradient behind with
         its own forward and take the cost's value into its backward launch (functional.head_bce_hint, models.GraphicalGAN.head_hint)"""
         F.drop_pending_costs()
+        F.drop_late_terms()
         self.model.head_hint = True
         try:
             return self.model.forward(feed, which, nets)
@@ -374,8 +375,11 @@ class Trainer(object):
         # (the filter-gradient slabs are summed by the pack kernel: legal under the same one-contribution condition)
         with F.defer_wgrad_reduce(self.single_contrib):
             grads = opt.compute_gradients(op.cost)
+            late = F.add_late_terms()        # (the penalty's value into the critic cost, on the penalty's stream: the backward pass did not wait for it)
             self._ahead_release('pack')
             keep = opt.pack(grads, fuse_update=fuse_update)
+            for ev in late:
+                torch.cuda.current_stream(self.device).wait_event(ev)
         self._costs_settled()
         return out[which + '_cost'].detach(), opt, keep
 
@@ -577,8 +581,11 @@ class Trainer(object):
         if sp is None:
             with F.defer_wgrad_reduce(self.single_contrib):
                 grads = opt.compute_gradients(op.cost)
+                late = F.add_late_terms()
                 self._ahead_release('pack')
                 keep = opt.pack(grads)
+                for ev in late:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
             opt.all_reduce()
             self._costs_settled()
             return out['disc_cost'].detach(), opt, (keep, out)

@@ -16,7 +16,8 @@ from ._core import (  # noqa: F401
     _skip_undefined, defer_wgrad_reduce, _wgrad_parts, _STREAMS, shared_stream, workspace, _TARGET, _SERIAL_BWD, serial_backward,
     _bwd_target, target_workgroups, _threading, _PLAN, _HINT_FILTER, _PLAIN, force_plain, launch_hint, _carries_hint, _planned_for,
     same_geometry, conv_geom, _geom, _SITE, site_scope, set_site_plan, record_sites, site_log, site_mismatches, RowSlot, _new_out, _adjacent, HEAD_LOGITS, _PENDING_COSTS, _tail_value, settle_cost,
-    pending_costs, drop_pending_costs, UNIT_SEEDS, unit_seed, is_unit_seed)
+    pending_costs, drop_pending_costs, UNIT_SEEDS, unit_seed, is_unit_seed, LATE_EXT, _LATE_TERMS, mark_ready, wait_ready, add_late_terms,
+    drop_late_terms)
 from .pointwise import ActFwd, ActBwd, leaky_relu, relu, tanh, sigmoid  # noqa: F401
 from .conv import (  # noqa: F401
     DEBUG_POISON_CHECK, PendingCast, ConvFwd, _fused_conv_backward, ConvDgrad, ConvDgradMasked, ConvWgrad, ChanSum, TALL_ROWS,

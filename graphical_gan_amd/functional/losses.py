@@ -6,7 +6,7 @@ from .. import _lib
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 from .._lib import check  # noqa: F401
-from ._core import _L, _p, _stream, _c, HEAD_LOGITS, _PENDING_COSTS, is_unit_seed  # noqa: F401
+from ._core import _L, _p, _stream, _c, HEAD_LOGITS, _PENDING_COSTS, is_unit_seed, LATE_EXT, _LATE_TERMS, mark_ready, wait_ready  # noqa: F401
 from .linear import cached_const  # noqa: F401
 
 
@@ -233,11 +233,23 @@ class MeanSum(Function):
             hrec['d_wout'] = new(hrec['H']) if hrec['want_out'] else None
             hrec['d_bout'] = new(1) if hrec['want_bout'] else None
             hrec['g_ptr'], hrec['g_version'] = outs[0].data_ptr(), outs[0]._version
-            hrec['tail'] = dict(kind='mean', terms=hh['terms'] + tuple((1, 0.0, 1.0) for _ in xs[nh:]), logits=xs[0], g=hh['g'], loss=loss,
-                                ext=[None] * nh + list(xs[nh:]))
+            if LATE_EXT[0] and len(xs) > nh:
+                # (the one-element terms -- the penalty -- stay out of the head's launch: the backward pass of these logits then does not wait
+                #  for whatever computes them; the caller adds them to the value later: functional.add_late_terms)
+                hrec['tail'] = dict(kind='mean', terms=hh['terms'], logits=xs[0], g=hh['g'], loss=loss, ext=None)
+                for x in xs[nh:]:
+                    _LATE_TERMS.append((loss, x))
+            else:
+                for x in xs[nh:]:
+                    wait_ready(x)
+                hrec['tail'] = dict(kind='mean', terms=hh['terms'] + tuple((1, 0.0, 1.0) for _ in xs[nh:]), logits=xs[0], g=hh['g'], loss=loss,
+                                    ext=[None] * nh + list(xs[nh:]))
             _PENDING_COSTS[loss.data_ptr()] = hrec['tail']
             ctx.unit_grads = outs
             return loss.reshape(())
+        for x in xs:
+            if x.numel() == 1:
+                wait_ready(x)          # (a one-element term whose producer ran on another stream and was not joined: LATE_EXT)
         if n <= _lib.BCE_MAX and not os.environ.get('GGAN_NO_BCE_FWD_GRAD'):
             # one launch for all terms; with it (as BceSum) the gradients for the unit seed of a train op, in ONE buffer so that
             # the halves of a batched critic's logits get adjacent slices (SplitRows.backward: no concatenation)
@@ -297,6 +309,8 @@ class GradPenalty(Function):
             check(_L().ggan_gp_penalty_fwd(_p(g), _p(slopes), _p(pen), B, D, lam, _stream()), 'ggan_gp_penalty_fwd')
         ctx.lam = lam
         ctx.save_for_backward(g, slopes)
+        if LATE_EXT[0]:
+            mark_ready(pen)
         return pen.reshape(())
 
     @staticmethod

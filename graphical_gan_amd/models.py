@@ -573,6 +573,13 @@ class GraphicalGAN(object):
         # while a step graph is built -- issued first, so that it runs beside the main pass in both directions (autograd keeps every
         # backward node on the stream of its forward)
         gp_early = None
+        # (round 6) the penalty's VALUE joins the cost late: the critic head that is going to write the cost with its backward launch (head_hint)
+        # leaves the penalty term out, the main stream is NOT joined with the penalty stream in front of the cost, and the Trainer adds the
+        # term behind the backward pass (functional.LATE_EXT / add_late_terms) -- the [fake; real] pass's backward then starts where its
+        # forward ends instead of where the penalty chain's first-order phase ends (headline -1.5 %; GGAN_NO_LATE_PENALTY: as before)
+        late_gp = (c.mode == 'wali-gp' and which == 'disc' and batched and self.fork_nets and self.fork_now and real_x.is_cuda
+                   and not os.environ.get('GGAN_NO_FORK_GP') and getattr(self, 'head_hint', False) and c.fuse and not c.K
+                   and not os.environ.get('GGAN_NO_HEAD_HINT') and not os.environ.get('GGAN_NO_LATE_PENALTY'))
         if (c.mode == 'wali-gp' and which == 'disc' and batched and self.fork_nets and self.fork_now and real_x.is_cuda
                 and not os.environ.get('GGAN_NO_FORK_GP')):
             # (the SECOND stream, behind the Extractor branch whose q_z it reads -- not a third one: every further stream of the process
@@ -584,7 +591,11 @@ class GraphicalGAN(object):
             self._gp_stream = self._side
             self._gp_stream.wait_stream(cur)                          # fake_x, p_z (Generator branch)
             with torch.cuda.stream(self._gp_stream):
-                gp_early = self._penalty(J, batched, real_x, fake_x, q_z, p_z, feed)
+                F.LATE_EXT[0] = late_gp
+                try:
+                    gp_early = self._penalty(J, batched, real_x, fake_x, q_z, p_z, feed)
+                finally:
+                    F.LATE_EXT[0] = False
         # MODE ali on the batched critic: the cost of this step is known before the critic runs -- sigmoid cross-entropy of its [fake; real]
         # logits with labels (1, 0) in a generator step, (0, 1) in a critic step (tflib/objs/gan_inference.py:47-79) -- and the caller
         # (engine.Trainer, head_hint) runs the backward at once: the critic head leaves that cost's gradient behind with its forward
@@ -606,7 +617,7 @@ class GraphicalGAN(object):
         with (lib.frozen('Discriminator') if which == 'gen' else lib.frozen()), F.head_bce_hint(hint, hkind):
             d_fake, d_real = self._critic(batched, real_x, q_z, p_z, fake_x, onehot if c.K else None, q_k if c.K else None,
                                           detach=which == 'disc')
-        if gp_early is not None:
+        if gp_early is not None and not late_gp:
             torch.cuda.current_stream(real_x.device).wait_stream(self._gp_stream)
         gen_params, disc_params = self._var_lists()
         rec_penalty = None
@@ -634,7 +645,11 @@ class GraphicalGAN(object):
                 # (the penalty pass reaches the critic's weights through second autograd leaves: the optimizer sums the two
                 #  gradient contributions of every weight where it packs the bucket, not with an addition launch per weight)
                 gp = gp_early if gp_early is not None else self._penalty(J, batched, real_x, fake_x, q_z, p_z, feed)
-            res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
+            F.LATE_EXT[0] = late_gp and gp is gp_early and gp is not None
+            try:
+                res = J.wali_gp(d_fake, d_real, gp, gen_params, disc_params)
+            finally:
+                F.LATE_EXT[0] = False
             out['gradient_penalty'] = gp
         else:
             res = J.ali(d_fake, d_real, gen_params, disc_params, lr=c.lr, beta1=c.beta1)
