@@ -9,8 +9,8 @@ gan_inference_cifar10.py (32x32x3, BATCH_SIZE=64) with the one MODE of that scri
 steps, each critic step with the penalty's double backward, and consumes 6 minibatches; `value` counts BATCH_SIZE images per iteration
 as the reference's own iteration counter does.  Per-GPU batch stays 64 as N grows (weak scaling).
 
-The one JSON line also carries `variants`: the other BASELINE configurations measured in the same process, each with its
-own ms_per_step, algorithmic GFLOP, roofline (dominant kernel) and cpu_baseline:
+The one JSON line also carries `variants`: the other BASELINE configurations, each measured in a process of its own at N = 1
+(`variant_leg`; GGAN_BENCH_VARIANTS_IN_PROCESS=1: behind the headline in this process, as rounds 2-5 did), each with its own ms_per_step, algorithmic GFLOP, roofline (dominant kernel) and cpu_baseline:
   ali                gan_inference_cifar10.py at the script's default MODE='ali' ("G+D", CRITIC_ITERS=1: the headline of rounds 1-4)
   gmgan-cifar10-K30  gmgan_inference_cifar10.py with the script's N_COMS=30;  gmgan-cifar10-K10: BASELINE configs[2] (K=10)
   gan-face           gan_inference_face.py 64x64x3 bs=64 (configs[3])
@@ -793,6 +793,54 @@ def dp_schedule_leg(args, head_ms):
             pass
 
 
+def variant_leg(v, args, vsteps, warmup):
+    """one of the other BASELINE configurations in a process of its own (N = 1): `python bench.py --dataset .. --mode .. --no-variants`, the
+    full record read back.  A workload run BEHIND another one in the same process maps its graph branches onto hardware queues the earlier
+    Trainer's streams left behind (gmgan: 1.10-1.11 ms behind the headline, 1.06-1.07 ms alone -- profiles/r06_notes.md section 13; the others
+    measure the same either way); a process of its own is also how a user runs the script.  None: the caller measures in this process."""
+    import subprocess
+    import tempfile
+    if os.environ.get('GGAN_BENCH_VARIANTS_IN_PROCESS') or os.environ.get('GGAN_FORCE_ALLREDUCE'):      # (the one-rank RCCL rehearsal keeps its process group)
+        return None
+    tmp = tempfile.NamedTemporaryFile(prefix='ggan_variant_', suffix='.json', delete=False)
+    tmp.close()
+    env = dict(os.environ, GGAN_BENCH_NO_DP_LEG='1', GGAN_BENCH_FULL=tmp.name)
+    env = {k: val for k, val in env.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(vsteps), '--warmup', str(warmup), '--no-variants',
+           '--repeats', '0', '--dataset', v['dataset']]
+    if v.get('mode'):
+        cmd += ['--mode', v['mode']]
+    if v.get('ssgan_mode'):
+        cmd += ['--ssgan-mode', v['ssgan_mode']]
+    if v.get('n_coms') is not None:
+        cmd += ['--n-coms', str(v['n_coms'])]
+    for flag, on in (('--no-graph', args.no_graph), ('--no-fuse', args.no_fuse), ('--no-cpu-baseline', args.no_cpu_baseline),
+                     ('--no-kernel-profile', args.no_kernel_profile), ('--no-ring', args.no_ring)):
+        if on:
+            cmd.append(flag)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get('GGAN_BENCH_VARIANT_TIMEOUT_S', '300')), env=env, cwd=ROOT)
+        if r.returncode != 0:
+            sys.stderr.write('[bench] variant %s: child exited %d (%s); measuring it in this process\n' % (v['key'], r.returncode, (r.stderr or '')[-200:]))
+            return None
+        with open(tmp.name) as f:
+            rec = json.load(f)
+        for drop in ('variants', 'dp_schedule_n1', '_full_path', 'repeat_ms_per_step'):
+            rec.pop(drop, None)
+        if rec.get('kernels'):
+            rec['kernels'] = rec['kernels'][:8]
+        rec['process'] = 'own'
+        return rec
+    except Exception as e:                                 # noqa: BLE001
+        sys.stderr.write('[bench] variant %s: %s: %s; measuring it in this process\n' % (v['key'], type(e).__name__, str(e)[:200]))
+        return None
+    finally:
+        try:
+            os.unlink(tmp.name)
+        except OSError:
+            pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -858,7 +906,7 @@ def main():
                      batch_size=args.batch_size)
     out = run_workload(head_spec, args, env, args.steps, args.warmup)
 
-    # the other BASELINE configurations, same process, same measurement (only next to the default headline workload)
+    # the other BASELINE configurations, same measurement, each in a process of its own at N = 1 (only next to the default headline workload)
     default_head = args.dataset == 'cifar10' and args.mode == 'wali-gp' and args.batch_size is None and not args.host_feed
     variants = []
     if not args.no_variants and (default_head or args.variants):
@@ -868,7 +916,11 @@ def main():
             if v['key'] not in want:
                 continue
             t0 = time.perf_counter()
-            r = run_workload(v, args, env, vsteps, min(args.warmup, 5), top_kernels=8)
+            r = variant_leg(v, args, vsteps, min(args.warmup, 5)) if world == 1 else None
+            if r is None:
+                r = run_workload(v, args, env, vsteps, min(args.warmup, 5), top_kernels=8)
+                if r is not None:
+                    r['process'] = 'shared with the headline'
             if r is not None:
                 r['key'] = v['key']
                 r['wall_s'] = round(time.perf_counter() - t0, 1)
