@@ -946,3 +946,53 @@ def test_head_that_knows_its_cost_is_bit_identical(gpu, monkeypatch, dataset, mo
     assert all(np.isfinite(v) for v in finals[1][1].values())
     for k in finals[0][0]:
         assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graph', [False, True])
+def test_penalty_value_joining_the_cost_late_is_bit_identical(gpu, monkeypatch, graph):
+    """wali-gp critic steps (round 6): the critic cost's VALUE needs the gradient penalty, its backward pass does not.  The head that writes the
+    cost with its backward launch leaves the one-element penalty term out, the main stream is not joined with the penalty stream in front
+    of the cost, and the Trainer adds the term behind the backward pass (functional.LATE_EXT / add_late_terms: one ggan_axpby launch on the
+    penalty's stream per critic step).  The sum is the same two terms in the same order => bit-identical costs and weights against
+    GGAN_NO_LATE_PENALTY=1, eager and graph-replayed; and the late launches are really issued."""
+    import torch
+    from graphical_gan_amd import functional as F, _lib
+    from graphical_gan_amd.models import Config
+    from graphical_gan_amd.engine import Trainer
+    finals, lates = [], []
+    for late in (False, True):
+        if late:
+            monkeypatch.delenv('GGAN_NO_LATE_PENALTY', raising=False)
+        else:
+            monkeypatch.setenv('GGAN_NO_LATE_PENALTY', '1')
+        _fresh()
+        np.random.seed(0)
+        cfg = Config('cifar10', batch_size=16, n_coms=0, mode='wali-gp', dim=16, dim_latent=32)
+        tr = Trainer(cfg, device=gpu, graph=graph, seed=4321)
+        batches = iter(tr.model.synthetic_ring(gpu, n=5, seed=99) * 60)
+        n_late = [0]
+        entry = F.add_late_terms
+
+        def counted():
+            evs = entry()
+            n_late[0] += len(evs)
+            return evs
+        monkeypatch.setattr(F, 'add_late_terms', counted)
+        costs = []
+        for it in range(4):
+            res = tr.iteration(it, batches)
+            if not graph:
+                costs.append({k: float(v) for k, v in res.items()})
+        monkeypatch.setattr(F, 'add_late_terms', entry)
+        tr.flush()
+        torch.cuda.synchronize()
+        assert not F.pending_costs() and not F._LATE_TERMS
+        lates.append(n_late[0])
+        finals.append(({k: v.copy() for k, v in tr.get_params().items()}, {k: float(v) for k, v in res.items()}, costs))
+    # (eager steps do not fork the penalty pass onto a stream of its own: nothing is late there, and the two runs must still agree)
+    assert lates[0] == 0 and (lates[1] > 0) == bool(graph), lates
+    assert finals[0][1] == finals[1][1] and finals[0][2] == finals[1][2]
+    assert all(np.isfinite(v) for v in finals[1][1].values())
+    for k in finals[0][0]:
+        assert np.array_equal(finals[0][0][k], finals[1][0][k]), k
