@@ -699,7 +699,10 @@ int conv_wgrad_thin(const ggan_conv_geom& g, const float* x, const float* gy, Gy
     }
     // (slab cap 64 keeps the consumer of the slabs cheap; with thousands of items -- the 512..1024-frame launches of the
     //  state-space scripts, 134 MB of gy to stream -- 64 x Co/16 workgroups leave half the chip idle: 256 small slabs then)
-    const int max_sk = (P.items >= 2048 && P.slab_stride <= 8192) ? 256 : 64;
+    //  (round 6: a 32-channel first layer has only Co / 16 = 2 column groups -- 64 slabs were 128 workgroups, half of the chip, for the
+    //   launch that ends the face critic's backward pass alone on the chip: 128 slabs there)
+    int max_sk = (P.items >= 2048 && P.slab_stride <= 8192) ? 256 : 64;
+    if (max_sk == 64 && g.Co / 16 <= 2 && P.slab_stride <= 8192 && !getenv("GGAN_THIN_WGRAD_SK64")) max_sk = 128;
     int sk = P.items < max_sk ? P.items : max_sk;
     if ((size_t)sk > cap_slabs) sk = (int)cap_slabs;
     if (sk < 1) sk = 1;

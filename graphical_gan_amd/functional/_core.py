@@ -128,6 +128,8 @@ def _wgrad_parts(x, gy, y, act, alpha, geom, with_bias):
     cap = min(64, max(1, -(-256 // tiles))) * stride
     if Ci <= 4 and stride <= 8192 and N * Ho >= 8192:        # thin layers at 512..1024 frames: up to 256 small slabs (conv_thin.hip)
         cap = 256 * stride
+    elif Ci <= 4 and stride <= 8192 and Co <= 32:            # ... a 32-channel thin layer: up to 128 (two column groups x 128 = the chip)
+        cap = max(cap, 128 * stride)
     part = torch.empty((cap,), dtype=torch.float32, device=x.device)
     n, st = C.c_int(0), C.c_size_t(0)
     g = _geom(geom)
