@@ -137,6 +137,26 @@ def ssgan_gflop_per_iteration(cfg):
 _STATIC_BUILD = None
 
 
+def _static_key(spec):
+    """the profiles/pmc_traffic.json table of a workload: its VARIANTS key, also when it runs as the headline of a process of its own
+    (variant_leg, or `python bench.py --mode ali` by hand)"""
+    key = spec.get('key', 'headline')
+    if key != 'headline':
+        return key
+    ds = spec.get('dataset')
+    if ds == 'cifar10' and spec.get('mode') == 'wali-gp' and not spec.get('n_coms') and not spec.get('batch_size'):
+        return 'headline'
+    for v in VARIANTS:
+        if v['dataset'] != ds or spec.get('batch_size'):
+            continue
+        if ds in ('moving_mnist', 'chairs'):
+            if v.get('ssgan_mode') == spec.get('ssgan_mode'):
+                return v['key']
+        elif v.get('mode') == spec.get('mode') and (v.get('n_coms') or 0) == (spec.get('n_coms') or 0):
+            return v['key']
+    return '(no static table)'
+
+
 def _pmc_table(workload_key):
     """Static figures that cannot be read from inside the process: per (kernel, grid) the duration inside the graph-replayed step
     (rocprofv3 --kernel-trace) and the counters of separate rocprofv3 --pmc passes of the same workload, written by tools/prof_round.sh /
@@ -389,7 +409,7 @@ def run_workload(spec, args, env, steps, warmup, top_kernels=None):
                 a[k] += r[k]
             a['rows'].append(r)
         agg = sorted(byname.values(), key=lambda r: -r['total_ms'])
-        tab, tag = _pmc_table(spec.get('key', 'headline'))
+        tab, tag = _pmc_table(_static_key(spec))
 
         def rows_of(a):
             """rows of one kernel, one per GRID (what rocprofv3 can tell apart): live eager-bracket figures next to the static in-graph / counter
