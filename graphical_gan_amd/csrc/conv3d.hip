@@ -63,19 +63,21 @@ __global__ void col2im3d_k(const C3 g, const float* __restrict__ col, float* __r
         const int l = (int)(t % (IT)g.L);
         const int n = (int)(t / (IT)g.L);
         VT acc = vzero<V>();
-        for (int dl = 0; dl < g.kl; ++dl) {
+        // only the taps of the voxel's residue class reach it (d = (coordinate + pad) mod stride, then every stride-th), in ascending order
+        // as before; walking all kl * k * k taps and skipping left 7 of 8 iterations of a stride-2 layer on `continue` (round 6)
+        for (int dl = (l + g.pl) % g.sl; dl < g.kl; dl += g.sl) {
             const int a = l + g.pl - dl;
-            if (a < 0 || a % g.sl) continue;
+            if (a < 0) break;
             const int ol = a / g.sl;
             if (ol >= g.Lo) continue;
-            for (int dh = 0; dh < g.k; ++dh) {
+            for (int dh = (h + g.ph) % g.s; dh < g.k; dh += g.s) {
                 const int b = h + g.ph - dh;
-                if (b < 0 || b % g.s) continue;
+                if (b < 0) break;
                 const int oh = b / g.s;
                 if (oh >= g.Ho) continue;
-                for (int dw = 0; dw < g.k; ++dw) {
+                for (int dw = (w + g.pw) % g.s; dw < g.k; dw += g.s) {
                     const int c = w + g.pw - dw;
-                    if (c < 0 || c % g.s) continue;
+                    if (c < 0) break;
                     const int ow = c / g.s;
                     if (ow >= g.Wo) continue;
                     vacc(acc, reinterpret_cast<const VT*>(col)[((((size_t)n * g.Lo + ol) * g.Ho + oh) * g.Wo + ow) * Kv +
