@@ -339,20 +339,34 @@ class StateSpaceGAN(object):
         # the transition operator's scan is one workgroup per sequence (32 of them) walking LEN-1 steps: it runs on the second
         # stream beside the Extractor's conv stack over all frames instead of in front of the chip
         cur = self._fork(feed['p_z_g'].device)
-        if cur is not None:
-            with torch.cuda.stream(self._side):
-                p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
         nf = self.cfg.B * self.cfg.LEN
         pair = feed.get('x_pair') if self.cfg.fuse else None
         slots = (F.RowSlot(pair, 0, nf), F.RowSlot(pair, nf, 2 * nf)) if pair is not None else (None, None)
-        real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0 / self.cfg.x_div, 0.0, -1.0, slots[1])      # 2*(x/div-.5)
-        q_z_l = self.DynamicExtractor(self.Extractor(real_x, real_y))
-        q_z_g = self.G_Extractor(real_x, real_y)
-        if cur is not None:
+
+        def extractor_side():
+            real_x = F.Axpby.apply(feed['real_x_unit'], feed['real_x_unit'], 2.0 / self.cfg.x_div, 0.0, -1.0, slots[1])      # 2*(x/div-.5)
+            return real_x, self.DynamicExtractor(self.Extractor(real_x, real_y)), self.G_Extractor(real_x, real_y)
+        if cur is not None and os.environ.get('GGAN_SSGAN_NETS') != 'scan_aside':
+            # (round 6) the whole Extractor family on the second stream, the scan and the frame generator on this one: the two halves of the
+            # nets pass share nothing, and -- autograd keeps a backward node on the stream of its forward -- neither do their backward
+            # passes: the scan's LEN-1 sequential steps per direction (32 workgroups) and the short products of the latent paths hide behind
+            # the other half's conv launches in BOTH directions.  (Before: only the forward scan ran aside; in a generator step the
+            # Extractor's backward -- its tail of short launches first -- queued behind the frame generator's on one stream.)
+            with torch.cuda.stream(self._side):
+                real_x, q_z_l, q_z_g = extractor_side()
+            p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
+            fake_x = self.Generator(feed['p_z_g'], p_z_l, p_y, out_slot=slots[0])
             cur.wait_stream(self._side)
         else:
-            p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
-        fake_x = self.Generator(feed['p_z_g'], p_z_l, p_y, out_slot=slots[0])
+            if cur is not None:
+                with torch.cuda.stream(self._side):
+                    p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
+            real_x, q_z_l, q_z_g = extractor_side()
+            if cur is not None:
+                cur.wait_stream(self._side)
+            else:
+                p_z_l = self.DynamicGenerator(feed['p_z_l_0'], feed['epsilon'])
+            fake_x = self.Generator(feed['p_z_g'], p_z_l, p_y, out_slot=slots[0])
         return dict(real_x=real_x, q_z_l=q_z_l, q_z_g=q_z_g, p_z_l=p_z_l, p_z_g=feed['p_z_g'], fake_x=fake_x)
 
     def forward(self, feed, which=None, nets=None):
