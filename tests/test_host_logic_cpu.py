@@ -356,3 +356,28 @@ def test_reference_hyperparameter_blocks_and_their_mode_rules():
         31, [3, 64, 64], 12288, 'res_w', 0, 40000, 50, 8, False)
     cfg = run.config(run.reference_block('ssgan_inference_moving_mnist', MODE='ali', ALI_MODE='3dcnn'))
     assert (cfg.seq_critic, cfg.ali_mode, cfg.LEN, cfg.lamb, cfg.lr) == (True, '3dcnn', 16, 0.1, 1e-4)
+
+
+def test_bench_static_tables_are_keyed_by_workload_not_by_role():
+    """bench.py measures the other BASELINE configurations in a process of their own, where each is the 'headline' of its process: the static
+    per-(kernel, grid) figures (profiles/pmc_traffic.json) must still come from the table of THAT workload (round 6: they came from the
+    G+D+GP step's table for every one of them)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    head = dict(key='headline', dataset='cifar10', mode='wali-gp', ssgan_mode='local_ep', n_coms=None, batch_size=None)
+    assert bench._static_key(head) == 'headline'
+    for v in bench.VARIANTS:
+        as_child = dict(head, dataset=v['dataset'], mode=v.get('mode', 'wali-gp'), ssgan_mode=v.get('ssgan_mode', 'local_ep'),
+                        n_coms=v.get('n_coms'))
+        assert bench._static_key(as_child) == v['key'], v
+        assert bench._static_key(dict(v)) == v['key']                       # (in-process: its own key)
+    assert bench._static_key(dict(head, batch_size=16)) not in [v['key'] for v in bench.VARIANTS] + ['headline']
+    import json
+    tab = json.load(open(os.path.join(root, 'profiles', 'pmc_traffic.json')))
+    for v in bench.VARIANTS:
+        assert v['key'] in tab or v['key'] == 'gmgan-cifar10-K30', v['key']      # (K = 30 reads the K = 10 table: same launch shapes)
+    assert 'headline' in tab and tab.get('_build') and tab.get('_tag')
